@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: batched hypothesis scoring, 1e6 2D-3D correspondences x 2048 pose
+hypotheses per GPU (config C4 points + the metric batch of SURVEY.md §8d), through the C ABI of libpgx.so.
+
+One step = one pass of the proposal hot path over one batch: score every hypothesis of the batch against all points
+(MSAC + compound-model score, scoring_function_with_compound_model.h:61-125), exchange the per-hypothesis results
+(RCCL all-gather when N > 1), fetch them and select the winner on the host.  Inputs (points, compound preference
+vector, hypotheses) are resident in HBM before the timed region starts.  Weak scaling: every rank scores its own 2048
+hypotheses against all points, value = (points x hypotheses of all ranks) / time.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+(RANK / LOCAL_RANK / WORLD_SIZE from the env; torch itself is not imported: the data plane is RCCL inside libpgx).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "progressive-x_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
+FLOPS_PER_PAIR_PNP = 25        # 9 mul + 9 add (3x4 projection) + 2 div + 2 sub + 2 mul + 1 add
+
+
+def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
+    """The oracle (a single-threaded C restatement of the reference path, kind = 'port') on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pgx_oracle as O
+    O.lib()
+    t0 = time.perf_counter()
+    O.score(O.PNP, pts, hyps[:8], T2, compound=comp, has_compound=True, exponent=2)
+    per_hyp = (time.perf_counter() - t0) / 8
+    m = int(max(8, min(hyps.shape[0], budget_s / max(per_hyp, 1e-9))))
+    t0 = time.perf_counter()
+    O.score(O.PNP, pts, hyps[:m], T2, compound=comp, has_compound=True, exponent=2)
+    dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": pts.shape[0] * m / dt, "unit": "residual-evals/s", "cores": 1, "kind": "port",
+            "models_per_sec": m / dt,
+            "sample": f"{m} of {hyps.shape[0]} hypotheses x all {pts.shape[0]} points, {dt:.1f} s, 1 thread",
+            "host_cpu": cpu, "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1000000)
+    ap.add_argument("--hyps", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pyprogressivex import _lib, datasets, parallel
+    rank, world, local = parallel.rank_env()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # ---- synthetic workload (identical points on every rank; per-rank hypothesis batches)
+    n_obj = 16
+    per_obj = args.points // 20
+    x1, x2, K, _, gt = datasets.make_poses(n_per_object=per_obj, n_objects=n_obj,
+                                           n_outliers=args.points - n_obj * per_obj, seed=0)
+    pts, f = datasets.normalize_pnp(x1, x2, K)
+    thr = 4.0 / f                       # find6DPoses default threshold 4 px (bindings.cpp:467), normalised (:96-98)
+    T2 = 9.0 / 4.0 * thr * thr          # progressive_x.h:523
+    hyps = datasets.make_pose_hypotheses(gt, M=args.hyps, seed=1 + rank)
+
+    ctx = _lib.Context(local)
+    info = ctx.device_info()
+    ctx.set_points(_lib.PNP, pts)
+    # a non-empty compound instance: the preference vector of the first accepted model (GT pose 0)
+    ctx.preference(gt[0], T2, slot=0)
+    ctx.compound_update([0])
+    comp = ctx.get_compound() if rank == 0 else None
+    ctx.score_upload(hyps)
+    if world > 1:
+        parallel.init_rccl(ctx, rank, world)
+
+    def step():
+        ctx.timer_start()
+        ctx.score_launch(T2, has_compound=True)
+        kernel_ms = ctx.timer_stop()     # HIP events on the stream the kernels run on
+        if world > 1:
+            ctx.score_allgather()
+            res = ctx.score_fetch_all(exponent=2)
+        else:
+            res = ctx.score_fetch(exponent=2)
+        best = parallel.select_best(res["scores"], res["counts"])
+        return kernel_ms, best, res
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        ctx.comm_barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kms, best, res = step()
+        kernel_ms.append(kms)
+    if world > 1:
+        ctx.comm_barrier()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = ctx.comm_allreduce_max(elapsed)
+
+    if rank == 0:
+        n, M = pts.shape[0], hyps.shape[0]
+        pairs_per_step = n * M * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        alg_bytes, pairs = ctx.score_algorithmic_bytes()
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "residual_evals_per_sec",
+            "value": pairs_per_step / (elapsed / args.steps),
+            "unit": "residual-evals/s",
+            "models_per_sec": M * world / (elapsed / args.steps),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4 multi-6D-pose points (1e6 2D-3D correspondences, 16 objects, 20% outliers) x "
+                                   "metric batch of 2048 pose hypotheses per GPU (16 GT + perturbed), PnP reprojection "
+                                   "residual, MSAC + compound-model score, compound instance = 1 model",
+                       "points": n, "hypotheses_per_gpu": M, "parallelism": f"hypothesis-sharded x{world}",
+                       "exchange": "rccl all-gather of (count,value,shared)" if world > 1 else "none",
+                       "device": info["name"], "cu_count": info["cu_count"]},
+            "winner": {"index": best, "inliers": int(res["counts"][best]) if best >= 0 else 0},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pgx::score_kernel<PnP> (+ score_reduce_kernel)", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "FP64-VALU bound by construction (~0.02 algorithmic B/pair); see valu_fp64"},
+            "valu_fp64": {"achieved_tflops": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12,
+                          "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS, "peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
+                          "frac_of_no_fma_peak": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS / 2),
+                          "flops_per_pair": FLOPS_PER_PAIR_PNP, "pairs_per_launch": pairs},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(pts, hyps, T2, comp)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_port"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        ctx.comm_barrier()
+        ctx.comm_destroy()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

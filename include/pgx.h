@@ -1,0 +1,137 @@
+/*
+ * pgx.h — C ABI of libpgx.so, the MI355X (gfx950) implementation of Progressive-X's data-parallel hot path:
+ * batched hypothesis scoring -> preference / Tanimoto validation -> PEARL unary costs + alpha-expansion labelling.
+ *
+ * The reference has no C ABI for this path: its boundary is a pybind11 module
+ * (/root/reference/src/pyprogressivex/src/bindings.cpp:394-494) whose five entry points call straight into C++
+ * templates.  The functions below are what a reference-side FFI for the hot loops would bind; each cites the
+ * reference interface it replaces (paths relative to /root/reference/src/pyprogressivex/).  INTEGRATION.md shows the
+ * ctypes / pybind11 stubs a maintainer would add.
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative pgx_status on failure
+ * (pgx_last_error gives the message); the caller owns every host buffer, the library copies in and out; one pgx_ctx
+ * per host thread and per GPU; all device work of a ctx is issued on one HIP stream owned by the ctx.
+ */
+#ifndef PGX_H
+#define PGX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgx_ctx pgx_ctx;
+
+enum pgx_status {
+    PGX_OK = 0,
+    PGX_ERR_INVALID = -1,   /* bad argument / call order */
+    PGX_ERR_HIP = -2,       /* HIP runtime error */
+    PGX_ERR_NOMEM = -3,
+    PGX_ERR_NOCONVERGE = -4,/* max-flow sweep cap hit */
+    PGX_ERR_COMM = -5,      /* RCCL error */
+    PGX_ERR_RANGE = -6      /* fixed-point range check failed */
+};
+
+/* problem types; the estimator template argument of progx::ProgressiveX (progressivex_python.cpp:119,252,343,489,616) */
+enum pgx_model_type {
+    PGX_LINE2D = 0,           /* point (x,y);            model (a,b,c)                        findLines            */
+    PGX_HOMOGRAPHY = 1,       /* point (x1,y1,x2,y2);    model H 3x3 row-major, one-way error findHomographies     */
+    PGX_FUNDAMENTAL = 2,      /* point (x1,y1,x2,y2);    model F 3x3 row-major, Sampson       findTwoViewMotions   */
+    PGX_PNP = 3,              /* point (u,v,X,Y,Z);      model [R|t] 3x4 row-major            find6DPoses          */
+    PGX_VANISHING_POINT = 4,  /* point (xs,ys,xe,ye);    model (v0,v1,v2)                     findVanishingPoints  */
+    PGX_HOMOGRAPHY_SYM = 5    /* point (x1,y1,x2,y2);    model [H | H^-1], symmetric transfer error               */
+};
+
+#define PGX_FIXED_SHIFT 32    /* min-cut energies are multiples of 2^-32 */
+#define PGX_UNIQUE_ID_BYTES 128
+
+/* ---- library / context ------------------------------------------------------------------------------------ */
+int pgx_version(void);
+int pgx_device_count(int *count);
+const char *pgx_global_error(void);                       /* message of the last failure that had no ctx */
+int pgx_create(int device_id, pgx_ctx **out);
+void pgx_destroy(pgx_ctx *ctx);
+const char *pgx_last_error(const pgx_ctx *ctx);
+int pgx_model_dims(int model_type, int *point_dim, int *param_dim);
+int pgx_sync(pgx_ctx *ctx);                               /* hipStreamSynchronize on the ctx stream */
+int pgx_timer_start(pgx_ctx *ctx);                        /* hipEventRecord on the ctx stream */
+int pgx_timer_stop(pgx_ctx *ctx, float *milliseconds);    /* record + synchronize + elapsed */
+int pgx_device_info(pgx_ctx *ctx, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- resident data ------------------------------------------------------------------------------------------
+ * replaces: cv::Mat points(N,d,CV_64F,...) (progressivex_python.cpp:75-93,203,335,454,567) — row-major N x d doubles. */
+int pgx_set_points(pgx_ctx *ctx, int model_type, const double *points, int64_t n);
+/* compound preference vector (progressive_x.h:141,524); NULL => all zeros */
+int pgx_set_compound(pgx_ctx *ctx, const double *compound);
+int pgx_get_compound(pgx_ctx *ctx, double *compound);
+
+/* ---- a1: MSACScoringFunctionWithCompoundModel::getScore, batched (scoring_function_with_compound_model.h:61-125)
+ * pgx_score = upload + launch + fetch.  models: M x param_dim row-major.  T2 = squared truncated threshold
+ * (9/4 thr^2, progressive_x.h:523).  has_compound = compound_model->size() > 0 (:110).  exponent as :39/:120.
+ * counts[m] = inlier_number (strict r^2 < T2, :85), values[m] = sum max(0, 1 - r^2/T2) (:94-97),
+ * shared[m] = sum min(compound, pref) (:115-117), scores[m] = values - pow(shared, exponent) (:120).
+ * masks (optional): M x ceil(n/64) uint64, bit i of row m = point i is an inlier of hypothesis m (:88).
+ * The early exit at :105-106 is a pure function of (count, best): callers apply
+ *   count + 1 < best_inlier_number  =>  Score()   in hypothesis order (see pyprogressivex/_proposal.py). */
+int pgx_score(pgx_ctx *ctx, const double *models, int M, double T2, int has_compound, int exponent,
+              int64_t *counts, double *values, double *shared, double *scores, uint64_t *masks);
+int pgx_score_upload(pgx_ctx *ctx, const double *models, int M);
+int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
+int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
+                    double *scores, uint64_t *masks);
+/* what one pgx_score_launch reads+writes at minimum (points + models + compound + results), for rooflines */
+int pgx_score_algorithmic_bytes(pgx_ctx *ctx, int want_masks, int64_t *bytes, int64_t *pairs);
+
+/* ---- a2/a3: Model::setPreferenceVector (progx_model.h:70-87) + the three reductions of isPutativeModelValid
+ * (progressive_x.h:583-585).  The preference vector is kept on the device in `slot` (>=0) for a4; pref_out optional. */
+int pgx_preference(pgx_ctx *ctx, const double *model, double T2, int slot, double *pref_out,
+                   double *dot, double *pref_sqnorm, double *comp_sqnorm);
+int pgx_get_preference(pgx_ctx *ctx, int slot, double *pref_out);
+/* ---- a4: updateCompoundModel (progressive_x.h:597-624): compound[i] = max_k stored pref_k[i] (stale vectors, as the
+ * reference does).  K == 0 leaves the compound vector untouched (:600-601). */
+int pgx_compound_update(pgx_ctx *ctx, const int32_t *slots, int K, double *compound_out);
+
+/* ---- a6: dataEnergyFunctor / EnergyDataStructure (PEARL.h:18-56,82-128): unary table N x (K+1), label K = outlier,
+ * quantised to multiples of 2^-32 for the min-cut.  Kept resident; Dq_out optional. */
+int pgx_pearl_unary(pgx_ctx *ctx, const double *models, int K, double threshold, double lambda, int64_t *Dq_out);
+int pgx_set_unary_q(pgx_ctx *ctx, const int64_t *Dq, int64_t n, int L);   /* tests: inject a table (no points needed) */
+
+/* ---- a20 consumer: neighbourhood graph as symmetric CSR (PEARL.h:532-536 setNeighbors loop).
+ * off[n+1], idx[off[n]], mult[off[n]]: each undirected pair appears in both rows with the same multiplicity
+ * (= number of directed entries in the raw getNeighbors lists; a symmetric raw list gives 2, U-6). */
+int pgx_set_graph(pgx_ctx *ctx, int64_t n, const int32_t *off, const int32_t *idx, const int32_t *mult);
+
+/* ---- a8/a19: GCoptimizationGeneralGraph::{setLabel, expansion, whatLabel} as used by PEARL::labeling
+ * (PEARL.h:507-551).  lambda = spatial coherence weight of ONE directed neighbour entry (PEARL.h:76-78),
+ * label_cost = model_complexity_weight (PEARL.h:144,529).  Energies are returned both as the exact fixed-point
+ * integer and as double (= energy_q / 2^32). */
+int pgx_set_labels(pgx_ctx *ctx, const int32_t *labels, int64_t n);
+int pgx_get_labels(pgx_ctx *ctx, int32_t *labels);
+int pgx_energy(pgx_ctx *ctx, double lambda, double label_cost, int64_t *energy_q, double *energy);
+int pgx_expand_alpha(pgx_ctx *ctx, double lambda, double label_cost, int alpha, int64_t *changed);
+int pgx_expansion(pgx_ctx *ctx, double lambda, double label_cost, int max_cycles,
+                  int64_t *energy_q, double *energy, int *cycles);
+/* counters of the last pgx_expansion / pgx_expand_alpha: [0]=min-cuts solved, [1]=push-relabel sweeps,
+ * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves */
+int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
+
+/* ---- a9: PEARL::parameterEstimation bookkeeping (PEARL.h:342-352, 369-371, 388-390) */
+int pgx_bucket(pgx_ctx *ctx, int L, int64_t *counts, int32_t *order);     /* order optional: stable, ascending index */
+int pgx_residual_sum(pgx_ctx *ctx, const double *model, int label, double *sum);
+
+/* ---- multi-GPU (no reference counterpart): hypotheses are sharded over ranks, every rank holds all
+ * points; RCCL all-gather of the per-hypothesis (count, value, shared) triples; all-reduce(max) of the compound vector */
+int pgx_comm_unique_id(uint8_t id[PGX_UNIQUE_ID_BYTES]);
+int pgx_comm_init(pgx_ctx *ctx, int nranks, int rank, const uint8_t id[PGX_UNIQUE_ID_BYTES]);
+int pgx_comm_destroy(pgx_ctx *ctx);
+int pgx_comm_barrier(pgx_ctx *ctx);
+int pgx_comm_allreduce_max_f64(pgx_ctx *ctx, double *value);                /* host scalar in/out, via device */
+int pgx_score_allgather(pgx_ctx *ctx);                                      /* after pgx_score_launch, asynchronous */
+int pgx_score_fetch_all(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
+                        double *scores);                                    /* nranks*M entries, rank-major */
+int pgx_compound_allreduce_max(pgx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGX_H */

@@ -1,0 +1,574 @@
+/*
+ * pgx_oracle.c — CPU oracle for the Progressive-X hot path (see pgx_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY — never linked into, or called from, the product path.
+ * PARITY UNPINNED (no reference tests / golden vectors / buildable reference).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ * Reference paths below are relative to /root/reference/src/pyprogressivex/.
+ */
+#include "pgx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* OpenCV's macros, which the reference picks up through <opencv2/core/core.hpp>
+ * (progx_model.h:36): MIN(a,b) ((a) > (b) ? (b) : (a)),  MAX(a,b) ((a) < (b) ? (b) : (a)). */
+#define CV_MIN(a, b) ((a) > (b) ? (b) : (a))
+#define CV_MAX(a, b) ((a) < (b) ? (b) : (a))
+
+int pgxo_model_dims(int model_type, int *point_dim, int *param_dim)
+{
+    static const int pd[6] = {2, 4, 4, 5, 4, 4};
+    static const int md[6] = {3, 9, 9, 12, 3, 18};
+    if (model_type < 0 || model_type > 5) return -1;
+    if (point_dim) *point_dim = pd[model_type];
+    if (param_dim) *param_dim = md[model_type];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Residuals
+ * ---------------------------------------------------------------------------------------- */
+
+/* U-4 [UPSTREAM-MEMORY]: Default2DLineEstimator (progressivex_python.cpp:489); model (a,b,c)
+ * with a^2+b^2=1 as returned at progressivex_python.cpp:529-531.  r = |a x + b y + c|. */
+static double line_residual(const double *p, const double *m)
+{
+    const double x = p[0], y = p[1];
+    return fabs(m[0] * x + m[1] * y + m[2]);
+}
+
+/* U-1 [UPSTREAM-MEMORY]: DefaultHomographyEstimator (progressivex_python.cpp:252); H row-major as
+ * flattened at progressivex_python.cpp:292-300.  One-way forward transfer error. */
+static double homography_sq(const double *p, const double *h)
+{
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    const double t1 = h[0] * x1 + h[1] * y1 + h[2];
+    const double t2 = h[3] * x1 + h[4] * y1 + h[5];
+    const double t3 = h[6] * x1 + h[7] * y1 + h[8];
+    const double d1 = x2 - (t1 / t3);
+    const double d2 = y2 - (t2 / t3);
+    return d1 * d1 + d2 * d2;
+}
+
+/* Symmetric transfer error (north-star wording); model = [H | H^-1]; forward + backward. */
+static double homography_sym_sq(const double *p, const double *h)
+{
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    const double *g = h + 9;
+    const double t1 = h[0] * x1 + h[1] * y1 + h[2];
+    const double t2 = h[3] * x1 + h[4] * y1 + h[5];
+    const double t3 = h[6] * x1 + h[7] * y1 + h[8];
+    const double d1 = x2 - (t1 / t3);
+    const double d2 = y2 - (t2 / t3);
+    const double s1 = g[0] * x2 + g[1] * y2 + g[2];
+    const double s2 = g[3] * x2 + g[4] * y2 + g[5];
+    const double s3 = g[6] * x2 + g[7] * y2 + g[8];
+    const double e1 = x1 - (s1 / s3);
+    const double e2 = y1 - (s2 / s3);
+    return (d1 * d1 + d2 * d2) + (e1 * e1 + e2 * e2);
+}
+
+/* U-2 [UPSTREAM-MEMORY]: DefaultFundamentalMatrixEstimator (progressivex_python.cpp:616);
+ * F row-major (progressivex_python.cpp:654-662); squared Sampson distance. */
+static double fundamental_sq(const double *p, const double *f)
+{
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    /* F^T x2 */
+    const double rxc = f[0] * x2 + f[3] * y2 + f[6];
+    const double ryc = f[1] * x2 + f[4] * y2 + f[7];
+    const double rwc = f[2] * x2 + f[5] * y2 + f[8];
+    const double r = x1 * rxc + y1 * ryc + rwc;
+    /* F x1 */
+    const double rx = f[0] * x1 + f[1] * y1 + f[2];
+    const double ry = f[3] * x1 + f[4] * y1 + f[5];
+    return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+}
+
+/* U-3 [UPSTREAM-MEMORY]: DefaultPnPEstimator (progressivex_python.cpp:119); P=[R|t] row-major 3x4
+ * (progressivex_python.cpp:156-167); data row (u_n, v_n, X, Y, Z) (progressivex_python.cpp:88-92).
+ * Squared reprojection error in normalised image coordinates. */
+static double pnp_sq(const double *p, const double *P)
+{
+    const double u = p[0], v = p[1], X = p[2], Y = p[3], Z = p[4];
+    const double px = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+    const double py = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+    const double pz = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+    const double du = u - (px / pz);
+    const double dv = v - (py / pz);
+    return du * du + dv * dv;
+}
+
+/* vanishing_point_estimator.h:166-189 (in-tree, exact operation order). */
+static double vp_residual(const double *p, const double *d)
+{
+    const double xs = p[0], ys = p[1], xe = p[2], ye = p[3];
+    double lx, ly, lz;
+    const double mx = (xs + xe) / 2.0, my = (ys + ye) / 2.0;
+    lx = my * d[2] - d[1];
+    ly = -(mx * d[2] - d[0]);
+    lz = mx * d[1] - my * d[0];
+    return fabs(lx * xs + ly * ys + lz) / sqrt(lx * lx + ly * ly);
+}
+
+double pgxo_squared_residual(int model_type, const double *pt, const double *model)
+{
+    double r;
+    switch (model_type) {
+    case PGXO_LINE2D: r = line_residual(pt, model); return r * r;
+    case PGXO_HOMOGRAPHY: return homography_sq(pt, model);
+    case PGXO_FUNDAMENTAL: return fundamental_sq(pt, model);
+    case PGXO_PNP: return pnp_sq(pt, model);
+    case PGXO_VANISHING_POINT: /* vanishing_point_estimator.h:134-140 */
+        r = vp_residual(pt, model); return r * r;
+    case PGXO_HOMOGRAPHY_SYM: return homography_sym_sq(pt, model);
+    default: return NAN;
+    }
+}
+
+/* Unsquared residual used by PEARL::parameterEstimation (PEARL.h:371,390).  For the estimators whose
+ * source is absent it is restated as sqrt(squaredResidual) [UPSTREAM-MEMORY]. */
+double pgxo_residual(int model_type, const double *pt, const double *model)
+{
+    switch (model_type) {
+    case PGXO_LINE2D: return line_residual(pt, model);
+    case PGXO_VANISHING_POINT: return vp_residual(pt, model);
+    default: return sqrt(pgxo_squared_residual(model_type, pt, model));
+    }
+}
+
+void pgxo_squared_residuals(int model_type, const double *pts, int64_t n, const double *model, double *out)
+{
+    int d = 0;
+    pgxo_model_dims(model_type, &d, NULL);
+    for (int64_t i = 0; i < n; ++i) out[i] = pgxo_squared_residual(model_type, pts + i * d, model);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a1  scoring_function_with_compound_model.h:61-125
+ * ---------------------------------------------------------------------------------------- */
+void pgxo_score(int model_type, const double *pts, int64_t n, const double *models, int M,
+                double T2, const double *compound, int has_compound, int exponent,
+                const int64_t *best_inlier_number,
+                int64_t *counts, double *values, double *shared, double *scores, uint64_t *masks)
+{
+    int d = 0, pdim = 0;
+    pgxo_model_dims(model_type, &d, &pdim);
+    const int64_t words = (n + 63) / 64;
+    double *pref = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int m = 0; m < M; ++m) {
+        const double *model = models + (int64_t)m * pdim;
+        const uint64_t best = best_inlier_number ? (uint64_t)best_inlier_number[m] : 0;
+        uint64_t inl = 0;
+        double value = 0.0;
+        int interrupted = 0;
+        if (masks) memset(masks + (int64_t)m * words, 0, sizeof(uint64_t) * (size_t)words);
+        memset(pref, 0, sizeof(double) * (size_t)n); /* :75 */
+        for (int64_t i = 0; i < n; ++i) {            /* :78 */
+            const double sq = pgxo_squared_residual(model_type, pts + i * d, model); /* :81 */
+            if (sq < T2) {                            /* :85 strict */
+                if (masks) masks[(int64_t)m * words + (i >> 6)] |= (uint64_t)1 << (i & 63); /* :88 */
+                ++inl;                                /* :91 */
+                const double sv = CV_MAX(0.0, 1.0 - sq / T2); /* :94 */
+                value += sv;                          /* :97 */
+                pref[i] = sv;                         /* :100 */
+            }
+            /* :105  point_number - point_idx + inlier_number < best.inlier_number (size_t arithmetic) */
+            if ((uint64_t)n - (uint64_t)i + inl < best) { interrupted = 1; break; }
+        }
+        if (interrupted) { /* :106 returns Score() */
+            counts[m] = 0; values[m] = 0.0; shared[m] = 0.0; scores[m] = 0.0;
+            if (masks) memset(masks + (int64_t)m * words, 0, sizeof(uint64_t) * (size_t)words);
+            continue;
+        }
+        double sh = 0.0;
+        double score = value;
+        if (has_compound) {                           /* :110 compound_model->size() > 0 */
+            for (int64_t i = 0; i < n; ++i)           /* :115-117 */
+                sh += CV_MIN(compound[i], pref[i]);
+            score -= pow(sh, (double)exponent);       /* :120  std::pow(double,int) */
+        }
+        counts[m] = (int64_t)inl; values[m] = value; shared[m] = sh; scores[m] = score;
+    }
+    free(pref);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2  progx_model.h:70-87 ; a3 progressive_x.h:583-588 ; a4 progressive_x.h:604-623
+ * ---------------------------------------------------------------------------------------- */
+void pgxo_preference(int model_type, const double *pts, int64_t n, const double *model, double T2,
+                     double *pref)
+{
+    int d = 0;
+    pgxo_model_dims(model_type, &d, NULL);
+    for (int64_t i = 0; i < n; ++i) {
+        const double sq = pgxo_squared_residual(model_type, pts + i * d, model);
+        const double v = 1.0 - sq / T2;
+        pref[i] = CV_MAX(0, v); /* progx_model.h:85  MAX(0, double) */
+    }
+}
+
+void pgxo_tanimoto_terms(const double *pref, const double *compound, int64_t n,
+                         double *dot, double *pref_sqnorm, double *comp_sqnorm)
+{
+    double d = 0.0, a = 0.0, b = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        d += pref[i] * compound[i];
+        a += pref[i] * pref[i];
+        b += compound[i] * compound[i];
+    }
+    *dot = d; *pref_sqnorm = a; *comp_sqnorm = b;
+}
+
+int pgxo_is_valid_tanimoto(double dot, double pref_sqnorm, double comp_sqnorm, double max_tanimoto,
+                           double *tanimoto)
+{
+    const double t = dot / (pref_sqnorm + comp_sqnorm - dot); /* progressive_x.h:584-585 */
+    if (tanimoto) *tanimoto = t;
+    if (max_tanimoto < t) return 0;                            /* :587  (NaN => valid) */
+    return 1;
+}
+
+void pgxo_compound_max(const double *prefs, int K, int64_t n, double *compound)
+{
+    for (int64_t i = 0; i < n; ++i) compound[i] = 0.0;       /* :604 */
+    for (int k = 0; k < K; ++k)
+        for (int64_t i = 0; i < n; ++i)
+            compound[i] = CV_MAX(compound[i], prefs[(int64_t)k * n + i]); /* :620-621 */
+}
+
+/* a5  progressive_x.h:495-513 */
+uint64_t pgxo_predicted_unseen_inliers(double one_minus_conf, uint64_t sample_size,
+                                       uint64_t iteration_number, uint64_t covered, uint64_t point_number)
+{
+    const uint64_t unseen = point_number - covered;
+    const double one_over_it = 1.0 / (double)iteration_number;
+    const double one_over_s = 1.0 / (double)sample_size;
+    const double ratio = pow(1.0 - pow(one_minus_conf, one_over_it), one_over_s);
+    return (uint64_t)round((double)unseen * ratio);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6  PEARL.h:82-128 (dataEnergyFunctor), thresholds PEARL.h:48-51
+ * ---------------------------------------------------------------------------------------- */
+void pgxo_unary(int model_type, const double *pts, int64_t n, const double *models, int K,
+                double threshold, double lambda, double *D)
+{
+    int d = 0, pdim = 0;
+    pgxo_model_dims(model_type, &d, &pdim);
+    const double T2 = 9.0 / 4.0 * threshold * threshold; /* :51 */
+    const double oml = 1.0 - lambda;                      /* :48 */
+    const int L = K + 1;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < K; ++k) {
+            const double sq = pgxo_squared_residual(model_type, pts + i * d, models + (int64_t)k * pdim);
+            double c;
+            if (sq > T2) c = 2.0 * oml;                   /* :123-124 */
+            else c = oml * sq / T2;                       /* :126-127 */
+            D[i * L + k] = c;
+        }
+        D[i * L + K] = oml;                               /* :100-101 */
+    }
+}
+
+/* Fixed-point quantisation used by the min-cut: round-to-nearest-even multiple of
+ * 2^-32; NaN (degenerate model) is priced like "beyond the threshold" by the caller passing 2(1-l). */
+int64_t pgxo_quantize(double x)
+{
+    return (int64_t)nearbyint(x * 4294967296.0);
+}
+
+void pgxo_unary_q(int model_type, const double *pts, int64_t n, const double *models, int K,
+                  double threshold, double lambda, int64_t *Dq)
+{
+    const int L = K + 1;
+    double *D = (double *)malloc(sizeof(double) * (size_t)(n * L > 0 ? n * L : 1));
+    pgxo_unary(model_type, pts, n, models, K, threshold, lambda, D);
+    const double far = 2.0 * (1.0 - lambda);
+    for (int64_t j = 0; j < n * L; ++j) {
+        double c = D[j];
+        if (c != c) c = far;
+        Dq[j] = pgxo_quantize(c);
+    }
+    free(D);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Max-flow (Dinic, int64 capacities) — stands in for the BK solver inside the absent GCoptimization
+ * library.  With integer capacities the *minimal sink side* (nodes that can still reach t in the
+ * residual graph of ANY maximum flow) is unique, which is what BK's what_segment(default=SOURCE)
+ * returns [U-5]; any correct max-flow therefore reproduces the labelling bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int nn;
+    int64_t na, cap_arcs;
+    int32_t *head, *nxt, *to, *level, *it;
+    int64_t *cap;
+} dinic_t;
+
+static void dn_init(dinic_t *g, int nn, int64_t max_arcs)
+{
+    g->nn = nn; g->na = 0; g->cap_arcs = max_arcs;
+    g->head = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    g->level = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    g->it = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    g->nxt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_arcs > 0 ? max_arcs : 1));
+    g->to = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_arcs > 0 ? max_arcs : 1));
+    g->cap = (int64_t *)malloc(sizeof(int64_t) * (size_t)(max_arcs > 0 ? max_arcs : 1));
+    for (int i = 0; i < nn; ++i) g->head[i] = -1;
+}
+static void dn_free(dinic_t *g)
+{
+    free(g->head); free(g->level); free(g->it); free(g->nxt); free(g->to); free(g->cap);
+}
+/* adds arc u->v (cap c) and v->u (cap rc) as a pair (a, a^1) */
+static void dn_add(dinic_t *g, int u, int v, int64_t c, int64_t rc)
+{
+    int64_t a = g->na;
+    g->to[a] = v; g->cap[a] = c; g->nxt[a] = g->head[u]; g->head[u] = (int32_t)a;
+    g->to[a + 1] = u; g->cap[a + 1] = rc; g->nxt[a + 1] = g->head[v]; g->head[v] = (int32_t)(a + 1);
+    g->na += 2;
+}
+static int dn_bfs(dinic_t *g, int s, int t, int32_t *queue)
+{
+    for (int i = 0; i < g->nn; ++i) g->level[i] = -1;
+    int qh = 0, qt = 0;
+    queue[qt++] = s; g->level[s] = 0;
+    while (qh < qt) {
+        int u = queue[qh++];
+        for (int32_t a = g->head[u]; a != -1; a = g->nxt[a]) {
+            int v = g->to[a];
+            if (g->cap[a] > 0 && g->level[v] < 0) { g->level[v] = g->level[u] + 1; queue[qt++] = v; }
+        }
+    }
+    return g->level[t] >= 0;
+}
+static int64_t dn_maxflow(dinic_t *g, int s, int t)
+{
+    int64_t flow = 0;
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * (size_t)g->nn);
+    int32_t *path = (int32_t *)malloc(sizeof(int32_t) * (size_t)g->nn); /* arc stack */
+    while (dn_bfs(g, s, t, queue)) {
+        memcpy(g->it, g->head, sizeof(int32_t) * (size_t)g->nn);
+        int depth = 0;
+        int u = s;
+        for (;;) {
+            if (u == t) {
+                int64_t bott = INT64_MAX;
+                for (int k = 0; k < depth; ++k) if (g->cap[path[k]] < bott) bott = g->cap[path[k]];
+                int first_sat = depth;
+                for (int k = 0; k < depth; ++k) {
+                    g->cap[path[k]] -= bott; g->cap[path[k] ^ 1] += bott;
+                    if (g->cap[path[k]] == 0 && k < first_sat) first_sat = k;
+                }
+                flow += bott;
+                depth = first_sat;
+                u = (depth == 0) ? s : g->to[path[depth - 1]];
+                continue;
+            }
+            int advanced = 0;
+            while (g->it[u] != -1) {
+                int32_t a = g->it[u];
+                int v = g->to[a];
+                if (g->cap[a] > 0 && g->level[v] == g->level[u] + 1) {
+                    path[depth++] = a; u = v; advanced = 1; break;
+                }
+                g->it[u] = g->nxt[a];
+            }
+            if (advanced) continue;
+            /* retreat */
+            g->level[u] = -1;
+            if (depth == 0) break;
+            int32_t a = path[--depth];
+            u = g->to[a ^ 1];
+            g->it[u] = g->nxt[a];
+        }
+    }
+    free(queue); free(path);
+    return flow;
+}
+/* reach[v]=1 iff v can reach t in the residual graph (reverse BFS from t) */
+static void dn_sink_side(dinic_t *g, int t, uint8_t *reach)
+{
+    int32_t *queue = (int32_t *)malloc(sizeof(int32_t) * (size_t)g->nn);
+    memset(reach, 0, (size_t)g->nn);
+    int qh = 0, qt = 0;
+    queue[qt++] = t; reach[t] = 1;
+    while (qh < qt) {
+        int v = queue[qh++];
+        for (int32_t a = g->head[v]; a != -1; a = g->nxt[a]) {
+            /* arc a is v->w ; its mate a^1 is w->v : w reaches v if cap[a^1] > 0 */
+            int w = g->to[a];
+            if (!reach[w] && g->cap[a ^ 1] > 0) { reach[w] = 1; queue[qt++] = w; }
+        }
+    }
+    free(queue);
+}
+
+int64_t pgxo_maxflow(int nnodes, int64_t narcs, const int32_t *from, const int32_t *to,
+                     const int64_t *cap, int s, int t, uint8_t *sink_side)
+{
+    dinic_t g;
+    dn_init(&g, nnodes, 2 * narcs);
+    for (int64_t a = 0; a < narcs; ++a) dn_add(&g, from[a], to[a], cap[a], 0);
+    int64_t f = dn_maxflow(&g, s, t);
+    if (sink_side) dn_sink_side(&g, t, sink_side);
+    dn_free(&g);
+    return f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8 / a19  alpha-expansion [U-5]: energy = sum_i D[i][l_i] + sum_{pairs} w_ij [l_i != l_j]
+ *           + h * #labels in use  (PEARL.h:519-529, 76-78; label cost incl. the outlier label).
+ * ---------------------------------------------------------------------------------------- */
+int64_t pgxo_energy(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                    const int32_t *mult, int64_t lambda_q, int64_t h_q, const int32_t *labels)
+{
+    int64_t e = 0;
+    int64_t *cnt = (int64_t *)calloc((size_t)L, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) {
+        e += Dq[i * L + labels[i]];
+        cnt[labels[i]]++;
+        if (off && lambda_q > 0)
+            for (int32_t a = off[i]; a < off[i + 1]; ++a) {
+                int32_t j = idx[a];
+                if (j < i && labels[j] != labels[i]) e += lambda_q * (int64_t)mult[a];
+            }
+    }
+    for (int l = 0; l < L; ++l) if (cnt[l] > 0) e += h_q;
+    free(cnt);
+    return e;
+}
+
+#define PGXO_INF ((int64_t)1 << 60)
+
+/* One expansion move on label alpha: optimal binary move, ties resolved towards alpha
+ * (BK: free nodes default to SOURCE = take alpha) [U-5].  Label costs via one auxiliary node per
+ * label (Delong et al., IJCV 2012): labels in use other than alpha pay h unless all their sites move;
+ * alpha pays h if it is unused and any site moves. */
+int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                      const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
+                      int64_t *flow_value)
+{
+    int64_t *cnt = (int64_t *)calloc((size_t)L, sizeof(int64_t));
+    int32_t *var = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t na = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        cnt[labels[i]]++;
+        var[i] = (labels[i] != alpha) ? (int32_t)na++ : -1;
+    }
+    if (flow_value) *flow_value = 0;
+    if (na == 0) { free(cnt); free(var); return 0; }
+
+    const int use_pair = (off != NULL && lambda_q > 0);
+    const int use_lc = (h_q > 0);
+    /* aux nodes */
+    int32_t *hub_of_label = (int32_t *)malloc(sizeof(int32_t) * (size_t)L);
+    int nhub = 0;
+    for (int l = 0; l < L; ++l) {
+        hub_of_label[l] = -1;
+        if (!use_lc) continue;
+        if (l == alpha) { if (cnt[l] == 0) hub_of_label[l] = (int32_t)(na + nhub++); }
+        else if (cnt[l] > 0) hub_of_label[l] = (int32_t)(na + nhub++);
+    }
+    const int S = (int)(na + nhub), T = S + 1, nn = T + 1;
+    int64_t narcs_est = 2 * na /* t-links */ + 2 * (int64_t)nhub;
+    if (use_pair) narcs_est += off[n];
+    if (use_lc) narcs_est += 2 * na * 2;
+    dinic_t g;
+    dn_init(&g, nn, 2 * narcs_est + 16);
+
+    for (int64_t i = 0; i < n; ++i) {
+        if (var[i] < 0) continue;
+        const int li = labels[i];
+        int64_t keep = Dq[i * L + li];      /* paid when x_i = 1 (sink side, keeps its label) */
+        const int64_t take = Dq[i * L + alpha]; /* paid when x_i = 0 (source side, takes alpha) */
+        if (use_pair)
+            for (int32_t a = off[i]; a < off[i + 1]; ++a) {
+                const int32_t j = idx[a];
+                const int64_t w = lambda_q * (int64_t)mult[a];
+                if (var[j] < 0) keep += w;                   /* neighbour already alpha */
+                else if (i < j) {
+                    if (labels[j] == li) dn_add(&g, var[i], var[j], w, w);
+                    else { keep += w; dn_add(&g, var[i], var[j], w, 0); } /* Kolmogorov-Zabih form */
+                }
+            }
+        dn_add(&g, S, var[i], keep, 0);
+        dn_add(&g, var[i], T, take, 0);
+        if (use_lc) {
+            if (hub_of_label[li] >= 0) dn_add(&g, hub_of_label[li], var[i], PGXO_INF, 0);
+            if (hub_of_label[alpha] >= 0) dn_add(&g, var[i], hub_of_label[alpha], PGXO_INF, 0);
+        }
+    }
+    if (use_lc)
+        for (int l = 0; l < L; ++l) {
+            if (hub_of_label[l] < 0) continue;
+            if (l == alpha) dn_add(&g, hub_of_label[l], T, h_q, 0);
+            else dn_add(&g, S, hub_of_label[l], h_q, 0);
+        }
+    const int64_t f = dn_maxflow(&g, S, T);
+    if (flow_value) *flow_value = f;
+    uint8_t *reach = (uint8_t *)malloc((size_t)nn);
+    dn_sink_side(&g, T, reach);
+    int changed = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (var[i] >= 0 && !reach[var[i]]) { labels[i] = alpha; ++changed; }
+    free(reach); dn_free(&g); free(hub_of_label); free(var); free(cnt);
+    return changed;
+}
+
+/* GCO-v3 "standard cycles" loop [U-5] as driven by PEARL.h:550-551 (max 1000 cycles). */
+int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                   const int32_t *mult, int64_t lambda_q, int64_t h_q, int32_t *labels, int max_cycles,
+                   int64_t *energy_q, int *cycles)
+{
+    int64_t new_e = pgxo_energy(n, L, Dq, off, idx, mult, lambda_q, h_q, labels);
+    int64_t old_e = new_e + 1;
+    int c = 0;
+    for (int cycle = 1; cycle <= max_cycles; ++cycle) {
+        if (new_e == old_e) break;
+        old_e = new_e;
+        for (int alpha = 0; alpha < L; ++alpha)
+            pgxo_expand_alpha(n, L, Dq, off, idx, mult, lambda_q, h_q, alpha, labels, NULL);
+        new_e = pgxo_energy(n, L, Dq, off, idx, mult, lambda_q, h_q, labels);
+        c = cycle;
+    }
+    if (energy_q) *energy_q = new_e;
+    if (cycles) *cycles = c;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9  PEARL.h:342-352 (bucket by label, ascending point index) ; PEARL.h:369-371 (residual sums)
+ * ---------------------------------------------------------------------------------------- */
+void pgxo_bucket(const int32_t *labels, int64_t n, int L, int64_t *counts, int32_t *order)
+{
+    int64_t *start = (int64_t *)calloc((size_t)L + 1, sizeof(int64_t));
+    for (int l = 0; l < L; ++l) counts[l] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int l = labels[i];
+        if (l >= L - 1) l = L - 1; /* label >= instance_number => outlier bucket (PEARL.h:348-351) */
+        counts[l]++;
+    }
+    for (int l = 0; l < L; ++l) start[l + 1] = start[l] + counts[l];
+    if (order)
+        for (int64_t i = 0; i < n; ++i) {
+            int l = labels[i];
+            if (l >= L - 1) l = L - 1;
+            order[start[l]++] = (int32_t)i;
+        }
+    free(start);
+}
+
+double pgxo_residual_sum(int model_type, const double *pts, int64_t n, const double *model,
+                         const int32_t *labels, int label)
+{
+    int d = 0;
+    pgxo_model_dims(model_type, &d, NULL);
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i)
+        if (labels[i] == label) s += pgxo_residual(model_type, pts + i * d, model);
+    return s;
+}

@@ -1,0 +1,215 @@
+"""ctypes view of the CPU oracle (oracle/pgx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never from the product package (progressive-x_amd/).
+PARITY UNPINNED (see pgx_oracle.h header and DESIGN.md §3).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpgx_oracle.so")
+
+LINE2D, HOMOGRAPHY, FUNDAMENTAL, PNP, VANISHING_POINT, HOMOGRAPHY_SYM = range(6)
+POINT_DIM = {0: 2, 1: 4, 2: 4, 3: 5, 4: 4, 5: 4}
+PARAM_DIM = {0: 3, 1: 9, 2: 9, 3: 12, 4: 3, 5: 18}
+FIXED_ONE = 1 << 32
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pgx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.pgxo_squared_residual.restype = C.c_double
+        _lib.pgxo_residual.restype = C.c_double
+        _lib.pgxo_residual_sum.restype = C.c_double
+        _lib.pgxo_quantize.restype = C.c_int64
+        _lib.pgxo_quantize.argtypes = [C.c_double]
+        _lib.pgxo_energy.restype = C.c_int64
+        _lib.pgxo_maxflow.restype = C.c_int64
+        _lib.pgxo_predicted_unseen_inliers.restype = C.c_uint64
+        _lib.pgxo_predicted_unseen_inliers.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    return _lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def squared_residuals(model_type, pts, model):
+    pts = _f64(pts); model = _f64(model)
+    out = np.empty(pts.shape[0], dtype=np.float64)
+    lib().pgxo_squared_residuals(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]),
+                                 _p(model, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def residual(model_type, pt, model):
+    pt = _f64(pt); model = _f64(model)
+    return lib().pgxo_residual(C.c_int(model_type), _p(pt, C.c_double), _p(model, C.c_double))
+
+
+def score(model_type, pts, models, T2, compound=None, has_compound=None, exponent=2,
+          best_inlier_number=None, want_masks=False):
+    pts = _f64(pts); models = _f64(models).reshape(-1, PARAM_DIM[model_type])
+    n, M = pts.shape[0], models.shape[0]
+    if has_compound is None:
+        has_compound = compound is not None
+    comp = _f64(compound) if compound is not None else np.zeros(n, dtype=np.float64)
+    best = None if best_inlier_number is None else np.ascontiguousarray(best_inlier_number, dtype=np.int64)
+    counts = np.zeros(M, dtype=np.int64)
+    values = np.zeros(M, dtype=np.float64)
+    shared = np.zeros(M, dtype=np.float64)
+    scores = np.zeros(M, dtype=np.float64)
+    masks = np.zeros((M, (n + 63) // 64), dtype=np.uint64) if want_masks else None
+    lib().pgxo_score(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(n), _p(models, C.c_double),
+                     C.c_int(M), C.c_double(T2), _p(comp, C.c_double), C.c_int(1 if has_compound else 0),
+                     C.c_int(int(exponent)), _p(best, C.c_int64), _p(counts, C.c_int64),
+                     _p(values, C.c_double), _p(shared, C.c_double), _p(scores, C.c_double),
+                     _p(masks, C.c_uint64))
+    return dict(counts=counts, values=values, shared=shared, scores=scores, masks=masks)
+
+
+def preference(model_type, pts, model, T2):
+    pts = _f64(pts); model = _f64(model)
+    out = np.empty(pts.shape[0], dtype=np.float64)
+    lib().pgxo_preference(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]),
+                          _p(model, C.c_double), C.c_double(T2), _p(out, C.c_double))
+    return out
+
+
+def tanimoto_terms(pref, compound):
+    pref = _f64(pref); compound = _f64(compound)
+    d, a, b = C.c_double(), C.c_double(), C.c_double()
+    lib().pgxo_tanimoto_terms(_p(pref, C.c_double), _p(compound, C.c_double), C.c_int64(pref.shape[0]),
+                              C.byref(d), C.byref(a), C.byref(b))
+    return d.value, a.value, b.value
+
+
+def is_valid_tanimoto(dot, pn, cn, max_tanimoto):
+    t = C.c_double()
+    ok = lib().pgxo_is_valid_tanimoto(C.c_double(dot), C.c_double(pn), C.c_double(cn),
+                                      C.c_double(max_tanimoto), C.byref(t))
+    return bool(ok), t.value
+
+
+def compound_max(prefs):
+    prefs = _f64(prefs)
+    K, n = prefs.shape
+    out = np.empty(n, dtype=np.float64)
+    lib().pgxo_compound_max(_p(prefs, C.c_double), C.c_int(K), C.c_int64(n), _p(out, C.c_double))
+    return out
+
+
+def predicted_unseen_inliers(one_minus_conf, sample_size, iteration_number, covered, point_number):
+    return int(lib().pgxo_predicted_unseen_inliers(one_minus_conf, sample_size, iteration_number,
+                                                   covered, point_number))
+
+
+def unary(model_type, pts, models, threshold, lam):
+    pts = _f64(pts); models = _f64(models).reshape(-1, PARAM_DIM[model_type])
+    n, K = pts.shape[0], models.shape[0]
+    D = np.empty((n, K + 1), dtype=np.float64)
+    lib().pgxo_unary(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(n), _p(models, C.c_double),
+                     C.c_int(K), C.c_double(threshold), C.c_double(lam), _p(D, C.c_double))
+    return D
+
+
+def unary_q(model_type, pts, models, threshold, lam):
+    pts = _f64(pts); models = _f64(models).reshape(-1, PARAM_DIM[model_type])
+    n, K = pts.shape[0], models.shape[0]
+    Dq = np.empty((n, K + 1), dtype=np.int64)
+    lib().pgxo_unary_q(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(n), _p(models, C.c_double),
+                       C.c_int(K), C.c_double(threshold), C.c_double(lam), _p(Dq, C.c_int64))
+    return Dq
+
+
+def quantize(x):
+    return int(lib().pgxo_quantize(float(x)))
+
+
+def quantize_lambda(lam):
+    """weight of ONE directed neighbour entry; forced even so that w/2 is exact."""
+    return 2 * int(np.rint(float(lam) * (1 << 31)))
+
+
+def _graph_args(graph):
+    if graph is None:
+        return None, None, None, ()
+    off, idx, mult = (_i32(g) for g in graph)
+    return _p(off, C.c_int32), _p(idx, C.c_int32), _p(mult, C.c_int32), (off, idx, mult)
+
+
+def energy(Dq, graph, lambda_q, h_q, labels):
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels)
+    n, L = Dq.shape
+    po, pi, pm, keep = _graph_args(graph)
+    return int(lib().pgxo_energy(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), po, pi, pm,
+                                 C.c_int64(lambda_q), C.c_int64(h_q), _p(labels, C.c_int32)))
+
+
+def expand_alpha(Dq, graph, lambda_q, h_q, alpha, labels):
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels).copy()
+    n, L = Dq.shape
+    po, pi, pm, keep = _graph_args(graph)
+    flow = C.c_int64()
+    changed = lib().pgxo_expand_alpha(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), po, pi, pm,
+                                      C.c_int64(lambda_q), C.c_int64(h_q), C.c_int(alpha),
+                                      _p(labels, C.c_int32), C.byref(flow))
+    return labels, int(changed), int(flow.value)
+
+
+def expansion(Dq, graph, lambda_q, h_q, labels, max_cycles=1000):
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels).copy()
+    n, L = Dq.shape
+    po, pi, pm, keep = _graph_args(graph)
+    e = C.c_int64(); cyc = C.c_int()
+    lib().pgxo_expansion(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), po, pi, pm, C.c_int64(lambda_q),
+                         C.c_int64(h_q), _p(labels, C.c_int32), C.c_int(max_cycles), C.byref(e),
+                         C.byref(cyc))
+    return labels, int(e.value), int(cyc.value)
+
+
+def maxflow(nnodes, frm, to, cap, s, t):
+    frm = _i32(frm); to = _i32(to); cap = np.ascontiguousarray(cap, dtype=np.int64)
+    side = np.zeros(nnodes, dtype=np.uint8)
+    f = lib().pgxo_maxflow(C.c_int(nnodes), C.c_int64(len(frm)), _p(frm, C.c_int32), _p(to, C.c_int32),
+                           _p(cap, C.c_int64), C.c_int(s), C.c_int(t), _p(side, C.c_uint8))
+    return int(f), side
+
+
+def bucket(labels, L):
+    labels = _i32(labels)
+    counts = np.zeros(L, dtype=np.int64)
+    order = np.empty(labels.shape[0], dtype=np.int32)
+    lib().pgxo_bucket(_p(labels, C.c_int32), C.c_int64(labels.shape[0]), C.c_int(L),
+                      _p(counts, C.c_int64), _p(order, C.c_int32))
+    return counts, order
+
+
+def residual_sum(model_type, pts, model, labels, label):
+    pts = _f64(pts); model = _f64(model); labels = _i32(labels)
+    return lib().pgxo_residual_sum(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]),
+                                   _p(model, C.c_double), _p(labels, C.c_int32), C.c_int(label))

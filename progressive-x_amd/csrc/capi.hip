@@ -1,0 +1,519 @@
+// capi.hip — the C ABI of libpgx.so (declared in include/pgx.h): context management, host<->device marshalling and
+// the thin wrappers around the kernel launchers.  No C++ type, exception or PyTorch object crosses this boundary.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+static thread_local std::string g_err;
+
+int fail(pgx_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return code;
+}
+
+int ensure(pgx_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return PGX_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8;  // a little slack so that growing M/K does not reallocate every call
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, PGX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PGX_OK;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+}  // namespace pgx
+
+using namespace pgx;
+
+extern "C" {
+
+int pgx_version(void) { return 100; }
+
+const char* pgx_global_error(void) { return g_err.c_str(); }
+
+int pgx_device_count(int* count)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        if (count) *count = 0;
+        return fail(nullptr, PGX_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    if (count) *count = c;
+    return PGX_OK;
+}
+
+int pgx_model_dims(int model_type, int* point_dim, int* param_dim)
+{
+    return model_dims(model_type, point_dim, param_dim) == 0 ? PGX_OK : PGX_ERR_INVALID;
+}
+
+int pgx_create(int device_id, pgx_ctx** out)
+{
+    if (!out) return fail(nullptr, PGX_ERR_INVALID, "pgx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PGX_ERR_HIP, "pgx_create: no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= count)
+        return fail(nullptr, PGX_ERR_INVALID, "pgx_create: device %d out of range [0,%d)", device_id, count);
+    pgx_ctx* ctx = new pgx_ctx();
+    ctx->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        int r = fail(nullptr, PGX_ERR_HIP, "pgx_create: HIP init failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return r;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return PGX_OK;
+}
+
+void pgx_destroy(pgx_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_free(ctx);
+    maxflow_free(ctx);
+    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
+                      &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
+                      &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
+                      &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch};
+    for (DevBuf* b : bufs) release(*b);
+    for (DevBuf& b : ctx->slots) release(b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pgx_last_error(const pgx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+#define CTX_GUARD(ctx)                                                            \
+    do {                                                                          \
+        if (!(ctx)) return fail(nullptr, PGX_ERR_INVALID, "ctx is NULL");        \
+        hipError_t e_ = hipSetDevice((ctx)->device);                              \
+        if (e_ != hipSuccess) return fail(ctx, PGX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+int pgx_sync(pgx_ctx* ctx)
+{
+    CTX_GUARD(ctx);
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_timer_start(pgx_ctx* ctx)
+{
+    CTX_GUARD(ctx);
+    PGX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_timer_stop(pgx_ctx* ctx, float* ms)
+{
+    CTX_GUARD(ctx);
+    PGX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PGX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float t = 0.f;
+    PGX_HIP(ctx, hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+    if (ms) *ms = t;
+    return PGX_OK;
+}
+
+int pgx_device_info(pgx_ctx* ctx, char* name, int name_len, int* cu_count, int64_t* hbm_bytes)
+{
+    CTX_GUARD(ctx);
+    hipDeviceProp_t prop;
+    PGX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return PGX_OK;
+}
+
+/* ---- resident data ---------------------------------------------------------------------------------------- */
+int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
+{
+    CTX_GUARD(ctx);
+    int d = 0, p = 0;
+    if (model_dims(model_type, &d, &p) != 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: bad model type %d", model_type);
+    if (!points || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: empty input");
+    if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: n must be < 2^31");
+    PGX_TRY(ensure(ctx, ctx->pts, (size_t)n * d * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->comp, (size_t)n * sizeof(double)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pts.p, points, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)n * sizeof(double), ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
+    ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
+    for (DevBuf& b : ctx->slots) release(b);
+    ctx->slots.clear();
+    return PGX_OK;
+}
+
+int pgx_set_compound(pgx_ctx* ctx, const double* compound)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_compound: points not set");
+    if (compound)
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->comp.p, compound, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    else
+        PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_get_compound(pgx_ctx* ctx, double* compound)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0 || !compound) return fail(ctx, PGX_ERR_INVALID, "pgx_get_compound: points not set");
+    PGX_HIP(ctx, hipMemcpyAsync(compound, ctx->comp.p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+/* ---- scoring ---------------------------------------------------------------------------------------------- */
+int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: points not set");
+    if (!models || M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: empty hypothesis batch");
+    PGX_TRY(ensure(ctx, ctx->models, (size_t)M * ctx->P * sizeof(double)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->models.p, models, (size_t)M * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may free `models` on return
+    ctx->M = M;
+    ctx->Mpad = ((M + 255) / 256) * 256;
+    return PGX_OK;
+}
+
+int pgx_score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
+{
+    CTX_GUARD(ctx);
+    ctx->score_has_compound = has_compound != 0;
+    return score_launch(ctx, T2, has_compound, want_masks);
+}
+
+static void finish_scores(int n, int has_compound, int exponent, const double* values, const double* shared,
+                          double* scores)
+{
+    if (!scores) return;
+    for (int m = 0; m < n; ++m) {
+        // scoring_function_with_compound_model.h:110,120: subtract pow(shared, exponent) iff the compound instance
+        // is non-empty; std::pow(double,int) promotes to pow(double,double).
+        scores[m] = has_compound ? values[m] - std::pow(shared[m], (double)exponent) : values[m];
+    }
+}
+
+int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values, double* shared, double* scores,
+                    uint64_t* masks)
+{
+    CTX_GUARD(ctx);
+    const int M = ctx->M;
+    if (M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: nothing launched");
+    std::vector<double> v((size_t)M), s((size_t)M);
+    std::vector<int64_t> c((size_t)M);
+    PGX_HIP(ctx, hipMemcpyAsync(c.data(), ctx->counts.p, (size_t)M * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(v.data(), ctx->values.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(s.data(), ctx->shared.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (masks) {
+        if (!ctx->have_masks) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: masks were not requested at launch");
+        PGX_HIP(ctx, hipMemcpyAsync(masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counts) memcpy(counts, c.data(), (size_t)M * sizeof(int64_t));
+    if (values) memcpy(values, v.data(), (size_t)M * sizeof(double));
+    if (shared) memcpy(shared, s.data(), (size_t)M * sizeof(double));
+    finish_scores(M, ctx->score_has_compound, exponent, v.data(), s.data(), scores);
+    return PGX_OK;
+}
+
+int pgx_score(pgx_ctx* ctx, const double* models, int M, double T2, int has_compound, int exponent,
+              int64_t* counts, double* values, double* shared, double* scores, uint64_t* masks)
+{
+    PGX_TRY(pgx_score_upload(ctx, models, M));
+    PGX_TRY(pgx_score_launch(ctx, T2, has_compound, masks != nullptr));
+    return pgx_score_fetch(ctx, exponent, counts, values, shared, scores, masks);
+}
+
+int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, int64_t* pairs)
+{
+    if (!ctx || ctx->n <= 0 || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_algorithmic_bytes: nothing to score");
+    // points once + compound once + models once + (count,value,shared) per hypothesis (+ optional bit masks)
+    int64_t b = ctx->n * ctx->D * 8 + ctx->n * 8 + (int64_t)ctx->M * ctx->P * 8 + (int64_t)ctx->M * 24;
+    if (want_masks) b += (int64_t)ctx->M * ((ctx->n + 63) / 64) * 8;
+    if (bytes) *bytes = b;
+    if (pairs) *pairs = ctx->n * (int64_t)ctx->M;
+    return PGX_OK;
+}
+
+/* ---- preference / compound -------------------------------------------------------------------------------- */
+static int slot_buffer(pgx_ctx* ctx, int slot, double** out)
+{
+    if (slot < 0 || slot > 4096) return fail(ctx, PGX_ERR_INVALID, "preference slot %d out of range", slot);
+    if ((int)ctx->slots.size() <= slot) ctx->slots.resize((size_t)slot + 1);
+    PGX_TRY(ensure(ctx, ctx->slots[slot], (size_t)ctx->n * sizeof(double)));
+    *out = ctx->slots[slot].as<double>();
+    return PGX_OK;
+}
+
+int pgx_preference(pgx_ctx* ctx, const double* model, double T2, int slot, double* pref_out, double* dot,
+                   double* pref_sqnorm, double* comp_sqnorm)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0 || !model) return fail(ctx, PGX_ERR_INVALID, "pgx_preference: points/model not set");
+    double* d_pref = nullptr;
+    PGX_TRY(slot_buffer(ctx, slot, &d_pref));
+    double out3[3] = {0, 0, 0};
+    PGX_TRY(preference_launch(ctx, model, T2, d_pref, out3));
+    if (dot) *dot = out3[0];
+    if (pref_sqnorm) *pref_sqnorm = out3[1];
+    if (comp_sqnorm) *comp_sqnorm = out3[2];
+    if (pref_out) {
+        PGX_HIP(ctx, hipMemcpyAsync(pref_out, d_pref, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PGX_OK;
+}
+
+int pgx_get_preference(pgx_ctx* ctx, int slot, double* pref_out)
+{
+    CTX_GUARD(ctx);
+    if (slot < 0 || slot >= (int)ctx->slots.size() || !ctx->slots[slot].p || !pref_out)
+        return fail(ctx, PGX_ERR_INVALID, "pgx_get_preference: slot %d is empty", slot);
+    PGX_HIP(ctx, hipMemcpyAsync(pref_out, ctx->slots[slot].p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_compound_update(pgx_ctx* ctx, const int32_t* slots, int K, double* compound_out)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: points not set");
+    if (K > 0) {  // progressive_x.h:600-601: nothing happens for an empty compound instance
+        if (!slots) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: slots is NULL");
+        PGX_TRY(compound_launch(ctx, slots, K));
+    }
+    if (compound_out) return pgx_get_compound(ctx, compound_out);
+    return PGX_OK;
+}
+
+/* ---- PEARL: unary table, labels, graph --------------------------------------------------------------------- */
+int pgx_pearl_unary(pgx_ctx* ctx, const double* models, int K, double threshold, double lambda, int64_t* Dq_out)
+{
+    CTX_GUARD(ctx);
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_pearl_unary: points not set");
+    if (K < 0 || (K > 0 && !models)) return fail(ctx, PGX_ERR_INVALID, "pgx_pearl_unary: bad model list");
+    const int L = K + 1;
+    PGX_TRY(ensure(ctx, ctx->kmodels, (size_t)(K > 0 ? K : 1) * ctx->P * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->dq, (size_t)L * (size_t)ctx->n * sizeof(int64_t)));
+    if (K > 0)
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->kmodels.p, models, (size_t)K * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_TRY(unary_launch(ctx, K, threshold, lambda));
+    ctx->L = L;
+    ctx->dq_n = ctx->n;
+    if (Dq_out) {  // ABI layout is point-major N x L (as the reference's per-point functor); device is label-major
+        std::vector<int64_t> tmp((size_t)L * (size_t)ctx->n);
+        PGX_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->dq.p, tmp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int l = 0; l < L; ++l)
+            for (int64_t i = 0; i < ctx->n; ++i) Dq_out[i * L + l] = tmp[(size_t)l * ctx->n + i];
+    } else {
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `models` may be freed by the caller
+    }
+    return PGX_OK;
+}
+
+int pgx_set_unary_q(pgx_ctx* ctx, const int64_t* Dq, int64_t n, int L)
+{
+    CTX_GUARD(ctx);
+    if (!Dq || n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_unary_q: empty table");
+    if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_unary_q: n must be < 2^31");
+    std::vector<int64_t> tmp((size_t)L * (size_t)n);
+    for (int l = 0; l < L; ++l)
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)l * n + i] = Dq[i * L + l];
+    PGX_TRY(ensure(ctx, ctx->dq, tmp.size() * sizeof(int64_t)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->dq.p, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->L = L;
+    ctx->dq_n = n;
+    return PGX_OK;
+}
+
+int pgx_set_labels(pgx_ctx* ctx, const int32_t* labels, int64_t n)
+{
+    CTX_GUARD(ctx);
+    if (!labels || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_labels: empty labels");
+    PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, labels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->labels_n = n;
+    return PGX_OK;
+}
+
+int pgx_get_labels(pgx_ctx* ctx, int32_t* labels)
+{
+    CTX_GUARD(ctx);
+    if (!labels || ctx->labels_n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_get_labels: labels not set");
+    PGX_HIP(ctx, hipMemcpyAsync(labels, ctx->labels.p, (size_t)ctx->labels_n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_set_graph(pgx_ctx* ctx, int64_t n, const int32_t* off, const int32_t* idx, const int32_t* mult)
+{
+    CTX_GUARD(ctx);
+    if (n <= 0 || !off) return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: empty graph");
+    const int64_t E = off[n];
+    if (E < 0 || off[0] != 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: malformed offsets");
+    if (E > 0 && (!idx || !mult)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: idx/mult missing");
+    int maxdeg = 0;
+    int64_t max_row = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int deg = off[i + 1] - off[i];
+        if (deg < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: offsets not monotone at row %lld", (long long)i);
+        if (deg > maxdeg) maxdeg = deg;
+        int64_t row = 0;
+        for (int32_t a = off[i]; a < off[i + 1]; ++a) {
+            if (idx[a] < 0 || idx[a] >= n || idx[a] == i)
+                return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: bad neighbour %d in row %lld", idx[a], (long long)i);
+            if (mult[a] <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: multiplicity must be positive");
+            row += mult[a];
+        }
+        if (row > max_row) max_row = row;
+    }
+    PGX_TRY(ensure(ctx, ctx->goff, (size_t)(n + 1) * sizeof(int32_t)));
+    PGX_TRY(ensure(ctx, ctx->gidx, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+    PGX_TRY(ensure(ctx, ctx->gmult, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+    PGX_TRY(ensure(ctx, ctx->grev, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->goff.p, off, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (E > 0) {
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->gidx.p, idx, (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->gmult.p, mult, (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gn = n; ctx->gE = E; ctx->max_degree = maxdeg; ctx->max_row_mult = max_row;
+    return graph_build_reverse(ctx);
+}
+
+static int flow_params(pgx_ctx* ctx, double lambda, double label_cost, int64_t* lambda_q, int64_t* h_q)
+{
+    if (!(lambda >= 0.0) || !(label_cost >= 0.0))
+        return fail(ctx, PGX_ERR_INVALID, "lambda and label_cost must be >= 0");
+    *lambda_q = quantize_lambda(lambda);
+    *h_q = quantize(label_cost);
+    // Range check: every excess / capacity sum must stay far below 2^63.
+    const double per_site = 4.0 + 2.0 * lambda * (double)(ctx->gn > 0 ? ctx->max_row_mult : 0);
+    const double total = per_site * (double)(ctx->dq_n > 0 ? ctx->dq_n : 1) + label_cost * (double)(ctx->L + 1);
+    if (total >= 1073741824.0)  // 2^30 * 2^32 = 2^62
+        return fail(ctx, PGX_ERR_RANGE, "fixed-point range exceeded: n*(4+2*lambda*row_mult)+L*h = %.3g >= 2^30", total);
+    return PGX_OK;
+}
+
+int pgx_energy(pgx_ctx* ctx, double lambda, double label_cost, int64_t* energy_q, double* energy)
+{
+    CTX_GUARD(ctx);
+    int64_t lq, hq, e = 0;
+    PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
+    PGX_TRY(energy_launch(ctx, lq, hq, &e));
+    if (energy_q) *energy_q = e;
+    if (energy) *energy = (double)e / 4294967296.0;
+    return PGX_OK;
+}
+
+int pgx_expand_alpha(pgx_ctx* ctx, double lambda, double label_cost, int alpha, int64_t* changed)
+{
+    CTX_GUARD(ctx);
+    int64_t lq, hq, ch = 0;
+    PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
+    for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
+    PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
+    if (changed) *changed = ch;
+    return PGX_OK;
+}
+
+// GCO-v3 "standard cycles" loop [U-5] as PEARL drives it (PEARL.h:550-551): cycle over the labels in index order until
+// a whole cycle leaves the energy unchanged, at most max_cycles cycles.
+int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles, int64_t* energy_q, double* energy,
+                  int* cycles)
+{
+    CTX_GUARD(ctx);
+    int64_t lq, hq;
+    PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
+    for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
+    int64_t new_e = 0;
+    PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
+    int64_t old_e = new_e + 1;
+    int done = 0;
+    for (int cycle = 1; cycle <= max_cycles; ++cycle) {
+        if (new_e == old_e) break;
+        old_e = new_e;
+        int64_t changed_total = 0;
+        for (int alpha = 0; alpha < ctx->L; ++alpha) {
+            int64_t ch = 0;
+            PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
+            changed_total += ch;
+        }
+        // a cycle that relabels nothing leaves the energy unchanged by construction: skip the recomputation
+        if (changed_total > 0) PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
+        done = cycle;
+    }
+    if (energy_q) *energy_q = new_e;
+    if (energy) *energy = (double)new_e / 4294967296.0;
+    if (cycles) *cycles = done;
+    return PGX_OK;
+}
+
+int pgx_expansion_stats(pgx_ctx* ctx, int64_t stats[8])
+{
+    if (!ctx || !stats) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_stats: NULL argument");
+    for (int k = 0; k < 8; ++k) stats[k] = ctx->stats[k];
+    return PGX_OK;
+}
+
+int pgx_bucket(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)
+{
+    CTX_GUARD(ctx);
+    if (!counts) return fail(ctx, PGX_ERR_INVALID, "pgx_bucket: counts is NULL");
+    return bucket_launch(ctx, L, counts, order);
+}
+
+int pgx_residual_sum(pgx_ctx* ctx, const double* model, int label, double* sum)
+{
+    CTX_GUARD(ctx);
+    if (!model || !sum) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sum: NULL argument");
+    return residual_sum_launch(ctx, model, label, sum);
+}
+
+}  // extern "C"

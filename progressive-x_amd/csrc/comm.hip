@@ -1,0 +1,196 @@
+// comm.hip — multi-GPU exchange for the sharded proposal loop (no reference counterpart: the reference
+// is single-threaded CPU code, /root/reference/src/pyprogressivex/include/progressive_x.h:251-489).
+//
+// One process per GPU.  Hypotheses are sharded over ranks, every rank holds all points and the compound preference
+// vector, so the only data-path exchange per batch is an RCCL all-gather of the per-hypothesis (count, value, shared)
+// triples (24 B x M per rank) over xGMI; the compound vector is kept identical on all ranks by recomputing it
+// redundantly (max is exact in any order) or, if ranks accepted different models, by an all-reduce(max).
+//
+// RCCL is bound lazily with dlopen so that single-GPU use never depends on it being loadable.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int load_rccl(pgx_ctx* ctx)
+{
+    if (g_rccl.handle) return PGX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return fail(ctx, PGX_ERR_COMM, "cannot load librccl: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define BIND(field, sym)                                                                         \
+    *(void**)(&a.field) = dlsym(h, sym);                                                         \
+    if (!a.field) { dlclose(h); return fail(ctx, PGX_ERR_COMM, "librccl lacks symbol %s", sym); }
+    BIND(GetUniqueId, "ncclGetUniqueId")
+    BIND(CommInitRank, "ncclCommInitRank")
+    BIND(CommDestroy, "ncclCommDestroy")
+    BIND(AllGather, "ncclAllGather")
+    BIND(AllReduce, "ncclAllReduce")
+    BIND(GroupStart, "ncclGroupStart")
+    BIND(GroupEnd, "ncclGroupEnd")
+    BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+    g_rccl = a;
+    return PGX_OK;
+}
+
+struct CommState {
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    DevBuf tmp;
+};
+
+#define PGX_NCCL(ctx, call)                                                                              \
+    do {                                                                                                 \
+        ncclResult_t r_ = (call);                                                                        \
+        if (r_ != ncclSuccess)                                                                           \
+            return fail(ctx, PGX_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+void comm_free(pgx_ctx* ctx)
+{
+    if (!ctx->comm) return;
+    if (ctx->comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm->comm);
+    release(ctx->comm->tmp);
+    delete ctx->comm;
+    ctx->comm = nullptr;
+}
+
+}  // namespace pgx
+
+using namespace pgx;
+
+static_assert(sizeof(ncclUniqueId) == PGX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" {
+
+int pgx_comm_unique_id(uint8_t id[PGX_UNIQUE_ID_BYTES])
+{
+    if (!id) return fail(nullptr, PGX_ERR_INVALID, "pgx_comm_unique_id: NULL");
+    PGX_TRY(load_rccl(nullptr));
+    ncclUniqueId u;
+    PGX_NCCL(nullptr, g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, PGX_UNIQUE_ID_BYTES);
+    return PGX_OK;
+}
+
+int pgx_comm_init(pgx_ctx* ctx, int nranks, int rank, const uint8_t id[PGX_UNIQUE_ID_BYTES])
+{
+    if (!ctx || !id) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_init: NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_init: bad rank %d/%d", rank, nranks);
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    PGX_TRY(load_rccl(ctx));
+    comm_free(ctx);
+    ctx->comm = new CommState();
+    ctx->comm->nranks = nranks;
+    ctx->comm->rank = rank;
+    ncclUniqueId u;
+    memcpy(&u, id, PGX_UNIQUE_ID_BYTES);
+    PGX_NCCL(ctx, g_rccl.CommInitRank(&ctx->comm->comm, nranks, u, rank));
+    return PGX_OK;
+}
+
+int pgx_comm_destroy(pgx_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, PGX_ERR_INVALID, "ctx is NULL");
+    (void)hipSetDevice(ctx->device);
+    comm_free(ctx);
+    return PGX_OK;
+}
+
+int pgx_comm_barrier(pgx_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_barrier: communicator not initialised");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    PGX_TRY(ensure(ctx, ctx->comm->tmp, 64));
+    PGX_HIP(ctx, hipMemsetAsync(ctx->comm->tmp.p, 0, 8, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.AllReduce(ctx->comm->tmp.p, ctx->comm->tmp.p, 1, ncclInt32, ncclSum, ctx->comm->comm, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_comm_allreduce_max_f64(pgx_ctx* ctx, double* value)
+{
+    if (!ctx || !ctx->comm || !value) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_allreduce_max_f64: communicator not initialised");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    PGX_TRY(ensure(ctx, ctx->comm->tmp, 64));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->comm->tmp.p, value, 8, hipMemcpyHostToDevice, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.AllReduce(ctx->comm->tmp.p, ctx->comm->tmp.p, 1, ncclFloat64, ncclMax, ctx->comm->comm, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(value, ctx->comm->tmp.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_score_allgather(pgx_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: communicator not initialised");
+    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: nothing launched");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t M = (size_t)ctx->M, G = (size_t)ctx->comm->nranks;
+    PGX_TRY(ensure(ctx, ctx->g_counts, G * M * 8));
+    PGX_TRY(ensure(ctx, ctx->g_values, G * M * 8));
+    PGX_TRY(ensure(ctx, ctx->g_shared, G * M * 8));
+    PGX_NCCL(ctx, g_rccl.GroupStart());
+    PGX_NCCL(ctx, g_rccl.AllGather(ctx->counts.p, ctx->g_counts.p, M, ncclInt64, ctx->comm->comm, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.AllGather(ctx->values.p, ctx->g_values.p, M, ncclFloat64, ctx->comm->comm, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.AllGather(ctx->shared.p, ctx->g_shared.p, M, ncclFloat64, ctx->comm->comm, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.GroupEnd());
+    return PGX_OK;
+}
+
+int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* values, double* shared, double* scores)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch_all: communicator not initialised");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t T = (size_t)ctx->M * (size_t)ctx->comm->nranks;
+    if (T == 0 || !ctx->g_counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch_all: nothing gathered");
+    std::vector<double> v(T), s(T);
+    std::vector<int64_t> c(T);
+    PGX_HIP(ctx, hipMemcpyAsync(c.data(), ctx->g_counts.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(v.data(), ctx->g_values.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(s.data(), ctx->g_shared.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counts) memcpy(counts, c.data(), T * 8);
+    if (values) memcpy(values, v.data(), T * 8);
+    if (shared) memcpy(shared, s.data(), T * 8);
+    if (scores)
+        for (size_t m = 0; m < T; ++m)
+            scores[m] = ctx->score_has_compound ? v[m] - std::pow(s[m], (double)exponent) : v[m];
+    return PGX_OK;
+}
+
+int pgx_compound_allreduce_max(pgx_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_allreduce_max: communicator not initialised");
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_allreduce_max: points not set");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    PGX_NCCL(ctx, g_rccl.AllReduce(ctx->comp.p, ctx->comp.p, (size_t)ctx->n, ncclFloat64, ncclMax, ctx->comm->comm, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+}  // extern "C"

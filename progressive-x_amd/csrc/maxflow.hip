@@ -1,0 +1,200 @@
+// maxflow.hip — HIP backend of the alpha-expansion move: kernels wrapping the per-site bodies of maxflow_body.cuh and
+// the launch plumbing for maxflow_driver.inl.
+//
+// Replaces: GCoptimizationGeneralGraph::alpha_expansion + BK max-flow behind pearl::PEARL::labeling
+//           (/root/reference/src/pyprogressivex/include/PEARL.h:507-551); upstream source absent [U-5].
+//
+// Layout: one lane per site, CSR neighbour rows (off/idx/mult/rev, symmetric), residual capacities per directed arc,
+// per-site int64 excess / sink residual / hub flows, int32 heights.  The kernels are latency/HBM bound irregular
+// gathers; cross-workgroup communication is through device-scope atomics only, and every kernel
+// boundary is a full synchronisation point, so no in-launch release/acquire protocol is needed.
+#include "maxflow_driver.inl"
+#include "pgx_internal.h"
+
+namespace pgx {
+
+constexpr int kMfBlock = 256;
+
+struct MaxflowState {
+    DevBuf cap, ex, rt, d, f, g, small;
+    int* h_flags = nullptr;  // pinned host mirror for flag read-backs
+};
+
+#define MF_SITE_KERNEL(name, body_call)                                                        \
+    __global__ __launch_bounds__(kMfBlock) void name(MfView v, int a0, int a1)                 \
+    {                                                                                          \
+        const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;                        \
+        if (u < v.n) { body_call; }                                                            \
+    }
+
+MF_SITE_KERNEL(mf_k_count, mf_body_count(v, u))
+MF_SITE_KERNEL(mf_k_init, mf_body_init_site(v, u))
+MF_SITE_KERNEL(mf_k_bfs_init, mf_body_bfs_init(v, u))
+MF_SITE_KERNEL(mf_k_bfs_level, mf_body_bfs_level(v, u, a0))
+MF_SITE_KERNEL(mf_k_count_active, mf_body_count_active(v, u))
+MF_SITE_KERNEL(mf_k_sweep, mf_body_sweep(v, u, a0, a1))
+MF_SITE_KERNEL(mf_k_apply, mf_body_apply(v, u))
+
+__global__ void mf_k_single(MfView v, int what, int a0, int a1)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    switch (what) {
+    case 0: mf_body_hub_setup(v); break;
+    case 1: mf_body_bfs_reset(v); break;
+    case 2: mf_body_bfs_finish(v, a0); break;
+    case 3: mf_body_sweep_epilogue(v, a0, a1); break;
+    }
+}
+
+__global__ __launch_bounds__(kMfBlock) void graph_reverse_kernel(int64_t n, const int* __restrict__ off,
+                                                                 const int* __restrict__ idx, int* __restrict__ rev,
+                                                                 int* __restrict__ bad)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    if (u >= n) return;
+    for (int a = off[u]; a < off[u + 1]; ++a) {
+        const int q = idx[a];
+        int r = -1;
+        for (int b = off[q]; b < off[q + 1]; ++b)
+            if (idx[b] == (int)u) { r = b; break; }
+        if (r < 0) { *bad = 1; r = a; }
+        rev[a] = r;
+    }
+}
+
+int graph_build_reverse(pgx_ctx* ctx)
+{
+    if (ctx->gE == 0) return PGX_OK;
+    PGX_TRY(ensure(ctx, ctx->scratch, 64));
+    PGX_HIP(ctx, hipMemsetAsync(ctx->scratch.p, 0, 4, ctx->stream));
+    const int blocks = (int)((ctx->gn + kMfBlock - 1) / kMfBlock);
+    hipLaunchKernelGGL(graph_reverse_kernel, dim3((unsigned)blocks), dim3(kMfBlock), 0, ctx->stream, ctx->gn,
+                       ctx->goff.as<int>(), ctx->gidx.as<int>(), ctx->grev.as<int>(), (int*)ctx->scratch.p);
+    PGX_HIP(ctx, hipGetLastError());
+    int bad = 0;
+    PGX_HIP(ctx, hipMemcpyAsync(&bad, ctx->scratch.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) {
+        ctx->gn = 0;
+        ctx->gE = 0;
+        return fail(ctx, PGX_ERR_INVALID, "pgx_set_graph: neighbour lists are not symmetric (u in N(v) but v not in N(u))");
+    }
+    return PGX_OK;
+}
+
+namespace {
+
+struct HipBackend {
+    pgx_ctx* ctx;
+    MaxflowState* st;
+    unsigned blocks;
+    hipError_t err = hipSuccess;
+
+    void check() { if (err == hipSuccess) err = hipGetLastError(); }
+    template <class K> void site(K k, const MfView& v, int a0 = 0, int a1 = 0)
+    {
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, a0, a1);
+        check();
+    }
+    void single(const MfView& v, int what, int a0 = 0, int a1 = 0)
+    {
+        hipLaunchKernelGGL(mf_k_single, dim3(1), dim3(64), 0, ctx->stream, v, what, a0, a1);
+        check();
+    }
+    int read_int(const int* dptr)
+    {
+        hipError_t e = hipMemcpyAsync(st->h_flags, dptr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        return st->h_flags[0];
+    }
+    void count_and_setup(const MfView& v)
+    {
+        hipError_t e = hipMemsetAsync(v.cnt, 0, sizeof(int) * (size_t)v.L, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        site(mf_k_count, v);
+        single(v, 0);
+    }
+    int read_count(const MfView& v, int l) { return read_int(v.cnt + l); }
+    void init_sites(const MfView& v) { site(mf_k_init, v); }
+    void bfs_reset(const MfView& v) { single(v, 1); }
+    void bfs_init(const MfView& v) { site(mf_k_bfs_init, v); }
+    void bfs_level(const MfView& v, int k) { site(mf_k_bfs_level, v, k); }
+    int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
+    void bfs_finish(const MfView& v, int slot) { single(v, 2, slot); }
+    void count_active(const MfView& v) { site(mf_k_count_active, v); }
+    void sweep(const MfView& v, int prev, int cur) { site(mf_k_sweep, v, prev, cur); }
+    void sweep_epilogue(const MfView& v, int cur, int next) { single(v, 3, cur, next); }
+    void apply(const MfView& v) { site(mf_k_apply, v); }
+};
+
+}  // namespace
+
+void maxflow_free(pgx_ctx* ctx)
+{
+    if (!ctx->mf) return;
+    MaxflowState* st = ctx->mf;
+    release(st->cap); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
+    release(st->small);
+    if (st->h_flags) (void)hipHostFree(st->h_flags);
+    delete st;
+    ctx->mf = nullptr;
+}
+
+int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
+{
+    const int64_t n = ctx->dq_n;
+    const int L = ctx->L;
+    if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: unary table not set");
+    if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
+    if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
+    const bool pair = lambda_q > 0;
+    if (pair && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
+    if (!ctx->mf) {
+        ctx->mf = new MaxflowState();
+        PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));
+    }
+    MaxflowState* st = ctx->mf;
+    const int64_t E = pair ? ctx->gE : 0;
+    PGX_TRY(ensure(ctx, st->cap, (size_t)(E > 0 ? E : 1) * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->ex, (size_t)n * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->rt, (size_t)n * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->f, (size_t)n * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->g, (size_t)n * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->d, (size_t)n * sizeof(int)));
+    // small state: hub_e[L] i64 | hubA_rt i64 | hubA_min[3] u64 | cnt[L] | hub_exists[L] | bfs_hub_d[L] | hub_min[3L] |
+    //              has_alpha_hub | bfs_hubA_d | flags[8]
+    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(6 * L + 2 + 8) * 4 + 64;
+    PGX_TRY(ensure(ctx, st->small, small_bytes));
+    char* sp = (char*)st->small.p;
+    MfView v;
+    v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
+    v.dq = ctx->dq.as<long long>();
+    v.labels = ctx->labels.as<int>();
+    v.off = pair ? ctx->goff.as<int>() : nullptr;
+    v.idx = ctx->gidx.as<int>(); v.mult = ctx->gmult.as<int>(); v.rev = ctx->grev.as<int>();
+    v.cap = st->cap.as<long long>(); v.ex = st->ex.as<long long>(); v.rt = st->rt.as<long long>();
+    v.d = st->d.as<int>(); v.f = st->f.as<long long>(); v.g = st->g.as<long long>();
+    v.hub_e = (long long*)sp; sp += (size_t)L * 8;
+    v.hubA_rt = (long long*)sp; sp += 8;
+    v.hubA_min = (unsigned long long*)sp; sp += 24;
+    v.cnt = (int*)sp; sp += (size_t)L * 4;
+    v.hub_exists = (int*)sp; sp += (size_t)L * 4;
+    v.bfs_hub_d = (int*)sp; sp += (size_t)L * 4;
+    v.hub_min = (int*)sp; sp += (size_t)3 * L * 4;
+    v.has_alpha_hub = (int*)sp; sp += 4;
+    v.bfs_hubA_d = (int*)sp; sp += 4;
+    v.flags = (int*)sp;
+    v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
+
+    HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock)};
+    MfTuning tune;
+    const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);
+    if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
+    if (r != 0)
+        return fail(ctx, PGX_ERR_NOCONVERGE, "push-relabel did not converge within %d global relabels (alpha=%d)",
+                    tune.max_relabels, alpha);
+    return PGX_OK;
+}
+
+}  // namespace pgx

@@ -1,0 +1,346 @@
+// maxflow_body.cuh — per-site bodies of the alpha-expansion min-cut (lock-free push-relabel + BFS global relabel).
+//
+// Replaces: GCoptimizationGeneralGraph::expansion -> alpha_expansion -> Energy::minimize (BK max-flow) as driven by
+//           pearl::PEARL::labeling, /root/reference/src/pyprogressivex/include/PEARL.h:507-551.  The GCoptimization
+//           sources are absent from the reference snapshot (empty graph-cut-ransac submodule): semantics restated in
+//           DESIGN.md §5.4 [U-5, U-6].
+//
+// The binary problem of one expansion move on label alpha (site p active iff label[p] != alpha;
+// x_p = 0 "take alpha" = SOURCE side, x_p = 1 "keep" = SINK side):
+//   t-links   keep_p = D[l_p][p] + sum_{q: l_q = alpha} w_pq + sum_{q active, l_q != l_p} w_pq / 2      (s -> p)
+//             take_p = D[alpha][p]                                                                     (p -> t)
+//   n-links   p <-> q, both active:  capacity w_pq (same label) or w_pq / 2 (different labels), both directions
+//   label costs (Delong et al., IJCV 2012; one "hub" node per label):
+//             beta in use, beta != alpha :  s -> y_beta (h),  y_beta -> p (inf) for every p with l_p = beta
+//             alpha unused               :  p -> y_alpha (inf) for every site, y_alpha -> t (h)
+// All capacities are int64 multiples of 2^-32, so the maximum flow is exact and the minimal sink side
+// {v : v reaches t in the residual graph} is unique => labels are bit-identical to the CPU oracle's Dinic solver and to
+// BK's what_segment(default = SOURCE), independent of push order, atomics and scheduling.
+//
+// Only the max-PREFLOW phase is run: when no site/hub with excess can reach t, the reverse BFS from t already yields
+// the minimal sink side (returning stranded excess to s never touches nodes that reach t).
+//
+// The bodies are host/device so that tests/emu can run the identical algorithm sequentially on the CPU (test
+// infrastructure for the host logic; the product path always runs the HIP kernels in maxflow.hip).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PGX_HD __host__ __device__ __forceinline__
+#else
+#define PGX_HD inline
+#endif
+
+namespace pgx {
+
+constexpr int kMfInf = 0x3fffffff;
+
+struct MfView {
+    int64_t n;
+    int L;
+    int alpha;
+    long long lambda_q, h_q;
+    const long long* dq;  // [L][n] label-major unary table
+    int* labels;          // [n]
+    const int* off;       // [n+1]   (nullptr => no pairwise term)
+    const int* idx;       // [E]
+    const int* mult;      // [E]
+    const int* rev;       // [E] index of the reverse arc
+    long long* cap;       // [E] residual capacity of arc a (row owner -> idx[a])
+    long long* ex;        // [n] excess
+    long long* rt;        // [n] residual capacity site -> t
+    int* d;               // [n] height / BFS distance to t
+    long long* f;         // [n] flow received from the site's beta hub (residual of p -> y_beta)
+    long long* g;         // [n] flow sent into the alpha hub (residual of y_alpha -> p)
+    // hubs
+    int* cnt;                      // [L] label histogram
+    int* hub_exists;               // [L] beta hub present
+    long long* hub_e;              // [L] beta hub excess
+    int* has_alpha_hub;            // [1]
+    long long* hubA_rt;            // [1] residual y_alpha -> t
+    int* bfs_hub_d;                // [L] BFS distance of beta hubs
+    int* bfs_hubA_d;               // [1]
+    int* hub_min;                  // [3][L] rotating: min member height of each beta hub
+    unsigned long long* hubA_min;  // [3] rotating: (height << 32 | site) of the lowest member with g > 0
+    int* flags;                    // [8]: 0 last BFS level that labelled a site, 1 work-left (boolean, being
+                                   //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep
+    int hmax;                      // heights >= hmax are treated as unreachable
+};
+
+// ---- atomics ---------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mf_add64(long long* p, long long v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+__device__ __forceinline__ long long mf_load64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool mf_cas64(long long* p, long long& expected, long long desired)
+{
+    const unsigned long long old = atomicCAS((unsigned long long*)p, (unsigned long long)expected, (unsigned long long)desired);
+    const bool ok = old == (unsigned long long)expected;
+    expected = (long long)old;
+    return ok;
+}
+__device__ __forceinline__ void mf_min32(int* p, int v) { atomicMin(p, v); }
+__device__ __forceinline__ void mf_minu64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
+__device__ __forceinline__ void mf_add32(int* p, int v) { atomicAdd(p, v); }
+__device__ __forceinline__ int mf_load32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mf_store32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+inline void mf_add64(long long* p, long long v) { *p += v; }
+inline long long mf_load64(const long long* p) { return *p; }
+inline bool mf_cas64(long long* p, long long& expected, long long desired)
+{
+    if (*p == expected) { *p = desired; return true; }
+    expected = *p;
+    return false;
+}
+inline void mf_min32(int* p, int v) { if (v < *p) *p = v; }
+inline void mf_minu64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
+inline void mf_add32(int* p, int v) { *p += v; }
+inline int mf_load32(const int* p) { return *p; }
+inline void mf_store32(int* p, int v) { *p = v; }
+#endif
+
+// take up to `want` out of a shared non-negative budget
+PGX_HD long long mf_reserve(long long* budget, long long want)
+{
+    long long old = mf_load64(budget);
+    while (old > 0) {
+        const long long take = old < want ? old : want;
+        if (mf_cas64(budget, old, old - take)) return take;
+    }
+    return 0;
+}
+
+PGX_HD unsigned long long mf_pack(int h, int site) { return ((unsigned long long)(unsigned)h << 32) | (unsigned)site; }
+
+// ---- per-move setup -----------------------------------------------------------------------------------------------
+PGX_HD void mf_body_count(const MfView& v, int64_t u) { mf_add32(&v.cnt[v.labels[u]], 1); }
+
+// one thread: decide which hubs exist (after mf_body_count ran for every site)
+PGX_HD void mf_body_hub_setup(const MfView& v)
+{
+    const bool lc = v.h_q > 0;
+    for (int l = 0; l < v.L; ++l) {
+        const bool ex = lc && l != v.alpha && v.cnt[l] > 0;
+        v.hub_exists[l] = ex ? 1 : 0;
+        v.hub_e[l] = ex ? v.h_q : 0;
+        v.bfs_hub_d[l] = kMfInf;
+        for (int r = 0; r < 3; ++r) v.hub_min[r * v.L + l] = kMfInf;
+    }
+    const bool ha = lc && v.cnt[v.alpha] == 0;
+    v.has_alpha_hub[0] = ha ? 1 : 0;
+    v.hubA_rt[0] = ha ? v.h_q : 0;
+    v.bfs_hubA_d[0] = kMfInf;
+    for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
+    for (int k = 0; k < 8; ++k) v.flags[k] = 0;
+}
+
+PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
+{
+    const int lu = v.labels[u];
+    v.f[u] = 0;
+    v.g[u] = 0;
+    v.d[u] = kMfInf;
+    if (lu == v.alpha) {  // inactive: already alpha
+        v.ex[u] = 0;
+        v.rt[u] = 0;
+        if (v.off)
+            for (int a = v.off[u]; a < v.off[u + 1]; ++a) v.cap[a] = 0;
+        return;
+    }
+    long long keep = v.dq[(int64_t)lu * v.n + u];
+    const long long take = v.dq[(int64_t)v.alpha * v.n + u];
+    if (v.off && v.lambda_q > 0)
+        for (int a = v.off[u]; a < v.off[u + 1]; ++a) {
+            const int q = v.idx[a];
+            const int lq = v.labels[q];
+            const long long w = v.lambda_q * (long long)v.mult[a];
+            if (lq == v.alpha) { keep += w; v.cap[a] = 0; }
+            else if (lq == lu) v.cap[a] = w;
+            else { keep += w / 2; v.cap[a] = w / 2; }
+        }
+    if (keep > take) { v.ex[u] = keep - take; v.rt[u] = 0; }
+    else { v.ex[u] = 0; v.rt[u] = take - keep; }
+}
+
+// ---- global relabel: level-synchronous reverse BFS from t --------------------------------------------------------
+PGX_HD void mf_bfs_mark(const MfView& v, int64_t u, int lu, int k)
+{
+    mf_store32(&v.d[u], k);
+    if (v.hub_exists[lu]) mf_min32(&v.bfs_hub_d[lu], k + 1);  // y_beta -> u has infinite capacity
+    if (v.has_alpha_hub[0] && mf_load64(&v.g[u]) > 0) {         // y_alpha -> u has residual g[u]
+        mf_minu64(&v.hubA_min[0], mf_pack(k, (int)u));          // slot 0 is the BFS result slot
+        mf_min32(&v.bfs_hubA_d[0], k + 1);
+    }
+}
+
+// one thread, before level 1
+PGX_HD void mf_body_bfs_reset(const MfView& v)
+{
+    for (int l = 0; l < v.L; ++l) v.bfs_hub_d[l] = kMfInf;
+    v.bfs_hubA_d[0] = (v.has_alpha_hub[0] && v.hubA_rt[0] > 0) ? 1 : kMfInf;
+    v.hubA_min[0] = ~0ull;
+    v.flags[0] = 0;
+    v.flags[1] = 0;
+}
+
+PGX_HD void mf_body_bfs_init(const MfView& v, int64_t u)
+{
+    const int lu = v.labels[u];
+    if (lu == v.alpha) return;
+    if (v.rt[u] > 0) { mf_bfs_mark(v, u, lu, 1); mf_store32(&v.flags[0], 1); }
+    else mf_store32(&v.d[u], kMfInf);
+}
+
+PGX_HD void mf_body_bfs_level(const MfView& v, int64_t u, int k)
+{
+    const int lu = v.labels[u];
+    if (lu == v.alpha) return;
+    if (mf_load32(&v.d[u]) != kMfInf) return;
+    bool found = false;
+    if (v.off)
+        for (int a = v.off[u]; a < v.off[u + 1] && !found; ++a)
+            if (mf_load64(&v.cap[a]) > 0 && mf_load32(&v.d[v.idx[a]]) == k - 1) found = true;
+    if (!found && v.has_alpha_hub[0] && mf_load32(&v.bfs_hubA_d[0]) == k - 1) found = true;       // u -> y_alpha (inf)
+    if (!found && v.hub_exists[lu] && v.f[u] > 0 && mf_load32(&v.bfs_hub_d[lu]) == k - 1) found = true;  // u -> y_beta
+    if (found) { mf_bfs_mark(v, u, lu, k); mf_store32(&v.flags[0], k); }
+}
+
+// one thread, after the BFS: publish hub heights for the sweeps (slot `slot`) and count active hubs
+PGX_HD void mf_body_bfs_finish(const MfView& v, int slot)
+{
+    for (int l = 0; l < v.L; ++l) {
+        const int hd = v.bfs_hub_d[l];
+        for (int r = 0; r < 3; ++r) v.hub_min[r * v.L + l] = kMfInf;
+        v.hub_min[slot * v.L + l] = hd == kMfInf ? kMfInf : hd - 1;
+        if (v.hub_exists[l] && v.hub_e[l] > 0 && hd != kMfInf) v.flags[1] = 1;
+    }
+    const unsigned long long pk = v.hubA_min[0];
+    for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
+    v.hubA_min[slot] = pk;
+}
+
+PGX_HD void mf_body_count_active(const MfView& v, int64_t u)
+{
+    if (v.labels[u] == v.alpha) return;
+    if (mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf) mf_store32(&v.flags[1], 1);
+}
+
+// ---- one push-relabel step for site u ------------------------------------------------------------------------------
+// prev/cur/next: rotating slots of the hub height scans (read prev, accumulate cur, clear next).
+PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
+{
+    const int lu = v.labels[u];
+    if (lu == v.alpha) return;
+    int du = v.d[u];
+    const bool hub_b = v.hub_exists[lu] != 0;
+    const bool hub_a = v.has_alpha_hub[0] != 0;
+    // hub heights as published by the previous scan
+    int hb = kMfInf;
+    if (hub_b) { const int m = v.hub_min[prev * v.L + lu]; hb = m == kMfInf ? kMfInf : m + 1; }
+    int ha = kMfInf, ha_site = -1;
+    if (hub_a) {
+        if (mf_load64(v.hubA_rt) > 0) ha = 1;
+        else {
+            const unsigned long long pk = v.hubA_min[prev];
+            if (pk != ~0ull) { ha = (int)(pk >> 32) + 1; ha_site = (int)(pk & 0xffffffffu); }
+        }
+    }
+    if (du != kMfInf) {
+        // pull from the beta hub along the admissible arc y_beta -> u
+        if (hub_b && hb == du + 1 && mf_load64(&v.hub_e[lu]) > 0) {
+            const long long want = v.rt[u] > 0 ? v.rt[u] : (long long)1 << 62;
+            const long long got = mf_reserve(&v.hub_e[lu], want);
+            if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); mf_store32(&v.flags[1], 1); }
+        }
+        long long e = mf_load64(&v.ex[u]);
+        if (e > 0) {
+            if (v.rt[u] > 0) {  // u -> t
+                const long long dl = e < v.rt[u] ? e : v.rt[u];
+                v.rt[u] -= dl;
+                mf_add64(&v.ex[u], -dl);
+                e -= dl;
+            }
+            if (e > 0) {
+                int best_h = kMfInf, best_a = -1, kind = 0;  // kind 1 n-link, 2 alpha hub, 3 beta hub
+                if (v.off)
+                    for (int a = v.off[u]; a < v.off[u + 1]; ++a)
+                        if (mf_load64(&v.cap[a]) > 0) {
+                            const int h = mf_load32(&v.d[v.idx[a]]);
+                            if (h < best_h) { best_h = h; best_a = a; kind = 1; }
+                        }
+                if (hub_a && ha < best_h && ha_site != (int)u) { best_h = ha; kind = 2; }
+                if (hub_b && v.f[u] > 0 && hb < best_h) { best_h = hb; kind = 3; }
+                if (kind == 0 || best_h == kMfInf) {
+                    du = kMfInf;  // no residual arc leads anywhere that reaches t
+                    mf_store32(&v.d[u], du);
+                } else if (du > best_h) {
+                    if (kind == 1) {
+                        const long long c = mf_load64(&v.cap[best_a]);
+                        const long long dl = e < c ? e : c;
+                        mf_add64(&v.cap[best_a], -dl);
+                        mf_add64(&v.cap[v.rev[best_a]], dl);
+                        mf_add64(&v.ex[u], -dl);
+                        mf_add64(&v.ex[v.idx[best_a]], dl);
+                        mf_store32(&v.flags[1], 1);
+                    } else if (kind == 2) {
+                        if (ha_site < 0) {  // budget y_alpha -> t still open
+                            const long long got = mf_reserve(v.hubA_rt, e);
+                            if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); mf_store32(&v.flags[1], 1); }
+                        } else {            // through the saturated hub into its lowest member: u -> y_alpha -> p*
+                            const long long got = mf_reserve(&v.g[ha_site], e);
+                            if (got > 0) {
+                                mf_add64(&v.g[u], got);
+                                mf_add64(&v.ex[u], -got);
+                                mf_add64(&v.ex[ha_site], got);
+                                mf_store32(&v.flags[1], 1);
+                            }
+                        }
+                    } else {  // back into the beta hub
+                        const long long dl = e < v.f[u] ? e : v.f[u];
+                        v.f[u] -= dl;
+                        mf_add64(&v.ex[u], -dl);
+                        mf_add64(&v.hub_e[lu], dl);
+                        mf_store32(&v.flags[1], 1);
+                    }
+                } else {
+                    du = best_h + 1;
+                    if (du >= v.hmax) du = kMfInf;
+                    mf_store32(&v.d[u], du);
+                }
+            }
+        }
+    }
+    // contribute to the next hub height scan with the final height
+    if (hub_b && du < mf_load32(&v.hub_min[cur * v.L + lu])) mf_min32(&v.hub_min[cur * v.L + lu], du);
+    if (hub_a && du != kMfInf && mf_load64(&v.g[u]) > 0) {
+        const unsigned long long pk = mf_pack(du, (int)u);
+        if (pk < v.hubA_min[cur]) mf_minu64(&v.hubA_min[cur], pk);
+    }
+    if (du != kMfInf && mf_load64(&v.ex[u]) > 0) mf_store32(&v.flags[1], 1);
+}
+
+// one thread per sweep: clear the slot the NEXT sweep will accumulate into; latch the work-left flag
+PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next)
+{
+    int act = v.flags[1];
+    for (int l = 0; l < v.L; ++l) {
+        v.hub_min[next * v.L + l] = kMfInf;
+        if (v.hub_exists[l] && v.hub_e[l] > 0 && v.hub_min[cur * v.L + l] != kMfInf) act = 1;
+    }
+    v.hubA_min[next] = ~0ull;
+    v.flags[4] = act;
+    v.flags[1] = 0;
+}
+
+// ---- apply the cut ---------------------------------------------------------------------------------------------
+PGX_HD void mf_body_apply(const MfView& v, int64_t u)
+{
+    if (v.labels[u] == v.alpha) return;
+    if (v.d[u] == kMfInf) {  // cannot reach t => SOURCE side => takes alpha
+        v.labels[u] = v.alpha;
+        mf_add32(&v.flags[2], 1);
+    }
+}
+
+}  // namespace pgx

@@ -1,0 +1,63 @@
+// maxflow_driver.inl — host orchestration of one expansion move, shared by the HIP backend (maxflow.hip) and the
+// sequential CPU emulation used by the host-logic tests (tests/emu).  `Backend` provides one method per kernel.
+//
+//   count/setup -> init sites -> repeat { global relabel (level-synchronous BFS from t) ; stop if nothing with excess
+//   can reach t ; a batch of push-relabel sweeps } -> apply cut.
+#pragma once
+#include "maxflow_body.cuh"
+
+namespace pgx {
+
+struct MfTuning {
+    int bfs_batch = 4;        // BFS levels issued between two flag read-backs
+    int sweeps_per_relabel = 24;
+    int sweep_check = 8;      // read the work-left flag every this many sweeps
+    int max_relabels = 4096;  // hard cap on global relabels per move
+};
+
+// returns 0 on success, 1 if the cap on global relabels was hit
+template <class Backend>
+int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t* changed, int64_t stats[8])
+{
+    *changed = 0;
+    be.count_and_setup(v);
+    const int cnt_alpha = be.read_count(v, v.alpha);
+    if ((int64_t)cnt_alpha == v.n) return 0;  // every site already carries alpha
+    be.init_sites(v);
+    stats[0] += 1;
+    int sweep_id = 0;
+    bool converged = false;
+    for (int it = 0; it < tune.max_relabels && !converged; ++it) {
+        // ---- global relabel
+        be.bfs_reset(v);
+        be.bfs_init(v);
+        int level = 1;
+        for (;;) {
+            for (int b = 0; b < tune.bfs_batch; ++b) be.bfs_level(v, ++level);
+            const int last = be.read_flag(v, 0);
+            if (last <= level - 2 || level >= v.hmax) break;
+        }
+        stats[2] += 1;
+        stats[3] += level;
+        const int slot = (sweep_id + 2) % 3;
+        be.bfs_finish(v, slot);
+        be.count_active(v);
+        if (be.read_flag(v, 1) == 0) { converged = true; break; }
+        // ---- push-relabel sweeps
+        for (int s = 0; s < tune.sweeps_per_relabel; ++s) {
+            const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
+            be.sweep(v, prev, cur);
+            be.sweep_epilogue(v, cur, next);
+            ++sweep_id;
+            stats[1] += 1;
+            if ((s + 1) % tune.sweep_check == 0 && be.read_flag(v, 4) == 0) break;
+        }
+    }
+    if (!converged) return 1;
+    be.apply(v);
+    *changed = be.read_flag(v, 2);
+    stats[4] += *changed;
+    return 0;
+}
+
+}  // namespace pgx

@@ -1,0 +1,107 @@
+// pgx_internal.h — context layout and helpers shared by the translation units of libpgx.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pgx.h"
+#include "residuals.cuh"
+
+namespace pgx {
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct MaxflowState;  // maxflow.hip
+struct CommState;     // comm.cpp
+
+}  // namespace pgx
+
+struct pgx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    int cu_count = 0;
+
+    // resident problem data
+    int model_type = -1, D = 0, P = 0;
+    int64_t n = 0;
+    pgx::DevBuf pts, comp;
+
+    // scoring
+    int M = 0, Mpad = 0, chunks = 0;
+    int64_t chunk = 0, words = 0;
+    bool have_masks = false;
+    int score_has_compound = 0;
+    pgx::DevBuf models, pcnt, pval, psh, counts, values, shared, masks;
+    pgx::DevBuf g_counts, g_values, g_shared;  // all-gathered results (multi-GPU)
+
+    // preference slots + reductions
+    std::vector<pgx::DevBuf> slots;
+    pgx::DevBuf red_partials, red_out;
+
+    // PEARL
+    int L = 0;          // labels of the resident unary table
+    int64_t dq_n = 0;   // sites of the resident unary table
+    pgx::DevBuf dq;     // label-major [L][n] int64
+    pgx::DevBuf kmodels;
+    pgx::DevBuf labels; // int32 [n]
+    int64_t labels_n = 0;
+    // graph (symmetric CSR)
+    int64_t gn = 0, gE = 0;
+    int max_degree = 0;
+    int64_t max_row_mult = 0;
+    pgx::DevBuf goff, gidx, gmult, grev;
+    pgx::MaxflowState* mf = nullptr;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
+
+    pgx::CommState* comm = nullptr;
+};
+
+namespace pgx {
+
+int fail(pgx_ctx* ctx, int code, const char* fmt, ...);
+int ensure(pgx_ctx* ctx, DevBuf& b, size_t bytes);
+void release(DevBuf& b);
+
+#define PGX_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return pgx::fail(ctx, PGX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define PGX_TRY(call)               \
+    do {                            \
+        int r_ = (call);            \
+        if (r_ != PGX_OK) return r_; \
+    } while (0)
+
+inline int64_t quantize(double x) { return (int64_t)__builtin_nearbyint(x * 4294967296.0); }
+// weight of one directed neighbour entry, forced even so that w/2 is exact in the expansion graph
+inline int64_t quantize_lambda(double lambda) { return 2 * (int64_t)__builtin_nearbyint(lambda * 2147483648.0); }
+
+// launchers implemented in the .hip translation units
+int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
+int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pref, double out3[3]);
+int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K);
+int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda);
+int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* sum);
+int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
+int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
+int graph_build_reverse(pgx_ctx* ctx);
+int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
+void maxflow_free(pgx_ctx* ctx);
+void comm_free(pgx_ctx* ctx);
+
+}  // namespace pgx

@@ -1,0 +1,432 @@
+// pointwise.hip — the HBM-bound, one-point-per-lane kernels of the hot path (gfx950).
+//
+//   preference_kernel   progx::Model::setPreferenceVector (progx_model.h:70-87) fused with the three reductions of
+//                       ProgressiveX::isPutativeModelValid (progressive_x.h:583-585)
+//   compound_kernel     ProgressiveX::updateCompoundModel (progressive_x.h:597-624)
+//   unary_kernel        pearl::dataEnergyFunctor (PEARL.h:82-128), all (point, label) pairs at once, quantised
+//   residual_sum_kernel PEARL::parameterEstimation's before/after sums (PEARL.h:369-371, 388-390)
+//   bucket_*            PEARL::parameterEstimation's label bucketing (PEARL.h:342-352): histogram + stable compaction
+//                       with wave ballot / prefix sums
+//   energy_kernel       GCoptimization::compute_energy (absent upstream, U-5): data + Potts + label costs, exact int64
+//
+// Model parameters are wave-uniform (kernel arguments or scalar loads); points are read once, coalesced per wave.
+// All floating-point reductions use a fixed tree (wave shuffle -> LDS -> per-block partial -> one-block final pass), so
+// results are bit-reproducible run to run.  Paths are relative to /root/reference/src/pyprogressivex/.
+#include "pgx_internal.h"
+
+namespace pgx {
+
+struct ModelArg {
+    double v[18];
+};
+
+constexpr int kPwBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+// block sum of up to 3 values; result valid in thread 0. Fixed order: lanes tree, then waves 0..3.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&x)[NV], double* lds /* >= 4*NV */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        x[k] = wave_sum(x[k]);
+        if (lane == 0) lds[wave * NV + k] = x[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double s = lds[k];
+            for (int w = 1; w < kPwBlock / 64; ++w) s += lds[w * NV + k];
+            x[k] = s;
+        }
+    }
+}
+
+// final pass: one block adds `count` partial NV-tuples in a fixed order
+template <int NV>
+__global__ __launch_bounds__(kPwBlock) void final_sum_kernel(const double* __restrict__ partials, int count,
+                                                             double* __restrict__ out)
+{
+    __shared__ double lds[4 * NV];
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < count; b += kPwBlock)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] += partials[(int64_t)b * NV + k];
+    block_sum<NV>(acc, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] = acc[k];
+}
+
+template <int MT>
+__device__ __forceinline__ void load_point(const double* __restrict__ pts, int64_t i, double (&pt)[Residual<MT>::D])
+{
+#pragma unroll
+    for (int k = 0; k < Residual<MT>::D; ++k) pt[k] = pts[i * Residual<MT>::D + k];
+}
+
+// ---- a2 + a3 -----------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(kPwBlock) void preference_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl,
+                                                              double T2, const double* __restrict__ comp,
+                                                              double* __restrict__ pref,
+                                                              double* __restrict__ partials)
+{
+    using R = Residual<MT>;
+    __shared__ double lds[12];
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (i < n) {
+        double pt[R::D];
+        load_point<MT>(pts, i, pt);
+        const double sq = R::squared(pt, mdl.v);
+        const double v = 1.0 - sq / T2;
+        const double p = cv_max(0.0, v);  // progx_model.h:85  MAX(0, ...)
+        pref[i] = p;
+        const double c = comp[i];
+        acc[0] = p * c;  // progressive_x.h:583 dot
+        acc[1] = p * p;  // :585 squaredNorm
+        acc[2] = c * c;
+    }
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        partials[(int64_t)blockIdx.x * 3 + 0] = acc[0];
+        partials[(int64_t)blockIdx.x * 3 + 1] = acc[1];
+        partials[(int64_t)blockIdx.x * 3 + 2] = acc[2];
+    }
+}
+
+template <int MT>
+static int preference_dispatch(pgx_ctx* ctx, const ModelArg& mdl, double T2, double* d_pref, int blocks)
+{
+    hipLaunchKernelGGL((preference_kernel<MT>), dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
+                       ctx->pts.as<double>(), ctx->n, mdl, T2, ctx->comp.as<double>(), d_pref,
+                       ctx->red_partials.as<double>());
+    PGX_HIP(ctx, hipGetLastError());
+    return PGX_OK;
+}
+
+int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pref, double out3[3])
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_preference: points not set");
+    ModelArg mdl;
+    for (int k = 0; k < 18; ++k) mdl.v[k] = k < ctx->P ? model[k] : 0.0;
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    PGX_TRY(ensure(ctx, ctx->red_partials, (size_t)blocks * 3 * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->red_out, 8 * sizeof(double)));
+    int r;
+    switch (ctx->model_type) {
+    case kLine2D: r = preference_dispatch<kLine2D>(ctx, mdl, T2, d_pref, blocks); break;
+    case kHomography: r = preference_dispatch<kHomography>(ctx, mdl, T2, d_pref, blocks); break;
+    case kFundamental: r = preference_dispatch<kFundamental>(ctx, mdl, T2, d_pref, blocks); break;
+    case kPnP: r = preference_dispatch<kPnP>(ctx, mdl, T2, d_pref, blocks); break;
+    case kVanishingPoint: r = preference_dispatch<kVanishingPoint>(ctx, mdl, T2, d_pref, blocks); break;
+    case kHomographySym: r = preference_dispatch<kHomographySym>(ctx, mdl, T2, d_pref, blocks); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "bad model type");
+    }
+    PGX_TRY(r);
+    hipLaunchKernelGGL((final_sum_kernel<3>), dim3(1), dim3(kPwBlock), 0, ctx->stream,
+                       ctx->red_partials.as<double>(), blocks, ctx->red_out.as<double>());
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(out3, ctx->red_out.p, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+// ---- a4 ----------------------------------------------------------------------------------------------------------
+struct SlotArg {
+    const double* p[32];
+};
+
+__global__ __launch_bounds__(kPwBlock) void compound_kernel(SlotArg slots, int K, int64_t n, double* __restrict__ comp)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    double c = 0.0;  // progressive_x.h:604 setConstant(0)
+    for (int k = 0; k < K; ++k) c = cv_max(c, slots.p[k][i]);  // :620-621
+    comp[i] = c;
+}
+
+int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K)
+{
+    if (K > 32) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: at most 32 models per call (got %d)", K);
+    SlotArg a;
+    for (int k = 0; k < 32; ++k) a.p[k] = nullptr;
+    for (int k = 0; k < K; ++k) {
+        if (slots[k] < 0 || slots[k] >= (int)ctx->slots.size() || !ctx->slots[slots[k]].p)
+            return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: slot %d holds no preference vector", slots[k]);
+        a.p[k] = ctx->slots[slots[k]].as<double>();
+    }
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    hipLaunchKernelGGL(compound_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, a, K, ctx->n,
+                       ctx->comp.as<double>());
+    PGX_HIP(ctx, hipGetLastError());
+    return PGX_OK;
+}
+
+// ---- a6 ----------------------------------------------------------------------------------------------------------
+// One lane per point, loop over the K active models (scalar loads of the parameters).  The table is stored
+// label-major [L][n] so that both this write and the per-label reads of the expansion kernels are coalesced.
+template <int MT>
+__global__ __launch_bounds__(kPwBlock) void unary_kernel(const double* __restrict__ pts, int64_t n,
+                                                         const double* __restrict__ models, int K, double T2,
+                                                         double oml, long long* __restrict__ dq)
+{
+    using R = Residual<MT>;
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    double pt[R::D];
+    load_point<MT>(pts, i, pt);
+    const double far = 2.0 * oml;
+    for (int k = 0; k < K; ++k) {
+        double mdl[R::P];
+#pragma unroll
+        for (int j = 0; j < R::P; ++j) mdl[j] = models[k * R::P + j];
+        const double sq = R::squared(pt, mdl);
+        double c;
+        if (sq > T2) c = far;            // PEARL.h:123-124
+        else c = oml * sq / T2;          // PEARL.h:126-127
+        if (c != c) c = far;             // NaN (degenerate model): priced as beyond the threshold
+        dq[(int64_t)k * n + i] = (long long)__builtin_nearbyint(c * 4294967296.0);
+    }
+    dq[(int64_t)K * n + i] = (long long)__builtin_nearbyint(oml * 4294967296.0);  // PEARL.h:100-101
+}
+
+int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_pearl_unary: points not set");
+    const double T2 = 9.0 / 4.0 * threshold * threshold;  // PEARL.h:51
+    const double oml = 1.0 - lambda;                       // PEARL.h:48
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    dim3 g((unsigned)blocks), b(kPwBlock);
+    const double* pts = ctx->pts.as<double>();
+    const double* mdl = ctx->kmodels.as<double>();
+    long long* dq = ctx->dq.as<long long>();
+    switch (ctx->model_type) {
+    case kLine2D: hipLaunchKernelGGL((unary_kernel<kLine2D>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    case kHomography: hipLaunchKernelGGL((unary_kernel<kHomography>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    case kFundamental: hipLaunchKernelGGL((unary_kernel<kFundamental>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    case kPnP: hipLaunchKernelGGL((unary_kernel<kPnP>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    case kVanishingPoint: hipLaunchKernelGGL((unary_kernel<kVanishingPoint>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    case kHomographySym: hipLaunchKernelGGL((unary_kernel<kHomographySym>), g, b, 0, ctx->stream, pts, ctx->n, mdl, K, T2, oml, dq); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "bad model type");
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    return PGX_OK;
+}
+
+// ---- a9: residual sums ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(kPwBlock) void residual_sum_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl,
+                                                                const int* __restrict__ labels, int label,
+                                                                double* __restrict__ partials)
+{
+    using R = Residual<MT>;
+    __shared__ double lds[4];
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    double acc[1] = {0.0};
+    if (i < n && labels[i] == label) {
+        double pt[R::D];
+        load_point<MT>(pts, i, pt);
+        acc[0] = R::plain(pt, mdl.v);  // PEARL.h:371 / :390  (unsquared residual)
+    }
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* sum)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sum: points not set");
+    if (ctx->labels_n != ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sum: labels not set");
+    ModelArg mdl;
+    for (int k = 0; k < 18; ++k) mdl.v[k] = k < ctx->P ? model[k] : 0.0;
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    PGX_TRY(ensure(ctx, ctx->red_partials, (size_t)blocks * 3 * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->red_out, 8 * sizeof(double)));
+    dim3 g((unsigned)blocks), b(kPwBlock);
+    const double* pts = ctx->pts.as<double>();
+    const int* lab = ctx->labels.as<int>();
+    double* part = ctx->red_partials.as<double>();
+    switch (ctx->model_type) {
+    case kLine2D: hipLaunchKernelGGL((residual_sum_kernel<kLine2D>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    case kHomography: hipLaunchKernelGGL((residual_sum_kernel<kHomography>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    case kFundamental: hipLaunchKernelGGL((residual_sum_kernel<kFundamental>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    case kPnP: hipLaunchKernelGGL((residual_sum_kernel<kPnP>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    case kVanishingPoint: hipLaunchKernelGGL((residual_sum_kernel<kVanishingPoint>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    case kHomographySym: hipLaunchKernelGGL((residual_sum_kernel<kHomographySym>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, label, part); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "bad model type");
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((final_sum_kernel<1>), dim3(1), dim3(kPwBlock), 0, ctx->stream, part, blocks,
+                       ctx->red_out.as<double>());
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(sum, ctx->red_out.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+// ---- a9: bucket by label (PEARL.h:342-352) -----------------------------------------------------------------------
+// Labels >= L-1 fall into the last (outlier) bucket, as `label < instance_number` does at PEARL.h:348.
+constexpr int kMaxBucketLabels = 64;
+
+__global__ __launch_bounds__(kPwBlock) void bucket_count_kernel(const int* __restrict__ labels, int64_t n, int L,
+                                                                unsigned* __restrict__ block_counts /*[blocks][L]*/)
+{
+    __shared__ unsigned hist[kMaxBucketLabels];
+    if (threadIdx.x < kMaxBucketLabels) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    int l = -1;
+    if (i < n) { l = labels[i]; if (l >= L - 1) l = L - 1; }
+    // one LDS atomic per (wave, label present): ballot per label value, lowest lane of each group adds the popcount
+    for (int k = 0; k < L; ++k) {
+        const unsigned long long b = __ballot(l == k);
+        if (b != 0 && (threadIdx.x & 63) == (unsigned)__ffsll((long long)b) - 1)
+            atomicAdd(&hist[k], (unsigned)__popcll(b));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < L) block_counts[(int64_t)blockIdx.x * L + threadIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan over blocks for every label (one thread per label; blocks <= a few thousand) + label starts
+__global__ void bucket_scan_kernel(unsigned* __restrict__ block_counts, int blocks, int L,
+                                   long long* __restrict__ counts, long long* __restrict__ starts)
+{
+    const int k = threadIdx.x;
+    if (k < L) {
+        long long run = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const unsigned c = block_counts[(int64_t)b * L + k];
+            block_counts[(int64_t)b * L + k] = (unsigned)run;  // offset of block b inside bucket k (fits: n < 2^31)
+            run += c;
+        }
+        counts[k] = run;
+    }
+    __syncthreads();
+    if (k == 0) {
+        long long s = 0;
+        for (int j = 0; j < L; ++j) { starts[j] = s; s += counts[j]; }
+    }
+}
+
+__global__ __launch_bounds__(kPwBlock) void bucket_scatter_kernel(const int* __restrict__ labels, int64_t n, int L,
+                                                                  const unsigned* __restrict__ block_offsets,
+                                                                  const long long* __restrict__ starts,
+                                                                  int* __restrict__ order)
+{
+    __shared__ unsigned wave_cnt[4][kMaxBucketLabels];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    int l = -1;
+    if (i < n) { l = labels[i]; if (l >= L - 1) l = L - 1; }
+    unsigned rank_in_wave = 0;
+    for (int k = 0; k < L; ++k) {
+        const unsigned long long b = __ballot(l == k);
+        if (l == k) rank_in_wave = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave][k] = (unsigned)__popcll(b);
+    }
+    __syncthreads();
+    if (l >= 0) {
+        unsigned before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w][l];
+        const long long pos = starts[l] + block_offsets[(int64_t)blockIdx.x * L + l] + before + rank_in_wave;
+        order[pos] = (int)i;
+    }
+}
+
+int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)
+{
+    if (ctx->labels_n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_bucket: labels not set");
+    if (L < 1 || L > kMaxBucketLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_bucket: L must be in [1,%d]", kMaxBucketLabels);
+    const int64_t n = ctx->labels_n;
+    const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
+    const size_t bc_bytes = (size_t)blocks * L * sizeof(unsigned);
+    const size_t need = bc_bytes + 2 * (size_t)L * sizeof(long long) + 64 + (order ? (size_t)n * sizeof(int) : 0);
+    PGX_TRY(ensure(ctx, ctx->scratch, need));
+    char* base = (char*)ctx->scratch.p;
+    unsigned* bc = (unsigned*)base;
+    size_t o = (bc_bytes + 15) & ~(size_t)15;
+    long long* d_counts = (long long*)(base + o); o += (size_t)L * sizeof(long long);
+    long long* d_starts = (long long*)(base + o); o += (size_t)L * sizeof(long long);
+    o = (o + 15) & ~(size_t)15;
+    int* d_order = (int*)(base + o);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
+                       ctx->labels.as<int>(), n, L, bc);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, bc, blocks, L, d_counts, d_starts);
+    if (order)
+        hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
+                           ctx->labels.as<int>(), n, L, bc, d_starts, d_order);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)L * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (order)
+        PGX_HIP(ctx, hipMemcpyAsync(order, d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+// ---- energy (U-5 compute_energy): exact int64 ----------------------------------------------------------------------
+__global__ __launch_bounds__(kPwBlock) void energy_kernel(const long long* __restrict__ dq, int64_t n, int L,
+                                                          const int* __restrict__ labels,
+                                                          const int* __restrict__ off, const int* __restrict__ idx,
+                                                          const int* __restrict__ mult, long long lambda_q,
+                                                          unsigned long long* __restrict__ energy,
+                                                          unsigned* __restrict__ used /*[L]*/)
+{
+    __shared__ unsigned long long lds[4];
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    unsigned long long e = 0;
+    if (i < n) {
+        const int li = labels[i];
+        e = (unsigned long long)dq[(int64_t)li * n + i];
+        used[li] = 1;  // benign race: every writer stores 1
+        if (off != nullptr && lambda_q > 0)
+            for (int a = off[i]; a < off[i + 1]; ++a) {
+                const int j = idx[a];
+                if (j < i && labels[j] != li) e += (unsigned long long)(lambda_q * (long long)mult[a]);
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(energy, lds[0] + lds[1] + lds[2] + lds[3]);  // integer: order-independent
+}
+
+int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q)
+{
+    const int64_t n = ctx->dq_n;
+    const int L = ctx->L;
+    if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: unary table not set");
+    if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: labels not set");
+    const bool pair = lambda_q > 0 && ctx->gn == n;
+    if (lambda_q > 0 && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: lambda > 0 but no graph set");
+    PGX_TRY(ensure(ctx, ctx->scratch, 16 + (size_t)L * sizeof(unsigned)));
+    unsigned long long* d_e = (unsigned long long*)ctx->scratch.p;
+    unsigned* d_used = (unsigned*)((char*)ctx->scratch.p + 16);
+    PGX_HIP(ctx, hipMemsetAsync(ctx->scratch.p, 0, 16 + (size_t)L * sizeof(unsigned), ctx->stream));
+    const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
+    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, ctx->dq.as<long long>(),
+                       n, L, ctx->labels.as<int>(), pair ? ctx->goff.as<int>() : (const int*)nullptr,
+                       ctx->gidx.as<int>(), ctx->gmult.as<int>(), (long long)lambda_q, d_e, d_used);
+    PGX_HIP(ctx, hipGetLastError());
+    std::vector<unsigned char> host(16 + (size_t)L * sizeof(unsigned));
+    PGX_HIP(ctx, hipMemcpyAsync(host.data(), ctx->scratch.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t e = (int64_t)(*(unsigned long long*)host.data());
+    const unsigned* used = (const unsigned*)(host.data() + 16);
+    for (int l = 0; l < L; ++l) if (used[l]) e += h_q;
+    *energy_q = e;
+    return PGX_OK;
+}
+
+}  // namespace pgx

@@ -1,0 +1,346 @@
+"""ctypes binding of libpgx.so (include/pgx.h) — the only door from the Python host code to the GPU.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is present the calls raise
+`PgxError`; nothing in this package ever routes to the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgx.so")
+
+LINE2D, HOMOGRAPHY, FUNDAMENTAL, PNP, VANISHING_POINT, HOMOGRAPHY_SYM = range(6)
+POINT_DIM = {0: 2, 1: 4, 2: 4, 3: 5, 4: 4, 5: 4}
+PARAM_DIM = {0: 3, 1: 9, 2: 9, 3: 12, 4: 3, 5: 18}
+FIXED_ONE = float(1 << 32)
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/pgx.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "pgx_version", "pgx_device_count", "pgx_global_error", "pgx_create", "pgx_destroy", "pgx_last_error",
+    "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_device_info",
+    "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
+    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
+    "pgx_preference", "pgx_get_preference", "pgx_compound_update",
+    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
+    "pgx_bucket", "pgx_residual_sum",
+    "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
+    "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
+]
+
+
+class PgxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libpgx.so (built by `make -C progressive-x_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgxError(
+            f"{LIB_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C progressive-x_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.pgx_global_error.restype = C.c_char_p
+    lib.pgx_last_error.restype = C.c_char_p
+    lib.pgx_last_error.argtypes = [C.c_void_p]
+    lib.pgx_destroy.restype = None
+    lib.pgx_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_count():
+    lib = load()
+    n = C.c_int(0)
+    lib.pgx_device_count(C.byref(n))
+    return n.value
+
+
+def comm_unique_id():
+    lib = load()
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    r = lib.pgx_comm_unique_id(buf)
+    if r != 0:
+        raise PgxError(f"pgx_comm_unique_id failed ({r}): {lib.pgx_global_error().decode()}")
+    return bytes(buf)
+
+
+class Context:
+    """One GPU context (pgx_ctx): resident points, compound vector, preference slots, unary table, graph, labels."""
+
+    def __init__(self, device_id=0):
+        self._lib = load()
+        h = C.c_void_p()
+        r = self._lib.pgx_create(C.c_int(int(device_id)), C.byref(h))
+        if r != 0:
+            raise PgxError(f"pgx_create(device={device_id}) failed ({r}): {self._lib.pgx_global_error().decode()}")
+        self._h = h
+        self.device_id = int(device_id)
+        self.model_type = None
+        self.n = 0
+        self.M = 0
+        self.nranks = 1
+        self.rank = 0
+
+    # -- plumbing ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pgx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, r, what):
+        if r != 0:
+            raise PgxError(f"{what} failed ({r}): {self._lib.pgx_last_error(self._h).decode()}")
+
+    def sync(self):
+        self._ck(self._lib.pgx_sync(self._h), "pgx_sync")
+
+    def timer_start(self):
+        self._ck(self._lib.pgx_timer_start(self._h), "pgx_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self._lib.pgx_timer_stop(self._h, C.byref(ms)), "pgx_timer_stop")
+        return float(ms.value)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        hbm = C.c_int64()
+        self._ck(self._lib.pgx_device_info(self._h, name, C.c_int(256), C.byref(cu), C.byref(hbm)), "pgx_device_info")
+        return dict(name=name.value.decode(), cu_count=cu.value, hbm_bytes=hbm.value)
+
+    # -- resident data -------------------------------------------------------------------------------------------
+    def set_points(self, model_type, points):
+        pts = _f64(points)
+        if pts.ndim != 2 or pts.shape[1] != POINT_DIM[model_type]:
+            raise ValueError(f"points must be [n,{POINT_DIM[model_type]}] for model type {model_type}")
+        self._ck(self._lib.pgx_set_points(self._h, C.c_int(model_type), _ptr(pts, C.c_double), C.c_int64(pts.shape[0])),
+                 "pgx_set_points")
+        self.model_type = model_type
+        self.n = pts.shape[0]
+
+    def set_compound(self, compound=None):
+        c = None if compound is None else _f64(compound)
+        self._ck(self._lib.pgx_set_compound(self._h, _ptr(c, C.c_double)), "pgx_set_compound")
+
+    def get_compound(self):
+        out = np.empty(self.n, dtype=np.float64)
+        self._ck(self._lib.pgx_get_compound(self._h, _ptr(out, C.c_double)), "pgx_get_compound")
+        return out
+
+    # -- scoring ---------------------------------------------------------------------------------------------------
+    def _models(self, models):
+        m = _f64(models).reshape(-1, PARAM_DIM[self.model_type])
+        return m
+
+    def score(self, models, T2, has_compound=False, exponent=2, want_masks=False):
+        m = self._models(models)
+        M = m.shape[0]
+        counts = np.empty(M, dtype=np.int64)
+        values = np.empty(M, dtype=np.float64)
+        shared = np.empty(M, dtype=np.float64)
+        scores = np.empty(M, dtype=np.float64)
+        masks = np.empty((M, (self.n + 63) // 64), dtype=np.uint64) if want_masks else None
+        self._ck(self._lib.pgx_score(self._h, _ptr(m, C.c_double), C.c_int(M), C.c_double(T2),
+                                     C.c_int(1 if has_compound else 0), C.c_int(int(exponent)),
+                                     _ptr(counts, C.c_int64), _ptr(values, C.c_double), _ptr(shared, C.c_double),
+                                     _ptr(scores, C.c_double), _ptr(masks, C.c_uint64)), "pgx_score")
+        self.M = M
+        return dict(counts=counts, values=values, shared=shared, scores=scores, masks=masks)
+
+    def score_upload(self, models):
+        m = self._models(models)
+        self._ck(self._lib.pgx_score_upload(self._h, _ptr(m, C.c_double), C.c_int(m.shape[0])), "pgx_score_upload")
+        self.M = m.shape[0]
+
+    def score_launch(self, T2, has_compound=False, want_masks=False):
+        self._ck(self._lib.pgx_score_launch(self._h, C.c_double(T2), C.c_int(1 if has_compound else 0),
+                                            C.c_int(1 if want_masks else 0)), "pgx_score_launch")
+
+    def score_fetch(self, exponent=2, want_masks=False):
+        M = self.M
+        counts = np.empty(M, dtype=np.int64)
+        values = np.empty(M, dtype=np.float64)
+        shared = np.empty(M, dtype=np.float64)
+        scores = np.empty(M, dtype=np.float64)
+        masks = np.empty((M, (self.n + 63) // 64), dtype=np.uint64) if want_masks else None
+        self._ck(self._lib.pgx_score_fetch(self._h, C.c_int(int(exponent)), _ptr(counts, C.c_int64),
+                                           _ptr(values, C.c_double), _ptr(shared, C.c_double),
+                                           _ptr(scores, C.c_double), _ptr(masks, C.c_uint64)), "pgx_score_fetch")
+        return dict(counts=counts, values=values, shared=shared, scores=scores, masks=masks)
+
+    def score_algorithmic_bytes(self, want_masks=False):
+        b = C.c_int64()
+        p = C.c_int64()
+        self._ck(self._lib.pgx_score_algorithmic_bytes(self._h, C.c_int(1 if want_masks else 0), C.byref(b),
+                                                       C.byref(p)), "pgx_score_algorithmic_bytes")
+        return b.value, p.value
+
+    # -- preference / compound -------------------------------------------------------------------------------------
+    def preference(self, model, T2, slot, want_pref=False):
+        m = _f64(model).reshape(-1)
+        out = np.empty(self.n, dtype=np.float64) if want_pref else None
+        d, a, b = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self._lib.pgx_preference(self._h, _ptr(m, C.c_double), C.c_double(T2), C.c_int(int(slot)),
+                                          _ptr(out, C.c_double), C.byref(d), C.byref(a), C.byref(b)),
+                 "pgx_preference")
+        return dict(pref=out, dot=d.value, pref_sqnorm=a.value, comp_sqnorm=b.value)
+
+    def get_preference(self, slot):
+        out = np.empty(self.n, dtype=np.float64)
+        self._ck(self._lib.pgx_get_preference(self._h, C.c_int(int(slot)), _ptr(out, C.c_double)),
+                 "pgx_get_preference")
+        return out
+
+    def compound_update(self, slots, want_compound=False):
+        s = _i32(slots).reshape(-1)
+        out = np.empty(self.n, dtype=np.float64) if want_compound else None
+        self._ck(self._lib.pgx_compound_update(self._h, _ptr(s, C.c_int32), C.c_int(s.shape[0]),
+                                               _ptr(out, C.c_double)), "pgx_compound_update")
+        return out
+
+    # -- PEARL -------------------------------------------------------------------------------------------------------
+    def pearl_unary(self, models, threshold, lam, want_table=False):
+        K = 0 if models is None else int(np.asarray(models).size // PARAM_DIM[self.model_type])
+        m = self._models(models) if K > 0 else None
+        out = np.empty((self.n, K + 1), dtype=np.int64) if want_table else None
+        self._ck(self._lib.pgx_pearl_unary(self._h, _ptr(m, C.c_double), C.c_int(K), C.c_double(threshold),
+                                           C.c_double(lam), _ptr(out, C.c_int64)), "pgx_pearl_unary")
+        self.L = K + 1
+        return out
+
+    def set_unary_q(self, Dq):
+        Dq = np.ascontiguousarray(Dq, dtype=np.int64)
+        self._ck(self._lib.pgx_set_unary_q(self._h, _ptr(Dq, C.c_int64), C.c_int64(Dq.shape[0]),
+                                           C.c_int(Dq.shape[1])), "pgx_set_unary_q")
+        self.L = Dq.shape[1]
+        if self.n == 0:
+            self.n = Dq.shape[0]
+
+    def set_graph(self, off, idx, mult):
+        off, idx, mult = _i32(off), _i32(idx), _i32(mult)
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.int32)
+            mult = np.ones(1, dtype=np.int32)
+        self._ck(self._lib.pgx_set_graph(self._h, C.c_int64(off.shape[0] - 1), _ptr(off, C.c_int32),
+                                         _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)), "pgx_set_graph")
+
+    def set_labels(self, labels):
+        lab = _i32(labels)
+        self._ck(self._lib.pgx_set_labels(self._h, _ptr(lab, C.c_int32), C.c_int64(lab.shape[0])), "pgx_set_labels")
+        self._nlabels = lab.shape[0]
+
+    def get_labels(self):
+        out = np.empty(self._nlabels, dtype=np.int32)
+        self._ck(self._lib.pgx_get_labels(self._h, _ptr(out, C.c_int32)), "pgx_get_labels")
+        return out
+
+    def energy(self, lam, label_cost):
+        eq = C.c_int64()
+        e = C.c_double()
+        self._ck(self._lib.pgx_energy(self._h, C.c_double(lam), C.c_double(label_cost), C.byref(eq), C.byref(e)),
+                 "pgx_energy")
+        return eq.value, e.value
+
+    def expand_alpha(self, lam, label_cost, alpha):
+        ch = C.c_int64()
+        self._ck(self._lib.pgx_expand_alpha(self._h, C.c_double(lam), C.c_double(label_cost), C.c_int(int(alpha)),
+                                            C.byref(ch)), "pgx_expand_alpha")
+        return ch.value
+
+    def expansion(self, lam, label_cost, max_cycles=1000):
+        eq = C.c_int64()
+        e = C.c_double()
+        cyc = C.c_int()
+        self._ck(self._lib.pgx_expansion(self._h, C.c_double(lam), C.c_double(label_cost), C.c_int(int(max_cycles)),
+                                         C.byref(eq), C.byref(e), C.byref(cyc)), "pgx_expansion")
+        return eq.value, e.value, cyc.value
+
+    def expansion_stats(self):
+        st = np.zeros(8, dtype=np.int64)
+        self._ck(self._lib.pgx_expansion_stats(self._h, _ptr(st, C.c_int64)), "pgx_expansion_stats")
+        return dict(mincuts=int(st[0]), sweeps=int(st[1]), global_relabels=int(st[2]), bfs_levels=int(st[3]),
+                    relabelled_sites=int(st[4]))
+
+    def bucket(self, L, want_order=True):
+        counts = np.zeros(L, dtype=np.int64)
+        order = np.empty(self._nlabels, dtype=np.int32) if want_order else None
+        self._ck(self._lib.pgx_bucket(self._h, C.c_int(int(L)), _ptr(counts, C.c_int64), _ptr(order, C.c_int32)),
+                 "pgx_bucket")
+        return counts, order
+
+    def residual_sum(self, model, label):
+        m = _f64(model).reshape(-1)
+        s = C.c_double()
+        self._ck(self._lib.pgx_residual_sum(self._h, _ptr(m, C.c_double), C.c_int(int(label)), C.byref(s)),
+                 "pgx_residual_sum")
+        return s.value
+
+    # -- multi-GPU ---------------------------------------------------------------------------------------------------
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self._lib.pgx_comm_init(self._h, C.c_int(int(nranks)), C.c_int(int(rank)), buf), "pgx_comm_init")
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_destroy(self):
+        self._ck(self._lib.pgx_comm_destroy(self._h), "pgx_comm_destroy")
+        self.nranks, self.rank = 1, 0
+
+    def comm_barrier(self):
+        self._ck(self._lib.pgx_comm_barrier(self._h), "pgx_comm_barrier")
+
+    def comm_allreduce_max(self, value):
+        v = C.c_double(float(value))
+        self._ck(self._lib.pgx_comm_allreduce_max_f64(self._h, C.byref(v)), "pgx_comm_allreduce_max_f64")
+        return v.value
+
+    def score_allgather(self):
+        self._ck(self._lib.pgx_score_allgather(self._h), "pgx_score_allgather")
+
+    def score_fetch_all(self, exponent=2):
+        T = self.M * self.nranks
+        counts = np.empty(T, dtype=np.int64)
+        values = np.empty(T, dtype=np.float64)
+        shared = np.empty(T, dtype=np.float64)
+        scores = np.empty(T, dtype=np.float64)
+        self._ck(self._lib.pgx_score_fetch_all(self._h, C.c_int(int(exponent)), _ptr(counts, C.c_int64),
+                                               _ptr(values, C.c_double), _ptr(shared, C.c_double),
+                                               _ptr(scores, C.c_double)), "pgx_score_fetch_all")
+        return dict(counts=counts, values=values, shared=shared, scores=scores)
+
+    def compound_allreduce_max(self):
+        self._ck(self._lib.pgx_compound_allreduce_max(self._h), "pgx_compound_allreduce_max")

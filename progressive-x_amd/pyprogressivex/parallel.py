@@ -1,0 +1,169 @@
+"""Multi-GPU sharding of the proposal loop — one process per GPU.
+
+Hypotheses are independent given (points, compound preference vector, T2): a batch of M hypotheses is split into
+contiguous shards, every rank scores its shard against ALL points on its own GPU, and one all-gather of the
+per-hypothesis (count, value, shared) triples (24 B each) makes the full score table available on every rank, which
+then runs the same deterministic selection (ties -> lowest hypothesis index, i.e. the sequential "first best wins").
+The reference has no counterpart (single-threaded CPU: progressive_x.h:251-489, no collectives anywhere).
+
+Data plane: RCCL all-gather inside libpgx.so (pgx_score_allgather), bootstrapped here with a file rendezvous for the
+ncclUniqueId (single node, which is what the launch contract covers).  For CPU tests of this host logic the exchange
+runs over torch.distributed/gloo with an injected scorer.
+"""
+import os
+import time
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharding / merging (pure host logic, backend independent)
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_bounds(M, world):
+    """Contiguous shards of equal padded length: (per_rank, [(lo, hi)] * world)."""
+    per = (M + world - 1) // world
+    return per, [(min(M, r * per), min(M, (r + 1) * per)) for r in range(world)]
+
+
+def shard_hypotheses(models, world, rank):
+    """This rank's shard, padded with NaN models (a NaN model never has an inlier) to the common shard length."""
+    models = np.ascontiguousarray(models, dtype=np.float64)
+    M, P = models.shape
+    per, bounds = shard_bounds(M, world)
+    lo, hi = bounds[rank]
+    shard = np.full((per, P), np.nan, dtype=np.float64)
+    shard[: hi - lo] = models[lo:hi]
+    return shard, lo, hi
+
+
+def merge_gathered(gathered, M, world):
+    """rank-major gathered arrays of length world*per -> the first M entries in global hypothesis order."""
+    per, bounds = shard_bounds(M, world)
+    out = {}
+    for key, arr in gathered.items():
+        arr = np.asarray(arr).reshape(world, per)
+        out[key] = np.concatenate([arr[r, : hi - lo] for r, (lo, hi) in enumerate(bounds)])
+    return out
+
+
+def select_best(scores, counts):
+    """Deterministic winner: highest score, ties -> lowest index; hypotheses without inliers never win."""
+    scores = np.where(np.asarray(counts) > 0, np.asarray(scores, dtype=np.float64), -np.inf)
+    scores = np.where(np.isnan(scores), -np.inf, scores)
+    best = int(np.argmax(scores))
+    return best if np.isfinite(scores[best]) else -1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rank environment + file rendezvous for the RCCL unique id
+# ---------------------------------------------------------------------------------------------------------------------
+def rank_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+def _launcher_key():
+    """Same value in every worker of one torchrun launch on this node, different between launches."""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: starttime
+    except OSError:
+        pass
+    return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+
+
+def exchange_unique_id(rank, world, make_id, timeout=300.0):
+    """rank 0 creates the 128-byte ncclUniqueId and publishes it through an atomically renamed file."""
+    if world == 1:
+        return make_id()
+    base = os.environ.get("PGX_RDV_DIR", "/tmp")
+    path = os.path.join(base, f"pgx_rdv_{_launcher_key()}.id")
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except OSError:
+            pass
+        time.sleep(0.05)
+    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout}s")
+
+
+def cleanup_unique_id(rank):
+    if rank == 0:
+        try:
+            os.remove(os.path.join(os.environ.get("PGX_RDV_DIR", "/tmp"), f"pgx_rdv_{_launcher_key()}.id"))
+        except OSError:
+            pass
+
+
+def init_rccl(ctx, rank, world):
+    """Binds `ctx` (a _lib.Context on this rank's GPU) into the node-wide RCCL communicator."""
+    from . import _lib
+    uid = exchange_unique_id(rank, world, _lib.comm_unique_id)
+    ctx.comm_init(world, rank, uid)
+    ctx.comm_barrier()
+    cleanup_unique_id(rank)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded scoring
+# ---------------------------------------------------------------------------------------------------------------------
+class RcclExchange:
+    """Data plane on the GPUs: libpgx's RCCL all-gather over xGMI."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.world, self.rank = ctx.nranks, ctx.rank
+
+    def score_shard(self, shard, T2, has_compound, exponent):
+        self.ctx.score_upload(shard)
+        self.ctx.score_launch(T2, has_compound=has_compound)
+        if self.world == 1:
+            return self.ctx.score_fetch(exponent)
+        self.ctx.score_allgather()
+        return self.ctx.score_fetch_all(exponent)
+
+
+class GlooExchange:
+    """CPU stand-in for tests of the host logic: `scorer(shard) -> dict` is injected, exchange over torch.distributed."""
+
+    def __init__(self, scorer, world, rank):
+        self.scorer, self.world, self.rank = scorer, world, rank
+
+    def score_shard(self, shard, T2, has_compound, exponent):
+        import torch
+        import torch.distributed as dist
+        local = self.scorer(shard, T2, has_compound, exponent)
+        if self.world == 1:
+            return local
+        out = {}
+        for key in ("counts", "values", "shared", "scores"):
+            t = torch.from_numpy(np.ascontiguousarray(local[key]))
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t)
+            out[key] = torch.cat(parts).numpy()
+        return out
+
+
+def score_sharded(exchange, models, T2, has_compound=False, exponent=2):
+    """Scores `models` (the same full batch on every rank) cooperatively; every rank returns the full table."""
+    models = np.ascontiguousarray(models, dtype=np.float64)
+    M = models.shape[0]
+    shard, lo, hi = shard_hypotheses(models, exchange.world, exchange.rank)
+    gathered = exchange.score_shard(shard, T2, has_compound, exponent)
+    keys = {k: gathered[k] for k in ("counts", "values", "shared", "scores")}
+    return merge_gathered(keys, M, exchange.world)

@@ -1,0 +1,96 @@
+// mf_emu.cpp — sequential CPU emulation of the HIP push-relabel expansion move (TEST INFRASTRUCTURE).
+//
+// Compiles progressive-x_amd/csrc/maxflow_body.cuh + maxflow_driver.inl with g++ and runs every "kernel" as a loop
+// over sites in a (optionally shuffled) order.  It lets `pytest -m "not gpu"` check the algorithm that the GPU runs
+// (graph construction, hub handling, BFS/sweep orchestration, termination) against the oracle's Dinic solver on
+// thousands of random instances without a GPU.  It is never loaded by the product package.
+#include <cstdint>
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "../../progressive-x_amd/csrc/maxflow_driver.inl"
+
+using namespace pgx;
+
+namespace {
+
+struct EmuBackend {
+    std::mt19937_64 rng;
+    bool shuffle;
+    std::vector<int64_t> order;
+    explicit EmuBackend(int64_t n, uint64_t seed) : rng(seed), shuffle(seed != 0), order((size_t)n)
+    {
+        std::iota(order.begin(), order.end(), 0);
+    }
+    template <class F> void each(F f)
+    {
+        if (shuffle) std::shuffle(order.begin(), order.end(), rng);
+        for (int64_t u : order) f(u);
+    }
+    void count_and_setup(const MfView& v)
+    {
+        for (int l = 0; l < v.L; ++l) v.cnt[l] = 0;
+        each([&](int64_t u) { mf_body_count(v, u); });
+        mf_body_hub_setup(v);
+    }
+    int read_count(const MfView& v, int l) { return v.cnt[l]; }
+    void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
+    void bfs_reset(const MfView& v) { mf_body_bfs_reset(v); }
+    void bfs_init(const MfView& v) { each([&](int64_t u) { mf_body_bfs_init(v, u); }); }
+    void bfs_level(const MfView& v, int k) { each([&](int64_t u) { mf_body_bfs_level(v, u, k); }); }
+    int read_flag(const MfView& v, int i) { return v.flags[i]; }
+    void bfs_finish(const MfView& v, int slot) { mf_body_bfs_finish(v, slot); }
+    void count_active(const MfView& v) { each([&](int64_t u) { mf_body_count_active(v, u); }); }
+    void sweep(const MfView& v, int prev, int cur) { each([&](int64_t u) { mf_body_sweep(v, u, prev, cur); }); }
+    void sweep_epilogue(const MfView& v, int cur, int next) { mf_body_sweep_epilogue(v, cur, next); }
+    void apply(const MfView& v) { each([&](int64_t u) { mf_body_apply(v, u); }); }
+};
+
+}  // namespace
+
+extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major, const int32_t* off,
+                                const int32_t* idx, const int32_t* mult, int64_t lambda_q, int64_t h_q, int alpha,
+                                int32_t* labels, uint64_t order_seed, int sweeps_per_relabel, int64_t* changed,
+                                int64_t* stats)
+{
+    std::vector<long long> dq((size_t)n * L);
+    for (int64_t i = 0; i < n; ++i)
+        for (int l = 0; l < L; ++l) dq[(size_t)l * n + i] = Dq_point_major[i * L + l];
+    const bool pair = off != nullptr && lambda_q > 0;
+    const int64_t E = pair ? off[n] : 0;
+    std::vector<int> rev((size_t)(E > 0 ? E : 1));
+    if (pair)
+        for (int64_t u = 0; u < n; ++u)
+            for (int a = off[u]; a < off[u + 1]; ++a) {
+                const int q = idx[a];
+                int r = -1;
+                for (int b = off[q]; b < off[q + 1]; ++b) if (idx[b] == u) { r = b; break; }
+                if (r < 0) return -10;  // graph not symmetric
+                rev[a] = r;
+            }
+    std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
+        hub_e((size_t)L), hubA_rt(1);
+    std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
+        bfs_hubA_d(1), hub_min((size_t)3 * L), flags(8);
+    std::vector<unsigned long long> hubA_min(3);
+    MfView v;
+    v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
+    v.dq = dq.data(); v.labels = labels;
+    v.off = pair ? off : nullptr; v.idx = idx; v.mult = mult; v.rev = rev.data();
+    v.cap = cap.data(); v.ex = ex.data(); v.rt = rt.data(); v.d = d.data(); v.f = f.data(); v.g = g.data();
+    v.cnt = cnt.data(); v.hub_exists = hub_exists.data(); v.hub_e = hub_e.data();
+    v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.bfs_hub_d = bfs_hub_d.data();
+    v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
+    v.flags = flags.data();
+    v.hmax = (int)(n + L + 3);
+    EmuBackend be(n, order_seed);
+    MfTuning tune;
+    if (sweeps_per_relabel > 0) { tune.sweeps_per_relabel = sweeps_per_relabel; tune.sweep_check = 1; }
+    int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r = mf_expand_alpha(be, v, tune, changed, st);
+    if (stats) for (int k = 0; k < 8; ++k) stats[k] = st[k];
+    return r;
+}

@@ -1,0 +1,284 @@
+"""GPU parity: the HIP hot path (through the C ABI of libpgx.so) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer work — inlier counts/masks, quantised unary costs, labels, energies, bucket
+orders — bit-exact; floating-point sums (scores, Tanimoto terms, residual sums) within 1e-5 relative (asserted at
+1e-9, only the summation order differs).  Residual-derived values that involve no reduction (preference vectors,
+compound max) are required to be bit-identical: the kernels use the oracle's operation order with FMA contraction off.
+"""
+import numpy as np
+import pytest
+
+from helpers import (MODEL_CASES, make_case, random_sym_graph, realistic_labeling_problem)
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b) / np.maximum(1e-300, np.maximum(np.abs(a), np.abs(b)))) if a.size else 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a2 / a3 / a4 : preference vector (bit-exact), Tanimoto terms, compound max
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 20011])
+def test_preference_bit_exact(gpu_ctx, oracle, name, n):
+    mt, pts, models, thr = make_case(name, n, 3, seed=n)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    comp = np.random.default_rng(7).uniform(0, 1, n)
+    gpu_ctx.set_compound(comp)
+    for k, model in enumerate(models):
+        got = gpu_ctx.preference(model, T2, slot=k, want_pref=True)
+        ref = oracle.preference(mt, pts, model, T2)
+        assert np.array_equal(got["pref"], ref), f"{name}: preference vector differs from the oracle"
+        d, a, b = oracle.tanimoto_terms(ref, comp)
+        assert abs(got["dot"] - d) <= REL * max(abs(d), 1e-300)
+        assert abs(got["pref_sqnorm"] - a) <= REL * max(abs(a), 1e-300)
+        assert abs(got["comp_sqnorm"] - b) <= REL * max(abs(b), 1e-300)
+        assert np.array_equal(gpu_ctx.get_preference(k), ref)
+    prefs = np.stack([oracle.preference(mt, pts, m, T2) for m in models])
+    got_c = gpu_ctx.compound_update(np.arange(len(models)), want_compound=True)
+    assert np.array_equal(got_c, oracle.compound_max(prefs))
+    # K == 0 leaves the compound vector untouched (progressive_x.h:600-601)
+    assert np.array_equal(gpu_ctx.compound_update(np.zeros(0, np.int32), want_compound=True), got_c)
+
+
+def test_preference_huge_threshold_exercises_every_lane(gpu_ctx, oracle):
+    # with T2 huge every pref is in (0,1): bit-equality of pref == bit-equality of every squared residual
+    for name in MODEL_CASES:
+        mt, pts, models, thr = make_case(name, 5000, 2, seed=3)
+        gpu_ctx.set_points(mt, pts)
+        for model in models:
+            sq = oracle.squared_residuals(mt, pts, model)
+            T2 = float(np.nanmax(sq[np.isfinite(sq)]) * 4 + 1)
+            got = gpu_ctx.preference(model, T2, slot=0, want_pref=True)["pref"]
+            assert np.array_equal(got, oracle.preference(mt, pts, model, T2)), name
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a1 : batched scoring
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("n,M", [(1, 1), (64, 3), (65, 257), (4097, 64), (20000, 300)])
+def test_score_matches_oracle(gpu_ctx, oracle, name, n, M):
+    mt, pts, models, thr = make_case(name, n, M, seed=n + M)
+    T2 = 2.25 * thr * thr
+    comp = np.random.default_rng(11).uniform(0, 1, n) * (np.random.default_rng(12).uniform(0, 1, n) < 0.5)
+    gpu_ctx.set_points(mt, pts)
+    for has_compound, exponent in ((False, 2), (True, 2), (True, 3), (True, 1)):
+        gpu_ctx.set_compound(comp if has_compound else None)
+        got = gpu_ctx.score(models, T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+        ref = oracle.score(mt, pts, models, T2, compound=comp, has_compound=has_compound, exponent=exponent,
+                           want_masks=True)
+        assert np.array_equal(got["counts"], ref["counts"]), f"{name}: inlier counts differ"
+        assert np.array_equal(got["masks"], ref["masks"]), f"{name}: inlier masks differ"
+        assert _rel(got["values"], ref["values"]) <= REL
+        assert _rel(got["shared"], ref["shared"]) <= REL
+        scale = np.maximum(np.abs(ref["values"]), np.abs(ref["shared"]) ** exponent) + 1e-300
+        assert np.max(np.abs(got["scores"] - ref["scores"]) / scale) <= 1e-9
+        # counts == popcount of the mask rows (checksum of the mask against the counter)
+        pop = np.array([sum(bin(int(w)).count("1") for w in row) for row in got["masks"]])
+        assert np.array_equal(pop, got["counts"])
+        # same launch without masks gives identical numbers (different template instance)
+        again = gpu_ctx.score(models, T2, has_compound=has_compound, exponent=exponent, want_masks=False)
+        assert np.array_equal(again["counts"], got["counts"]) and np.array_equal(again["values"], got["values"])
+
+
+def test_score_threshold_boundary_is_strict(gpu_ctx, oracle):
+    # line x = 0, points at |x| = 2 exactly: r^2 == T2 = 4 -> NOT an inlier for the scorer (strict <, :85) ...
+    mt = 0
+    pts = np.array([[2.0, 5.0], [-2.0, 1.0], [1.999999, 0.0], [0.0, 0.0], [2.0000001, 3.0]])
+    model = np.array([[1.0, 0.0, 0.0]])
+    gpu_ctx.set_points(mt, pts)
+    got = gpu_ctx.score(model, 4.0, want_masks=True)
+    ref = oracle.score(mt, pts, model, 4.0, want_masks=True)
+    assert got["counts"][0] == ref["counts"][0] == 2
+    assert np.array_equal(got["masks"], ref["masks"])
+    # ... but IS within the threshold for PEARL's data term (r^2 > T2 test, PEARL.h:123): thr with 9/4 thr^2 == 4
+    thr = 4.0 / 3.0
+    Dq = gpu_ctx.pearl_unary(model, thr, 0.25, want_table=True)
+    assert np.array_equal(Dq, oracle.unary_q(mt, pts, model, thr, 0.25))
+
+
+def test_score_early_exit_predicate_is_order_free(oracle):
+    # scoring_function_with_compound_model.h:105-106 fires iff count + 1 < best: pure function of the full count,
+    # which is why the batched kernel needs no point ordering (checked on the oracle itself; host logic applies it).
+    mt, pts, models, thr = make_case("line", 500, 20, seed=5)
+    T2 = 2.25 * thr * thr
+    full = oracle.score(mt, pts, models, T2)
+    for best in (0, 1, 5, 50, 400):
+        cut = oracle.score(mt, pts, models, T2, best_inlier_number=np.full(len(models), best))
+        interrupted = full["counts"] + 1 < best
+        assert np.array_equal(cut["counts"], np.where(interrupted, 0, full["counts"]))
+
+
+def test_score_is_reproducible_and_batch_invariant(gpu_ctx):
+    mt, pts, models, thr = make_case("pnp", 30000, 512, seed=9)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    a = gpu_ctx.score(models, T2)
+    b = gpu_ctx.score(models, T2)
+    assert np.array_equal(a["values"], b["values"]) and np.array_equal(a["counts"], b["counts"])
+    # scoring a sub-batch gives bitwise the same per-hypothesis numbers when the point chunking is unchanged
+    c = gpu_ctx.score(models[:256], T2)
+    assert np.array_equal(c["counts"], a["counts"][:256])
+    assert _rel(c["values"], a["values"][:256]) <= REL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a6 : unary table
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_unary_table_bit_exact(gpu_ctx, oracle, name):
+    mt, pts, models, thr = make_case(name, 3001, 7, seed=21)
+    gpu_ctx.set_points(mt, pts)
+    for lam in (0.0, 0.1, 0.5):
+        got = gpu_ctx.pearl_unary(models, thr, lam, want_table=True)
+        assert np.array_equal(got, oracle.unary_q(mt, pts, models, thr, lam)), name
+    got0 = gpu_ctx.pearl_unary(None, thr, 0.3, want_table=True)  # K = 0: only the outlier label
+    assert got0.shape == (3001, 1) and np.all(got0 == oracle.quantize(0.7))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a9 : bucket + residual sums
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,L", [(1, 2), (255, 3), (256, 4), (257, 11), (100003, 7)])
+def test_bucket_matches_oracle(gpu_ctx, oracle, n, L):
+    rng = np.random.default_rng(n)
+    labels = rng.integers(0, L + 1, n).astype(np.int32)  # includes values >= L-1 -> outlier bucket
+    gpu_ctx.set_labels(labels)
+    counts, order = gpu_ctx.bucket(L)
+    rc, ro = oracle.bucket(labels, L)
+    assert np.array_equal(counts, rc)
+    assert np.array_equal(order, ro)  # stable: ascending point index inside every bucket (PEARL.h:342-352)
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_residual_sum(gpu_ctx, oracle, name):
+    mt, pts, models, thr = make_case(name, 5003, 2, seed=31)
+    labels = np.random.default_rng(1).integers(0, 3, 5003).astype(np.int32)
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.set_labels(labels)
+    for k, model in enumerate(models):
+        got = gpu_ctx.residual_sum(model, k)
+        ref = oracle.residual_sum(mt, pts, model, labels, k)
+        assert abs(got - ref) <= REL * max(abs(ref), 1e-300), name
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a8 / a19 : energy, single expansion moves, full expansion
+# ----------------------------------------------------------------------------------------------------------------------
+def test_energy_and_moves_random_small(gpu_ctx, oracle):
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        n = int(rng.integers(2, 300))
+        L = int(rng.integers(2, 7))
+        Dq = (rng.integers(0, 1 << 20, (n, L)) << 12).astype(np.int64)
+        graph = random_sym_graph(rng, n, float(rng.choice([0.0, 0.02, 0.2])))
+        lam = float(rng.choice([0.0, 0.1, 0.45]))
+        h = float(rng.choice([0.0, 0.0005, 0.01, 2.0]))
+        lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+        labels = rng.integers(0, L, n).astype(np.int32)
+        if trial % 3 == 0:
+            labels[:] = rng.integers(0, L)
+        gpu_ctx.set_unary_q(Dq)
+        gpu_ctx.set_graph(*graph)
+        gpu_ctx.set_labels(labels)
+        eq, e = gpu_ctx.energy(lam, h)
+        assert eq == oracle.energy(Dq, graph, lq, hq, labels)
+        assert e == eq / 2.0 ** 32
+        for alpha in rng.permutation(L):
+            ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, int(alpha), labels)
+            changed = gpu_ctx.expand_alpha(lam, h, int(alpha))
+            got = gpu_ctx.get_labels()
+            assert np.array_equal(got, ref), f"trial {trial} alpha {alpha}: labels differ from the oracle min-cut"
+            assert changed == ref_changed
+            labels = ref
+
+
+@pytest.mark.parametrize("n,lam,h", [(3000, 0.3, 10.0), (3000, 0.0, 10.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0)])
+def test_full_expansion_matches_oracle(gpu_ctx, oracle, n, lam, h):
+    Dq, graph = realistic_labeling_problem(n, L=6, lam=lam, seed=n)
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    labels0 = np.zeros(n, dtype=np.int32)
+    ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, labels0)
+    gpu_ctx.set_unary_q(Dq)
+    gpu_ctx.set_graph(*graph)
+    gpu_ctx.set_labels(labels0)
+    eq, e, cycles = gpu_ctx.expansion(lam, h)
+    assert np.array_equal(gpu_ctx.get_labels(), ref_labels)
+    assert eq == ref_e and cycles == ref_cycles
+    # idempotence: a second run from the optimum changes nothing and needs exactly one (empty) cycle
+    eq2, _, cycles2 = gpu_ctx.expansion(lam, h)
+    assert eq2 == eq and cycles2 == 1 and np.array_equal(gpu_ctx.get_labels(), ref_labels)
+    st = gpu_ctx.expansion_stats()
+    assert st["relabelled_sites"] == 0
+
+
+def test_expansion_energy_never_increases(gpu_ctx, oracle):
+    Dq, graph = realistic_labeling_problem(5000, L=5, lam=0.2, seed=77)
+    lam, h = 0.2, 8.0
+    gpu_ctx.set_unary_q(Dq)
+    gpu_ctx.set_graph(*graph)
+    gpu_ctx.set_labels(np.random.default_rng(0).integers(0, 5, 5000).astype(np.int32))
+    prev, _ = gpu_ctx.energy(lam, h)
+    for cycle in range(3):
+        for alpha in range(5):
+            gpu_ctx.expand_alpha(lam, h, alpha)
+            cur, _ = gpu_ctx.energy(lam, h)
+            assert cur <= prev
+            prev = cur
+
+
+def test_asymmetric_graph_is_rejected(gpu_ctx):
+    from pyprogressivex._lib import PgxError
+    off = np.array([0, 1, 1], dtype=np.int32)
+    with pytest.raises(PgxError):
+        gpu_ctx.set_graph(off, np.array([1], np.int32), np.array([1], np.int32))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# full BASELINE size: 1e6 2D-3D correspondences x 2048 pose hypotheses, size-independent properties
+# ----------------------------------------------------------------------------------------------------------------------
+def test_metric_batch_full_size_properties(gpu_ctx, oracle):
+    from pyprogressivex import datasets
+    x1, x2, K, gt_labels, gt_poses = datasets.make_poses()
+    pts, f = datasets.normalize_pnp(x1, x2, K)
+    hyps = datasets.make_pose_hypotheses(gt_poses, M=2048)
+    thr = 4.0 / f
+    T2 = 2.25 * thr * thr
+    n = pts.shape[0]
+    assert n == 1000000 and hyps.shape == (2048, 12)
+    gpu_ctx.set_points(3, pts)
+    comp = np.zeros(n)
+    comp[:50000] = 0.5
+    gpu_ctx.set_compound(comp)
+    full = gpu_ctx.score(hyps, T2, has_compound=True, exponent=2)
+    # (1) the 16 ground-truth poses recover (almost all of) their 5e4 inliers
+    assert np.all(full["counts"][:16] > 45000)
+    # (2) oracle on a bounded sample of hypotheses over ALL points: counts exact, sums to 1e-9
+    sample = np.array([0, 5, 15, 16, 100, 2047])
+    ref = oracle.score(3, pts, hyps[sample], T2, compound=comp, has_compound=True, exponent=2)
+    assert np.array_equal(full["counts"][sample], ref["counts"])
+    assert _rel(full["values"][sample], ref["values"]) <= REL
+    assert _rel(full["shared"][sample], ref["shared"]) <= REL
+    # (3) additivity over a split of the points (integer counts add exactly)
+    half = n // 2
+    gpu_ctx.set_points(3, pts[:half])
+    a = gpu_ctx.score(hyps, T2)
+    gpu_ctx.set_points(3, pts[half:])
+    b = gpu_ctx.score(hyps, T2)
+    assert np.array_equal(a["counts"] + b["counts"], full["counts"])
+    assert _rel(a["values"] + b["values"], full["values"]) <= 1e-9
+    # (4) masks of a 64-hypothesis slice agree with the counters and with the oracle's mask for one of them
+    gpu_ctx.set_points(3, pts)
+    m64 = gpu_ctx.score(hyps[:64], T2, want_masks=True)
+    pop = np.unpackbits(m64["masks"].view(np.uint8), axis=1).sum(axis=1)
+    assert np.array_equal(pop, m64["counts"])
+    refm = oracle.score(3, pts, hyps[3:4], T2, want_masks=True)
+    assert np.array_equal(refm["masks"][0], m64["masks"][3])

@@ -1,0 +1,255 @@
+"""CPU tests of the oracle itself: hand-checkable known answers, exact-rational cross-checks of every residual formula,
+max-flow against scipy, expansion moves against brute force, and the committed golden vectors.
+
+The reference ships no tests or golden vectors for this path => parity is UNPINNED against upstream;
+these tests pin the oracle against the mathematics it restates and against regressions.
+"""
+import itertools
+import os
+from fractions import Fraction as Fr
+
+import numpy as np
+import pytest
+
+from helpers import MODEL_CASES, make_case, random_sym_graph
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_v1.npz")
+
+
+# ---- hand-checkable residuals ----------------------------------------------------------------------------------------
+def test_residual_known_answers(oracle):
+    O = oracle
+    # axis-aligned line x = 3:  (1, 0, -3)
+    assert O.squared_residuals(O.LINE2D, [[5.0, 9.0], [3.0, -1.0]], [1.0, 0.0, -3.0]).tolist() == [4.0, 0.0]
+    # identity homography: residual = squared displacement
+    assert O.squared_residuals(O.HOMOGRAPHY, [[1, 2, 4, 6]], np.eye(3).reshape(-1)).tolist() == [25.0]
+    # pure translation (2, 0): maps (1,2) -> (3,2)
+    H = np.array([1, 0, 2, 0, 1, 0, 0, 0, 1.0])
+    assert O.squared_residuals(O.HOMOGRAPHY, [[1, 2, 3, 2]], H).tolist() == [0.0]
+    # symmetric transfer error under identity = 2 x one-way
+    Hs = np.concatenate([np.eye(3).reshape(-1), np.eye(3).reshape(-1)])
+    assert O.squared_residuals(O.HOMOGRAPHY_SYM, [[1, 2, 4, 6]], Hs).tolist() == [50.0]
+    # pure x-translation F = [t]_x with t = (1,0,0): epipolar lines are horizontal, Sampson = dy^2 / 2
+    F = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0.0])
+    assert O.squared_residuals(O.FUNDAMENTAL, [[0, 0, 7, 0], [0, 0, 7, 2]], F).tolist() == [0.0, 2.0]
+    # PnP, P = [I | 0]: projection of (2, 4, 2) is (1, 2)
+    P = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(-1)
+    assert O.squared_residuals(O.PNP, [[1, 2, 2, 4, 2], [0, 0, 2, 4, 2]], P).tolist() == [0.0, 5.0]
+    # vanishing point at infinity in direction x (v2 = 0): horizontal segments have zero residual
+    vp = np.array([1.0, 0.0, 0.0])
+    assert O.squared_residuals(O.VANISHING_POINT, [[0, 5, 10, 5]], vp).tolist() == [0.0]
+    # vertical segment of half-length 3: its start point is 3 px away from the horizontal line through its midpoint
+    assert O.squared_residuals(O.VANISHING_POINT, [[4, 2, 4, 8]], vp).tolist() == [9.0]
+    # unsquared residual used by PEARL's refit test
+    assert O.residual(O.LINE2D, [5.0, 9.0], [1.0, 0.0, -3.0]) == 2.0
+    assert O.residual(O.HOMOGRAPHY, [1, 2, 4, 6], np.eye(3).reshape(-1)) == 5.0
+
+
+def _exact_sq(name, p, m):
+    p = [Fr(float(x)) for x in p]
+    m = [Fr(float(x)) for x in m]
+    if name == "line":
+        return (m[0] * p[0] + m[1] * p[1] + m[2]) ** 2
+    if name in ("homography", "homography_sym"):
+        t1 = m[0] * p[0] + m[1] * p[1] + m[2]
+        t2 = m[3] * p[0] + m[4] * p[1] + m[5]
+        t3 = m[6] * p[0] + m[7] * p[1] + m[8]
+        r = (p[2] - t1 / t3) ** 2 + (p[3] - t2 / t3) ** 2
+        if name == "homography_sym":
+            g = m[9:]
+            s1 = g[0] * p[2] + g[1] * p[3] + g[2]
+            s2 = g[3] * p[2] + g[4] * p[3] + g[5]
+            s3 = g[6] * p[2] + g[7] * p[3] + g[8]
+            r += (p[0] - s1 / s3) ** 2 + (p[1] - s2 / s3) ** 2
+        return r
+    if name == "fundamental":
+        x1, y1, x2, y2 = p
+        Fx = [m[0] * x1 + m[1] * y1 + m[2], m[3] * x1 + m[4] * y1 + m[5], m[6] * x1 + m[7] * y1 + m[8]]
+        Ftx = [m[0] * x2 + m[3] * y2 + m[6], m[1] * x2 + m[4] * y2 + m[7], m[2] * x2 + m[5] * y2 + m[8]]
+        num = (x2 * Fx[0] + y2 * Fx[1] + Fx[2]) ** 2
+        return num / (Fx[0] ** 2 + Fx[1] ** 2 + Ftx[0] ** 2 + Ftx[1] ** 2)
+    if name == "pnp":
+        u, v, X, Y, Z = p
+        px = m[0] * X + m[1] * Y + m[2] * Z + m[3]
+        py = m[4] * X + m[5] * Y + m[6] * Z + m[7]
+        pz = m[8] * X + m[9] * Y + m[10] * Z + m[11]
+        return (u - px / pz) ** 2 + (v - py / pz) ** 2
+    if name == "vanishing_point":
+        xs, ys, xe, ye = p
+        mx, my = (xs + xe) / 2, (ys + ye) / 2
+        lx, ly, lz = my * m[2] - m[1], -(mx * m[2] - m[0]), mx * m[1] - my * m[0]
+        return (lx * xs + ly * ys + lz) ** 2 / (lx * lx + ly * ly)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_residuals_against_exact_rational_arithmetic(oracle, name):
+    """Independent check of every formula: evaluate the published definition in exact rational arithmetic."""
+    mt, pts, models, thr = make_case(name, 40, 4, seed=1)
+    for model in models:
+        got = oracle.squared_residuals(mt, pts, model)
+        for i in range(pts.shape[0]):
+            ex = float(_exact_sq(name, pts[i], model))
+            assert abs(got[i] - ex) <= 1e-9 * max(abs(ex), 1e-30) + 1e-18 * max(1.0, abs(ex)), (name, i)
+
+
+# ---- a1 semantics -----------------------------------------------------------------------------------------------------
+def test_score_semantics(oracle):
+    O = oracle
+    pts = np.array([[0.0, 0], [1.0, 0], [2.0, 0], [3.0, 0]])
+    model = np.array([[1.0, 0, 0]])  # r^2 = x^2 : 0, 1, 4, 9
+    s = O.score(O.LINE2D, pts, model, 4.0, want_masks=True)
+    assert s["counts"][0] == 2 and s["masks"][0, 0] == 0b0011          # strict <
+    assert s["values"][0] == (1 - 0 / 4) + (1 - 1 / 4) and s["shared"][0] == 0.0
+    assert s["scores"][0] == s["values"][0]                            # empty compound: no subtraction (:110)
+    comp = np.array([0.5, 1.0, 1.0, 1.0])
+    s2 = O.score(O.LINE2D, pts, model, 4.0, compound=comp, exponent=2)
+    assert s2["shared"][0] == min(0.5, 1.0) + min(1.0, 0.75)           # :115-117
+    assert s2["scores"][0] == s2["values"][0] - 1.25 ** 2              # :120
+    s3 = O.score(O.LINE2D, pts, model, 4.0, compound=comp, exponent=0)
+    assert s3["scores"][0] == s3["values"][0] - 1.0                    # pow(x, 0) == 1 is still subtracted
+    # early exit (:105-106): Score() iff count + 1 < best
+    assert O.score(O.LINE2D, pts, model, 4.0, best_inlier_number=[3])["counts"][0] == 2
+    assert O.score(O.LINE2D, pts, model, 4.0, best_inlier_number=[4])["counts"][0] == 0
+
+
+def test_preference_tanimoto_compound_unseen(oracle):
+    O = oracle
+    pts = np.array([[0.0, 0], [1.0, 0], [3.0, 0]])
+    pref = O.preference(O.LINE2D, pts, [1.0, 0, 0], 4.0)
+    assert pref.tolist() == [1.0, 0.75, 0.0]                           # max(0, 1 - r^2/T^2), progx_model.h:85
+    d, a, b = O.tanimoto_terms(pref, np.array([1.0, 0.0, 1.0]))
+    assert (d, a, b) == (1.0, 1.0 + 0.5625, 2.0)
+    ok, t = O.is_valid_tanimoto(d, a, b, 0.5)
+    assert t == 1.0 / (1.5625 + 2.0 - 1.0) and ok                      # 0.39 < 0.5 -> valid
+    assert not O.is_valid_tanimoto(d, a, b, 0.3)[0]
+    ok, t = O.is_valid_tanimoto(0.0, 0.0, 0.0, 0.4)                    # 0/0 = NaN -> valid (progressive_x.h:587)
+    assert ok and np.isnan(t)
+    assert O.compound_max(np.array([[0.1, 0.9, 0.0], [0.5, 0.2, 0.0]])).tolist() == [0.5, 0.9, 0.0]
+    # progressive_x.h:495-513
+    for args in [(0.5, 4, 1000, 1, 5000), (0.1, 3, 400, 600, 1886), (0.05, 2, 10, 0, 100)]:
+        omc, m, it, cov, n = args
+        want = int(round((n - cov) * (1 - omc ** (1.0 / it)) ** (1.0 / m)))
+        assert O.predicted_unseen_inliers(*args) == want
+
+
+def test_unary_semantics(oracle):
+    O = oracle
+    pts = np.array([[0.0, 0], [1.0, 0], [2.0, 0], [2.5, 0]])
+    thr, lam = 4.0 / 3.0, 0.25                                         # T2 = 9/4 thr^2 = 4
+    D = O.unary(O.LINE2D, pts, [[1.0, 0, 0]], thr, lam)
+    T2 = 9.0 / 4.0 * thr * thr
+    assert D[:, 1].tolist() == [0.75] * 4                              # outlier label: 1 - lambda (PEARL.h:100-101)
+    assert D[0, 0] == 0.0 and D[1, 0] == 0.75 * 1.0 / T2
+    assert D[2, 0] == 0.75 * 4.0 / T2                                  # r^2 == T2 is NOT beyond the threshold (:123)
+    assert D[3, 0] == 1.5                                              # beyond: 2 (1 - lambda)
+    Dq = O.unary_q(O.LINE2D, pts, [[1.0, 0, 0]], thr, lam)
+    assert Dq[3, 0] == 3 << 31 and Dq[0, 1] == 3 << 30
+    assert O.quantize_lambda(0.25) == 1 << 30 and O.quantize_lambda(0.1) % 2 == 0
+
+
+# ---- max-flow / expansion ----------------------------------------------------------------------------------------------
+def test_maxflow_against_scipy(oracle):
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_flow
+    rng = np.random.default_rng(0)
+    for _ in range(150):
+        nn = int(rng.integers(4, 14))
+        na = int(rng.integers(5, 50))
+        fr, to = rng.integers(0, nn, na), rng.integers(0, nn, na)
+        keep = fr != to
+        fr, to = fr[keep], to[keep]
+        cap = rng.integers(0, 30, len(fr))
+        f, side = oracle.maxflow(nn, fr, to, cap, 0, nn - 1)
+        A = np.zeros((nn, nn), dtype=np.int32)
+        np.add.at(A, (fr, to), cap)
+        assert f == maximum_flow(csr_matrix(A), 0, nn - 1).flow_value
+        assert side[nn - 1] == 1 and (f == 0 or side[0] == 0)
+
+
+def _energy_py(Dq, graph, lq, hq, lab):
+    off, idx, mult = graph
+    e = sum(int(Dq[i, lab[i]]) for i in range(len(lab)))
+    for i in range(len(lab)):
+        for a in range(off[i], off[i + 1]):
+            if idx[a] < i and lab[idx[a]] != lab[i]:
+                e += lq * int(mult[a])
+    return e + hq * len(set(int(x) for x in lab))
+
+
+def test_expansion_move_is_optimal_and_maximal(oracle):
+    """Every move must (1) reach the minimum over all 2^k binary moves and (2) be the UNION of all optimal moves
+    (ties -> alpha; BK's what_segment default SOURCE) — brute force on <= 9 sites."""
+    rng = np.random.default_rng(1)
+    for trial in range(250):
+        n, L = int(rng.integers(2, 10)), int(rng.integers(2, 5))
+        Dq = rng.integers(0, 12, (n, L)).astype(np.int64)
+        graph = random_sym_graph(rng, n, 0.4)
+        lq, hq = int(rng.integers(0, 4)) * 2, int(rng.integers(0, 8))
+        lab = rng.integers(0, L, n).astype(np.int32)
+        assert oracle.energy(Dq, graph, lq, hq, lab) == _energy_py(Dq, graph, lq, hq, lab)
+        alpha = int(rng.integers(0, L))
+        new, changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, lab)
+        act = [i for i in range(n) if lab[i] != alpha]
+        best, union = None, lab.copy()
+        for bits in itertools.product([0, 1], repeat=len(act)):
+            l2 = lab.copy()
+            for b, i in zip(bits, act):
+                if b == 0:
+                    l2[i] = alpha
+            e = _energy_py(Dq, graph, lq, hq, l2)
+            if best is None or e < best:
+                best, union = e, l2.copy()
+            elif e == best:
+                union[l2 == alpha] = alpha
+        assert _energy_py(Dq, graph, lq, hq, new) == best
+        assert np.array_equal(new, union)
+        assert changed == int(np.sum(new != lab))
+
+
+def test_full_expansion_small_reaches_global_optimum_mostly(oracle):
+    """alpha-expansion is a local search; on tiny instances it must at least never be worse than any single-label
+    labelling and never increase the energy from its start."""
+    rng = np.random.default_rng(4)
+    for _ in range(40):
+        n, L = int(rng.integers(3, 9)), int(rng.integers(2, 4))
+        Dq = rng.integers(0, 20, (n, L)).astype(np.int64)
+        graph = random_sym_graph(rng, n, 0.5)
+        lq, hq = 2 * int(rng.integers(0, 4)), int(rng.integers(0, 10))
+        start = np.zeros(n, np.int32)
+        lab, e, cyc = oracle.expansion(Dq, graph, lq, hq, start)
+        assert e == oracle.energy(Dq, graph, lq, hq, lab) <= oracle.energy(Dq, graph, lq, hq, start)
+        for l in range(L):
+            assert e <= oracle.energy(Dq, graph, lq, hq, np.full(n, l, np.int32))
+        assert 1 <= cyc <= 1000
+
+
+def test_bucket_and_residual_sum(oracle):
+    labels = np.array([2, 0, 1, 0, 5, 2, 1], dtype=np.int32)
+    counts, order = oracle.bucket(labels, 3)                           # L = 3: labels >= 2 are the outlier bucket
+    assert counts.tolist() == [2, 2, 3] and order.tolist() == [1, 3, 2, 6, 0, 4, 5]
+    pts = np.array([[1.0, 0], [2.0, 0], [3.0, 0]])
+    assert oracle.residual_sum(0, pts, [1.0, 0, 0], np.array([1, 0, 1], np.int32), 1) == 4.0
+
+
+# ---- committed golden vectors ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_golden_vectors(oracle, name):
+    g = np.load(GOLDEN)
+    mt = MODEL_CASES[name]
+    pts, models, thr, comp = g[f"{name}_pts"], g[f"{name}_models"], float(g[f"{name}_thr"][0]), g[f"{name}_comp"]
+    T2 = 2.25 * thr * thr
+    assert np.array_equal(oracle.squared_residuals(mt, pts, models[0]), g[f"{name}_sq0"])
+    sc = oracle.score(mt, pts, models, T2, compound=comp, has_compound=True, exponent=2, want_masks=True)
+    for k in ("counts", "values", "shared", "scores", "masks"):
+        assert np.array_equal(sc[k], g[f"{name}_{k}"]), k
+    assert np.array_equal(oracle.preference(mt, pts, models[0], T2), g[f"{name}_pref0"])
+    assert np.array_equal(oracle.unary_q(mt, pts, models[:3], thr, 0.1), g[f"{name}_unary_q"])
+
+
+def test_golden_expansion(oracle):
+    g = np.load(GOLDEN)
+    graph = (g["exp_off"], g["exp_idx"], g["exp_mult"])
+    lab, e, cyc = oracle.expansion(g["exp_Dq"], graph, int(g["exp_lq"][0]), int(g["exp_hq"][0]),
+                                   np.zeros(400, np.int32))
+    assert np.array_equal(lab, g["exp_labels"]) and e == int(g["exp_energy"][0]) and cyc == int(g["exp_cycles"][0])
