@@ -1,8 +1,245 @@
-"""Placeholder — replaced by the full drop-in API in the next milestone."""
+"""The five entry points of the reference's pybind11 module, same names / argument order / defaults / return layout /
+error messages (/root/reference/src/pyprogressivex/src/bindings.cpp:9-392 wrappers, :410-491 defaults) and the
+parameter plumbing of the problem drivers (/root/reference/src/pyprogressivex/src/progressivex_python.cpp:41-666),
+including their quirks: unknown sampler ids print to stderr and return zero models,
+findTwoViewMotions ignores scoring_exponent, findLines ignores weights, only findVanishingPoints forwards do_logging.
+
+Extensions that do not change the reference behaviour when left at their defaults (keyword-only):
+  seed=None                     reproducible sampling (the reference seeds from std::random_device)
+  max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
+  residual="transfer"           findHomographies: "symmetric" switches to the symmetric transfer error (U-1 switch)
+"""
+import sys
+
+import numpy as np
+
+from . import _engine, _estimators, _graph, _lib, _proposal
+
+_ctx = None
 
 
-def _todo(*a, **k):
-    raise NotImplementedError("pyprogressivex API not wired yet")
+def _context():
+    """One GPU context per process (device = $PGX_DEVICE or $LOCAL_RANK or 0).  Raises if libpgx.so or the GPU is
+    missing — there is no CPU path."""
+    global _ctx
+    if _ctx is None:
+        import os
+        dev = int(os.environ.get("PGX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _ctx = _lib.Context(dev)
+    return _ctx
 
 
-find6DPoses = findHomographies = findTwoViewMotions = findFundamentalMatrices = findLines = findVanishingPoints = _todo
+def _as_f64(a):
+    # py::array_t<double> with forcecast (bindings.cpp:10): any dtype is converted; the raw buffer is then read as if
+    # C-contiguous, which np.ascontiguousarray makes explicit
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+
+
+def _shape2(a):
+    if a.ndim < 2:
+        raise ValueError("array must be 2-dimensional")  # pybind11 would fail on buf.shape[1]
+    return a.shape[0], a.shape[1]
+
+
+def _weights(weights_):
+    w = np.asarray(weights_, dtype=np.float64)
+    return None if w.ndim == 0 or w.size == 0 else np.ascontiguousarray(w).reshape(-1)   # bindings.cpp:200-208
+
+
+def _unknown_sampler(sampler_id):
+    # progressivex_python.cpp:240-245 (message kept literally, including its omission of id 3)
+    sys.stderr.write(f"Unknown sampler identifier: {sampler_id}. The accepted samplers are 0 (uniform sampling), "
+                     "1 (PROSAC sampling), 2 (P-NAPSAC sampling)\n")
+
+
+def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
+         maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
+         do_logging=False, weights=None, seed=None, max_outer_iterations=10):
+    n = pts.shape[0]
+    if getattr(sampler_factory, "unknown", False):
+        # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
+        _unknown_sampler(sampler_factory.sampler_id)
+        return [], np.zeros(n, dtype=np.int32), None
+    ctx = _context()
+    rng = np.random.default_rng(seed)
+    graph = _graph.radius_graph(graph_points, radius)       # FlannNeighborhoodGraph(&points, radius) [U-7]
+    sampler = sampler_factory(n, rng, graph)
+    s = _engine.MultiModelSettings()
+    s.minimum_number_of_inliers = int(minimum_point_number)          # progressivex_python.cpp:261
+    s.inlier_outlier_threshold = float(threshold)                    # :263
+    s.set_confidence(float(conf))                                    # :265
+    s.maximum_tanimoto_similarity = float(maximum_tanimoto_similarity)   # :267
+    s.spatial_coherence_weight = float(spatial_coherence_weight)     # :269
+    s.max_iteration_number = int(max_iters)                          # :271
+    if maximum_model_number > 0:                                     # :273-274
+        s.maximum_model_number = int(maximum_model_number)
+    s.point_weights = weights
+    s.max_outer_iterations = int(max_outer_iterations)
+    px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
+                              do_logging=do_logging)
+    models, stats = px.run()
+    labeling = np.asarray(stats.labeling, dtype=np.int64).astype(np.int32)     # bindings.cpp:152-156
+    return models, labeling, stats
+
+
+def _stack(estimator, models, cols):
+    rows = estimator.rows_per_model
+    out = np.zeros((rows * len(models), cols), dtype=np.float64)
+    for k, m in enumerate(models):
+        out[rows * k: rows * (k + 1)] = estimator.output(m.descriptor)
+    return out
+
+
+def _sampler_factory(sampler_id, valid):
+    def make(n, rng, graph):
+        kind = valid[sampler_id]
+        if kind == "uniform":
+            return _proposal.UniformSampler(n, rng)
+        if kind == "prosac":
+            return _proposal.ProsacSampler(n, rng)
+        if kind == "pnapsac":
+            return _proposal.ProgressiveNapsacSampler(n, rng, graph)
+        return _proposal.NapsacSampler(n, rng, graph)
+    make.unknown = sampler_id not in valid
+    make.sampler_id = sampler_id
+    return make
+
+
+def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
+                     neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
+                     minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
+                     do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer"):
+    """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
+    corrs = _as_f64(corrs)
+    n, dim = _shape2(corrs)
+    if dim != 4 or n < 4:
+        raise ValueError("corrs should be an array with dims [n,4], n>=4")           # bindings.cpp:119-124
+    if do_logging and sampler_id == 1:
+        print("Note: PROSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
+    if do_logging and sampler_id == 2:
+        print("Note: Progressive NAPSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
+    est = (_estimators.SymmetricHomographyEstimator() if residual == "symmetric" else _estimators.HomographyEstimator())
+    # NB: the driver never calls progressive_x.log(): do_logging only triggers the sampler notes (:219-226)
+    models, labels, _ = _run(est, corrs, corrs, neighborhood_ball_radius,
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}),
+                             threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
+                             maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
+                             minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
+                             scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
+                             max_outer_iterations=max_outer_iterations)
+    return _stack(est, models, 3), labels
+
+
+def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
+                       neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
+                       minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
+                       do_logging=False, *, seed=None, max_outer_iterations=10):
+    """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
+    corrs = _as_f64(corrs)
+    n, dim = _shape2(corrs)
+    if dim != 4 or n < 7:
+        raise ValueError("corrs should be an array with dims [n,4], n>=7")           # bindings.cpp:344-349
+    if do_logging and sampler_id == 1:
+        print("Note: PROSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
+    if do_logging and sampler_id == 2:
+        print("Note: Progressive NAPSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
+    est = _estimators.FundamentalEstimator()
+    # the driver ignores scoring_exponent (never calls setScoringExponent: :621-638) => ProgressiveX's default 2
+    models, labels, _ = _run(est, corrs, corrs, neighborhood_ball_radius,
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}),
+                             threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
+                             maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
+                             minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
+                             scoring_exponent=2, do_logging=False, seed=seed,
+                             max_outer_iterations=max_outer_iterations)
+    return _stack(est, models, 3), labels
+
+
+findFundamentalMatrices = findTwoViewMotions   # name used by BASELINE.json's north star
+
+
+def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
+                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
+                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
+                        do_logging=False, *, seed=None, max_outer_iterations=10):
+    """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
+    exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
+    lines = _as_f64(lines)
+    n, dim = _shape2(lines)
+    if dim != 4 or n < 2:
+        raise ValueError("lines should be an array with dims [n,4], n>=2")           # bindings.cpp:188-193
+    if do_logging and sampler_id == 1:
+        print("Note: PROSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
+    est = _estimators.VanishingPointEstimator()
+    models, labels, _ = _run(est, lines, lines, neighborhood_ball_radius,
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac"}),
+                             threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
+                             maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
+                             minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
+                             scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
+                             weights=_weights(weights), seed=seed, max_outer_iterations=max_outer_iterations)
+    return _stack(est, models, 3), labels
+
+
+def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_weight=0.0,
+              neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
+              minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
+              do_logging=False, *, seed=None, max_outer_iterations=10):
+    """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
+    (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
+    points = _as_f64(points)
+    n, dim = _shape2(points)
+    if dim != 2 or n < 2:
+        raise ValueError("Points should be an array with dims [n,3], n>=2")          # bindings.cpp:267-270 (sic)
+    _weights(weights)
+    if do_logging and sampler_id == 1:
+        print("Note: PROSAC sampler requires the points to be order by quality, e.g., SNN ratio.")
+    est = _estimators.LineEstimator()
+    models, labels, _ = _run(est, points, points, neighborhood_ball_radius,
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "napsac"}),
+                             threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
+                             maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
+                             minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
+                             scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
+                             max_outer_iterations=max_outer_iterations)
+    return _stack(est, models, 3), labels
+
+
+def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_weight=0.1,
+                neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
+                minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10):
+    """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
+    import time
+    x1 = _as_f64(x1y1)
+    n, dim = _shape2(x1)
+    if dim != 2 or n < 3:
+        raise ValueError("x1y1 should be an array with dims [n,2], n>=3")            # bindings.cpp:26-31
+    x2 = _as_f64(x2y2z2)
+    na, dima = _shape2(x2)
+    if dima != 3:
+        raise ValueError("x2y2z2 should be an array with dims [n,3], n>=3")          # :37-39
+    if na != n:
+        raise ValueError("x1y1 and x2y2z2 should be the same size")                  # :40-42
+    Km = _as_f64(K)
+    if Km.ndim != 2 or Km.shape != (3, 3):
+        raise ValueError("K should be an array with dims [3,3]")                     # :48-50
+    Kinv = np.linalg.inv(Km)                                                          # progressivex_python.cpp:69-70
+    un = Kinv[0, 0] * x1[:, 0] + Kinv[0, 1] * x1[:, 1] + Kinv[0, 2]                    # :88
+    vn = Kinv[1, 0] * x1[:, 0] + Kinv[1, 1] * x1[:, 1] + Kinv[1, 2]                    # :89
+    normalized = np.ascontiguousarray(np.column_stack([un, vn, x2]))                   # :88-92
+    raw = np.column_stack([x1, x2])                                                    # :82-86 (graph on RAW points)
+    f = 0.5 * (Km[0, 0] + Km[1, 1])                                                    # :96
+    t0 = time.perf_counter()
+    est = _estimators.PnPEstimator()
+
+    def factory(n_, rng, graph):
+        print("Neighborhood calculation time = %f secs." % (time.perf_counter() - t0))   # :109
+        return _proposal.UniformSampler(n_, rng)                                          # :112 always uniform
+
+    models, labels, _ = _run(est, normalized, raw, neighborhood_ball_radius, factory,
+                             threshold=threshold / f, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
+                             maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
+                             minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
+                             scoring_exponent=2, do_logging=False, seed=seed,
+                             max_outer_iterations=max_outer_iterations)
+    return _stack(est, models, 4), labels

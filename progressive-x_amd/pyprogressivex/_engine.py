@@ -1,0 +1,323 @@
+"""Host restatement of the Progressive-X outer loop and of PEARL, driving libpgx for every O(N) step.
+
+ProgressiveX.run  <- progx::ProgressiveX<...>::run / initialize / isPutativeModelValid / updateCompoundModel /
+                     getPredictedUnseenInliers   (/root/reference/src/pyprogressivex/include/progressive_x.h:251-624)
+Pearl.run         <- pearl::PEARL<...>::run / labeling / parameterEstimation / rejectInstances / getLabeling
+                     (/root/reference/src/pyprogressivex/include/PEARL.h:218-555)
+
+The control flow — including the reference's quirks that SURVEY.md §3.2 lists — is reproduced literally; all N-length
+work (preference vectors, Tanimoto reductions, compound max, unary costs, alpha-expansion, label bucketing, residual
+sums) runs in HIP kernels behind the C ABI.  Model refits (3x3 / 9x9 solves) stay on the host in round 1.
+"""
+import math
+import sys
+import time
+
+import numpy as np
+
+from . import _proposal
+
+
+class MultiModelSettings:
+    """progx::MultiModelSettings (progressive_x.h:32-73) with the defaults of its constructor."""
+
+    def __init__(self):
+        self.minimum_number_of_inliers = 20
+        self.max_proposal_number_without_change = 10
+        self.maximum_model_number = sys.maxsize
+        self.maximum_tanimoto_similarity = 0.5
+        self.confidence = 0.95
+        self.one_minus_confidence = 0.05
+        self.inlier_outlier_threshold = 2.0
+        self.spatial_coherence_weight = 0.14
+        self.point_weights = None
+        # proposal_engine_settings (:66-71)
+        self.max_iteration_number = 5000
+        self.max_local_optimization_number = 50
+        # not in the reference: its outer loop is hard-capped at 10 proposals (progressive_x.h:272)
+        self.max_outer_iterations = 10
+
+    def set_confidence(self, c):  # :49-53
+        self.confidence = c
+        self.one_minus_confidence = 1.0 - c
+
+
+class Statistics:
+    def __init__(self):
+        self.processing_time = 0.0
+        self.total_time_of_proposal_engine = 0.0
+        self.total_time_of_model_validation = 0.0
+        self.total_time_of_optimization = 0.0
+        self.total_time_of_compound_model_calculation = 0.0
+        self.iteration_statistics = []
+        self.inliers_of_each_model = []
+        self.labeling = None
+        self.pearl_iterations = 0
+        self.expansion_cycles = 0
+
+
+class Model:
+    """progx::Model (progx_model.h:43-99): descriptor + the device slot holding its (stale) preference vector."""
+    __slots__ = ("descriptor", "slot")
+
+    def __init__(self, descriptor, slot=-1):
+        self.descriptor = np.asarray(descriptor, dtype=np.float64).copy()
+        self.slot = slot
+
+
+def predicted_unseen_inliers(one_minus_confidence, sample_size, iteration_number, covered, point_number):
+    """progressive_x.h:495-513 (size_t arithmetic: point_number - covered wraps if covered > point_number)."""
+    unseen = (point_number - covered) % (1 << 64)
+    ratio = math.pow(1.0 - math.pow(one_minus_confidence, 1.0 / iteration_number), 1.0 / sample_size)
+    v = unseen * ratio
+    return int(math.floor(v + 0.5)) if v >= 0 else int(math.ceil(v - 0.5))  # std::round: halves away from zero
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PEARL
+# ---------------------------------------------------------------------------------------------------------------------
+class Pearl:
+    def __init__(self, ctx, estimator, pts, threshold, spatial_coherence_weight, minimum_inlier_number, point_weights,
+                 maximum_iteration_number=100, do_logging=False):
+        self.ctx, self.est, self.pts = ctx, estimator, pts
+        self.threshold = threshold
+        self.lam = spatial_coherence_weight
+        self.model_complexity_weight = float(minimum_inlier_number)   # PEARL.h:144
+        self.epsilon = 1e-5                                           # PEARL.h:145
+        self.minimum_inlier_number = int(minimum_inlier_number)
+        self.maximum_iteration_number = maximum_iteration_number
+        self.point_weights = point_weights
+        self.do_logging = do_logging
+        self.n = pts.shape[0]
+        self.has_engine = False      # alpha_expansion_engine != nullptr
+        self.outliers_number = 0
+        self.points_per_instance = []
+        self.iterations = 0
+        self.cycles = 0
+
+    # PEARL.h:476-555
+    def labeling(self, models, init_with_previous):
+        if len(models) == 0:
+            return None
+        K = len(models)
+        # a fresh GCoptimizationGeneralGraph starts from the all-zero labelling (PEARL.h:507-508); the previous labels
+        # are only carried over when nothing was rejected (PEARL.h:541-547)
+        if not (init_with_previous and self.has_engine):
+            self.ctx.set_labels(np.zeros(self.n, dtype=np.int32))
+        desc = np.stack([m.descriptor for m in models])
+        self.ctx.pearl_unary(desc, self.threshold, self.lam)          # PEARL.h:512-519 data term
+        lam = self.lam if self.lam > 0.0 else 0.0                     # :523-525, :532 smooth term only if > 0
+        h = self.model_complexity_weight if self.model_complexity_weight > 0.0 else 0.0   # :528-529
+        eq, e, cycles = self.ctx.expansion(lam, h, 1000)              # :550-551
+        self.has_engine = True
+        self.cycles += cycles
+        return e
+
+    # PEARL.h:319-401
+    def parameter_estimation(self, models):
+        if not self.has_engine:
+            return False
+        K = len(models)
+        counts, order = self.ctx.bucket(K + 1, want_order=True)       # :342-352
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        self.points_per_instance = [order[starts[k]:starts[k + 1]].astype(np.int64) for k in range(K)]
+        self.outliers_number = int(counts[K])
+        changed = False
+        for k in range(K):
+            inl = self.points_per_instance[k]
+            if len(inl) < self.est.nonminimal_sample_size:            # :365
+                continue
+            before = self.ctx.residual_sum(models[k].descriptor, k)   # :369-371
+            fits = self.est.nonminimal(self.pts, inl, self.point_weights, init=models[k].descriptor)   # :375-380
+            if len(fits) != 1:                                        # :384
+                continue
+            after = self.ctx.residual_sum(fits[0], k)                 # :388-390
+            if after < before:                                        # :393
+                models[k].descriptor = np.asarray(fits[0], dtype=np.float64)
+                changed = True
+        return changed
+
+    # PEARL.h:275-315
+    def reject_instances(self, models):
+        changed = False
+        for k in range(len(models) - 1, -1, -1):
+            cnt = len(self.points_per_instance[k])
+            if cnt < self.minimum_inlier_number:
+                self.outliers_number += cnt
+                del self.points_per_instance[k]
+                del models[k]
+                changed = True
+                if self.do_logging:
+                    print(f"[Optimization] Instance {k} is rejected due to having too few inliers ({cnt}).")
+        return changed
+
+    # PEARL.h:405-472
+    def run(self, models):
+        iteration_number = 0
+        energy, previous_energy = sys.float_info.max, -1.0
+        model_rejected = False
+        convergence = False
+        while not convergence and iteration_number < self.maximum_iteration_number:
+            iteration_number += 1
+            if self.do_logging:
+                print(f"[Optimization] Iteration {iteration_number}.")
+            init_prev = iteration_number > 1 and not model_rejected           # :429-431
+            e = self.labeling(models, init_prev)                              # :434
+            if e is not None:
+                energy = e
+            if self.do_logging:
+                print(f"[Optimization] The energy of the labeling is {energy}.")
+            params_changed = self.parameter_estimation(models)               # :453
+            model_rejected = self.reject_instances(models)                   # :458
+            if (not model_rejected and not params_changed and abs(energy - previous_energy) < self.epsilon
+                    and iteration_number > 1):                               # :463-467
+                convergence = True
+            previous_energy = energy
+        self.iterations += iteration_number
+        return True
+
+    # PEARL.h:218-247
+    def get_labeling(self):
+        if not self.has_engine:
+            return np.zeros(self.n, dtype=np.int64), 0
+        lab = self.ctx.get_labels().astype(np.int64)
+        return lab, int(lab.max()) if lab.size else 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Progressive-X
+# ---------------------------------------------------------------------------------------------------------------------
+class ProgressiveX:
+    def __init__(self, ctx, estimator, pts, graph, sampler, settings, scoring_exponent=2, do_logging=False,
+                 exchange=None):
+        self.ctx, self.est, self.pts, self.graph = ctx, estimator, pts, graph
+        self.sampler, self.settings = sampler, settings
+        self.scoring_exponent = int(scoring_exponent)   # setExponent(const int) truncates (scoring_function...h:39)
+        self.do_logging = do_logging
+        self.exchange = exchange
+        self.models = []
+        self.statistics = Statistics()
+        self.n = pts.shape[0]
+        self._next_slot = 0
+
+    def _log(self, msg):
+        if self.do_logging:
+            print(msg)
+
+    # progressive_x.h:519-559
+    def initialize(self):
+        s = self.settings
+        self.statistics.labeling = np.zeros(self.n, dtype=np.int64)                          # :522
+        self.T2 = 9.0 / 4.0 * s.inlier_outlier_threshold * s.inlier_outlier_threshold        # :523
+        self.ctx.set_points(self.est.model_type, self.pts)                                   # compound := 0 (:524)
+        if self.graph is not None and s.spatial_coherence_weight > 0.0:
+            self.ctx.set_graph(*self.graph)
+        self.pearl = Pearl(self.ctx, self.est, self.pts, s.inlier_outlier_threshold, s.spatial_coherence_weight,
+                           s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging)   # :527-534
+        self.engine = _proposal.ProposalEngine(self.ctx, self.est, self.pts, self.sampler, s, self.exchange)
+
+    # progressive_x.h:565-591
+    def is_putative_model_valid(self, model, inlier_number):
+        s = self.settings
+        if inlier_number < max(self.est.sample_size, s.minimum_number_of_inliers):            # :574
+            return False
+        model.slot = self._next_slot
+        self._next_slot += 1
+        r = self.ctx.preference(model.descriptor, self.T2, model.slot)                        # :578-579
+        denom = r["pref_sqnorm"] + r["comp_sqnorm"] - r["dot"]
+        tanimoto = r["dot"] / denom if denom != 0.0 else float("nan")                          # :583-585 (0/0 -> NaN)
+        if s.maximum_tanimoto_similarity < tanimoto:                                           # :587 (NaN -> valid)
+            return False
+        return True
+
+    # progressive_x.h:597-624
+    def update_compound_model(self):
+        if len(self.models) == 0:
+            return
+        self.ctx.compound_update([m.slot for m in self.models])    # max over the STORED (stale) preference vectors
+
+    # progressive_x.h:251-489
+    def run(self):
+        t_main = time.perf_counter()
+        self._log("Progressive-X is started...")
+        self.initialize()
+        s, st = self.settings, self.statistics
+        number_of_ransac_iterations = 0
+        unaccepted = 0
+        self._log("The main iteration is started...")
+        for current_iteration in range(s.max_outer_iterations):                               # :272 (hard 10 upstream)
+            self._log("-------------------------------------------")
+            self._log(f"Iteration {current_iteration + 1}.")
+            it_stats = dict(time_of_proposal_engine=0.0, time_of_model_validation=0.0, time_of_optimization=0.0,
+                            time_of_compound_model_update=0.0, number_of_instances=0)
+            # ---- proposal (:294)
+            t0 = time.perf_counter()
+            prop = self.engine.run(self.T2, has_compound=len(self.models) > 0, exponent=self.scoring_exponent,
+                                   weights=s.point_weights)
+            it_stats["time_of_proposal_engine"] = time.perf_counter() - t0
+            if prop is None or prop["model"] is None:                                         # :301-303
+                continue
+            putative = Model(prop["model"])
+            inliers = prop["inliers"]
+            number_of_ransac_iterations += prop["iterations"]                                 # :317-318
+            self._log(f"A model proposed with {len(inliers)} inliers\nin {it_stats['time_of_proposal_engine']} "
+                      f"seconds ({prop['iterations']} iterations).")
+            # ---- validation (:334)
+            self._log("Check if the model should be added to the compound instance.")
+            t0 = time.perf_counter()
+            if not self.is_putative_model_valid(putative, len(inliers)):
+                self._log("The model is not accepted to be added to the compound instances. The number of "
+                          f"consecutively rejected proposals is {unaccepted} (< {s.max_proposal_number_without_change})")
+                unaccepted += 1                                                               # :342 (never reset)
+                if unaccepted == s.max_proposal_number_without_change:
+                    break
+                continue
+            it_stats["time_of_model_validation"] = time.perf_counter() - t0
+            self._log(f"The model has been accepted in {it_stats['time_of_model_validation']} seconds.")
+            # ---- optimisation (:366-403)
+            t0 = time.perf_counter()
+            self.models.append(putative)                                                      # :369
+            self._log("Model optimization started...")
+            if len(self.models) == 1:
+                st.inliers_of_each_model.append(inliers)                                      # :378-379
+                st.labeling[:] = 1                                                            # :382
+                st.labeling[inliers] = 0                                                      # :383-384
+            else:
+                self.pearl.run(self.models)                                                   # :390
+                st.labeling, model_number = self.pearl.get_labeling()                         # :396
+                if model_number != len(self.models):
+                    self._log("Models have been removed during the optimization.\n")
+            it_stats["time_of_optimization"] = time.perf_counter() - t0
+            self._log(f"Model optimization finished in {it_stats['time_of_optimization']} seconds.")
+            # ---- compound update (:423)
+            t0 = time.perf_counter()
+            self.update_compound_model()
+            it_stats["time_of_compound_model_update"] = time.perf_counter() - t0
+            self._log(f"Compound instance (containing {len(self.models)} models) is updated in "
+                      f"{it_stats['time_of_compound_model_update']} seconds.")
+            it_stats["number_of_instances"] = len(self.models)
+            # ---- predicted unseen inliers (:447-457)
+            if number_of_ransac_iterations > 0:
+                if len(self.models) == 1:
+                    covered = len(st.inliers_of_each_model)    # quirk :451 — the COUNT of models (= 1), not of inliers
+                else:
+                    covered = self.n - self.pearl.outliers_number
+                unseen = predicted_unseen_inliers(s.one_minus_confidence, self.est.sample_size,
+                                                  number_of_ransac_iterations, covered, self.n)
+            else:
+                unseen = self.n
+            st.iteration_statistics.append(it_stats)
+            st.total_time_of_proposal_engine += it_stats["time_of_proposal_engine"]
+            st.total_time_of_model_validation += it_stats["time_of_model_validation"]
+            st.total_time_of_optimization += it_stats["time_of_optimization"]
+            st.total_time_of_compound_model_calculation += it_stats["time_of_compound_model_update"]
+            self._log(f"The predicted number of inliers (with confidence {s.confidence})\nnot covered by the compound "
+                      f"instance is {unseen}.")
+            if unseen < s.minimum_number_of_inliers:                                          # :468
+                break
+            if len(self.models) >= s.maximum_model_number:                                    # :472
+                break
+        st.processing_time = time.perf_counter() - t_main
+        st.pearl_iterations = self.pearl.iterations
+        st.expansion_cycles = self.pearl.cycles
+        return self.models, st

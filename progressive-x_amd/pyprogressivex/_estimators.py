@@ -1,0 +1,429 @@
+"""Estimators: batched minimal solvers (hypothesis generation) and non-minimal refits, host side (numpy).
+
+Replaces the Estimator concept of the reference (`sampleSize()`, `nonMinimalSampleSize()`, `estimateModel`,
+`estimateModelNonminimal`; exemplar in-tree: vanishing_point_estimator.h:34-226 and
+solver_vanishing_point_two_lines.h:128-237, paths relative to /root/reference/src/pyprogressivex/include/).
+Only the vanishing-point solver exists in the snapshot; the line / homography / fundamental / PnP solvers live in the
+absent graph-cut-ransac submodule and are restated from the literature [UPSTREAM-MEMORY] — SURVEY.md §8f ranks them
+"next" (GPU versions), so round 1 keeps them on the host: they produce the hypothesis batches that the HIP scorer
+consumes and the refits PEARL asks for.  Residuals are NOT computed here — that is libpgx's job.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class Estimator:
+    model_type = None
+    sample_size = 0
+    nonminimal_sample_size = 0
+    rows_per_model = 1       # rows of the returned model array per instance (3 for 3x3 / 3x4 matrices)
+    cols = 3
+
+    def minimal(self, pts, samples):
+        """samples [S, m] -> (models [H, P], sample_of_model [H]); several or zero solutions per sample allowed."""
+        raise NotImplementedError
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        """Least-squares fit to pts[idx] -> list of models (the reference accepts the refit only if exactly 1)."""
+        raise NotImplementedError
+
+    def descriptor(self, model):
+        return np.asarray(model, dtype=np.float64)
+
+    def output(self, model):
+        return np.asarray(model, dtype=np.float64).reshape(self.rows_per_model, self.cols)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2D line  (Default2DLineEstimator, progressivex_python.cpp:489)  [U-4]
+# ---------------------------------------------------------------------------------------------------------------------
+class LineEstimator(Estimator):
+    model_type = _lib.LINE2D
+    sample_size = 2
+    nonminimal_sample_size = 2
+
+    def minimal(self, pts, samples):
+        a, b = pts[samples[:, 0]], pts[samples[:, 1]]
+        d = b - a
+        ln = np.linalg.norm(d, axis=1)
+        ok = ln > 0
+        nrm = np.column_stack([-d[:, 1], d[:, 0]]) / np.where(ok, ln, 1.0)[:, None]
+        c = -(nrm * a).sum(axis=1)
+        models = np.column_stack([nrm, c])
+        return models[ok], np.nonzero(ok)[0]
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        p = pts[idx]
+        w = np.ones(len(idx)) if weights is None else np.asarray(weights)[idx]
+        if w.sum() <= 0:
+            return []
+        mean = (p * w[:, None]).sum(axis=0) / w.sum()
+        q = (p - mean) * np.sqrt(w)[:, None]
+        evals, evecs = np.linalg.eigh(q.T @ q)
+        nrm = evecs[:, 0]
+        return [np.array([nrm[0], nrm[1], -nrm @ mean])]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# vanishing point: solver_vanishing_point_two_lines.h (in-tree, exact restatement)
+# ---------------------------------------------------------------------------------------------------------------------
+class VanishingPointEstimator(Estimator):
+    model_type = _lib.VANISHING_POINT
+    sample_size = 2            # solver_vanishing_point_two_lines.h:70-73
+    nonminimal_sample_size = 2  # the same solver class is used for both (progressivex_python.cpp:343-346)
+
+    @staticmethod
+    def _cross(a1, b1, c1, a2, b2, c2):  # :106-121
+        return b1 * c2 - c1 * b2, -(a1 * c2 - c1 * a2), a1 * b2 - b1 * a2
+
+    def minimal(self, pts, samples):
+        s0, s1 = pts[samples[:, 0]], pts[samples[:, 1]]
+        one = np.ones(len(samples))
+        l0 = self._cross(s0[:, 0], s0[:, 1], one, s0[:, 2], s0[:, 3], one)      # :174-176
+        l1 = self._cross(s1[:, 0], s1[:, 1], one, s1[:, 2], s1[:, 3], one)      # :177-179
+        v = np.column_stack(self._cross(l0[0], l0[1], l0[2], l1[0], l1[1], l1[2]))  # :180-182
+        ln = np.sqrt((v * v).sum(axis=1))                                        # :123-131 vec_norm
+        ok = ln > 0
+        v = v / np.where(ok, ln, 1.0)[:, None]
+        return v[ok], np.nonzero(ok)[0]
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        p = pts[idx]
+        x0, y0, x1, y1 = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+        mx, my, mz = (x0 + x1) / 2.0, (y0 + y1) / 2.0, 1.0                       # :212-215
+        A = np.column_stack([y0 * mz - my, mx - x0 * mz, x0 * my - y0 * mx])     # :217
+        if weights is not None and len(weights) > 0:
+            A = A * np.asarray(weights)[idx][:, None]                             # :218
+        evals, evecs = np.linalg.eigh(A.T @ A)                                    # :227 SelfAdjointEigenSolver
+        v = evecs[:, int(np.argmin(evals))]                                       # :230-233
+        n = np.linalg.norm(v)
+        return [v / n] if n > 0 else []
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# homography (DefaultHomographyEstimator, progressivex_python.cpp:252)  [UPSTREAM-MEMORY]: 4-point, h33 = 1
+# ---------------------------------------------------------------------------------------------------------------------
+def _dlt_rows(x1, y1, x2, y2):
+    z = np.zeros_like(x1)
+    o = np.ones_like(x1)
+    r1 = np.stack([-x1, -y1, -o, z, z, z, x2 * x1, x2 * y1, x2], axis=-1)
+    r2 = np.stack([z, z, z, -x1, -y1, -o, y2 * x1, y2 * y1, y2], axis=-1)
+    return r1, r2
+
+
+def _hartley(xy):
+    c = xy.mean(axis=0)
+    d = np.sqrt(((xy - c) ** 2).sum(axis=1)).mean()
+    s = np.sqrt(2.0) / d if d > 0 else 1.0
+    T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+    return (xy - c) * s, T
+
+
+class HomographyEstimator(Estimator):
+    model_type = _lib.HOMOGRAPHY
+    sample_size = 4
+    nonminimal_sample_size = 4
+    rows_per_model = 3
+
+    def minimal(self, pts, samples):
+        scale = max(1.0, float(np.abs(pts).max()))     # isotropic pre-scaling: coordinates O(1) for the 8x8 solve
+        p = pts[samples] / scale                       # [S,4,4]
+        r1, r2 = _dlt_rows(p[..., 0], p[..., 1], p[..., 2], p[..., 3])
+        A = np.concatenate([r1, r2], axis=1)           # [S,8,9]
+        lhs, rhs = A[:, :, :8], -A[:, :, 8]
+        ok = np.abs(np.linalg.det(lhs)) > 1e-14
+        h = np.zeros((len(samples), 9))
+        if ok.any():
+            h[ok, :8] = np.linalg.solve(lhs[ok], rhs[ok][..., None])[..., 0]
+            h[ok, 8] = 1.0
+            # undo the scaling: H = S^-1 Hn S with S = diag(1/scale, 1/scale, 1)
+            h[ok, 2] *= scale
+            h[ok, 5] *= scale
+            h[ok, 6] /= scale
+            h[ok, 7] /= scale
+        ok &= np.isfinite(h).all(axis=1)
+        return h[ok], np.nonzero(ok)[0]
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        p = pts[idx]
+        if len(p) < 4:
+            return []
+        a, T1 = _hartley(p[:, :2])
+        b, T2 = _hartley(p[:, 2:])
+        r1, r2 = _dlt_rows(a[:, 0], a[:, 1], b[:, 0], b[:, 1])
+        A = np.vstack([r1, r2])
+        if weights is not None and len(weights) > 0:
+            w = np.asarray(weights)[idx]
+            A = A * np.concatenate([w, w])[:, None]
+        _, _, vt = np.linalg.svd(A, full_matrices=False)
+        Hn = vt[-1].reshape(3, 3)
+        H = np.linalg.inv(T2) @ Hn @ T1
+        if not np.isfinite(H).all() or abs(H[2, 2]) < 1e-300:
+            return []
+        return [(H / H[2, 2]).reshape(-1)]
+
+
+class SymmetricHomographyEstimator(HomographyEstimator):
+    """Same solvers; the model carried to the kernels is [H | H^-1] (symmetric transfer error switch)."""
+    model_type = _lib.HOMOGRAPHY_SYM
+
+    @staticmethod
+    def _augment(models):
+        out = []
+        keep = []
+        for k, h in enumerate(models):
+            H = h.reshape(3, 3)
+            if abs(np.linalg.det(H)) < 1e-300:
+                continue
+            out.append(np.concatenate([h, np.linalg.inv(H).reshape(-1)]))
+            keep.append(k)
+        return (np.array(out).reshape(-1, 18), np.array(keep, dtype=np.int64))
+
+    def minimal(self, pts, samples):
+        models, src = super().minimal(pts, samples)
+        aug, keep = self._augment(models)
+        return aug, src[keep]
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        res = super().nonminimal(pts, idx, weights, init)
+        return [m for m in self._augment(np.array(res).reshape(-1, 9))[0]]
+
+    def output(self, model):
+        return np.asarray(model[:9], dtype=np.float64).reshape(3, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fundamental matrix (DefaultFundamentalMatrixEstimator, progressivex_python.cpp:616)  [UPSTREAM-MEMORY]
+# 7-point minimal (up to 3 solutions), normalised 8-point non-minimal
+# ---------------------------------------------------------------------------------------------------------------------
+class FundamentalEstimator(Estimator):
+    model_type = _lib.FUNDAMENTAL
+    sample_size = 7
+    nonminimal_sample_size = 8
+    rows_per_model = 3
+
+    @staticmethod
+    def _rows(p):
+        x1, y1, x2, y2 = p[..., 0], p[..., 1], p[..., 2], p[..., 3]
+        o = np.ones_like(x1)
+        return np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, o], axis=-1)
+
+    def minimal(self, pts, samples):
+        p = pts[samples]
+        scale = max(1.0, float(np.abs(pts).max()))
+        A = self._rows(p / scale)                      # [S,7,9], isotropic pre-scaling for conditioning
+        _, _, vt = np.linalg.svd(A, full_matrices=True)
+        F1, F2 = vt[:, 7].reshape(-1, 3, 3), vt[:, 8].reshape(-1, 3, 3)
+        models, src = [], []
+        # det(l F1 + (1-l) F2) is a cubic in l: interpolate it at 4 nodes
+        ls = np.array([0.0, 1.0, -1.0, 2.0])
+        vals = np.stack([np.linalg.det(l * F1 + (1 - l) * F2) for l in ls], axis=1)
+        V = np.vander(ls, 4)
+        coef = np.linalg.solve(V, vals.T).T            # [S,4] highest power first
+        D = np.diag([1 / scale, 1 / scale, 1.0])
+        for s in range(len(samples)):
+            c = coef[s]
+            if not np.isfinite(c).all():
+                continue
+            roots = np.roots(c) if abs(c[0]) > 1e-14 * np.abs(c).max() else np.roots(c[1:])
+            for r in roots:
+                if abs(r.imag) > 1e-9 * max(1.0, abs(r.real)):
+                    continue
+                F = D @ (r.real * F1[s] + (1 - r.real) * F2[s]) @ D
+                nrm = np.linalg.norm(F)
+                if nrm > 0 and np.isfinite(nrm):
+                    models.append((F / nrm).reshape(-1))
+                    src.append(s)
+        return np.array(models).reshape(-1, 9), np.array(src, dtype=np.int64)
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        p = pts[idx]
+        if len(p) < 8:
+            return []
+        a, T1 = _hartley(p[:, :2])
+        b, T2 = _hartley(p[:, 2:])
+        A = self._rows(np.column_stack([a, b]))
+        if weights is not None and len(weights) > 0:
+            A = A * np.asarray(weights)[idx][:, None]
+        _, _, vt = np.linalg.svd(A, full_matrices=False)
+        F = vt[-1].reshape(3, 3)
+        u, s, v = np.linalg.svd(F)
+        F = u @ np.diag([s[0], s[1], 0.0]) @ v
+        F = T2.T @ F @ T1
+        nrm = np.linalg.norm(F)
+        if not np.isfinite(nrm) or nrm == 0:
+            return []
+        return [(F / nrm).reshape(-1)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PnP (DefaultPnPEstimator, progressivex_python.cpp:119)  [UPSTREAM-MEMORY]: P3P minimal (Grunert's quartic + Horn
+# alignment, up to 4 solutions), Gauss-Newton reprojection refinement as the non-minimal fit
+# ---------------------------------------------------------------------------------------------------------------------
+def _kabsch(A, B):
+    """Batched rigid alignment B ~ R A + t for [S,3,3] point triples (rows = points)."""
+    ca, cb = A.mean(axis=1, keepdims=True), B.mean(axis=1, keepdims=True)
+    H = np.einsum("sij,sik->sjk", A - ca, B - cb)
+    U, _, Vt = np.linalg.svd(H)
+    d = np.sign(np.linalg.det(np.einsum("sij,sjk->sik", Vt.transpose(0, 2, 1), U.transpose(0, 2, 1))))
+    Dm = np.zeros_like(H)
+    Dm[:, 0, 0] = 1
+    Dm[:, 1, 1] = 1
+    Dm[:, 2, 2] = d
+    R = Vt.transpose(0, 2, 1) @ Dm @ U.transpose(0, 2, 1)
+    t = cb[:, 0] - np.einsum("sij,sj->si", R, ca[:, 0])
+    return R, t
+
+
+class PnPEstimator(Estimator):
+    model_type = _lib.PNP
+    sample_size = 3
+    nonminimal_sample_size = 6
+    rows_per_model = 3
+    cols = 4
+
+    def minimal(self, pts, samples):
+        p = pts[samples]                                     # [S,3,5]
+        f = np.concatenate([p[..., :2], np.ones(p.shape[:2] + (1,))], axis=-1)
+        f = f / np.linalg.norm(f, axis=-1, keepdims=True)    # unit bearings
+        X = p[..., 2:]
+        a = np.linalg.norm(X[:, 1] - X[:, 2], axis=1)
+        b = np.linalg.norm(X[:, 0] - X[:, 2], axis=1)
+        c = np.linalg.norm(X[:, 0] - X[:, 1], axis=1)
+        ca = (f[:, 1] * f[:, 2]).sum(axis=1)
+        cb = (f[:, 0] * f[:, 2]).sum(axis=1)
+        cg = (f[:, 0] * f[:, 1]).sum(axis=1)
+        ok = (a > 0) & (b > 0) & (c > 0)
+        with np.errstate(all="ignore"):
+            a2, b2, c2 = a * a, b * b, c * c
+            q = (a2 - c2) / b2
+            r = (a2 + c2) / b2
+            # Grunert / Fischler-Bolles quartic in v = s3 / s1
+            A4 = (q - 1) ** 2 - 4 * c2 / b2 * ca ** 2
+            A3 = 4 * (q * (1 - q) * cb - (1 - r) * ca * cg + 2 * c2 / b2 * ca ** 2 * cb)
+            A2 = 2 * (q ** 2 - 1 + 2 * q ** 2 * cb ** 2 + 2 * (b2 - c2) / b2 * ca ** 2
+                      - 4 * r * ca * cb * cg + 2 * (b2 - a2) / b2 * cg ** 2)
+            A1 = 4 * (-q * (1 + q) * cb + 2 * a2 / b2 * cg ** 2 * cb - (1 - r) * ca * cg)
+            A0 = (1 + q) ** 2 - 4 * a2 / b2 * cg ** 2
+        coef = np.stack([A4, A3, A2, A1, A0], axis=1)
+        ok &= np.isfinite(coef).all(axis=1) & (np.abs(A4) > 1e-14)
+        S = len(samples)
+        comp = np.zeros((S, 4, 4))
+        comp[:, 1, 0] = comp[:, 2, 1] = comp[:, 3, 2] = 1.0
+        safeA4 = np.where(ok, A4, 1.0)
+        comp[:, 0, 3] = -A0 / safeA4
+        comp[:, 1, 3] = -A1 / safeA4
+        comp[:, 2, 3] = -A2 / safeA4
+        comp[:, 3, 3] = -A3 / safeA4
+        comp[~ok] = 0
+        roots = np.linalg.eigvals(comp)                      # [S,4]
+        models, src = [], []
+        for k in range(4):
+            v = roots[:, k]
+            real = ok & (np.abs(v.imag) < 1e-8 * np.maximum(1.0, np.abs(v.real))) & (v.real > 0)
+            if not real.any():
+                continue
+            sidx = np.nonzero(real)[0]
+            vv = v.real[sidx]
+            qq, cga, cba, caa = q[sidx], cg[sidx], cb[sidx], ca[sidx]
+            a2s, b2s, c2s = a2[sidx], b2[sidx], c2[sidx]
+            with np.errstate(all="ignore"):
+                u = ((-1 + qq) * vv * vv - 2 * qq * cba * vv + 1 + qq) / (2 * (cga - vv * caa))
+                s1 = np.sqrt(b2s / (1 + vv * vv - 2 * vv * cba))
+            s2, s3 = u * s1, vv * s1
+            good = np.isfinite(s1) & np.isfinite(s2) & (s1 > 0) & (s2 > 0) & (s3 > 0)
+            # consistency with the two unused side constraints
+            e1 = s1 ** 2 + s2 ** 2 - 2 * s1 * s2 * cga - c2s
+            e2 = s2 ** 2 + s3 ** 2 - 2 * s2 * s3 * caa - a2s
+            good &= (np.abs(e1) < 1e-6 * c2s) & (np.abs(e2) < 1e-6 * a2s)
+            if not good.any():
+                continue
+            sidx = sidx[good]
+            depth = np.stack([s1[good], s2[good], s3[good]], axis=1)
+            Y = f[sidx] * depth[..., None]                    # camera-frame points
+            R, t = _kabsch(X[sidx], Y)
+            P = np.concatenate([R, t[..., None]], axis=2).reshape(-1, 12)
+            fin = np.isfinite(P).all(axis=1)
+            models.append(P[fin])
+            src.append(sidx[fin])
+        if not models:
+            return np.zeros((0, 12)), np.zeros(0, dtype=np.int64)
+        models, src = np.vstack(models), np.concatenate(src)
+        o = np.argsort(src, kind="stable")
+        return models[o], src[o]
+
+    @staticmethod
+    def _dlt(p):
+        u, v, X = p[:, 0], p[:, 1], p[:, 2:]
+        Xh = np.column_stack([X, np.ones(len(p))])
+        z = np.zeros_like(Xh)
+        A = np.vstack([np.column_stack([Xh, z, -u[:, None] * Xh]), np.column_stack([z, Xh, -v[:, None] * Xh])])
+        _, _, vt = np.linalg.svd(A, full_matrices=False)
+        P = vt[-1].reshape(3, 4)
+        if np.linalg.det(P[:, :3]) < 0:
+            P = -P
+        U, s, Vt = np.linalg.svd(P[:, :3])
+        R = U @ Vt
+        return np.column_stack([R, P[:, 3] / s.mean()])
+
+    def nonminimal(self, pts, idx, weights=None, init=None):
+        p = pts[idx]
+        if len(p) < 4:
+            return []
+        if init is not None:
+            P = np.asarray(init, dtype=np.float64).reshape(3, 4).copy()
+        elif len(p) >= 6:
+            P = self._dlt(p)
+        else:
+            return []
+        w = np.ones(len(p)) if weights is None or len(weights) == 0 else np.asarray(weights)[idx]
+        R, t = P[:, :3], P[:, 3]
+        for _ in range(10):                                  # Gauss-Newton on the reprojection error
+            Xc = p[:, 2:] @ R.T + t
+            z = Xc[:, 2]
+            if np.any(np.abs(z) < 1e-12):
+                return []
+            proj = Xc[:, :2] / z[:, None]
+            res = (proj - p[:, :2])
+            J = np.zeros((len(p), 2, 6))
+            inv = 1.0 / z
+            dpdX = np.zeros((len(p), 2, 3))
+            dpdX[:, 0, 0] = inv
+            dpdX[:, 1, 1] = inv
+            dpdX[:, 0, 2] = -Xc[:, 0] * inv * inv
+            dpdX[:, 1, 2] = -Xc[:, 1] * inv * inv
+            Xr = Xc - t                                      # R X
+            skew = np.zeros((len(p), 3, 3))
+            skew[:, 0, 1], skew[:, 0, 2] = Xr[:, 2], -Xr[:, 1]
+            skew[:, 1, 0], skew[:, 1, 2] = -Xr[:, 2], Xr[:, 0]
+            skew[:, 2, 0], skew[:, 2, 1] = Xr[:, 1], -Xr[:, 0]
+            J[:, :, :3] = dpdX @ skew                         # d(exp([w]_x) R X)/dw = -[R X]_x (= skew)
+            J[:, :, 3:] = dpdX
+            Jw = (J * w[:, None, None]).reshape(-1, 6)
+            rw = (res * w[:, None]).reshape(-1)
+            try:
+                delta = np.linalg.lstsq(Jw, -rw, rcond=None)[0]
+            except np.linalg.LinAlgError:
+                return []
+            om = delta[:3]
+            ang = np.linalg.norm(om)
+            if ang > 0:                                       # R <- exp([omega]_x) R ; t <- t + dt
+                k = om / ang
+                Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+                R = (np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * (Kx @ Kx)) @ R
+            t = t + delta[3:]
+            if np.linalg.norm(delta) < 1e-12:
+                break
+        out = np.column_stack([R, t])
+        return [out.reshape(-1)] if np.isfinite(out).all() else []
+
+
+ESTIMATORS = {
+    "line": LineEstimator,
+    "vanishing_point": VanishingPointEstimator,
+    "homography": HomographyEstimator,
+    "homography_sym": SymmetricHomographyEstimator,
+    "fundamental": FundamentalEstimator,
+    "pnp": PnPEstimator,
+}

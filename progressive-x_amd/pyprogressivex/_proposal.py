@@ -1,0 +1,199 @@
+"""Proposal engine: samplers + batched hypothesis generation + GPU scoring + the sequential RANSAC semantics.
+
+Replaces: gcransac::GCRANSAC<Estimator, Graph, MSACScoringFunctionWithCompoundModel>::run as called by
+ProgressiveX::run (/root/reference/src/pyprogressivex/include/progressive_x.h:294-299, settings :541-545) and the
+sampler classes selected at progressivex_python.cpp:112-115,215-245,353-366,466-482,579-609.  The GC-RANSAC sources are
+absent from the snapshot (empty submodule), so the loop is restated [UPSTREAM-MEMORY, U-9]:
+
+  * all `max_iters` minimal samples of one proposal are drawn up front and solved in a batch (host, numpy);
+  * every resulting hypothesis is scored on the GPU in ONE launch (pgx_score) with the compound-model term;
+  * the reference's sequential behaviour is then replayed on the host over the score table, in hypothesis order:
+    the early exit `count + 1 < best.inlier_number` (scoring_function_with_compound_model.h:105-106), "first strictly
+    better score wins", and the adaptive iteration bound log(1-conf)/log(1-(inl/N)^m) — so for a given hypothesis list
+    the CPU restatement and the GPU path select the same model;
+  * local optimisation = iterated least-squares refits on the inliers of a new so-far-best model (simplified stand-in
+    for GC-RANSAC's graph-cut + inner-RANSAC local optimisation, capped by max_local_optimization_number = 50,
+    progressive_x.h:68).
+"""
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# samplers  (ids as in progressivex_python.cpp:215-245)
+# ---------------------------------------------------------------------------------------------------------------------
+class UniformSampler:
+    """gcransac::sampler::UniformSampler: m distinct indices uniformly at random."""
+
+    def __init__(self, n, rng):
+        self.n, self.rng = n, rng
+
+    def reset(self):
+        pass
+
+    def draw(self, count, m):
+        if self.n < m:
+            return np.zeros((0, m), dtype=np.int64)
+        # rejection-free: argsort of random keys on a (count, k) window would cost O(count n); use per-row choice via
+        # sorting random floats only for small m: draw with replacement and redraw rows that contain duplicates
+        s = self.rng.integers(0, self.n, (count, m))
+        for _ in range(32):
+            srt = np.sort(s, axis=1)
+            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+            if not bad.any():
+                break
+            s[bad] = self.rng.integers(0, self.n, (int(bad.sum()), m))
+        return s
+
+
+class ProsacSampler(UniformSampler):
+    """PROSAC-style progressive sampling: points are assumed ordered by quality; sample t draws from the top-n_t
+    prefix whose length grows linearly to n over `count` draws (simplified growth function) [UPSTREAM-MEMORY]."""
+
+    def draw(self, count, m):
+        if self.n < m:
+            return np.zeros((0, m), dtype=np.int64)
+        tops = np.minimum(self.n, np.maximum(m, (m + (self.n - m) * (np.arange(count) + 1) / count).astype(np.int64)))
+        s = (self.rng.random((count, m)) * tops[:, None]).astype(np.int64)
+        for _ in range(32):
+            srt = np.sort(s, axis=1)
+            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+            if not bad.any():
+                break
+            s[bad] = (self.rng.random((int(bad.sum()), m)) * tops[bad][:, None]).astype(np.int64)
+        return s
+
+
+class NapsacSampler(UniformSampler):
+    """NAPSAC: first point uniform, the remaining m-1 from its neighbourhood ball; samples whose centre has fewer than
+    m-1 neighbours are skipped (the reference's sampler fails and the RANSAC iteration is spent) [UPSTREAM-MEMORY]."""
+
+    def __init__(self, n, rng, graph):
+        super().__init__(n, rng)
+        self.off, self.idx = np.asarray(graph[0], dtype=np.int64), np.asarray(graph[1], dtype=np.int64)
+
+    def draw(self, count, m):
+        centers = self.rng.integers(0, self.n, count)
+        deg = self.off[centers + 1] - self.off[centers]
+        ok = deg >= m - 1
+        centers, deg = centers[ok], deg[ok]
+        if len(centers) == 0:
+            return np.zeros((0, m), dtype=np.int64)
+        pick = (self.rng.random((len(centers), m - 1)) * deg[:, None]).astype(np.int64)
+        for _ in range(32):
+            srt = np.sort(pick, axis=1)
+            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1) if m > 2 else np.zeros(len(centers), bool)
+            if not bad.any():
+                break
+            pick[bad] = (self.rng.random((int(bad.sum()), m - 1)) * deg[bad][:, None]).astype(np.int64)
+        nbr = self.idx[self.off[centers][:, None] + pick]
+        return np.column_stack([centers, nbr])
+
+
+class ProgressiveNapsacSampler(NapsacSampler):
+    """P-NAPSAC stand-in: NAPSAC blended linearly into global uniform sampling over the first 0.5 * n draws
+    (the reference's blending length, progressivex_python.cpp:235) [UPSTREAM-MEMORY]."""
+
+    def draw(self, count, m):
+        local = super().draw(count, m)
+        glob = UniformSampler.draw(self, count, m)
+        blend = max(1.0, 0.5 * self.n)
+        k = min(len(local), len(glob))
+        use_global = self.rng.random(k) < np.minimum(1.0, np.arange(k) / blend)
+        out = local[:k].copy()
+        out[use_global] = glob[:k][use_global]
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sequential replay of the RANSAC loop over a scored batch
+# ---------------------------------------------------------------------------------------------------------------------
+def ransac_iteration_bound(inlier_number, n, sample_size, confidence):
+    """Standard termination criterion used by GC-RANSAC [UPSTREAM-MEMORY]: log(1-conf) / log(1 - q^m)."""
+    q = min(1.0, max(0.0, inlier_number / float(n)))
+    qm = q ** sample_size
+    if qm <= 0.0:
+        return np.inf
+    if qm >= 1.0:
+        return 1.0
+    return np.log(1.0 - confidence) / np.log(1.0 - qm)
+
+
+def replay_sequential(counts, scores, iteration_of, n, sample_size, confidence, max_iters, min_iters=0):
+    """Walks the scored hypotheses in generation order exactly as a sequential RANSAC would.
+
+    Returns (best_index or -1, iteration_number, list of indices that became so-far-best in order)."""
+    best, best_score, best_count = -1, -np.inf, 0
+    bound = float(max_iters)
+    history = []
+    it_best = 0
+    for h in range(len(counts)):
+        it = int(iteration_of[h]) + 1
+        if it > bound and it > min_iters:
+            break
+        c = int(counts[h])
+        if c + 1 < best_count:          # scoring_function_with_compound_model.h:105-106 -> Score()
+            continue
+        s = float(scores[h])
+        if c > 0 and s > best_score:    # strictly better => replaces the so-far-best
+            best, best_score, best_count, it_best = h, s, c, it
+            history.append(h)
+            bound = min(float(max_iters), ransac_iteration_bound(c, n, sample_size, confidence))
+    iterations = int(max(it_best, min(float(max_iters), np.ceil(bound)), 1))
+    return best, iterations, history
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the proposal engine
+# ---------------------------------------------------------------------------------------------------------------------
+class ProposalEngine:
+    def __init__(self, ctx, estimator, pts, sampler, settings, exchange=None):
+        self.ctx, self.est, self.pts, self.sampler, self.s = ctx, estimator, pts, sampler, settings
+        self.exchange = exchange     # parallel.RcclExchange for multi-GPU sharding, None = single GPU
+        self.n = pts.shape[0]
+
+    def _score(self, models, T2, has_compound, exponent):
+        if self.exchange is not None and self.exchange.world > 1:
+            from . import parallel
+            return parallel.score_sharded(self.exchange, models, T2, has_compound, exponent)
+        return self.ctx.score(models, T2, has_compound=has_compound, exponent=exponent)
+
+    def run(self, T2, has_compound, exponent, weights=None):
+        """One GC-RANSAC-style proposal.  Returns dict(model, inliers (ascending indices), iterations) or None."""
+        est, s = self.est, self.s
+        self.sampler.reset()
+        samples = self.sampler.draw(int(s.max_iteration_number), est.sample_size)
+        if len(samples) == 0:
+            return None
+        models, src = est.minimal(self.pts, samples)
+        if len(models) == 0:
+            return dict(model=None, inliers=np.zeros(0, np.int64), iterations=len(samples))
+        table = self._score(models, T2, has_compound, exponent)
+        best, iters, history = replay_sequential(table["counts"], table["scores"], src, self.n, est.sample_size,
+                                                 s.confidence, s.max_iteration_number)
+        if best < 0:
+            return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iters)
+        model, score = models[best].copy(), float(table["scores"][best])
+        # local optimisation: iterated LSQ refits scored with the same compound term
+        lo_budget = int(s.max_local_optimization_number)
+        while lo_budget > 0:
+            lo_budget -= 1
+            one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+            inl = mask_to_indices(one["masks"][0], self.n)
+            if len(inl) < est.nonminimal_sample_size:
+                break
+            fits = est.nonminimal(self.pts, inl, weights, init=model)
+            if len(fits) != 1:
+                break
+            cand = self.ctx.score(fits[0][None, :], T2, has_compound=has_compound, exponent=exponent)
+            if float(cand["scores"][0]) > score and int(cand["counts"][0]) > 0:
+                model, score = np.asarray(fits[0], dtype=np.float64), float(cand["scores"][0])
+            else:
+                break
+        final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iters,
+                    score=float(final["scores"][0]))
+
+
+def mask_to_indices(mask_row, n):
+    bits = np.unpackbits(np.ascontiguousarray(mask_row).view(np.uint8), bitorder="little")[:n]
+    return np.nonzero(bits)[0].astype(np.int64)

@@ -1,0 +1,111 @@
+"""OracleContext — a stand-in for pyprogressivex._lib.Context whose every method is answered by the CPU oracle.
+
+TEST INFRASTRUCTURE: lets the host control flow (ProgressiveX.run / Pearl.run / ProposalEngine) be exercised on a box
+without a GPU, and lets the GPU tests assert that the whole pipeline returns the same model set and labelling as the
+CPU restatement for the same hypothesis list.  Never imported by the product package.
+"""
+import numpy as np
+
+import pgx_oracle as O
+
+
+class OracleContext:
+    def __init__(self, device_id=0):
+        self.model_type = None
+        self.n = 0
+        self.M = 0
+        self.nranks, self.rank = 1, 0
+        self.slots = {}
+        self.comp = None
+        self.graph = None
+        self.labels = None
+        self.Dq = None
+        self._stats = dict(mincuts=0, sweeps=0, global_relabels=0, bfs_levels=0, relabelled_sites=0)
+
+    def close(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def set_points(self, model_type, points):
+        self.pts = np.ascontiguousarray(points, dtype=np.float64)
+        self.model_type = model_type
+        self.n = self.pts.shape[0]
+        self.comp = np.zeros(self.n)
+        self.slots = {}
+
+    def set_compound(self, compound=None):
+        self.comp = np.zeros(self.n) if compound is None else np.asarray(compound, dtype=np.float64).copy()
+
+    def get_compound(self):
+        return self.comp.copy()
+
+    def score(self, models, T2, has_compound=False, exponent=2, want_masks=False):
+        r = O.score(self.model_type, self.pts, models, T2, compound=self.comp, has_compound=has_compound,
+                    exponent=exponent, want_masks=want_masks)
+        self.M = len(r["counts"])
+        return r
+
+    def preference(self, model, T2, slot, want_pref=False):
+        p = O.preference(self.model_type, self.pts, model, T2)
+        self.slots[slot] = p
+        d, a, b = O.tanimoto_terms(p, self.comp)
+        return dict(pref=p.copy() if want_pref else None, dot=d, pref_sqnorm=a, comp_sqnorm=b)
+
+    def get_preference(self, slot):
+        return self.slots[slot].copy()
+
+    def compound_update(self, slots, want_compound=False):
+        slots = list(slots)
+        if len(slots) > 0:
+            self.comp = O.compound_max(np.stack([self.slots[s] for s in slots]))
+        return self.comp.copy() if want_compound else None
+
+    def pearl_unary(self, models, threshold, lam, want_table=False):
+        models = np.zeros((0, O.PARAM_DIM[self.model_type])) if models is None else models
+        self.Dq = O.unary_q(self.model_type, self.pts, models, threshold, lam)
+        self.L = self.Dq.shape[1]
+        return self.Dq.copy() if want_table else None
+
+    def set_unary_q(self, Dq):
+        self.Dq = np.ascontiguousarray(Dq, dtype=np.int64)
+        self.L = self.Dq.shape[1]
+
+    def set_graph(self, off, idx, mult):
+        self.graph = (np.asarray(off, np.int32), np.asarray(idx, np.int32), np.asarray(mult, np.int32))
+
+    def set_labels(self, labels):
+        self.labels = np.asarray(labels, dtype=np.int32).copy()
+
+    def get_labels(self):
+        return self.labels.copy()
+
+    def _g(self, lam):
+        if lam > 0 and self.graph is not None and len(self.graph[1]) > 0:
+            return self.graph
+        return (np.zeros(self.Dq.shape[0] + 1, np.int32), np.zeros(1, np.int32), np.ones(1, np.int32))
+
+    def energy(self, lam, label_cost):
+        e = O.energy(self.Dq, self._g(lam), O.quantize_lambda(lam), O.quantize(label_cost), self.labels)
+        return e, e / 2.0 ** 32
+
+    def expand_alpha(self, lam, label_cost, alpha):
+        self.labels, ch, _ = O.expand_alpha(self.Dq, self._g(lam), O.quantize_lambda(lam), O.quantize(label_cost),
+                                            alpha, self.labels)
+        return ch
+
+    def expansion(self, lam, label_cost, max_cycles=1000):
+        self.labels, e, cyc = O.expansion(self.Dq, self._g(lam), O.quantize_lambda(lam), O.quantize(label_cost),
+                                          self.labels, max_cycles)
+        return e, e / 2.0 ** 32, cyc
+
+    def expansion_stats(self):
+        return dict(self._stats)
+
+    def bucket(self, L, want_order=True):
+        counts, order = O.bucket(self.labels, L)
+        return counts, (order if want_order else None)
+
+    def residual_sum(self, model, label):
+        return O.residual_sum(self.model_type, self.pts, model, self.labels, label)

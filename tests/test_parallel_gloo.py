@@ -1,0 +1,68 @@
+"""N > 1 host logic on CPU: world_size = 2 over torch.distributed/gloo.  Each rank scores its shard of the hypothesis
+batch (scorer injected: the oracle), the all-gather + merge must give every rank the full table in global hypothesis
+order, identical to the single-process result, and both ranks must select the same winner."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(r"{root}", "progressive-x_amd"), os.path.join(r"{root}", "oracle"), r"{here}"]
+import torch.distributed as dist
+import pgx_oracle as O
+from pyprogressivex import parallel
+from helpers import make_case
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mt, pts, models, thr = make_case("pnp", 3000, 37, seed=4)      # 37 hypotheses: ragged shards (19 + 18)
+T2 = 2.25 * thr * thr
+comp = np.linspace(0, 1, 3000)
+def scorer(shard, T2, has_compound, exponent):
+    return O.score(mt, pts, shard, T2, compound=comp, has_compound=has_compound, exponent=exponent)
+ex = parallel.GlooExchange(scorer, world, rank)
+table = parallel.score_sharded(ex, models, T2, has_compound=True, exponent=2)
+full = O.score(mt, pts, models, T2, compound=comp, has_compound=True, exponent=2)
+for k in ("counts", "values", "shared", "scores"):
+    assert np.array_equal(table[k], full[k]), k
+best = parallel.select_best(table["scores"], table["counts"])
+assert best == parallel.select_best(full["scores"], full["counts"])
+shard, lo, hi = parallel.shard_hypotheses(models, world, rank)
+assert shard.shape[0] == 19 and np.isnan(shard[hi - lo:]).all()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok best", best)
+'''
+
+
+def test_sharded_scoring_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, here=HERE))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok best" in o for o in outs)
+
+
+def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
+    from pyprogressivex import parallel
+    monkeypatch.setenv("PGX_RDV_DIR", str(tmp_path))
+    uid = bytes(range(128))
+    assert parallel.exchange_unique_id(0, 2, lambda: uid) == uid
+    assert parallel.exchange_unique_id(1, 2, lambda: b"", timeout=5) == uid
+    parallel.cleanup_unique_id(0)
+    assert not list(tmp_path.iterdir())
