@@ -8,6 +8,9 @@ Extensions that do not change the reference behaviour when left at their default
   seed=None                     reproducible sampling (the reference seeds from std::random_device)
   max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
   residual="transfer"           findHomographies: "symmetric" switches to the symmetric transfer error (U-1 switch)
+  neighborhood="flann_like"     U-7 switch: "flann_like" (<= 5 nearest neighbours inside the ball, what upstream's
+                                checks=6 approximate search can return at most), "radius" (all points in the ball),
+                                or "knn:<k>"
 """
 import sys
 
@@ -54,7 +57,7 @@ def _unknown_sampler(sampler_id):
 
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
-         do_logging=False, weights=None, seed=None, max_outer_iterations=10):
+         do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
     n = pts.shape[0]
     if getattr(sampler_factory, "unknown", False):
         # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
@@ -62,7 +65,13 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         return [], np.zeros(n, dtype=np.int32), None
     ctx = _context()
     rng = np.random.default_rng(seed)
-    graph = _graph.radius_graph(graph_points, radius)       # FlannNeighborhoodGraph(&points, radius) [U-7]
+    # FlannNeighborhoodGraph(&points, radius) [U-7]
+    if neighborhood == "radius":
+        graph = _graph.radius_graph(graph_points, radius)
+    elif str(neighborhood).startswith("knn:"):
+        graph = _graph.knn_graph(graph_points, int(str(neighborhood)[4:]))
+    else:
+        graph = _graph.flann_like_graph(graph_points, radius)
     sampler = sampler_factory(n, rng, graph)
     s = _engine.MultiModelSettings()
     s.minimum_number_of_inliers = int(minimum_point_number)          # progressivex_python.cpp:261
@@ -108,7 +117,7 @@ def _sampler_factory(sampler_id, valid):
 def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-                     do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer"):
+                     do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like"):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -126,14 +135,14 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
     return _stack(est, models, 3), labels
 
 
 def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
-                       do_logging=False, *, seed=None, max_outer_iterations=10):
+                       do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -151,7 +160,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
     return _stack(est, models, 3), labels
 
 
@@ -161,7 +170,7 @@ findFundamentalMatrices = findTwoViewMotions   # name used by BASELINE.json's no
 def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-                        do_logging=False, *, seed=None, max_outer_iterations=10):
+                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -177,14 +186,15 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
-                             weights=_weights(weights), seed=seed, max_outer_iterations=max_outer_iterations)
+                             weights=_weights(weights), seed=seed, max_outer_iterations=max_outer_iterations,
+                             neighborhood=neighborhood)
     return _stack(est, models, 3), labels
 
 
 def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_weight=0.0,
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-              do_logging=False, *, seed=None, max_outer_iterations=10):
+              do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -201,13 +211,14 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
     return _stack(est, models, 3), labels
 
 
 def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_weight=0.1,
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
-                minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10):
+                minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
+                neighborhood="flann_like"):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
     import time
     x1 = _as_f64(x1y1)
@@ -241,5 +252,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
     return _stack(est, models, 4), labels

@@ -2,10 +2,18 @@
 
 Replaces: gcransac::neighborhood::FlannNeighborhoodGraph(&points, radius) + getNeighbors(i)
 (/root/reference/src/pyprogressivex/src/progressivex_python.cpp:104,207,339,458,571; PEARL.h:534).  The FLANN
-implementation is absent from the snapshot [U-7]: restated as an EXACT radius search in the full d-dimensional data
-space (scipy cKDTree), which makes the raw lists symmetric, so PEARL's setNeighbors loop (PEARL.h:532-536) inserts every
-undirected pair twice => multiplicity 2 per pair [U-6].  A k-NN variant (BASELINE config C5) is provided too; its raw
-lists are not symmetric, so pairs get multiplicity 1 or 2.
+implementation is absent from the snapshot [U-7, UPSTREAM-MEMORY]: upstream runs OpenCV's FlannBasedMatcher
+(4 kd-trees, SearchParams(checks = 6)).radiusMatch in the full d-dimensional data space and drops the first match
+(the point itself) — an APPROXIMATE search that inspects about six candidates per query, so every list holds at most a
+handful of points inside the ball and the lists are not symmetric.  Three deterministic restatements are provided:
+
+  flann_like_graph(points, radius, k=5)   default of the drop-in API: the k nearest neighbours inside the ball
+                                          (exact), i.e. the list length upstream's checks=6 search can return at most
+  radius_graph(points, radius)            every point inside the ball (symmetric lists => multiplicity 2, U-6)
+  knn_graph(points, k)                    plain k-NN (BASELINE config C5 asks for a k-NN graph)
+
+PEARL's setNeighbors loop (PEARL.h:532-536) inserts one entry per DIRECTED list element, so an undirected pair gets
+multiplicity 1 or 2 depending on whether one or both lists contain it [U-6].
 """
 import numpy as np
 
@@ -46,6 +54,22 @@ def radius_graph(points, radius):
     if pairs.shape[0] == 0:
         return np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
     return csr_from_pairs(n, pairs[:, 0], pairs[:, 1], np.full(pairs.shape[0], 2))
+
+
+def flann_like_graph(points, radius, k=5):
+    from scipy.spatial import cKDTree
+    pts = np.asarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    kk = min(k + 1, n)
+    if kk <= 1:
+        return np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    dist, nbr = cKDTree(pts).query(pts, k=kk, distance_upper_bound=float(radius))
+    src = np.repeat(np.arange(n), kk)
+    dst = nbr.reshape(-1)
+    ok = np.isfinite(dist.reshape(-1)) & (dst < n) & (dst != src)
+    if not ok.any():
+        return np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return symmetrize(n, src[ok], dst[ok])
 
 
 def knn_graph(points, k):
