@@ -2,6 +2,7 @@
 // the thin wrappers around the kernel launchers.  No C++ type, exception or PyTorch object crosses this boundary.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "pgx_internal.h"
@@ -92,6 +93,8 @@ int pgx_create(int device_id, pgx_ctx** out)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    const char* nf = std::getenv("PGX_NO_FILTER");
+    ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : 1;
     *out = ctx;
     return PGX_OK;
 }
@@ -103,7 +106,7 @@ void pgx_destroy(pgx_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_free(ctx);
     maxflow_free(ctx);
-    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
+    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch};
@@ -172,7 +175,27 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: n must be < 2^31");
     PGX_TRY(ensure(ctx, ctx->pts, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->comp, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pmax, (size_t)n * sizeof(double)));
+    // score-filter scales (score.hip Filter<>): Umax = largest |observed image coordinate|, pmax[i] = max(|the
+    // coordinates the projective map multiplies|, 1).  Model types without a filter get pmax = 1, Umax = 0.
+    std::vector<double> pmax((size_t)n, 1.0);
+    double umax = 0.0;
+    int obs0 = -1, obs1 = -1, in0 = 0, in1 = -1;
+    if (model_type == kPnP) { obs0 = 0; obs1 = 1; in0 = 2; in1 = 4; }
+    else if (model_type == kHomography) { obs0 = 2; obs1 = 3; in0 = 0; in1 = 1; }
+    if (obs0 >= 0)
+        for (int64_t i = 0; i < n; ++i) {
+            const double* r = points + i * d;
+            const double a = std::fabs(r[obs0]), b = std::fabs(r[obs1]);
+            if (!(a <= umax)) umax = a;   // NaN propagates into umax => filter disabled
+            if (!(b <= umax)) umax = b;
+            double pm = 1.0;
+            for (int k = in0; k <= in1; ++k) { const double v = std::fabs(r[k]); if (!(v <= pm)) pm = v; }
+            pmax[(size_t)i] = pm;
+        }
+    ctx->umax = umax;
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts.p, points, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pmax.p, pmax.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)n * sizeof(double), ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
@@ -272,6 +295,7 @@ int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, in
     if (!ctx || ctx->n <= 0 || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_algorithmic_bytes: nothing to score");
     // points once + compound once + models once + (count,value,shared) per hypothesis (+ optional bit masks)
     int64_t b = ctx->n * ctx->D * 8 + ctx->n * 8 + (int64_t)ctx->M * ctx->P * 8 + (int64_t)ctx->M * 24;
+    if (ctx->last_score_filtered) b += ctx->n * 8;  // per-point scale of the rejection filter
     if (want_masks) b += (int64_t)ctx->M * ((ctx->n + 63) / 64) * 8;
     if (bytes) *bytes = b;
     if (pairs) *pairs = ctx->n * (int64_t)ctx->M;

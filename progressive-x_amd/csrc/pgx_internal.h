@@ -35,6 +35,10 @@ struct pgx_ctx {
     int model_type = -1, D = 0, P = 0;
     int64_t n = 0;
     pgx::DevBuf pts, comp;
+    pgx::DevBuf pmax;        // per point max(|coords the filter scales by|, 1)  (score filter)
+    double umax = 0.0;       // max |observed image coordinate| over all points
+    int filter_enabled = 1;  // PGX_NO_FILTER=1 in the environment disables the rejection filter (A/B, debugging)
+    int last_score_filtered = 0;
 
     // scoring
     int M = 0, Mpad = 0, chunks = 0;

@@ -14,16 +14,86 @@
 //     which keeps multi-GPU replicas identical without communication).
 // The kernel is FP64-VALU bound (≈0.02 algorithmic bytes per pair); MFMA is deliberately unused: there is no
 // dense contraction, every pair is a projective map + divide + compare.
+#include <cmath>
+
 #include "pgx_internal.h"
 
 namespace pgx {
 
 constexpr int kScoreBlock = 256;
 
-template <int MT, bool MASK>
+// ---- conservative rejection filter ------------------------------------------------------------
+// Most (point, hypothesis) pairs are far from the threshold.  For those the two IEEE divisions of the reprojection /
+// transfer residual (~110 of ~230 VALU cycles per wave-iteration) are wasted: the pair only has to be PROVEN an outlier.
+// reject() evaluates the division-free form  (u pz - px)^2 + (v pz - py)^2 > T2 (1 + 2^-20) pz^2  with FMA arithmetic
+// and returns true only when, additionally, pz is large enough against the rounding error E <= 4.5 eps L_h P_i of the
+// projection (L_h = largest row 1-norm of the hypothesis, P_i = max(|coords of point i|, 1), both precomputed) that the
+// inequality cannot be flipped by rounding in either arithmetic:  E (1 + Umax + T) 2^24 / T <= |pz|, with the host
+// guaranteeing Umax / T <= 2^28 (otherwise the unfiltered instance is launched).  Every pair that is not rejected —
+// including everything involving NaN/Inf, for which all comparisons are false — goes through the exact, oracle-order,
+// no-FMA path below, so counts, masks and scores are bit-identical to the unfiltered kernel; the proof that no true
+// inlier (exact r^2 < T2) can be rejected is in DESIGN.md §5.2.
+constexpr double kFilterDelta = 1.0 / 1048576.0;  // 2^-20 > 12 * 2^-24
+
+template <int MT> struct Filter {
+    static constexpr bool enabled = false;
+    struct Lane {};
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD&, double) { return {}; }
+    template <class PT, class MD>
+    static __device__ __forceinline__ bool reject(const PT&, const MD&, const Lane&, double, double) { return false; }
+};
+
+template <> struct Filter<kPnP> {
+    static constexpr bool enabled = true;
+    struct Lane { double c; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard) {
+        const double l0 = fabs(m[0]) + fabs(m[1]) + fabs(m[2]) + fabs(m[3]);
+        const double l1 = fabs(m[4]) + fabs(m[5]) + fabs(m[6]) + fabs(m[7]);
+        const double l2 = fabs(m[8]) + fabs(m[9]) + fabs(m[10]) + fabs(m[11]);
+        return {guard * fmax(l0, fmax(l1, l2))};
+    }
+    template <class PT, class MD>
+    static __device__ __forceinline__ bool reject(const PT& p, const MD& m, const Lane& ln, double pmax, double T2d) {
+        const double px = __builtin_fma(m[0], p[2], __builtin_fma(m[1], p[3], __builtin_fma(m[2], p[4], m[3])));
+        const double py = __builtin_fma(m[4], p[2], __builtin_fma(m[5], p[3], __builtin_fma(m[6], p[4], m[7])));
+        const double pz = __builtin_fma(m[8], p[2], __builtin_fma(m[9], p[3], __builtin_fma(m[10], p[4], m[11])));
+        const double a = __builtin_fma(p[0], pz, -px);
+        const double b = __builtin_fma(p[1], pz, -py);
+        const double lhs = __builtin_fma(b, b, a * a);
+        const double rhs = (pz * pz) * T2d;
+        const bool trust = ln.c * pmax <= fabs(pz);  // false on NaN
+        return trust && (lhs > rhs);                 // false on NaN
+    }
+};
+
+template <> struct Filter<kHomography> {
+    static constexpr bool enabled = true;
+    struct Lane { double c; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard) {
+        const double l0 = fabs(h[0]) + fabs(h[1]) + fabs(h[2]);
+        const double l1 = fabs(h[3]) + fabs(h[4]) + fabs(h[5]);
+        const double l2 = fabs(h[6]) + fabs(h[7]) + fabs(h[8]);
+        return {guard * fmax(l0, fmax(l1, l2))};
+    }
+    template <class PT, class MD>
+    static __device__ __forceinline__ bool reject(const PT& p, const MD& h, const Lane& ln, double pmax, double T2d) {
+        const double t1 = __builtin_fma(h[0], p[0], __builtin_fma(h[1], p[1], h[2]));
+        const double t2 = __builtin_fma(h[3], p[0], __builtin_fma(h[4], p[1], h[5]));
+        const double t3 = __builtin_fma(h[6], p[0], __builtin_fma(h[7], p[1], h[8]));
+        const double a = __builtin_fma(p[2], t3, -t1);
+        const double b = __builtin_fma(p[3], t3, -t2);
+        const double lhs = __builtin_fma(b, b, a * a);
+        const double rhs = (t3 * t3) * T2d;
+        const bool trust = ln.c * pmax <= fabs(t3);
+        return trust && (lhs > rhs);
+    }
+};
+
+template <int MT, bool MASK, bool FILT>
 __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     const double* __restrict__ pts, int64_t n, const double* __restrict__ models, int M, int Mpad,
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
+    const double* __restrict__ pmax, double guard,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
     unsigned long long* __restrict__ masks, int64_t words)
 {
@@ -38,6 +108,10 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     for (int k = 0; k < R::P; ++k)
         mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");  // NaN model: never an inlier
 
+    using F = Filter<MT>;
+    const typename F::Lane flane = F::prep(mdl, guard);
+    const double T2d = T2 * (1.0 + kFilterDelta);
+
     unsigned cnt = 0;
     double val = 0.0, sh = 0.0;
     unsigned long long word = 0;
@@ -47,13 +121,18 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
         double pt[R::D];
 #pragma unroll
         for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
-        const double sq = R::squared(pt, mdl);
-        const bool inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
-        if (inl) {
-            ++cnt;                                        // :91
-            const double s = cv_max(0.0, 1.0 - sq / T2);  // :94
-            val += s;                                     // :97
-            if (has_comp) sh += cv_min(comp[i], s);       // :115-117 (pref = 0 for non-inliers adds +0)
+        bool inl = false;
+        bool rejected = false;
+        if (FILT && F::enabled) rejected = F::reject(pt, mdl, flane, pmax[i], T2d);
+        if (live && !rejected) {  // exact path: oracle operation order, no contraction
+            const double sq = R::squared(pt, mdl);
+            inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
+            if (inl) {
+                ++cnt;                                        // :91
+                const double s = cv_max(0.0, 1.0 - sq / T2);  // :94
+                val += s;                                     // :97
+                if (has_comp) sh += cv_min(comp[i], s);       // :115-117 (pref = 0 for non-inliers adds +0)
+            }
         }
         if (MASK) {
             word |= (unsigned long long)(inl ? 1 : 0) << (i & 63);
@@ -69,46 +148,72 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     psh[o] = sh;
 }
 
-// Adds the chunk partials of each hypothesis in chunk order (fixed => bit-reproducible).
-__global__ __launch_bounds__(256) void score_reduce_kernel(
+// Adds the chunk partials of each hypothesis in a FIXED order (bit-reproducible): 64 hypotheses per block, 16 waves
+// each summing the chunks k = wave, wave+16, ... sequentially, then the 16 wave sums are added in wave order.
+constexpr int kReduceWaves = 16;
+__global__ __launch_bounds__(64 * kReduceWaves) void score_reduce_kernel(
     const unsigned* __restrict__ pcnt, const double* __restrict__ pval, const double* __restrict__ psh,
     int chunks, int Mpad, int M, long long* __restrict__ counts, double* __restrict__ values,
     double* __restrict__ shared)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+    __shared__ long long lc[kReduceWaves][64];
+    __shared__ double lv[kReduceWaves][64], ls[kReduceWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
     long long c = 0;
     double v = 0.0, s = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const int64_t o = (int64_t)k * Mpad + m;
-        c += pcnt[o];
-        v += pval[o];
-        s += psh[o];
+    if (m < M)
+        for (int k = wave; k < chunks; k += kReduceWaves) {
+            const int64_t o = (int64_t)k * Mpad + m;
+            c += pcnt[o];
+            v += pval[o];
+            s += psh[o];
+        }
+    lc[wave][lane] = c; lv[wave][lane] = v; ls[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && m < M) {
+        for (int w = 1; w < kReduceWaves; ++w) { c += lc[w][lane]; v += lv[w][lane]; s += ls[w][lane]; }
+        counts[m] = c;
+        values[m] = v;
+        shared[m] = s;
     }
-    counts[m] = c;
-    values[m] = v;
-    shared[m] = s;
+}
+
+template <int MT, bool MASK, bool FILT>
+static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double guard)
+{
+    dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
+    hipLaunchKernelGGL((score_kernel<MT, MASK, FILT>), grid, dim3(kScoreBlock), 0, ctx->stream, ctx->pts.as<double>(),
+                       ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
+                       ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
+                       ctx->psh.as<double>(), MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr,
+                       ctx->words);
 }
 
 template <int MT>
 static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
 {
-    dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
-    dim3 block(kScoreBlock);
-    if (want_masks)
-        hipLaunchKernelGGL((score_kernel<MT, true>), grid, block, 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
-                           ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
-                           ctx->chunk, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                           ctx->masks.as<unsigned long long>(), ctx->words);
-    else
-        hipLaunchKernelGGL((score_kernel<MT, false>), grid, block, 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
-                           ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
-                           ctx->chunk, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                           (unsigned long long*)nullptr, ctx->words);
+    // filter guard (see Filter<> above): usable iff Umax / T <= 2^28 and everything is finite
+    const double T = std::sqrt(T2);
+    double guard = 0.0;
+    bool filt = Filter<MT>::enabled && ctx->filter_enabled && T > 0.0 && std::isfinite(T) && std::isfinite(ctx->umax) &&
+                ctx->umax <= T * 268435456.0;
+    if (filt) {
+        guard = 4.5 * 1.1102230246251565e-16 * (1.0 + ctx->umax + T) * 16777216.0 / T;
+        filt = std::isfinite(guard);
+    }
+    ctx->last_score_filtered = filt ? 1 : 0;
+    if (want_masks) {
+        if (filt) score_launch_one<MT, true, true>(ctx, T2, has_compound, guard);
+        else score_launch_one<MT, true, false>(ctx, T2, has_compound, guard);
+    } else {
+        if (filt) score_launch_one<MT, false, true>(ctx, T2, has_compound, guard);
+        else score_launch_one<MT, false, false>(ctx, T2, has_compound, guard);
+    }
     PGX_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream,
-                       ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(), ctx->chunks,
-                       ctx->Mpad, ctx->M, ctx->counts.as<long long>(), ctx->values.as<double>(),
+    hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
+                       ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
+                       ctx->chunks, ctx->Mpad, ctx->M, ctx->counts.as<long long>(), ctx->values.as<double>(),
                        ctx->shared.as<double>());
     PGX_HIP(ctx, hipGetLastError());
     return PGX_OK;

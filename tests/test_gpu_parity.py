@@ -105,6 +105,59 @@ def test_score_threshold_boundary_is_strict(gpu_ctx, oracle):
     assert np.array_equal(Dq, oracle.unary_q(mt, pts, model, thr, 0.25))
 
 
+@pytest.mark.parametrize("name", ["pnp", "homography"])
+def test_score_filter_adversarial(gpu_ctx, oracle, name):
+    """The rejection filter (score.hip Filter<>) must never change a result: thresholds placed exactly ON residuals,
+    hypotheses a hair away from ground truth, vanishing denominators, NaN/Inf inputs, and magnitudes that must trip the
+    host guard all have to reproduce the oracle's counts and masks bit for bit."""
+    mt, pts, models, thr = make_case(name, 4096, 64, seed=77)
+    rng = np.random.default_rng(5)
+    pts = pts.copy()
+    models = models.copy()
+    gt = models[0].copy()
+    # hypotheses at relative distance 1e-12 .. 1e-3 from a ground-truth model: residuals straddle the threshold
+    for k in range(8, 40):
+        models[k] = gt * (1.0 + rng.normal(0, 10.0 ** rng.uniform(-12, -3), gt.shape))
+    # denominators that cancel to ~0 for the ground-truth model (pz = 0 / t3 = 0), and exact zeros
+    if name == "pnp":
+        P = gt.reshape(3, 4)
+        for i in range(0, 200):
+            X, Y = pts[i, 2], pts[i, 3]
+            pts[i, 4] = -(P[2, 0] * X + P[2, 1] * Y + P[2, 3]) / P[2, 2] * (1.0 + (i % 5) * 1e-16)
+    else:
+        H = gt.reshape(3, 3)
+        for i in range(0, 200):
+            pts[i, 1] = -(H[2, 0] * pts[i, 0] + H[2, 2]) / H[2, 1] * (1.0 + (i % 5) * 1e-16) if H[2, 1] != 0 else 0.0
+    pts[200:210] = 0.0
+    pts[210, 0] = np.nan
+    pts[211, -1] = np.inf
+    pts[212, 0] = -np.inf
+    models[40] = np.nan
+    models[41] = 0.0
+    models[42, 0] = np.inf
+    models[43] = gt * 1e150
+    models[44] = gt * 1e-150
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.set_compound(None)
+    sq0 = oracle.squared_residuals(mt, pts, gt)
+    finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
+    T2s = [2.25 * thr * thr, finite[len(finite) // 3], np.nextafter(finite[len(finite) // 3], np.inf),
+           np.nextafter(finite[len(finite) // 3], 0), finite[0], finite[-1] * 4, 1e-30, 1e30]
+    for T2 in T2s:
+        got = gpu_ctx.score(models, float(T2), want_masks=True)
+        ref = oracle.score(mt, pts, models, float(T2), want_masks=True)
+        assert np.array_equal(got["counts"], ref["counts"]), (name, T2)
+        assert np.array_equal(got["masks"], ref["masks"]), (name, T2)
+        assert _rel(got["values"], ref["values"]) <= REL
+    # huge observed coordinates: Umax / T exceeds the guard => the library must fall back to the unfiltered instance
+    big = pts.copy()
+    big[300:310, 0 if name == "pnp" else 2] = 1e13
+    gpu_ctx.set_points(mt, big)
+    got = gpu_ctx.score(models, 2.25 * thr * thr, want_masks=True)
+    ref = oracle.score(mt, big, models, 2.25 * thr * thr, want_masks=True)
+    assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["masks"], ref["masks"])
+
+
 def test_score_early_exit_predicate_is_order_free(oracle):
     # scoring_function_with_compound_model.h:105-106 fires iff count + 1 < best: pure function of the full count,
     # which is why the batched kernel needs no point ordering (checked on the oracle itself; host logic applies it).
