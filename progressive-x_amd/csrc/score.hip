@@ -116,14 +116,13 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     double val = 0.0, sh = 0.0;
     unsigned long long word = 0;
 
-    for (int64_t i = i0; i < i1; ++i) {
-        const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
-        double pt[R::D];
-#pragma unroll
-        for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
+    // One point per step; the body is written once and instantiated for a group of kUnroll points whose scalar loads
+    // are all issued before the first use, so one s_waitcnt covers kUnroll points (SMEM returns out of order: the
+    // only usable wait is lgkmcnt(0), which makes per-point prefetching impossible).
+    auto step = [&](int64_t i, const double (&pt)[R::D], double pm) {
         bool inl = false;
         bool rejected = false;
-        if (FILT && F::enabled) rejected = F::reject(pt, mdl, flane, pmax[i], T2d);
+        if (FILT && F::enabled) rejected = F::reject(pt, mdl, flane, pm, T2d);
         if (live && !rejected) {  // exact path: oracle operation order, no contraction
             const double sq = R::squared(pt, mdl);
             inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
@@ -141,6 +140,28 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
                 word = 0;
             }
         }
+    };
+    constexpr int kUnroll = 4;
+    int64_t i = i0;
+    for (; i + kUnroll <= i1; i += kUnroll) {
+        const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
+        double pt[kUnroll][R::D];
+        double pm[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+            for (int k = 0; k < R::D; ++k) pt[u][k] = prow[u * R::D + k];
+            pm[u] = (FILT && F::enabled) ? pmax[i + u] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], pm[u]);
+    }
+    for (; i < i1; ++i) {
+        const double* __restrict__ prow = pts + i * R::D;
+        double pt[R::D];
+#pragma unroll
+        for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
+        step(i, pt, (FILT && F::enabled) ? pmax[i] : 1.0);
     }
     const int64_t o = (int64_t)blockIdx.y * Mpad + m;
     pcnt[o] = cnt;
