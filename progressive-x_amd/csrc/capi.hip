@@ -95,6 +95,9 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     const char* nf = std::getenv("PGX_NO_FILTER");
     ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : 1;
+    const char* df = std::getenv("PGX_SCORE_DEFERRED");
+    ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
     *out = ctx;
     return PGX_OK;
 }

@@ -39,6 +39,8 @@ struct pgx_ctx {
     double umax = 0.0;       // max |observed image coordinate| over all points
     int filter_enabled = 1;  // PGX_NO_FILTER=1 in the environment disables the rejection filter (A/B, debugging)
     int last_score_filtered = 0;
+    int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)
+    int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)
 
     // scoring
     int M = 0, Mpad = 0, chunks = 0;

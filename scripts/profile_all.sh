@@ -1,0 +1,12 @@
+# usage (on the GPU box, through gpurun): bash scripts/profile_all.sh <tag>
+# kernel-trace stats + separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ) of the default bench; summaries -> gpurun_out/
+set -x
+TAG=${1:-run}
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_${TAG}_stats -o bench -- $B > $R/gpurun_out/p_${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/p_${TAG}_fetch -o bench -- $B > $R/gpurun_out/p_${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/p_${TAG}_write -o bench -- $B > $R/gpurun_out/p_${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -d $R/gpurun_out/p_${TAG}_sq -o bench -- $B > $R/gpurun_out/p_${TAG}_sq.log 2>&1
+cd $R && python scripts/rocpd_summary.py gpurun_out/p_${TAG}_stats/bench_results.db gpurun_out/p_${TAG}_fetch/bench_results.db gpurun_out/p_${TAG}_write/bench_results.db gpurun_out/p_${TAG}_sq/bench_results.db > gpurun_out/profile_${TAG}.txt
