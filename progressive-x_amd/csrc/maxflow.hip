@@ -16,24 +16,76 @@ namespace pgx {
 constexpr int kMfBlock = 256;
 
 struct MaxflowState {
-    DevBuf cap, ex, rt, d, f, g, small;
+    DevBuf cap, ex, rt, d, f, g, small, front;
     int* h_flags = nullptr;  // pinned host mirror for flag read-backs
 };
 
-#define MF_SITE_KERNEL(name, body_call)                                                        \
-    __global__ __launch_bounds__(kMfBlock) void name(MfView v, int a0, int a1)                 \
-    {                                                                                          \
-        const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;                        \
-        if (u < v.n) { body_call; }                                                            \
-    }
+constexpr int kMfMaxLabels = 64;
 
-MF_SITE_KERNEL(mf_k_count, mf_body_count(v, u))
-MF_SITE_KERNEL(mf_k_init, mf_body_init_site(v, u))
-MF_SITE_KERNEL(mf_k_bfs_init, mf_body_bfs_init(v, u))
-MF_SITE_KERNEL(mf_k_bfs_level, mf_body_bfs_level(v, u, a0))
-MF_SITE_KERNEL(mf_k_count_active, mf_body_count_active(v, u))
-MF_SITE_KERNEL(mf_k_sweep, mf_body_sweep(v, u, a0, a1))
-MF_SITE_KERNEL(mf_k_apply, mf_body_apply(v, u))
+__global__ __launch_bounds__(kMfBlock) void mf_k_count(MfView v, int, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    // per-block LDS histogram, one global atomic per (block, label present)
+    __shared__ int hist[kMfMaxLabels];
+    if (threadIdx.x < kMfMaxLabels) hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (u < v.n) atomicAdd(&hist[v.labels[u]], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < v.L && hist[threadIdx.x] > 0) atomicAdd(&v.cnt[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_init(MfView v, int, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    if (u < v.n) mf_body_init_site(v, u);
+}
+
+// Kernels whose per-site body reports a boolean and/or accumulates per-label minima: both are aggregated per block in
+// LDS and flushed with at most (L + 1) global operations per block.
+enum { kBfsInit = 0, kBfsLevel = 1, kCountActive = 2, kSweep = 3, kApply = 4 };
+
+template <int WHAT>
+__global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    bool r = false;
+    if (u < v.n) {
+        if (WHAT == kBfsInit) r = mf_body_bfs_init(v, u, s_min);
+        else if (WHAT == kCountActive) r = mf_body_count_active(v, u);
+        else if (WHAT == kSweep) r = mf_body_sweep(v, u, a0, a1, s_min);
+        else r = mf_body_apply(v, u);
+    }
+    if (WHAT == kBfsLevel) {
+        // frontier part: sites labelled a0-1 (grid-stride over the frontier; trip counts are wave-uniform because
+        // the append inside is wave-aggregated), then the hub part if a hub received distance a0-1
+        const int F = v.fcount[(a0 - 1) % 3];
+        const int stride = (int)(gridDim.x * kMfBlock);
+        const int rounds = (F + stride - 1) / stride;
+        for (int it = 0; it < rounds; ++it) {
+            const int q = it * stride + (int)u;
+            if (q < F) r |= mf_body_bfs_expand(v, v.front[(a0 - 1) & 1][q], a0, s_min);
+        }
+        const int ev = mf_bfs_hub_events(v, a0);
+        if (ev != 0 && u < v.n) r |= mf_body_bfs_hubpass(v, u, a0, (ev & 1) != 0, s_min);
+        if (blockIdx.x == 0 && threadIdx.x == 0) v.fcount[(a0 + 1) % 3] = 0;  // slot of the level after this one
+    }
+    const int count = __syncthreads_count(r ? 1 : 0);
+    if (WHAT == kBfsInit || WHAT == kBfsLevel) {
+        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], WHAT == kBfsInit ? 1 : a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (WHAT == kSweep) {
+        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf)
+            atomicMin(&v.hub_min[a1 * v.L + threadIdx.x], s_min[threadIdx.x]);
+        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (WHAT == kCountActive) {
+        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0 && count > 0) atomicAdd(&v.flags[2], count);
+    }
+}
 
 __global__ void mf_k_single(MfView v, int what, int a0, int a1)
 {
@@ -118,14 +170,14 @@ struct HipBackend {
     int read_count(const MfView& v, int l) { return read_int(v.cnt + l); }
     void init_sites(const MfView& v) { site(mf_k_init, v); }
     void bfs_reset(const MfView& v) { single(v, 1); }
-    void bfs_init(const MfView& v) { site(mf_k_bfs_init, v); }
-    void bfs_level(const MfView& v, int k) { site(mf_k_bfs_level, v, k); }
+    void bfs_init(const MfView& v) { site(mf_k_agg<kBfsInit>, v); }
+    void bfs_level(const MfView& v, int k) { site(mf_k_agg<kBfsLevel>, v, k); }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
     void bfs_finish(const MfView& v, int slot) { single(v, 2, slot); }
-    void count_active(const MfView& v) { site(mf_k_count_active, v); }
-    void sweep(const MfView& v, int prev, int cur) { site(mf_k_sweep, v, prev, cur); }
+    void count_active(const MfView& v) { site(mf_k_agg<kCountActive>, v); }
+    void sweep(const MfView& v, int prev, int cur) { site(mf_k_agg<kSweep>, v, prev, cur); }
     void sweep_epilogue(const MfView& v, int cur, int next) { single(v, 3, cur, next); }
-    void apply(const MfView& v) { site(mf_k_apply, v); }
+    void apply(const MfView& v) { site(mf_k_agg<kApply>, v); }
 };
 
 }  // namespace
@@ -135,7 +187,7 @@ void maxflow_free(pgx_ctx* ctx)
     if (!ctx->mf) return;
     MaxflowState* st = ctx->mf;
     release(st->cap); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
-    release(st->small);
+    release(st->small); release(st->front);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
     delete st;
     ctx->mf = nullptr;
@@ -148,6 +200,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: unary table not set");
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
     if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
+    if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
     const bool pair = lambda_q > 0;
     if (pair && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
     if (!ctx->mf) {
@@ -164,7 +217,8 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     PGX_TRY(ensure(ctx, st->d, (size_t)n * sizeof(int)));
     // small state: hub_e[L] i64 | hubA_rt i64 | hubA_min[3] u64 | cnt[L] | hub_exists[L] | bfs_hub_d[L] | hub_min[3L] |
     //              has_alpha_hub | bfs_hubA_d | flags[8]
-    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(6 * L + 2 + 8) * 4 + 64;
+    PGX_TRY(ensure(ctx, st->front, (size_t)2 * n * sizeof(int)));
+    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(9 * L + 2 + 3 + 8) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
     MfView v;
@@ -182,6 +236,9 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.hub_exists = (int*)sp; sp += (size_t)L * 4;
     v.bfs_hub_d = (int*)sp; sp += (size_t)L * 4;
     v.hub_min = (int*)sp; sp += (size_t)3 * L * 4;
+    v.fcount = (int*)sp; sp += 12;
+    v.front[0] = st->front.as<int>();
+    v.front[1] = st->front.as<int>() + n;
     v.has_alpha_hub = (int*)sp; sp += 4;
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;

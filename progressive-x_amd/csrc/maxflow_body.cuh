@@ -63,6 +63,8 @@ struct MfView {
     int* bfs_hubA_d;               // [1]
     int* hub_min;                  // [3][L] rotating: min member height of each beta hub
     unsigned long long* hubA_min;  // [3] rotating: (height << 32 | site) of the lowest member with g > 0
+    int* front[2];                 // BFS frontiers (site ids), ping-pong by level parity
+    int* fcount;                   // [3] frontier sizes, rotating by level % 3
     int* flags;                    // [8]: 0 last BFS level that labelled a site, 1 work-left (boolean, being
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep
     int hmax;                      // heights >= hmax are treated as unreachable
@@ -80,6 +82,19 @@ __device__ __forceinline__ bool mf_cas64(long long* p, long long& expected, long
     return ok;
 }
 __device__ __forceinline__ void mf_min32(int* p, int v) { atomicMin(p, v); }
+__device__ __forceinline__ bool mf_cas32(int* p, int expected, int desired) { return atomicCAS(p, expected, desired) == expected; }
+// wave-aggregated append: every ACTIVE lane calls it; lanes with want == true get consecutive slots from one atomic
+__device__ __forceinline__ void mf_append(int* counter, int* list, int value, bool want)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
 __device__ __forceinline__ void mf_minu64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
 __device__ __forceinline__ void mf_add32(int* p, int v) { atomicAdd(p, v); }
 __device__ __forceinline__ int mf_load32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -94,6 +109,15 @@ inline bool mf_cas64(long long* p, long long& expected, long long desired)
     return false;
 }
 inline void mf_min32(int* p, int v) { if (v < *p) *p = v; }
+inline bool mf_cas32(int* p, int expected, int desired)
+{
+    if (*p == expected) { *p = desired; return true; }
+    return false;
+}
+inline void mf_append(int* counter, int* list, int value, bool want)
+{
+    if (want) list[(*counter)++] = value;
+}
 inline void mf_minu64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
 inline void mf_add32(int* p, int v) { *p += v; }
 inline int mf_load32(const int* p) { return *p; }
@@ -164,14 +188,30 @@ PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
 }
 
 // ---- global relabel: level-synchronous reverse BFS from t --------------------------------------------------------
-PGX_HD void mf_bfs_mark(const MfView& v, int64_t u, int lu, int k)
+// hub_acc: where per-label minima are accumulated — the global array itself in the sequential emulation, a per-block
+// LDS array on the device (flushed with one global atomic per label per block; a direct global atomicMin per site
+// serialises ~N atomics on L addresses and was measured to dominate the kernels).
+PGX_HD void mf_acc_min(int* acc, int val)
 {
-    mf_store32(&v.d[u], k);
-    if (v.hub_exists[lu]) mf_min32(&v.bfs_hub_d[lu], k + 1);  // y_beta -> u has infinite capacity
-    if (v.has_alpha_hub[0] && mf_load64(&v.g[u]) > 0) {         // y_alpha -> u has residual g[u]
-        mf_minu64(&v.hubA_min[0], mf_pack(k, (int)u));          // slot 0 is the BFS result slot
-        mf_min32(&v.bfs_hubA_d[0], k + 1);
+    if (val < mf_load32(acc)) mf_min32(acc, val);
+}
+
+// Labels site u with BFS distance k (if still unlabelled), records what that implies for the hubs and appends u to the
+// frontier of level k.  Must be called convergently by all active lanes (wave-aggregated append); `want` selects lanes.
+PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want)
+{
+    bool mine = false;
+    if (want) mine = mf_cas32(&v.d[u], kMfInf, k);
+    if (mine) {
+        const int lu = v.labels[u];
+        if (v.hub_exists[lu]) mf_acc_min(&hub_acc[lu], k + 1);      // y_beta -> u has infinite capacity
+        if (v.has_alpha_hub[0] && mf_load64(&v.g[u]) > 0) {          // y_alpha -> u has residual g[u]
+            mf_minu64(&v.hubA_min[0], mf_pack(k, (int)u));           // slot 0 is the BFS result slot
+            mf_min32(&v.bfs_hubA_d[0], k + 1);
+        }
     }
+    mf_append(&v.fcount[k % 3], v.front[k & 1], (int)u, mine);
+    return mine;
 }
 
 // one thread, before level 1
@@ -180,30 +220,50 @@ PGX_HD void mf_body_bfs_reset(const MfView& v)
     for (int l = 0; l < v.L; ++l) v.bfs_hub_d[l] = kMfInf;
     v.bfs_hubA_d[0] = (v.has_alpha_hub[0] && v.hubA_rt[0] > 0) ? 1 : kMfInf;
     v.hubA_min[0] = ~0ull;
+    v.fcount[0] = v.fcount[1] = v.fcount[2] = 0;
     v.flags[0] = 0;
     v.flags[1] = 0;
 }
 
-PGX_HD void mf_body_bfs_init(const MfView& v, int64_t u)
+// level 1: sites with residual capacity to t.  Returns true iff the site was labelled.
+PGX_HD bool mf_body_bfs_init(const MfView& v, int64_t u, int* hub_acc)
 {
-    const int lu = v.labels[u];
-    if (lu == v.alpha) return;
-    if (v.rt[u] > 0) { mf_bfs_mark(v, u, lu, 1); mf_store32(&v.flags[0], 1); }
-    else mf_store32(&v.d[u], kMfInf);
+    const bool active = v.labels[u] != v.alpha;
+    if (active) mf_store32(&v.d[u], kMfInf);
+    return mf_bfs_label(v, u, 1, hub_acc, active && v.rt[u] > 0);
 }
 
-PGX_HD void mf_body_bfs_level(const MfView& v, int64_t u, int k)
+// level k, frontier part: site w was labelled k-1; every active unlabelled neighbour u with residual u -> w gets k
+PGX_HD bool mf_body_bfs_expand(const MfView& v, int64_t w, int k, int* hub_acc)
+{
+    bool any = false;
+    if (!v.off) return false;
+    for (int a = v.off[w]; a < v.off[w + 1]; ++a) {
+        const int u = v.idx[a];
+        const bool want = v.labels[u] != v.alpha && mf_load64(&v.cap[v.rev[a]]) > 0 && mf_load32(&v.d[u]) == kMfInf;
+        any |= mf_bfs_label(v, u, k, hub_acc, want);
+    }
+    return any;
+}
+
+// level k, hub part (only run when some hub received distance k-1): u -> y_alpha (inf) / u -> y_beta (residual f[u])
+PGX_HD bool mf_body_bfs_hubpass(const MfView& v, int64_t u, int k, bool alpha_event, int* hub_acc)
 {
     const int lu = v.labels[u];
-    if (lu == v.alpha) return;
-    if (mf_load32(&v.d[u]) != kMfInf) return;
-    bool found = false;
-    if (v.off)
-        for (int a = v.off[u]; a < v.off[u + 1] && !found; ++a)
-            if (mf_load64(&v.cap[a]) > 0 && mf_load32(&v.d[v.idx[a]]) == k - 1) found = true;
-    if (!found && v.has_alpha_hub[0] && mf_load32(&v.bfs_hubA_d[0]) == k - 1) found = true;       // u -> y_alpha (inf)
-    if (!found && v.hub_exists[lu] && v.f[u] > 0 && mf_load32(&v.bfs_hub_d[lu]) == k - 1) found = true;  // u -> y_beta
-    if (found) { mf_bfs_mark(v, u, lu, k); mf_store32(&v.flags[0], k); }
+    bool want = false;
+    if (lu != v.alpha && mf_load32(&v.d[u]) == kMfInf)
+        want = alpha_event || (v.hub_exists[lu] && v.f[u] > 0 && mf_load32(&v.bfs_hub_d[lu]) == k - 1);
+    return mf_bfs_label(v, u, k, hub_acc, want);
+}
+
+// uniform per level: which hub events fire at level k (bit 0: alpha hub, bit 1: some beta hub)
+PGX_HD int mf_bfs_hub_events(const MfView& v, int k)
+{
+    int ev = 0;
+    if (v.has_alpha_hub[0] && mf_load32(&v.bfs_hubA_d[0]) == k - 1) ev |= 1;
+    for (int l = 0; l < v.L; ++l)
+        if (v.hub_exists[l] && mf_load32(&v.bfs_hub_d[l]) == k - 1) ev |= 2;
+    return ev;
 }
 
 // one thread, after the BFS: publish hub heights for the sweeps (slot `slot`) and count active hubs
@@ -220,21 +280,28 @@ PGX_HD void mf_body_bfs_finish(const MfView& v, int slot)
     v.hubA_min[slot] = pk;
 }
 
-PGX_HD void mf_body_count_active(const MfView& v, int64_t u)
+PGX_HD bool mf_body_count_active(const MfView& v, int64_t u)
 {
-    if (v.labels[u] == v.alpha) return;
-    if (mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf) mf_store32(&v.flags[1], 1);
+    if (v.labels[u] == v.alpha) return false;
+    return mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf;
 }
 
 // ---- one push-relabel step for site u ------------------------------------------------------------------------------
 // prev/cur/next: rotating slots of the hub height scans (read prev, accumulate cur, clear next).
-PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
+// returns true iff this site did or still has work (the caller latches flags[1])
+PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc)
 {
     const int lu = v.labels[u];
-    if (lu == v.alpha) return;
-    int du = v.d[u];
+    if (lu == v.alpha) return false;
+    bool work = false;
     const bool hub_b = v.hub_exists[lu] != 0;
     const bool hub_a = v.has_alpha_hub[0] != 0;
+    // A hub's height is rescanned only while it holds excess (members pull); otherwise the last known height is carried
+    // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
+    // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
+    const bool scan_b = hub_b && mf_load64(&v.hub_e[lu]) > 0;
+    if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
+    int du = v.d[u];
     // hub heights as published by the previous scan
     int hb = kMfInf;
     if (hub_b) { const int m = v.hub_min[prev * v.L + lu]; hb = m == kMfInf ? kMfInf : m + 1; }
@@ -251,7 +318,7 @@ PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
         if (hub_b && hb == du + 1 && mf_load64(&v.hub_e[lu]) > 0) {
             const long long want = v.rt[u] > 0 ? v.rt[u] : (long long)1 << 62;
             const long long got = mf_reserve(&v.hub_e[lu], want);
-            if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); mf_store32(&v.flags[1], 1); }
+            if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); work = true; }
         }
         long long e = mf_load64(&v.ex[u]);
         if (e > 0) {
@@ -282,18 +349,18 @@ PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
                         mf_add64(&v.cap[v.rev[best_a]], dl);
                         mf_add64(&v.ex[u], -dl);
                         mf_add64(&v.ex[v.idx[best_a]], dl);
-                        mf_store32(&v.flags[1], 1);
+                        work = true;
                     } else if (kind == 2) {
                         if (ha_site < 0) {  // budget y_alpha -> t still open
                             const long long got = mf_reserve(v.hubA_rt, e);
-                            if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); mf_store32(&v.flags[1], 1); }
+                            if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); work = true; }
                         } else {            // through the saturated hub into its lowest member: u -> y_alpha -> p*
                             const long long got = mf_reserve(&v.g[ha_site], e);
                             if (got > 0) {
                                 mf_add64(&v.g[u], got);
                                 mf_add64(&v.ex[u], -got);
                                 mf_add64(&v.ex[ha_site], got);
-                                mf_store32(&v.flags[1], 1);
+                                work = true;
                             }
                         }
                     } else {  // back into the beta hub
@@ -301,7 +368,7 @@ PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
                         v.f[u] -= dl;
                         mf_add64(&v.ex[u], -dl);
                         mf_add64(&v.hub_e[lu], dl);
-                        mf_store32(&v.flags[1], 1);
+                        work = true;
                     }
                 } else {
                     du = best_h + 1;
@@ -312,19 +379,24 @@ PGX_HD void mf_body_sweep(const MfView& v, int64_t u, int prev, int cur)
         }
     }
     // contribute to the next hub height scan with the final height
-    if (hub_b && du < mf_load32(&v.hub_min[cur * v.L + lu])) mf_min32(&v.hub_min[cur * v.L + lu], du);
+    if (scan_b && du != kMfInf) mf_acc_min(&hub_acc[lu], du);
     if (hub_a && du != kMfInf && mf_load64(&v.g[u]) > 0) {
         const unsigned long long pk = mf_pack(du, (int)u);
         if (pk < v.hubA_min[cur]) mf_minu64(&v.hubA_min[cur], pk);
     }
-    if (du != kMfInf && mf_load64(&v.ex[u]) > 0) mf_store32(&v.flags[1], 1);
+    if (du != kMfInf && mf_load64(&v.ex[u]) > 0) work = true;
+    return work;
 }
 
 // one thread per sweep: clear the slot the NEXT sweep will accumulate into; latch the work-left flag
 PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next)
 {
     int act = v.flags[1];
+    const int prev = (cur + 2) % 3;
     for (int l = 0; l < v.L; ++l) {
+        // no scan was requested for this hub in this sweep: keep its last known height
+        if (v.hub_exists[l] && v.hub_e[l] <= 0 && v.hub_min[cur * v.L + l] == kMfInf)
+            v.hub_min[cur * v.L + l] = v.hub_min[prev * v.L + l];
         v.hub_min[next * v.L + l] = kMfInf;
         if (v.hub_exists[l] && v.hub_e[l] > 0 && v.hub_min[cur * v.L + l] != kMfInf) act = 1;
     }
@@ -334,13 +406,14 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next)
 }
 
 // ---- apply the cut ---------------------------------------------------------------------------------------------
-PGX_HD void mf_body_apply(const MfView& v, int64_t u)
+PGX_HD bool mf_body_apply(const MfView& v, int64_t u)
 {
-    if (v.labels[u] == v.alpha) return;
+    if (v.labels[u] == v.alpha) return false;
     if (v.d[u] == kMfInf) {  // cannot reach t => SOURCE side => takes alpha
         v.labels[u] = v.alpha;
-        mf_add32(&v.flags[2], 1);
+        return true;           // the caller counts relabelled sites into flags[2]
     }
+    return false;
 }
 
 }  // namespace pgx

@@ -6,6 +6,7 @@
 // thousands of random instances without a GPU.  It is never loaded by the product package.
 #include <cstdint>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <random>
@@ -39,14 +40,40 @@ struct EmuBackend {
     int read_count(const MfView& v, int l) { return v.cnt[l]; }
     void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
     void bfs_reset(const MfView& v) { mf_body_bfs_reset(v); }
-    void bfs_init(const MfView& v) { each([&](int64_t u) { mf_body_bfs_init(v, u); }); }
-    void bfs_level(const MfView& v, int k) { each([&](int64_t u) { mf_body_bfs_level(v, u, k); }); }
+    void bfs_init(const MfView& v) { each([&](int64_t u) { if (mf_body_bfs_init(v, u, v.bfs_hub_d)) v.flags[0] = 1; }); }
+    void bfs_level(const MfView& v, int k)
+    {
+        const int F = v.fcount[(k - 1) % 3];
+        std::vector<int> fr(v.front[(k - 1) & 1], v.front[(k - 1) & 1] + F);
+        if (shuffle) std::shuffle(fr.begin(), fr.end(), rng);
+        for (int w : fr) if (mf_body_bfs_expand(v, w, k, v.bfs_hub_d)) v.flags[0] = k;
+        // NB: on the device hub distances accumulated during level k become visible only after the level's kernel,
+        // and the event test uses distance k-1, which no label written at level k (>= k+1) can produce: same here.
+        const int ev = mf_bfs_hub_events(v, k);
+        if (ev != 0) each([&](int64_t u) { if (mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, v.bfs_hub_d)) v.flags[0] = k; });
+        v.fcount[(k + 1) % 3] = 0;
+    }
     int read_flag(const MfView& v, int i) { return v.flags[i]; }
     void bfs_finish(const MfView& v, int slot) { mf_body_bfs_finish(v, slot); }
-    void count_active(const MfView& v) { each([&](int64_t u) { mf_body_count_active(v, u); }); }
-    void sweep(const MfView& v, int prev, int cur) { each([&](int64_t u) { mf_body_sweep(v, u, prev, cur); }); }
-    void sweep_epilogue(const MfView& v, int cur, int next) { mf_body_sweep_epilogue(v, cur, next); }
-    void apply(const MfView& v) { each([&](int64_t u) { mf_body_apply(v, u); }); }
+    void count_active(const MfView& v) { each([&](int64_t u) { if (mf_body_count_active(v, u)) v.flags[1] = 1; }); dump(v, "after bfs"); }
+    void sweep(const MfView& v, int prev, int cur)
+    {
+        each([&](int64_t u) { if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L)) v.flags[1] = 1; });
+    }
+    void dump(const MfView& v, const char* tag)
+    {
+        if (!std::getenv("MF_EMU_DEBUG")) return;
+        std::fprintf(stderr, "%s flags=[%d %d %d %d %d] hubA_rt=%lld hubA_d=%d\n", tag, v.flags[0], v.flags[1], v.flags[2],
+                     v.flags[3], v.flags[4], (long long)v.hubA_rt[0], v.bfs_hubA_d[0]);
+        for (int l = 0; l < v.L; ++l)
+            if (v.hub_exists[l]) std::fprintf(stderr, "  hub %d e=%lld bfs_d=%d min=[%d %d %d]\n", l, (long long)v.hub_e[l], v.bfs_hub_d[l],
+                v.hub_min[l], v.hub_min[v.L + l], v.hub_min[2 * v.L + l]);
+        for (int64_t u = 0; u < v.n; ++u)
+            std::fprintf(stderr, "  u=%lld l=%d d=%d ex=%lld rt=%lld f=%lld g=%lld\n", (long long)u, v.labels[u], v.d[u], (long long)v.ex[u],
+                         (long long)v.rt[u], (long long)v.f[u], (long long)v.g[u]);
+    }
+    void sweep_epilogue(const MfView& v, int cur, int next) { mf_body_sweep_epilogue(v, cur, next); dump(v, "after sweep"); }
+    void apply(const MfView& v) { each([&](int64_t u) { if (mf_body_apply(v, u)) v.flags[2] += 1; }); }
 };
 
 }  // namespace
@@ -74,7 +101,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
-        bfs_hubA_d(1), hub_min((size_t)3 * L), flags(8);
+        bfs_hubA_d(1), hub_min((size_t)3 * L), front0((size_t)n), front1((size_t)n), fcount(3), flags(8);
     std::vector<unsigned long long> hubA_min(3);
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
@@ -85,6 +112,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.bfs_hub_d = bfs_hub_d.data();
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
     v.flags = flags.data();
+    v.front[0] = front0.data(); v.front[1] = front1.data(); v.fcount = fcount.data();
     v.hmax = (int)(n + L + 3);
     EmuBackend be(n, order_seed);
     MfTuning tune;
