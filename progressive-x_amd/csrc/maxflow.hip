@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
         if (WHAT == kBfsInit) r = mf_body_bfs_init(v, u, s_min);
         else if (WHAT == kCountActive) r = mf_body_count_active(v, u);
         else if (WHAT == kSweep) r = mf_body_sweep(v, u, a0, a1, s_min);
-        else r = mf_body_apply(v, u);
+        else if (WHAT == kApply) r = mf_body_apply(v, u);
     }
     if (WHAT == kBfsLevel) {
         // frontier part: sites labelled a0-1 (grid-stride over the frontier; trip counts are wave-uniform because

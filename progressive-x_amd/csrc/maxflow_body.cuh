@@ -124,6 +124,19 @@ inline int mf_load32(const int* p) { return *p; }
 inline void mf_store32(int* p, int v) { *p = v; }
 #endif
 
+// One lane per wave among those with `cond` (all lanes on the host).  Used to thin out contenders on the few hub budget
+// words: without it every member of a hub CASes the same address in the same sweep (measured: ~2e5 serialised L2
+// atomics per hub per sweep at N = 2e5); the budget is small, so a few winners per sweep drain it just as fast.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool mf_elect(bool cond)
+{
+    const unsigned long long mask = __ballot(cond);
+    return cond && (__lane_id() == __ffsll((long long)mask) - 1);
+}
+#else
+inline bool mf_elect(bool cond) { return cond; }
+#endif
+
 // take up to `want` out of a shared non-negative budget
 PGX_HD long long mf_reserve(long long* budget, long long want)
 {
@@ -299,7 +312,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     // A hub's height is rescanned only while it holds excess (members pull); otherwise the last known height is carried
     // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
     // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
-    const bool scan_b = hub_b && mf_load64(&v.hub_e[lu]) > 0;
+    const bool scan_b = hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
     if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
     int du = v.d[u];
     // hub heights as published by the previous scan
@@ -307,15 +320,15 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     if (hub_b) { const int m = v.hub_min[prev * v.L + lu]; hb = m == kMfInf ? kMfInf : m + 1; }
     int ha = kMfInf, ha_site = -1;
     if (hub_a) {
-        if (mf_load64(v.hubA_rt) > 0) ha = 1;
+        if (v.hubA_rt[0] > 0) ha = 1;  // plain read (gate); the reservation below is atomic
         else {
             const unsigned long long pk = v.hubA_min[prev];
             if (pk != ~0ull) { ha = (int)(pk >> 32) + 1; ha_site = (int)(pk & 0xffffffffu); }
         }
     }
     if (du != kMfInf) {
-        // pull from the beta hub along the admissible arc y_beta -> u
-        if (hub_b && hb == du + 1 && mf_load64(&v.hub_e[lu]) > 0) {
+        // pull from the beta hub along the admissible arc y_beta -> u (one contender per wave and sweep)
+        if (mf_elect(hub_b && hb == du + 1 && v.hub_e[lu] > 0)) {
             const long long want = v.rt[u] > 0 ? v.rt[u] : (long long)1 << 62;
             const long long got = mf_reserve(&v.hub_e[lu], want);
             if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); work = true; }
@@ -351,7 +364,10 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                         mf_add64(&v.ex[v.idx[best_a]], dl);
                         work = true;
                     } else if (kind == 2) {
-                        if (ha_site < 0) {  // budget y_alpha -> t still open
+                        const bool elected = mf_elect(true);  // one contender per wave and sweep on the hub words
+                        if (!elected) {
+                            work = true;
+                        } else if (ha_site < 0) {  // budget y_alpha -> t still open
                             const long long got = mf_reserve(v.hubA_rt, e);
                             if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); work = true; }
                         } else {            // through the saturated hub into its lowest member: u -> y_alpha -> p*
