@@ -112,10 +112,20 @@ def cleanup_unique_id(rank):
 
 def init_rccl(ctx, rank, world):
     """Binds `ctx` (a _lib.Context on this rank's GPU) into the node-wide RCCL communicator."""
+    import sys
     from . import _lib
-    uid = exchange_unique_id(rank, world, _lib.comm_unique_id)
-    ctx.comm_init(world, rank, uid)
-    ctx.comm_barrier()
+    # RCCL prints a version banner on stdout when it initialises; callers (bench.py) reserve stdout for one JSON line,
+    # so the C-level stdout is pointed at stderr for the duration of the bootstrap.
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        uid = exchange_unique_id(rank, world, _lib.comm_unique_id)
+        ctx.comm_init(world, rank, uid)
+        ctx.comm_barrier()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     cleanup_unique_id(rank)
 
 

@@ -335,3 +335,30 @@ def test_metric_batch_full_size_properties(gpu_ctx, oracle):
     assert np.array_equal(pop, m64["counts"])
     refm = oracle.score(3, pts, hyps[3:4], T2, want_masks=True)
     assert np.array_equal(refm["masks"][0], m64["masks"][3])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RCCL plumbing with a single rank (the 1-GPU box cannot run N > 1; the N > 1 host logic is covered by the gloo test)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_rccl_single_rank_allgather(gpu_ctx):
+    from pyprogressivex import _lib, parallel
+    mt, pts, models, thr = make_case("pnp", 5000, 100, seed=2)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.comm_init(1, 0, _lib.comm_unique_id())
+    try:
+        gpu_ctx.comm_barrier()
+        assert gpu_ctx.comm_allreduce_max(3.25) == 3.25
+        table = parallel.score_sharded(parallel.RcclExchange(gpu_ctx), models, T2)
+        gpu_ctx.score_upload(models)
+        gpu_ctx.score_launch(T2)
+        gpu_ctx.score_allgather()
+        allg = gpu_ctx.score_fetch_all()
+        direct = gpu_ctx.score_fetch()
+        for k in ("counts", "values", "shared", "scores"):
+            assert np.array_equal(allg[k], direct[k]) and np.array_equal(table[k], direct[k])
+        gpu_ctx.set_compound(np.linspace(0, 1, 5000))
+        gpu_ctx.compound_allreduce_max()
+        assert np.array_equal(gpu_ctx.get_compound(), np.linspace(0, 1, 5000))
+    finally:
+        gpu_ctx.comm_destroy()
