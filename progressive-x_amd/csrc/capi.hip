@@ -94,7 +94,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     const char* nf = std::getenv("PGX_NO_FILTER");
-    ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : 1;
+    ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : ((nf && nf[0] == '2') ? 2 : 1);
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
@@ -109,7 +109,7 @@ void pgx_destroy(pgx_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_free(ctx);
     maxflow_free(ctx);
-    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
+    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch};
@@ -182,6 +182,7 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     // score-filter scales (score.hip Filter<>): Umax = largest |observed image coordinate|, pmax[i] = max(|the
     // coordinates the projective map multiplies|, 1).  Model types without a filter get pmax = 1, Umax = 0.
     std::vector<double> pmax((size_t)n, 1.0);
+    std::vector<float> p32((size_t)n * 8, 0.0f);
     double umax = 0.0;
     int obs0 = -1, obs1 = -1, in0 = 0, in1 = -1;
     if (model_type == kPnP) { obs0 = 0; obs1 = 1; in0 = 2; in1 = 4; }
@@ -195,8 +196,13 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
             double pm = 1.0;
             for (int k = in0; k <= in1; ++k) { const double v = std::fabs(r[k]); if (!(v <= pm)) pm = v; }
             pmax[(size_t)i] = pm;
+            float* q = p32.data() + (size_t)i * 8;   // f32 row of the pre-filter: coords, then the scale rounded up
+            for (int k = 0; k < d; ++k) q[k] = (float)r[k];
+            q[5] = (float)(pm * 1.000001);
         }
     ctx->umax = umax;
+    PGX_TRY(ensure(ctx, ctx->pts32, (size_t)n * 8 * sizeof(float)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pts32.p, p32.data(), (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts.p, points, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pmax.p, pmax.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)n * sizeof(double), ctx->stream));
@@ -298,7 +304,8 @@ int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, in
     if (!ctx || ctx->n <= 0 || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_algorithmic_bytes: nothing to score");
     // points once + compound once + models once + (count,value,shared) per hypothesis (+ optional bit masks)
     int64_t b = ctx->n * ctx->D * 8 + ctx->n * 8 + (int64_t)ctx->M * ctx->P * 8 + (int64_t)ctx->M * 24;
-    if (ctx->last_score_filtered) b += ctx->n * 8;  // per-point scale of the rejection filter
+    if (ctx->last_score_filtered == 1) b += ctx->n * 8;   // per-point scale of the FP64 rejection filter
+    if (ctx->last_score_filtered == 2) b += ctx->n * 32;  // f32 rows of the FP32 pre-filter
     if (want_masks) b += (int64_t)ctx->M * ((ctx->n + 63) / 64) * 8;
     if (bytes) *bytes = b;
     if (pairs) *pairs = ctx->n * (int64_t)ctx->M;

@@ -36,8 +36,9 @@ struct pgx_ctx {
     int64_t n = 0;
     pgx::DevBuf pts, comp;
     pgx::DevBuf pmax;        // per point max(|coords the filter scales by|, 1)  (score filter)
+    pgx::DevBuf pts32;       // N x 8 f32: coordinates + filter scale (FP32 pre-filter)
     double umax = 0.0;       // max |observed image coordinate| over all points
-    int filter_enabled = 1;  // PGX_NO_FILTER=1 in the environment disables the rejection filter (A/B, debugging)
+    int filter_enabled = 1;  // PGX_NO_FILTER: 1 = no rejection filter, 2 = FP64 filter only (A/B, debugging)
     int last_score_filtered = 0;
     int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)
     int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)

@@ -89,11 +89,89 @@ template <> struct Filter<kHomography> {
     }
 };
 
-template <int MT, bool MASK, bool FILT>
+// ---- FP32 pre-filter -------------------------------------------------------------------------------
+// Same inequality evaluated in single precision on f32 copies of the point (one 32-byte row: coords, scale) and of the
+// hypothesis: 18 VALU ops at the f32 rate instead of 17 at the f64 rate.  Error budget: inputs rounded to f32 and three
+// chained FMAs give |p~ - p*| <= E32 = 5.5 * 2^-24 * (L3_h P_i + t_h) (L3_h = largest 1-norm of the multiplying part of a
+// row, t_h = largest |constant term|); with tau = 2^-10 the trust test E32 (1 + U + T) / (tau T) <= |p~z| (one FMA +
+// compare per pair; constants rounded up) and the host guard U / T <= tau * 2^24 bound every error term by tau T |p~z|,
+// and the chain of inequalities of §5.2 gives a~^2 + b~^2 <= p~z^2 T^2 (1 + 7.7 tau + O(tau^2) + 6 * 2^-24)
+// < p~z^2 T^2 (1 + 2^-7) for every pair the exact path accepts.  Candidates go straight to the exact FP64 path.
+constexpr double kFilter32Delta = 1.0 / 128.0;  // 2^-7
+constexpr double kInflate = 1.000001;           // (float)(x * kInflate) >= x for every finite double x > 0
+
+__device__ __forceinline__ float f32_up(double x) { return (float)(x * kInflate); }
+
+template <int MT> struct Filter32 {
+    static constexpr bool enabled = false;
+    struct Lane {};
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD&, double) { return {}; }
+    static __device__ __forceinline__ bool reject(const float*, const Lane&, float) { return false; }
+};
+
+template <> struct Filter32<kPnP> {
+    static constexpr bool enabled = true;
+    struct Lane { float m[12]; float c1, c0; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard32) {
+        Lane ln;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ln.m[k] = (float)m[k];
+        const double l3 = fmax(fabs(m[0]) + fabs(m[1]) + fabs(m[2]),
+                               fmax(fabs(m[4]) + fabs(m[5]) + fabs(m[6]), fabs(m[8]) + fabs(m[9]) + fabs(m[10])));
+        const double t = fmax(fabs(m[3]), fmax(fabs(m[7]), fabs(m[11])));
+        ln.c1 = f32_up(guard32 * l3);
+        ln.c0 = fmaxf(f32_up(guard32 * t), 1e-30f);
+        return ln;
+    }
+    // p = (u, v, X, Y, Z, scale, -, -) in f32
+    static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float T2d) {
+        const float* m = ln.m;
+        const float px = __builtin_fmaf(m[0], p[2], __builtin_fmaf(m[1], p[3], __builtin_fmaf(m[2], p[4], m[3])));
+        const float py = __builtin_fmaf(m[4], p[2], __builtin_fmaf(m[5], p[3], __builtin_fmaf(m[6], p[4], m[7])));
+        const float pz = __builtin_fmaf(m[8], p[2], __builtin_fmaf(m[9], p[3], __builtin_fmaf(m[10], p[4], m[11])));
+        const float a = __builtin_fmaf(p[0], pz, -px);
+        const float b = __builtin_fmaf(p[1], pz, -py);
+        const float lhs = __builtin_fmaf(b, b, a * a);
+        const float rhs = (pz * pz) * T2d;
+        const bool trust = __builtin_fmaf(ln.c1, p[5], ln.c0) <= fabsf(pz);  // false on NaN
+        return trust && (lhs > rhs);                                         // false on NaN
+    }
+};
+
+template <> struct Filter32<kHomography> {
+    static constexpr bool enabled = true;
+    struct Lane { float m[9]; float c1, c0; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32) {
+        Lane ln;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ln.m[k] = (float)h[k];
+        const double l2 = fmax(fabs(h[0]) + fabs(h[1]), fmax(fabs(h[3]) + fabs(h[4]), fabs(h[6]) + fabs(h[7])));
+        const double t = fmax(fabs(h[2]), fmax(fabs(h[5]), fabs(h[8])));
+        ln.c1 = f32_up(guard32 * l2);
+        ln.c0 = fmaxf(f32_up(guard32 * t), 1e-30f);
+        return ln;
+    }
+    // p = (x1, y1, x2, y2, -, scale, -, -) in f32
+    static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float T2d) {
+        const float* h = ln.m;
+        const float t1 = __builtin_fmaf(h[0], p[0], __builtin_fmaf(h[1], p[1], h[2]));
+        const float t2 = __builtin_fmaf(h[3], p[0], __builtin_fmaf(h[4], p[1], h[5]));
+        const float t3 = __builtin_fmaf(h[6], p[0], __builtin_fmaf(h[7], p[1], h[8]));
+        const float a = __builtin_fmaf(p[2], t3, -t1);
+        const float b = __builtin_fmaf(p[3], t3, -t2);
+        const float lhs = __builtin_fmaf(b, b, a * a);
+        const float rhs = (t3 * t3) * T2d;
+        const bool trust = __builtin_fmaf(ln.c1, p[5], ln.c0) <= fabsf(t3);
+        return trust && (lhs > rhs);
+    }
+};
+
+// FILT: 0 = no filter, 1 = FP64 filter, 2 = FP32 pre-filter
+template <int MT, bool MASK, int FILT>
 __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     const double* __restrict__ pts, int64_t n, const double* __restrict__ models, int M, int Mpad,
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
-    const double* __restrict__ pmax, double guard,
+    const double* __restrict__ pmax, double guard, const float* __restrict__ pts32, double guard32,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
     unsigned long long* __restrict__ masks, int64_t words)
 {
@@ -109,8 +187,11 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
         mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");  // NaN model: never an inlier
 
     using F = Filter<MT>;
+    using F32 = Filter32<MT>;
     const typename F::Lane flane = F::prep(mdl, guard);
+    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
     const double T2d = T2 * (1.0 + kFilterDelta);
+    const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
 
     unsigned cnt = 0;
     double val = 0.0, sh = 0.0;
@@ -119,10 +200,11 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     // One point per step; the body is written once and instantiated for a group of kUnroll points whose scalar loads
     // are all issued before the first use, so one s_waitcnt covers kUnroll points (SMEM returns out of order: the
     // only usable wait is lgkmcnt(0), which makes per-point prefetching impossible).
-    auto step = [&](int64_t i, const double (&pt)[R::D], double pm) {
+    auto step = [&](int64_t i, const double (&pt)[R::D], double pm, const float* p32) {
         bool inl = false;
         bool rejected = false;
-        if (FILT && F::enabled) rejected = F::reject(pt, mdl, flane, pm, T2d);
+        if (FILT == 1 && F::enabled) rejected = F::reject(pt, mdl, flane, pm, T2d);
+        if (FILT == 2 && F32::enabled) rejected = F32::reject(p32, flane32, T2d32);
         if (live && !rejected) {  // exact path: oracle operation order, no contraction
             const double sq = R::squared(pt, mdl);
             inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
@@ -147,21 +229,31 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
         const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
         double pt[kUnroll][R::D];
         double pm[kUnroll];
+        float p32[kUnroll][8];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
             for (int k = 0; k < R::D; ++k) pt[u][k] = prow[u * R::D + k];
-            pm[u] = (FILT && F::enabled) ? pmax[i + u] : 1.0;
+            pm[u] = (FILT == 1 && F::enabled) ? pmax[i + u] : 1.0;
+            if (FILT == 2 && F32::enabled) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p32[u][k] = pts32[(i + u) * 8 + k];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], pm[u]);
+        for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], pm[u], p32[u]);
     }
     for (; i < i1; ++i) {
         const double* __restrict__ prow = pts + i * R::D;
         double pt[R::D];
+        float p32[8];
 #pragma unroll
         for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
-        step(i, pt, (FILT && F::enabled) ? pmax[i] : 1.0);
+        if (FILT == 2 && F32::enabled) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p32[k] = pts32[i * 8 + k];
+        }
+        step(i, pt, (FILT == 1 && F::enabled) ? pmax[i] : 1.0, p32);
     }
     const int64_t o = (int64_t)blockIdx.y * Mpad + m;
     pcnt[o] = cnt;
@@ -314,13 +406,14 @@ static void score_launch_deferred(pgx_ctx* ctx, double T2, int has_compound, dou
                        MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words);
 }
 
-template <int MT, bool MASK, bool FILT>
-static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double guard)
+template <int MT, bool MASK, int FILT>
+static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double guard, double guard32 = 0.0)
 {
     dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
     hipLaunchKernelGGL((score_kernel<MT, MASK, FILT>), grid, dim3(kScoreBlock), 0, ctx->stream, ctx->pts.as<double>(),
                        ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
-                       ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
+                       ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pts32.as<float>(), guard32,
+                       ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
                        ctx->psh.as<double>(), MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr,
                        ctx->words);
 }
@@ -337,23 +430,32 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         guard = 4.5 * 1.1102230246251565e-16 * (1.0 + ctx->umax + T) * 16777216.0 / T;
         filt = std::isfinite(guard);
     }
-    ctx->last_score_filtered = filt ? 1 : 0;
+    // FP32 pre-filter: tau = 2^-10, needs Umax / T <= tau * 2^24 = 2^14
+    double guard32 = 0.0;
+    bool filt32 = filt && ctx->filter_enabled == 1 && ctx->umax <= T * 16384.0;
+    if (filt32) {
+        guard32 = 5.5 * 5.9604644775390625e-8 * (1.0 + ctx->umax + T) * 1024.0 / T;
+        filt32 = std::isfinite(guard32) && guard32 < 1e30;
+    }
+    ctx->last_score_filtered = filt32 ? 2 : (filt ? 1 : 0);
     // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
     // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).
     const bool deferred = filt && ctx->score_deferred;
     if constexpr (Filter<MT>::enabled) {
         if (want_masks) {
             if (deferred) score_launch_deferred<MT, true>(ctx, T2, has_compound, guard);
-            else if (filt) score_launch_one<MT, true, true>(ctx, T2, has_compound, guard);
-            else score_launch_one<MT, true, false>(ctx, T2, has_compound, guard);
+            else if (filt32) score_launch_one<MT, true, 2>(ctx, T2, has_compound, guard, guard32);
+            else if (filt) score_launch_one<MT, true, 1>(ctx, T2, has_compound, guard);
+            else score_launch_one<MT, true, 0>(ctx, T2, has_compound, guard);
         } else {
             if (deferred) score_launch_deferred<MT, false>(ctx, T2, has_compound, guard);
-            else if (filt) score_launch_one<MT, false, true>(ctx, T2, has_compound, guard);
-            else score_launch_one<MT, false, false>(ctx, T2, has_compound, guard);
+            else if (filt32) score_launch_one<MT, false, 2>(ctx, T2, has_compound, guard, guard32);
+            else if (filt) score_launch_one<MT, false, 1>(ctx, T2, has_compound, guard);
+            else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
         }
     } else {
-        if (want_masks) score_launch_one<MT, true, false>(ctx, T2, has_compound, guard);
-        else score_launch_one<MT, false, false>(ctx, T2, has_compound, guard);
+        if (want_masks) score_launch_one<MT, true, 0>(ctx, T2, has_compound, guard);
+        else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
     }
     PGX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
