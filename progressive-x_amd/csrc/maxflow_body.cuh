@@ -270,12 +270,15 @@ PGX_HD bool mf_body_bfs_hubpass(const MfView& v, int64_t u, int k, bool alpha_ev
 }
 
 // uniform per level: which hub events fire at level k (bit 0: alpha hub, bit 1: some beta hub)
+// Plain (cached) reads on purpose: every thread of every level evaluates this, and L2-scope loads of the same few
+// words from 2e5 threads measured ~30 us per level.  A hub's distance k-1 was written by an EARLIER kernel (level
+// k-2's flush writes k-1); writes racing in THIS kernel store k+1, so a stale read cannot fake or hide an event.
 PGX_HD int mf_bfs_hub_events(const MfView& v, int k)
 {
     int ev = 0;
-    if (v.has_alpha_hub[0] && mf_load32(&v.bfs_hubA_d[0]) == k - 1) ev |= 1;
+    if (v.has_alpha_hub[0] && v.bfs_hubA_d[0] == k - 1) ev |= 1;
     for (int l = 0; l < v.L; ++l)
-        if (v.hub_exists[l] && mf_load32(&v.bfs_hub_d[l]) == k - 1) ev |= 2;
+        if (v.hub_exists[l] && v.bfs_hub_d[l] == k - 1) ev |= 2;
     return ev;
 }
 

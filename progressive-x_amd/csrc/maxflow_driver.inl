@@ -10,8 +10,8 @@ namespace pgx {
 
 struct MfTuning {
     int bfs_batch = 8;        // BFS levels issued between two flag read-backs
-    int sweeps_per_relabel = 12;
-    int sweep_check = 4;      // read the work-left flag every this many sweeps
+    int sweeps_per_relabel = 48;
+    int sweep_check = 8;      // read the work-left flag every this many sweeps
     int max_relabels = 4096;  // hard cap on global relabels per move
 };
 
