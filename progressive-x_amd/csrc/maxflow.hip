@@ -9,8 +9,10 @@
 // gathers; cross-workgroup communication is through device-scope atomics only, and every kernel
 // boundary is a full synchronisation point, so no in-launch release/acquire protocol is needed.
 #include <cstdlib>
+#include <vector>
 
 #include "maxflow_driver.inl"
+#include "maxflow_l0.cuh"
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -95,6 +97,49 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     } else {
         if (threadIdx.x == 0 && count > 0) atomicAdd(&v.flags[2], count);
     }
+}
+
+// ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
+__global__ __launch_bounds__(kMfBlock) void mf_k_l0_reduce(const long long* __restrict__ dq, const int* __restrict__ labels,
+                                                           int64_t n, int L, int alpha, long long* __restrict__ sums)
+{
+    __shared__ unsigned long long s_sum[2 * kMfMaxLabels];
+    if (threadIdx.x < 2 * kMfMaxLabels) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    if (u < n) {
+        const int lu = labels[u];
+        if (lu != alpha) {
+            long long rt, ex;
+            l0_site_terms(dq, n, u, lu, alpha, &rt, &ex);
+            if (rt) atomicAdd(&s_sum[lu * 2], (unsigned long long)rt);
+            if (ex) atomicAdd(&s_sum[lu * 2 + 1], (unsigned long long)ex);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * L && s_sum[threadIdx.x] != 0)
+        atomicAdd((unsigned long long*)&sums[threadIdx.x], s_sum[threadIdx.x]);
+}
+
+struct L0Arg {
+    int switch_any;
+    unsigned char all[kMfMaxLabels];
+};
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply(const long long* __restrict__ dq, int* __restrict__ labels,
+                                                          int64_t n, int alpha, L0Arg dec, int* __restrict__ changed)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    bool sw = false;
+    if (u < n) {
+        const int lu = labels[u];
+        if (lu != alpha && l0_site_switches(dq, n, u, lu, alpha, dec.switch_any, dec.all[lu])) {
+            labels[u] = alpha;
+            sw = true;
+        }
+    }
+    const int c = __syncthreads_count(sw ? 1 : 0);
+    if (threadIdx.x == 0 && c > 0) atomicAdd(changed, c);
 }
 
 __global__ void mf_k_single(MfView v, int what, int a0, int a1)
@@ -203,6 +248,55 @@ void maxflow_free(pgx_ctx* ctx)
     ctx->mf = nullptr;
 }
 
+// lambda = 0: one reduction pass, a host decision over <= 64 labels, one apply pass (maxflow_l0.cuh)
+static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* changed)
+{
+    const int64_t n = ctx->dq_n;
+    const int L = ctx->L;
+    *changed = 0;
+    if (!ctx->mf) {
+        ctx->mf = new MaxflowState();
+        PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));
+    }
+    MaxflowState* st = ctx->mf;
+    // small state: sums[2L] i64 | cnt[L] i32 | changed i32
+    const size_t bytes = (size_t)2 * L * 8 + (size_t)L * 4 + 8;
+    PGX_TRY(ensure(ctx, st->small, bytes + 4096));
+    long long* d_sums = (long long*)st->small.p;
+    int* d_cnt = (int*)((char*)st->small.p + (size_t)2 * L * 8);
+    int* d_changed = d_cnt + L;
+    PGX_HIP(ctx, hipMemsetAsync(st->small.p, 0, bytes, ctx->stream));
+    const unsigned blocks = (unsigned)((n + kMfBlock - 1) / kMfBlock);
+    MfView v{};
+    v.n = n; v.L = L; v.alpha = alpha; v.labels = ctx->labels.as<int>(); v.cnt = d_cnt;
+    hipLaunchKernelGGL(mf_k_count, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+    hipLaunchKernelGGL(mf_k_l0_reduce, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
+                       ctx->labels.as<int>(), n, L, alpha, d_sums);
+    PGX_HIP(ctx, hipGetLastError());
+    std::vector<unsigned char> host(bytes);
+    PGX_HIP(ctx, hipMemcpyAsync(host.data(), st->small.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long long* sums = (const long long*)host.data();
+    const int* cnt = (const int*)(host.data() + (size_t)2 * L * 8);
+    if ((int64_t)cnt[alpha] == n) return PGX_OK;
+    ctx->stats[0] += 1;
+    L0Decision dec;
+    l0_decide(L, alpha, (long long)h_q, sums, cnt, &dec);
+    if (!dec.switch_any) return PGX_OK;
+    L0Arg arg;
+    arg.switch_any = 1;
+    for (int l = 0; l < kMfMaxLabels; ++l) arg.all[l] = (l < L && dec.all[l]) ? 1 : 0;
+    hipLaunchKernelGGL(mf_k_l0_apply, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
+                       ctx->labels.as<int>(), n, alpha, arg, d_changed);
+    PGX_HIP(ctx, hipGetLastError());
+    int ch = 0;
+    PGX_HIP(ctx, hipMemcpyAsync(&ch, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *changed = ch;
+    ctx->stats[4] += ch;
+    return PGX_OK;
+}
+
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
 {
     const int64_t n = ctx->dq_n;
@@ -211,7 +305,9 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
     if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
+    if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
     const bool pair = lambda_q > 0;
+    if (!pair) return expand_alpha_l0(ctx, h_q, alpha, changed);
     if (pair && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();

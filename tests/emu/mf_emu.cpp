@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../progressive-x_amd/csrc/maxflow_driver.inl"
+#include "../../progressive-x_amd/csrc/maxflow_l0.cuh"
 
 using namespace pgx;
 
@@ -87,6 +88,31 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     for (int64_t i = 0; i < n; ++i)
         for (int l = 0; l < L; ++l) dq[(size_t)l * n + i] = Dq_point_major[i * L + l];
     const bool pair = off != nullptr && lambda_q > 0;
+    if (!pair && std::getenv("MF_EMU_FORCE_FLOW") == nullptr) {  // the product's lambda = 0 path: closed form
+        std::vector<long long> sums((size_t)2 * L, 0);
+        std::vector<int> cnt((size_t)L, 0);
+        for (int64_t u = 0; u < n; ++u) {
+            const int lu = labels[u];
+            cnt[lu]++;
+            if (lu == alpha) continue;
+            long long rt, ex;
+            l0_site_terms(dq.data(), n, u, lu, alpha, &rt, &ex);
+            sums[lu * 2] += rt; sums[lu * 2 + 1] += ex;
+        }
+        *changed = 0;
+        if (cnt[alpha] == n) return 0;
+        L0Decision dec;
+        l0_decide(L, alpha, h_q, sums.data(), cnt.data(), &dec);
+        for (int64_t u = 0; u < n; ++u) {
+            const int lu = labels[u];
+            if (lu != alpha && l0_site_switches(dq.data(), n, u, lu, alpha, dec.switch_any, dec.all[lu])) {
+                labels[u] = alpha;
+                ++*changed;
+            }
+        }
+        if (stats) for (int k = 0; k < 8; ++k) stats[k] = 0;
+        return 0;
+    }
     const int64_t E = pair ? off[n] : 0;
     std::vector<int> rev((size_t)(E > 0 ? E : 1));
     if (pair)

@@ -72,3 +72,21 @@ def test_emulated_cycle_on_radius_graph(emu, oracle):
         assert np.array_equal(got, ref)
         assert st[1] < 2000 and st[2] < 100  # sweeps / global relabels stay small on realistic energies
         lab = ref
+
+
+def test_closed_form_lambda0_move_matches_oracle_with_ties(emu, oracle):
+    """lambda = 0: the product solves a move in closed form (maxflow_l0.cuh).  Tiny integer costs make ties between
+    'switch all', 'switch individually' and 'nobody switches' frequent; every case must equal the oracle's min-cut."""
+    rng = np.random.default_rng(7)
+    for trial in range(4000):
+        n, L = int(rng.integers(1, 12)), int(rng.integers(2, 6))
+        Dq = rng.integers(0, 4, (n, L)).astype(np.int64)
+        graph = (np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+        hq = int(rng.integers(0, 7))
+        lab = rng.integers(0, L, n).astype(np.int32)
+        if rng.random() < 0.4:
+            lab[:] = rng.integers(0, L)
+        alpha = int(rng.integers(0, L))
+        ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, 0, hq, alpha, lab)
+        got, ch, _ = emu_expand(emu, Dq, graph, 0, hq, alpha, lab)
+        assert np.array_equal(got, ref) and ch == ref_changed, (trial, n, L, hq, alpha)
