@@ -137,15 +137,27 @@ __device__ __forceinline__ bool mf_elect(bool cond)
 inline bool mf_elect(bool cond) { return cond; }
 #endif
 
-// take up to `want` out of a shared non-negative budget
+// Take up to `want` out of a shared budget, wait-free: one fetch-add, plus one refund when the budget ran short.  The
+// word may be transiently negative (readers treat <= 0 as empty); `old` can only UNDER-state what is available, so the
+// sum of grants never exceeds the budget.  (A CAS loop here cost O(k^2) retries with k ~ 3000 contenders per hub word:
+// the sweep kernel went from ~30 us to ~250 us whenever a large label cost was being drained.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ long long mf_fetch_add64(long long* p, long long v)
+{
+    return (long long)atomicAdd((unsigned long long*)p, (unsigned long long)v);
+}
+#else
+inline long long mf_fetch_add64(long long* p, long long v) { const long long o = *p; *p += v; return o; }
+#endif
+
 PGX_HD long long mf_reserve(long long* budget, long long want)
 {
-    long long old = mf_load64(budget);
-    while (old > 0) {
-        const long long take = old < want ? old : want;
-        if (mf_cas64(budget, old, old - take)) return take;
-    }
-    return 0;
+    if (want <= 0 || mf_load64(budget) <= 0) return 0;
+    const long long old = mf_fetch_add64(budget, -want);
+    if (old >= want) return want;
+    const long long got = old > 0 ? old : 0;
+    mf_fetch_add64(budget, want - got);
+    return got;
 }
 
 PGX_HD unsigned long long mf_pack(int h, int site) { return ((unsigned long long)(unsigned)h << 32) | (unsigned)site; }
@@ -332,7 +344,9 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     if (du != kMfInf) {
         // pull from the beta hub along the admissible arc y_beta -> u (one contender per wave and sweep)
         if (mf_elect(hub_b && hb == du + 1 && v.hub_e[lu] > 0)) {
-            const long long want = v.rt[u] > 0 ? v.rt[u] : (long long)1 << 62;
+            // own sink residual if any, otherwise whatever is visible in the hub right now (bounded: no overflow when
+            // several wave leaders subtract concurrently)
+            const long long want = v.rt[u] > 0 ? v.rt[u] : mf_load64(&v.hub_e[lu]);
             const long long got = mf_reserve(&v.hub_e[lu], want);
             if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); work = true; }
         }
