@@ -63,7 +63,7 @@ def flann_like_graph(points, radius, k=5):
     kk = min(k + 1, n)
     if kk <= 1:
         return np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
-    dist, nbr = cKDTree(pts).query(pts, k=kk, distance_upper_bound=float(radius))
+    dist, nbr = cKDTree(pts).query(pts, k=kk, distance_upper_bound=float(radius), workers=-1)
     src = np.repeat(np.arange(n), kk)
     dst = nbr.reshape(-1)
     ok = np.isfinite(dist.reshape(-1)) & (dst < n) & (dst != src)
@@ -79,7 +79,7 @@ def knn_graph(points, k):
     k = min(k, n - 1)
     if k <= 0:
         return np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
-    _, nbr = cKDTree(pts).query(pts, k=k + 1)
+    _, nbr = cKDTree(pts).query(pts, k=k + 1, workers=-1)
     src = np.repeat(np.arange(n), k)
     return symmetrize(n, src, nbr[:, 1:].reshape(-1))
 

@@ -362,3 +362,66 @@ def test_rccl_single_rank_allgather(gpu_ctx):
         assert np.array_equal(gpu_ctx.get_compound(), np.linspace(0, 1, 5000))
     finally:
         gpu_ctx.comm_destroy()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# error paths of the C ABI (status codes + messages, never a crash) and a BASELINE-size labelling move
+# ----------------------------------------------------------------------------------------------------------------------
+def test_abi_error_paths():
+    from pyprogressivex import _lib
+    ctx = _lib.Context(0)
+    try:
+        with pytest.raises(_lib.PgxError, match="points not set"):
+            ctx.model_type = 0
+            ctx.score(np.zeros((1, 3)), 1.0)
+        with pytest.raises(ValueError):
+            ctx.set_points(0, np.zeros((4, 3)))                      # wrong point dimension for lines
+        with pytest.raises(_lib.PgxError, match="empty input"):
+            ctx.set_points(0, np.zeros((0, 2)))
+        ctx.set_points(0, np.random.default_rng(0).random((100, 2)))
+        with pytest.raises(_lib.PgxError, match="unary table not set"):
+            ctx.set_labels(np.zeros(100, np.int32))
+            ctx.expansion(0.1, 1.0)
+        ctx.pearl_unary(np.array([[1.0, 0.0, -0.5]]), 0.1, 0.2)
+        with pytest.raises(_lib.PgxError, match="no graph set|needs a graph"):
+            ctx.expansion(0.2, 1.0)                                   # lambda > 0 without pgx_set_graph
+        with pytest.raises(_lib.PgxError, match="out of range"):
+            ctx.expand_alpha(0.0, 1.0, 7)
+        with pytest.raises(_lib.PgxError, match="fixed-point range"):
+            ctx.energy(0.0, 1e12)                                     # label cost beyond the 2^30 budget
+        with pytest.raises(_lib.PgxError, match="slot"):
+            ctx.compound_update([5])
+        with pytest.raises(_lib.PgxError, match="at most"):
+            ctx.set_unary_q(np.zeros((10, 65), np.int64))
+            ctx.set_labels(np.zeros(10, np.int32))
+            ctx.expand_alpha(0.0, 0.0, 0)
+        with pytest.raises(_lib.PgxError):
+            ctx.comm_barrier()                                        # communicator not initialised
+    finally:
+        ctx.close()
+
+
+def test_single_move_at_c5_size_matches_oracle(gpu_ctx, oracle):
+    """BASELINE config C5 shape: 2e5 line segments, 6 vanishing points, k-NN(8) graph on the midpoints; one expansion
+    move from a noisy labelling must reproduce the oracle's min-cut labels exactly (the full expansion is covered at
+    smaller sizes; Dinic needs ~17 s for it here)."""
+    from pyprogressivex import _graph, datasets
+    pts, gt, vps = datasets.make_vanishing_points(seed=0)
+    n = pts.shape[0]
+    graph = _graph.knn_graph(0.5 * (pts[:, :2] + pts[:, 2:]), 8)
+    lam, h, thr = 0.1, 20.0, 1.5
+    gpu_ctx.set_points(4, pts)
+    Dq = gpu_ctx.pearl_unary(vps, thr, lam, want_table=True)
+    assert np.array_equal(Dq, oracle.unary_q(4, pts, vps, thr, lam))
+    labels = np.where(gt == 0, 6, gt - 1).astype(np.int32)
+    flip = np.random.default_rng(1).random(n) < 0.3
+    labels[flip] = np.random.default_rng(2).integers(0, 7, int(flip.sum()))
+    gpu_ctx.set_graph(*graph)
+    gpu_ctx.set_labels(labels)
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    assert gpu_ctx.energy(lam, h)[0] == oracle.energy(Dq, graph, lq, hq, labels)
+    for alpha in (2, 6):
+        ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, labels)
+        assert gpu_ctx.expand_alpha(lam, h, alpha) == ref_changed
+        labels = gpu_ctx.get_labels()
+        assert np.array_equal(labels, ref)
