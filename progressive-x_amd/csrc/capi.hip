@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 
 #include "pgx_internal.h"
 
@@ -95,6 +97,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     const char* nf = std::getenv("PGX_NO_FILTER");
     ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : ((nf && nf[0] == '2') ? 2 : 1);
+    if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
@@ -109,7 +112,7 @@ void pgx_destroy(pgx_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_free(ctx);
     maxflow_free(ctx);
-    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
+    DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->perm, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch};
@@ -236,16 +239,79 @@ int pgx_get_compound(pgx_ctx* ctx, double* compound)
 }
 
 /* ---- scoring ---------------------------------------------------------------------------------------------- */
+// Locality key of a hypothesis: where it sends a probe point, quantised to a 16+16 bit Morton code.  A wave scores 64
+// hypotheses against the same point and pays for the exact path whenever ANY of them has a candidate there (the union
+// over lanes); hypotheses that explain the same image region share their candidates, so ordering the batch by this key
+// shrinks the union (metric batch: 26 % -> ~7 % of wave-steps on the exact path).  Pure scheduling: results are
+// written back in the caller's order (score_reduce_kernel / mask rows use `perm`).
+static uint32_t spread16(uint32_t x)
+{
+    x &= 0xffff;
+    x = (x | (x << 8)) & 0x00ff00ff;
+    x = (x | (x << 4)) & 0x0f0f0f0f;
+    x = (x | (x << 2)) & 0x33333333;
+    x = (x | (x << 1)) & 0x55555555;
+    return x;
+}
+
+static bool locality_keys(const pgx_ctx* ctx, const double* models, int M, std::vector<uint64_t>& keys)
+{
+    const int P = ctx->P;
+    std::vector<double> kx((size_t)M), ky((size_t)M);
+    for (int m = 0; m < M; ++m) {
+        const double* q = models + (size_t)m * P;
+        double x, y;
+        if (ctx->model_type == kPnP) {            // projection of the object origin
+            x = q[3] / q[11]; y = q[7] / q[11];
+        } else if (ctx->model_type == kHomography || ctx->model_type == kHomographySym) {  // image of the probe (0,0)
+            x = q[2] / q[8]; y = q[5] / q[8];
+        } else return false;
+        kx[(size_t)m] = x; ky[(size_t)m] = y;
+    }
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int m = 0; m < M; ++m) {
+        if (std::isfinite(kx[m])) { lo[0] = std::min(lo[0], kx[m]); hi[0] = std::max(hi[0], kx[m]); }
+        if (std::isfinite(ky[m])) { lo[1] = std::min(lo[1], ky[m]); hi[1] = std::max(hi[1], ky[m]); }
+    }
+    keys.resize((size_t)M);
+    for (int m = 0; m < M; ++m) {
+        if (!std::isfinite(kx[m]) || !std::isfinite(ky[m]) || !(hi[0] > lo[0]) || !(hi[1] > lo[1])) {
+            keys[(size_t)m] = ~0ull;  // degenerate hypotheses last
+            continue;
+        }
+        const uint32_t qx = (uint32_t)((kx[m] - lo[0]) / (hi[0] - lo[0]) * 65535.0);
+        const uint32_t qy = (uint32_t)((ky[m] - lo[1]) / (hi[1] - lo[1]) * 65535.0);
+        keys[(size_t)m] = (uint64_t)(spread16(qx) | (spread16(qy) << 1));
+    }
+    return true;
+}
+
 int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
 {
     CTX_GUARD(ctx);
     if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: points not set");
     if (!models || M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: empty hypothesis batch");
-    PGX_TRY(ensure(ctx, ctx->models, (size_t)M * ctx->P * sizeof(double)));
-    PGX_HIP(ctx, hipMemcpyAsync(ctx->models.p, models, (size_t)M * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int P = ctx->P;
+    std::vector<int> perm((size_t)M);
+    for (int m = 0; m < M; ++m) perm[(size_t)m] = m;
+    std::vector<uint64_t> keys;
+    std::vector<double> sorted;
+    const double* src = models;
+    if (ctx->score_sort && M > 64 && locality_keys(ctx, models, M, keys)) {
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return keys[(size_t)a] < keys[(size_t)b]; });
+        sorted.resize((size_t)M * P);
+        for (int m = 0; m < M; ++m)
+            std::memcpy(sorted.data() + (size_t)m * P, models + (size_t)perm[(size_t)m] * P, (size_t)P * sizeof(double));
+        src = sorted.data();
+    }
+    ctx->Mpad = ((M + 255) / 256) * 256;
+    perm.resize((size_t)ctx->Mpad, 0);
+    PGX_TRY(ensure(ctx, ctx->models, (size_t)M * P * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->models.p, src, (size_t)M * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->perm.p, perm.data(), (size_t)ctx->Mpad * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may free `models` on return
     ctx->M = M;
-    ctx->Mpad = ((M + 255) / 256) * 256;
     return PGX_OK;
 }
 

@@ -49,6 +49,8 @@ struct pgx_ctx {
     bool have_masks = false;
     int score_has_compound = 0;
     pgx::DevBuf models, pcnt, pval, psh, counts, values, shared, masks;
+    pgx::DevBuf perm;        // perm[sorted position] = caller's hypothesis index (locality ordering, capi.hip)
+    int score_sort = 1;      // PGX_NO_SORT=1 keeps the caller's order (A/B)
     pgx::DevBuf g_counts, g_values, g_shared;  // all-gathered results (multi-GPU)
 
     // preference slots + reductions

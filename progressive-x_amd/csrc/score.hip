@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
     const double* __restrict__ pmax, double guard, const float* __restrict__ pts32, double guard32,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words)
+    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
 {
     using R = Residual<MT>;
     const int m = blockIdx.x * kScoreBlock + threadIdx.x;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
         if (MASK) {
             word |= (unsigned long long)(inl ? 1 : 0) << (i & 63);
             if ((i & 63) == 63 || i == i1 - 1) {
-                if (live) masks[(int64_t)m * words + (i >> 6)] = word;  // :88 inlier list as a bit mask
+                if (live) masks[(int64_t)perm[m] * words + (i >> 6)] = word;  // :88 inlier list as a bit mask (row = caller's index)
                 word = 0;
             }
         }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel_deferred(
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
     const double* __restrict__ pmax, double guard,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words)
+    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
 {
     using R = Residual<MT>;
     using F = Filter<MT>;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel_deferred(
         const bool word_end = MASK && ((last & 63) == 63 || last == i1 - 1);
         if (word_end || __any(qn > kQueue - 4)) drain();
         if (word_end) {
-            if (live) masks[(int64_t)m * words + (last >> 6)] = word;
+            if (live) masks[(int64_t)perm[m] * words + (last >> 6)] = word;
             word = 0;
         }
     };
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel_deferred(
 constexpr int kReduceWaves = 16;
 __global__ __launch_bounds__(64 * kReduceWaves) void score_reduce_kernel(
     const unsigned* __restrict__ pcnt, const double* __restrict__ pval, const double* __restrict__ psh,
-    int chunks, int Mpad, int M, long long* __restrict__ counts, double* __restrict__ values,
-    double* __restrict__ shared)
+    int chunks, int Mpad, int M, const int* __restrict__ perm, long long* __restrict__ counts,
+    double* __restrict__ values, double* __restrict__ shared)
 {
     __shared__ long long lc[kReduceWaves][64];
     __shared__ double lv[kReduceWaves][64], ls[kReduceWaves][64];
@@ -389,9 +389,10 @@ __global__ __launch_bounds__(64 * kReduceWaves) void score_reduce_kernel(
     __syncthreads();
     if (wave == 0 && m < M) {
         for (int w = 1; w < kReduceWaves; ++w) { c += lc[w][lane]; v += lv[w][lane]; s += ls[w][lane]; }
-        counts[m] = c;
-        values[m] = v;
-        shared[m] = s;
+        const int o = perm[m];  // hypotheses were scored in locality order: results go back to the caller's order
+        counts[o] = c;
+        values[o] = v;
+        shared[o] = s;
     }
 }
 
@@ -403,7 +404,8 @@ static void score_launch_deferred(pgx_ctx* ctx, double T2, int has_compound, dou
                        ctx->pts.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
                        ctx->comp.as<double>(), has_compound, ctx->chunk, ctx->pmax.as<double>(), guard,
                        ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                       MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words);
+                       MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words,
+                       ctx->perm.as<int>());
 }
 
 template <int MT, bool MASK, int FILT>
@@ -415,7 +417,7 @@ static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double g
                        ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pts32.as<float>(), guard32,
                        ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
                        ctx->psh.as<double>(), MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr,
-                       ctx->words);
+                       ctx->words, ctx->perm.as<int>());
 }
 
 template <int MT>
@@ -460,8 +462,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     PGX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
                        ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                       ctx->chunks, ctx->Mpad, ctx->M, ctx->counts.as<long long>(), ctx->values.as<double>(),
-                       ctx->shared.as<double>());
+                       ctx->chunks, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
+                       ctx->values.as<double>(), ctx->shared.as<double>());
     PGX_HIP(ctx, hipGetLastError());
     return PGX_OK;
 }
