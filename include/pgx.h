@@ -112,7 +112,7 @@ int pgx_expand_alpha(pgx_ctx *ctx, double lambda, double label_cost, int alpha, 
 int pgx_expansion(pgx_ctx *ctx, double lambda, double label_cost, int max_cycles,
                   int64_t *energy_q, double *energy, int *cycles);
 /* counters of the last pgx_expansion / pgx_expand_alpha: [0]=min-cuts solved, [1]=push-relabel sweeps,
- * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves */
+ * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves, [5]=wave passes */
 int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 
 /* ---- a9: PEARL::parameterEstimation bookkeeping (PEARL.h:342-352, 369-371, 388-390) */

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_init(MfView v, int, int)
 
 // Kernels whose per-site body reports a boolean and/or accumulates per-label minima: both are aggregated per block in
 // LDS and flushed with at most (L + 1) global operations per block.
-enum { kBfsInit = 0, kBfsLevel = 1, kCountActive = 2, kSweep = 3, kApply = 4 };
+enum { kBfsInit = 0, kBfsLevel = 1, kCountActive = 2, kApply = 4 };
 
 template <int WHAT>
 __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     if (u < v.n) {
         if (WHAT == kBfsInit) r = mf_body_bfs_init(v, u, s_min);
         else if (WHAT == kCountActive) r = mf_body_count_active(v, u);
-        else if (WHAT == kSweep) r = mf_body_sweep(v, u, a0, a1, s_min);
         else if (WHAT == kApply) r = mf_body_apply(v, u);
     }
     if (WHAT == kBfsLevel) {
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
         // Eight lanes share one frontier site and stride over its arcs ("virtual warp"): a lane-per-site loop is a
         // chain of ~5 dependent gathers per arc (measured ~45 us per level for frontiers of a few thousand sites).
         const int F = v.fcount[(a0 - 1) % 3];
-        const int* __restrict__ fin = v.front[(a0 - 1) & 1];
+        const int* __restrict__ fin = v.order + v.lvl[a0 - 1];
         const int sub = (int)(threadIdx.x & 7);
         const int64_t ngroups = ((int64_t)gridDim.x * kMfBlock) >> 3;
         for (int64_t q = ((int64_t)blockIdx.x * kMfBlock + threadIdx.x) >> 3; v.off != nullptr && q < F; q += ngroups) {
@@ -82,21 +81,57 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
         }
         const int ev = mf_bfs_hub_events(v, a0);
         if (ev != 0 && u < v.n) r |= mf_body_bfs_hubpass(v, u, a0, (ev & 1) != 0, s_min);
-        if (blockIdx.x == 0 && threadIdx.x == 0) v.fcount[(a0 + 1) % 3] = 0;  // slot of the level after this one
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            v.lvl[a0] = mf_level_base(v, a0);
+            v.fcount[(a0 + 1) % 3] = 0;  // slot of the level after this one
+        }
     }
     const int count = __syncthreads_count(r ? 1 : 0);
     if (WHAT == kBfsInit || WHAT == kBfsLevel) {
         if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
         if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], WHAT == kBfsInit ? 1 : a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (WHAT == kSweep) {
-        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf)
-            atomicMin(&v.hub_min[a1 * v.L + threadIdx.x], s_min[threadIdx.x]);
-        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (WHAT == kCountActive) {
-        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && count > 0) {
+            __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&v.flags[3], count);  // number of active sites after this global relabel (diagnostics)
+        }
     } else {
         if (threadIdx.x == 0 && count > 0) atomicAdd(&v.flags[2], count);
     }
+}
+
+// One push-relabel sweep: (1) beta-hub pull requests, summed per label in LDS; (2) one reservation per (workgroup, label)
+// on the hub's excess word; (3) the grant is split in LDS arrival order and every site runs its discharge step.
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    __shared__ unsigned long long s_want[kMfMaxLabels];
+    __shared__ long long s_got[kMfMaxLabels];
+    if (threadIdx.x < kMfMaxLabels) { s_min[threadIdx.x] = kMfInf; s_want[threadIdx.x] = 0; s_got[threadIdx.x] = 0; }
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    long long want = 0, before = 0;
+    int lu = 0;
+    if (u < v.n) {
+        want = mf_body_pull_want(v, u, prev);
+        if (want > 0) { lu = v.labels[u]; before = (long long)atomicAdd(&s_want[lu], (unsigned long long)want); }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < v.L && s_want[threadIdx.x] > 0)
+        s_got[threadIdx.x] = mf_reserve(&v.hub_e[threadIdx.x], (long long)s_want[threadIdx.x]);
+    __syncthreads();
+    bool r = false;
+    if (u < v.n) {
+        long long got = 0;
+        if (want > 0) {
+            got = s_got[lu] - before;
+            got = got < 0 ? 0 : (got > want ? want : got);
+        }
+        r = mf_body_sweep(v, u, prev, cur, s_min, got);
+    }
+    const int count = __syncthreads_count(r ? 1 : 0);
+    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.hub_min[cur * v.L + threadIdx.x], s_min[threadIdx.x]);
+    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
@@ -142,13 +177,23 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply(const long long* __res
     if (threadIdx.x == 0 && c > 0) atomicAdd(changed, c);
 }
 
+// ---- wave pass: the sites of BFS level k push into level k-1 (maxflow_body.cuh mf_body_wave) -------------------------
+constexpr int kWaveBlocks = 256;
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
+{
+    const int lo = v.lvl[k], hi = v.lvl[k + 1];
+    for (int i = lo + (int)(blockIdx.x * kMfBlock + threadIdx.x); i < hi; i += kWaveBlocks * kMfBlock)
+        mf_body_wave(v, v.order[i], k);
+}
+
 __global__ void mf_k_single(MfView v, int what, int a0, int a1)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     switch (what) {
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
-    case 2: mf_body_bfs_finish(v, a0); break;
+    case 2: mf_body_bfs_finish(v, a0, a1); break;
     case 3: mf_body_sweep_epilogue(v, a0, a1); break;
     }
 }
@@ -191,10 +236,13 @@ int graph_build_reverse(pgx_ctx* ctx)
 
 namespace {
 
+static int ctx_debug_level() { const char* e = std::getenv("PGX_MF_DEBUG"); return e ? std::atoi(e) : 0; }
+
 struct HipBackend {
     pgx_ctx* ctx;
     MaxflowState* st;
     unsigned blocks;
+    bool v_has_graph;
     hipError_t err = hipSuccess;
 
     void check() { if (err == hipSuccess) err = hipGetLastError(); }
@@ -228,9 +276,54 @@ struct HipBackend {
     void bfs_init(const MfView& v) { site(mf_k_agg<kBfsInit>, v); }
     void bfs_level(const MfView& v, int k) { site(mf_k_agg<kBfsLevel>, v, k); }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
-    void bfs_finish(const MfView& v, int slot) { single(v, 2, slot); }
+    void read_flags(const MfView& v, int out[8])
+    {
+        hipError_t e = hipMemcpyAsync(st->h_flags, v.flags, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        for (int k = 0; k < 8; ++k) out[k] = st->h_flags[k];
+    }
+    void wave(const MfView& v, int k)
+    {
+        hipLaunchKernelGGL(mf_k_wave, dim3(kWaveBlocks), dim3(kMfBlock), 0, ctx->stream, v, k);
+        check();
+    }
+    template <class T> T peek(const T* dptr)
+    {
+        T x{};
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(&x, dptr, sizeof(T), hipMemcpyDeviceToHost);
+        return x;
+    }
+    void debug_dump(const MfView& v, int nact)
+    {
+        for (int l = 0; l < v.L; ++l)
+            if (peek(v.hub_exists + l))
+                std::fprintf(stderr, "    hub %d: e=%lld d=%d cnt=%d\n", l, peek(v.hub_e + l), peek(v.bfs_hub_d + l), peek(v.cnt + l));
+        if (peek(v.has_alpha_hub)) std::fprintf(stderr, "    hubA: rt=%lld d=%d\n", peek(v.hubA_rt), peek(v.bfs_hubA_d));
+        (void)nact;
+        if (ctx_debug_level() < 3) return;
+        std::vector<long long> ex((size_t)v.n), rt((size_t)v.n);
+        std::vector<int> d((size_t)v.n), lab((size_t)v.n);
+        (void)hipMemcpy(ex.data(), v.ex, sizeof(long long) * (size_t)v.n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(rt.data(), v.rt, sizeof(long long) * (size_t)v.n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(d.data(), v.d, sizeof(int) * (size_t)v.n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(lab.data(), v.labels, sizeof(int) * (size_t)v.n, hipMemcpyDeviceToHost);
+        long long n_act = 0, n_stuck = 0, n_exit = 0, n_relay = 0;
+        double s_act = 0, s_stuck = 0, s_rt = 0;
+        for (int64_t u = 0; u < v.n; ++u) {
+            if (lab[u] == v.alpha) continue;
+            if (ex[u] > 0 && d[u] != kMfInf) { ++n_act; s_act += (double)ex[u]; }
+            if (ex[u] > 0 && d[u] == kMfInf) { ++n_stuck; s_stuck += (double)ex[u]; }
+            if (rt[u] > 0) { ++n_exit; s_rt += (double)rt[u]; }
+            if (ex[u] <= 0 && rt[u] <= 0 && d[u] != kMfInf) ++n_relay;
+        }
+        std::fprintf(stderr, "    active %lld (sum %.4g)  stuck %lld (sum %.4g)  exits %lld (sum rt %.6g)  relays %lld\n", n_act, s_act / 4294967296.0,
+                     n_stuck, s_stuck / 4294967296.0, n_exit, s_rt / 4294967296.0, n_relay);
+    }
+    void bfs_finish(const MfView& v, int slot, int last_level) { single(v, 2, slot, last_level); }
     void count_active(const MfView& v) { site(mf_k_agg<kCountActive>, v); }
-    void sweep(const MfView& v, int prev, int cur) { site(mf_k_agg<kSweep>, v, prev, cur); }
+    void sweep(const MfView& v, int prev, int cur) { site(mf_k_sweep, v, prev, cur); }
     void sweep_epilogue(const MfView& v, int cur, int next) { single(v, 3, cur, next); }
     void apply(const MfView& v) { site(mf_k_agg<kApply>, v); }
 };
@@ -323,7 +416,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     PGX_TRY(ensure(ctx, st->d, (size_t)n * sizeof(int)));
     // small state: hub_e[L] i64 | hubA_rt i64 | hubA_min[3] u64 | cnt[L] | hub_exists[L] | bfs_hub_d[L] | hub_min[3L] |
     //              has_alpha_hub | bfs_hubA_d | flags[8]
-    PGX_TRY(ensure(ctx, st->front, (size_t)2 * n * sizeof(int)));
+    PGX_TRY(ensure(ctx, st->front, (size_t)(2 * n + L + 32) * sizeof(int)));  // order[n] | lvl[n + L + 32]
     const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(9 * L + 2 + 3 + 8) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
@@ -343,15 +436,17 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.bfs_hub_d = (int*)sp; sp += (size_t)L * 4;
     v.hub_min = (int*)sp; sp += (size_t)3 * L * 4;
     v.fcount = (int*)sp; sp += 12;
-    v.front[0] = st->front.as<int>();
-    v.front[1] = st->front.as<int>() + n;
+    v.order = st->front.as<int>();
+    v.lvl = st->front.as<int>() + n;
     v.has_alpha_hub = (int*)sp; sp += 4;
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
 
-    HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock)};
+    HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair};
     MfTuning tune;
+    if (const char* e = std::getenv("PGX_MF_WAVE")) tune.wave = std::atoi(e);
+    if (const char* e = std::getenv("PGX_MF_DEBUG")) tune.debug = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
     if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) tune.bfs_batch = x; }

@@ -63,8 +63,9 @@ struct MfView {
     int* bfs_hubA_d;               // [1]
     int* hub_min;                  // [3][L] rotating: min member height of each beta hub
     unsigned long long* hubA_min;  // [3] rotating: (height << 32 | site) of the lowest member with g > 0
-    int* front[2];                 // BFS frontiers (site ids), ping-pong by level parity
-    int* fcount;                   // [3] frontier sizes, rotating by level % 3
+    int* order;                    // [n] sites in BFS order: level k occupies order[lvl[k] .. lvl[k] + fcount[k % 3])
+    int* lvl;                      // [hmax + 16] start of each level in `order` (lvl[k + 1] is written by level k + 1)
+    int* fcount;                   // [3] level sizes, rotating by level % 3
     int* flags;                    // [8]: 0 last BFS level that labelled a site, 1 work-left (boolean, being
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep
     int hmax;                      // heights >= hmax are treated as unreachable
@@ -221,6 +222,9 @@ PGX_HD void mf_acc_min(int* acc, int val)
     if (val < mf_load32(acc)) mf_min32(acc, val);
 }
 
+// Where level k starts in `order`: behind level k-1, whose size is final when level k runs (uniform plain reads).
+PGX_HD int mf_level_base(const MfView& v, int k) { return k <= 1 ? 0 : v.lvl[k - 1] + v.fcount[(k - 1) % 3]; }
+
 // Labels site u with BFS distance k (if still unlabelled), records what that implies for the hubs and appends u to the
 // frontier of level k.  Must be called convergently by all active lanes (wave-aggregated append); `want` selects lanes.
 PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want)
@@ -235,7 +239,7 @@ PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool w
             mf_min32(&v.bfs_hubA_d[0], k + 1);
         }
     }
-    mf_append(&v.fcount[k % 3], v.front[k & 1], (int)u, mine);
+    mf_append(&v.fcount[k % 3], v.order + mf_level_base(v, k), (int)u, mine);
     return mine;
 }
 
@@ -246,8 +250,11 @@ PGX_HD void mf_body_bfs_reset(const MfView& v)
     v.bfs_hubA_d[0] = (v.has_alpha_hub[0] && v.hubA_rt[0] > 0) ? 1 : kMfInf;
     v.hubA_min[0] = ~0ull;
     v.fcount[0] = v.fcount[1] = v.fcount[2] = 0;
+    v.lvl[0] = v.lvl[1] = 0;
     v.flags[0] = 0;
     v.flags[1] = 0;
+    v.flags[3] = 0;
+    v.flags[7] = 0;
 }
 
 // level 1: sites with residual capacity to t.  Returns true iff the site was labelled.
@@ -295,29 +302,112 @@ PGX_HD int mf_bfs_hub_events(const MfView& v, int k)
 }
 
 // one thread, after the BFS: publish hub heights for the sweeps (slot `slot`) and count active hubs
-PGX_HD void mf_body_bfs_finish(const MfView& v, int slot)
+PGX_HD void mf_body_bfs_finish(const MfView& v, int slot, int last_level)
 {
+    v.lvl[last_level + 1] = mf_level_base(v, last_level + 1);  // closes the level table for the wave pass
     for (int l = 0; l < v.L; ++l) {
         const int hd = v.bfs_hub_d[l];
         for (int r = 0; r < 3; ++r) v.hub_min[r * v.L + l] = kMfInf;
         v.hub_min[slot * v.L + l] = hd == kMfInf ? kMfInf : hd - 1;
-        if (v.hub_exists[l] && v.hub_e[l] > 0 && hd != kMfInf) v.flags[1] = 1;
+        if (v.hub_exists[l] && v.hub_e[l] > 0 && hd != kMfInf) { v.flags[1] = 1; v.flags[7] = 1; }  // [7]: a hub can still deliver
     }
     const unsigned long long pk = v.hubA_min[0];
     for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
     v.hubA_min[slot] = pk;
 }
 
+// After a global relabel: does site u hold excess that can reach t?
 PGX_HD bool mf_body_count_active(const MfView& v, int64_t u)
 {
-    if (v.labels[u] == v.alpha) return false;
-    return mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf;
+    return v.labels[u] != v.alpha && mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf;
+}
+
+// ---- wave pass --------------------------------------------------------------------------------------------------
+// Right after a global relabel the heights are exact distances and `order` lists the sites level by level.  Visiting
+// the levels from the farthest to the nearest and letting every site push along ALL its arcs into the level below moves
+// excess over the whole length of a shortest path in one pass (a lock-step sweep moves it one hop: with paths of 100+
+// arcs, as in the moves that hand a new instance its ~5e4 points at N = 1e6, a round of 48 sweeps never reached t and a
+// move took up to 239 global relabels).  Only n-links and t-links; hub arcs are left to the sweeps.
+PGX_HD void mf_body_wave(const MfView& v, int64_t u, int k)
+{
+    long long e = mf_load64(&v.ex[u]);
+    if (e <= 0) return;
+    const long long r = v.rt[u];
+    if (r > 0) {
+        const long long dl = e < r ? e : r;
+        v.rt[u] = r - dl;
+        mf_add64(&v.ex[u], -dl);
+        e -= dl;
+    }
+    if (e <= 0 || !v.off) return;
+    for (int a = v.off[u]; a < v.off[u + 1] && e > 0; ++a) {
+        const long long c = mf_load64(&v.cap[a]);
+        if (c <= 0) continue;
+        const int w = v.idx[a];
+        if (mf_load32(&v.d[w]) != k - 1) continue;
+        const long long dl = e < c ? e : c;
+        mf_add64(&v.cap[a], -dl);
+        mf_add64(&v.cap[v.rev[a]], dl);
+        mf_add64(&v.ex[u], -dl);
+        mf_add64(&v.ex[w], dl);
+        e -= dl;
+    }
+}
+
+// ---- beta-hub pulls ------------------------------------------------------------------------------------------------
+// The arc y_beta -> u is admissible when the hub sits one above u.  What u asks for is what it can pass on at once:
+// its own residual to t, or else the residual of its admissible n-links.  (Measured at N = 1e6, h = 5000: when one
+// elected member per wave pulled and members without a t residual asked for "everything visible", a single stale-height
+// member hoarded the whole label cost and dribbled it back over several global relabels: 13-19 ms per steady-state
+// move, ~16 deliveries per sweep per hub.)  A member that is eligible but can pass nothing on has a stale height: it is
+// lifted instead (relabelling a node without an admissible residual arc is valid whether or not it holds excess), which
+// is what lets the hub height rise to the members that can deliver.
+// The requests of a workgroup are summed per label in LDS and reserved with one atomic per (workgroup, label);
+// the grant is split in LDS arrival order (maxflow.hip mf_k_sweep).  The sequential emulation reserves per site.
+PGX_HD long long mf_body_pull_want(const MfView& v, int64_t u, int prev)
+{
+    const int lu = v.labels[u];
+    if (lu == v.alpha || !v.hub_exists[lu] || v.hub_e[lu] <= 0) return 0;  // plain (cached) reads: gates only
+    const int du = v.d[u];
+    if (du == kMfInf) return 0;
+    const int m = v.hub_min[prev * v.L + lu];
+    if (m != du) return 0;  // hub height m + 1 must be exactly one above u
+    const long long e = mf_load64(&v.ex[u]);
+    if (v.rt[u] > 0) return v.rt[u] > e ? v.rt[u] - e : 0;
+    if (e > 0) return 0;  // already holds excess it has not placed yet
+    long long adm = 0;
+    int best_h = v.f[u] > 0 ? du + 1 : kMfInf;  // residual u -> y_beta, hub height du + 1
+    if (v.has_alpha_hub[0]) {                   // u -> y_alpha (inf), then y_alpha -> t or y_alpha -> its lowest member
+        int ha = kMfInf;
+        long long room = 0;
+        if (v.hubA_rt[0] > 0) { ha = 1; room = v.hubA_rt[0]; }
+        else {
+            const unsigned long long pk = v.hubA_min[prev];
+            const int site = (int)(pk & 0xffffffffu);
+            if (pk != ~0ull && site != (int)u) { ha = (int)(pk >> 32) + 1; room = mf_load64(&v.g[site]); }
+        }
+        if (ha < best_h) best_h = ha;
+        if (ha < du && room > 0) adm += room;
+    }
+    if (v.off)
+        for (int a = v.off[u]; a < v.off[u + 1]; ++a) {
+            const long long c = mf_load64(&v.cap[a]);
+            if (c <= 0) continue;
+            const int h = mf_load32(&v.d[v.idx[a]]);
+            if (h < best_h) best_h = h;
+            if (h < du) adm += c;
+        }
+    if (adm > 0) return adm;
+    int nd = best_h == kMfInf ? kMfInf : best_h + 1;
+    if (nd >= v.hmax) nd = kMfInf;
+    if (nd > du) mf_store32(&v.d[u], nd);
+    return 0;
 }
 
 // ---- one push-relabel step for site u ------------------------------------------------------------------------------
 // prev/cur/next: rotating slots of the hub height scans (read prev, accumulate cur, clear next).
 // returns true iff this site did or still has work (the caller latches flags[1])
-PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc)
+PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, long long granted)
 {
     const int lu = v.labels[u];
     if (lu == v.alpha) return false;
@@ -327,6 +417,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     // A hub's height is rescanned only while it holds excess (members pull); otherwise the last known height is carried
     // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
     // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
+    if (granted > 0) { v.f[u] += granted; mf_add64(&v.ex[u], granted); work = true; }  // y_beta -> u (mf_body_pull_want)
     const bool scan_b = hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
     if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
     int du = v.d[u];
@@ -342,14 +433,6 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
         }
     }
     if (du != kMfInf) {
-        // pull from the beta hub along the admissible arc y_beta -> u (one contender per wave and sweep)
-        if (mf_elect(hub_b && hb == du + 1 && v.hub_e[lu] > 0)) {
-            // own sink residual if any, otherwise whatever is visible in the hub right now (bounded: no overflow when
-            // several wave leaders subtract concurrently)
-            const long long want = v.rt[u] > 0 ? v.rt[u] : mf_load64(&v.hub_e[lu]);
-            const long long got = mf_reserve(&v.hub_e[lu], want);
-            if (got > 0) { v.f[u] += got; mf_add64(&v.ex[u], got); work = true; }
-        }
         long long e = mf_load64(&v.ex[u]);
         if (e > 0) {
             if (v.rt[u] > 0) {  // u -> t

@@ -2,8 +2,10 @@
 // sequential CPU emulation used by the host-logic tests (tests/emu).  `Backend` provides one method per kernel.
 //
 //   count/setup -> init sites -> repeat { global relabel (level-synchronous BFS from t) ; stop if nothing with excess
-//   can reach t ; a batch of push-relabel sweeps } -> apply cut.
+//   can reach t ; wave pass down the BFS levels ; a batch of push-relabel sweeps } -> apply cut.
 #pragma once
+#include <cstdio>
+
 #include "maxflow_body.cuh"
 
 namespace pgx {
@@ -13,6 +15,8 @@ struct MfTuning {
     int sweeps_per_relabel = 48;
     int sweep_check = 8;      // read the work-left flag every this many sweeps
     int max_relabels = 4096;  // hard cap on global relabels per move
+    int debug = 0;            // PGX_MF_DEBUG=1: one stderr line per global relabel
+    int wave = 1;             // run the level-ordered wave pass after each global relabel
 };
 
 // returns 0 on success, 1 if the cap on global relabels was hit
@@ -40,9 +44,19 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         stats[2] += 1;
         stats[3] += level;
         const int slot = (sweep_id + 2) % 3;
-        be.bfs_finish(v, slot);
+        be.bfs_finish(v, slot, level);
         be.count_active(v);
-        if (be.read_flag(v, 1) == 0) { converged = true; break; }
+        int fl[8];
+        be.read_flags(v, fl);
+        if (fl[1] == 0) { converged = true; break; }
+        if (tune.debug)
+            std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d\n", v.alpha, it, level, fl[3], fl[7]);
+        if (tune.debug > 1) be.debug_dump(v, fl[3]);
+        // ---- wave pass over the BFS levels, farthest first
+        if (tune.wave && v.off != nullptr) {
+            for (int k = level; k >= 1; --k) be.wave(v, k);
+            stats[5] += 1;
+        }
         // ---- push-relabel sweeps
         for (int s = 0; s < tune.sweeps_per_relabel; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;

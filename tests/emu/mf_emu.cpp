@@ -45,21 +45,35 @@ struct EmuBackend {
     void bfs_level(const MfView& v, int k)
     {
         const int F = v.fcount[(k - 1) % 3];
-        std::vector<int> fr(v.front[(k - 1) & 1], v.front[(k - 1) & 1] + F);
+        const int base = mf_level_base(v, k);
+        std::vector<int> fr(v.order + v.lvl[k - 1], v.order + v.lvl[k - 1] + F);
         if (shuffle) std::shuffle(fr.begin(), fr.end(), rng);
         for (int w : fr) if (mf_body_bfs_expand(v, w, k, v.bfs_hub_d)) v.flags[0] = k;
         // NB: on the device hub distances accumulated during level k become visible only after the level's kernel,
         // and the event test uses distance k-1, which no label written at level k (>= k+1) can produce: same here.
         const int ev = mf_bfs_hub_events(v, k);
         if (ev != 0) each([&](int64_t u) { if (mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, v.bfs_hub_d)) v.flags[0] = k; });
+        v.lvl[k] = base;
         v.fcount[(k + 1) % 3] = 0;
     }
     int read_flag(const MfView& v, int i) { return v.flags[i]; }
-    void bfs_finish(const MfView& v, int slot) { mf_body_bfs_finish(v, slot); }
+    void read_flags(const MfView& v, int out[8]) { for (int k = 0; k < 8; ++k) out[k] = v.flags[k]; }
+    void wave(const MfView& v, int k)
+    {
+        std::vector<int> lv(v.order + v.lvl[k], v.order + v.lvl[k + 1]);
+        if (shuffle) std::shuffle(lv.begin(), lv.end(), rng);
+        for (int u : lv) mf_body_wave(v, u, k);
+    }
+    void debug_dump(const MfView&, int) {}
+    void bfs_finish(const MfView& v, int slot, int last_level) { mf_body_bfs_finish(v, slot, last_level); }
     void count_active(const MfView& v) { each([&](int64_t u) { if (mf_body_count_active(v, u)) v.flags[1] = 1; }); dump(v, "after bfs"); }
     void sweep(const MfView& v, int prev, int cur)
     {
-        each([&](int64_t u) { if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L)) v.flags[1] = 1; });
+        each([&](int64_t u) {
+            const long long want = mf_body_pull_want(v, u, prev);
+            const long long got = want > 0 ? mf_reserve(&v.hub_e[v.labels[u]], want) : 0;
+            if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, got)) v.flags[1] = 1;
+        });
     }
     void dump(const MfView& v, const char* tag)
     {
@@ -127,7 +141,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
-        bfs_hubA_d(1), hub_min((size_t)3 * L), front0((size_t)n), front1((size_t)n), fcount(3), flags(8);
+        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 32)), fcount(3), flags(8);
     std::vector<unsigned long long> hubA_min(3);
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
@@ -138,7 +152,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.bfs_hub_d = bfs_hub_d.data();
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
     v.flags = flags.data();
-    v.front[0] = front0.data(); v.front[1] = front1.data(); v.fcount = fcount.data();
+    v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data();
     v.hmax = (int)(n + L + 3);
     EmuBackend be(n, order_seed);
     MfTuning tune;
