@@ -22,6 +22,9 @@ constexpr int kMfBlock = 256;
 struct MaxflowState {
     DevBuf cap, ex, rt, d, f, g, small, front;
     int* h_flags = nullptr;  // pinned host mirror for flag read-backs
+    DevBuf lists;            // act[2][n] | mark[n]
+    int next_stamp = 1;
+    int64_t mark_n = 0;
 };
 
 constexpr int kMfMaxLabels = 64;
@@ -134,6 +137,42 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
     if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- list-mode sweeps (maxflow_driver.inl): only the sites that can act are visited ------------------------------------
+__global__ __launch_bounds__(kMfBlock) void mf_k_build_list(MfView v, int stamp, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    const bool want = u < v.n && mf_listed(v, u);
+    if (want) v.mark[u] = stamp;
+    mf_list_append(v, 0, (int)u, want);
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp)
+{
+    __shared__ int s_min[kMfMaxLabels];  // unused in list mode (no beta-hub scans); the body wants an accumulator
+    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    __syncthreads();
+    const int cnt = v.acnt[parity];
+    const int* __restrict__ in = v.act[parity];
+    bool any = false;
+    const int stride = (int)(gridDim.x * kMfBlock);
+    const int rounded = (cnt + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole workgroups iterate together (convergent appends)
+    for (int i = (int)(blockIdx.x * kMfBlock + threadIdx.x); i < rounded; i += stride) {
+        int pushed = -1;
+        bool again = false;
+        int u = -1;
+        if (i < cnt) {
+            u = in[i];
+            any |= mf_body_sweep(v, u, prev, cur, s_min, 0, true, &pushed);
+            again = mf_listed(v, u) && mf_list_claim(v, u, stamp);
+        }
+        mf_list_append(v, 1 - parity, u, again);
+        const bool fresh = pushed >= 0 && mf_list_claim(v, pushed, stamp);
+        mf_list_append(v, 1 - parity, pushed, fresh);
+    }
+    const int count = __syncthreads_count(any ? 1 : 0);
+    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
 __global__ __launch_bounds__(kMfBlock) void mf_k_l0_reduce(const long long* __restrict__ dq, const int* __restrict__ labels,
                                                            int64_t n, int L, int alpha, long long* __restrict__ sums)
@@ -187,14 +226,14 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
         mf_body_wave(v, v.order[i], k);
 }
 
-__global__ void mf_k_single(MfView v, int what, int a0, int a1)
+__global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     switch (what) {
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
-    case 3: mf_body_sweep_epilogue(v, a0, a1); break;
+    case 3: mf_body_sweep_epilogue(v, a0, a1, a2); break;
     }
 }
 
@@ -243,6 +282,7 @@ struct HipBackend {
     MaxflowState* st;
     unsigned blocks;
     bool v_has_graph;
+    unsigned list_blocks;
     hipError_t err = hipSuccess;
 
     void check() { if (err == hipSuccess) err = hipGetLastError(); }
@@ -251,9 +291,9 @@ struct HipBackend {
         hipLaunchKernelGGL(k, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, a0, a1);
         check();
     }
-    void single(const MfView& v, int what, int a0 = 0, int a1 = 0)
+    void single(const MfView& v, int what, int a0 = 0, int a1 = 0, int a2 = 0)
     {
-        hipLaunchKernelGGL(mf_k_single, dim3(1), dim3(64), 0, ctx->stream, v, what, a0, a1);
+        hipLaunchKernelGGL(mf_k_single, dim3(1), dim3(64), 0, ctx->stream, v, what, a0, a1, a2);
         check();
     }
     int read_int(const int* dptr)
@@ -324,7 +364,24 @@ struct HipBackend {
     void bfs_finish(const MfView& v, int slot, int last_level) { single(v, 2, slot, last_level); }
     void count_active(const MfView& v) { site(mf_k_agg<kCountActive>, v); }
     void sweep(const MfView& v, int prev, int cur) { site(mf_k_sweep, v, prev, cur); }
-    void sweep_epilogue(const MfView& v, int cur, int next) { single(v, 3, cur, next); }
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { single(v, 3, cur, next, consumed); }
+    int take_stamps(const MfView& v, int count)
+    {
+        if (st->next_stamp > 0x3fff0000 - count) {  // stamps only grow: start over with a clean mark array
+            hipError_t e = hipMemsetAsync(v.mark, 0, sizeof(int) * (size_t)v.n, ctx->stream);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            st->next_stamp = 1;
+        }
+        const int s = st->next_stamp;
+        st->next_stamp += count;
+        return s;
+    }
+    void build_list(const MfView& v, int stamp) { site(mf_k_build_list, v, stamp); }
+    void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
+    {
+        hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
+        check();
+    }
     void apply(const MfView& v) { site(mf_k_agg<kApply>, v); }
 };
 
@@ -335,7 +392,7 @@ void maxflow_free(pgx_ctx* ctx)
     if (!ctx->mf) return;
     MaxflowState* st = ctx->mf;
     release(st->cap); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
-    release(st->small); release(st->front);
+    release(st->small); release(st->front); release(st->lists);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
     delete st;
     ctx->mf = nullptr;
@@ -417,7 +474,14 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     // small state: hub_e[L] i64 | hubA_rt i64 | hubA_min[3] u64 | cnt[L] | hub_exists[L] | bfs_hub_d[L] | hub_min[3L] |
     //              has_alpha_hub | bfs_hubA_d | flags[8]
     PGX_TRY(ensure(ctx, st->front, (size_t)(2 * n + L + 32) * sizeof(int)));  // order[n] | lvl[n + L + 32]
-    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(9 * L + 2 + 3 + 8) * 4 + 64;
+    if (st->mark_n != n) {  // act[2][n] | mark[n]; stamps restart with a zeroed mark array
+        PGX_TRY(ensure(ctx, st->lists, (size_t)3 * n * sizeof(int)));
+        if (hipMemsetAsync(st->lists.as<int>() + 2 * n, 0, sizeof(int) * (size_t)n, ctx->stream) != hipSuccess)
+            return fail(ctx, PGX_ERR_HIP, "expansion move: clearing the list marks failed");
+        st->mark_n = n;
+        st->next_stamp = 1;
+    }
+    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(9 * L + 2 + 3 + 8 + 2) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
     MfView v;
@@ -436,6 +500,8 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.bfs_hub_d = (int*)sp; sp += (size_t)L * 4;
     v.hub_min = (int*)sp; sp += (size_t)3 * L * 4;
     v.fcount = (int*)sp; sp += 12;
+    v.acnt = (int*)sp; sp += 8;
+    v.act[0] = st->lists.as<int>(); v.act[1] = st->lists.as<int>() + n; v.mark = st->lists.as<int>() + 2 * n;
     v.order = st->front.as<int>();
     v.lvl = st->front.as<int>() + n;
     v.has_alpha_hub = (int*)sp; sp += 4;
@@ -443,9 +509,12 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
 
-    HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair};
+    HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
     MfTuning tune;
     if (const char* e = std::getenv("PGX_MF_WAVE")) tune.wave = std::atoi(e);
+    if (const char* e = std::getenv("PGX_MF_LIST_DIV")) tune.list_div = std::atoi(e);
+    if (const char* e = std::getenv("PGX_MF_SWEEPS_LIST")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_list = x; }
+    if (tune.list_div > 0) be.list_blocks = (unsigned)((n / tune.list_div + kMfBlock - 1) / kMfBlock + 1);
     if (const char* e = std::getenv("PGX_MF_DEBUG")) tune.debug = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }

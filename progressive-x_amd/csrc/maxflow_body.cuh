@@ -66,8 +66,12 @@ struct MfView {
     int* order;                    // [n] sites in BFS order: level k occupies order[lvl[k] .. lvl[k] + fcount[k % 3])
     int* lvl;                      // [hmax + 16] start of each level in `order` (lvl[k + 1] is written by level k + 1)
     int* fcount;                   // [3] level sizes, rotating by level % 3
+    int* act[2];                   // [n] each: work lists of the list-mode sweeps (read one, write the other)
+    int* acnt;                     // [2] their sizes
+    int* mark;                     // [n] stamp of the last list a site was appended to (stamps only grow)
     int* flags;                    // [8]: 0 last BFS level that labelled a site, 1 work-left (boolean, being
-                                   //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep
+                                   //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep,
+                                   //      6 a list-mode sweep pushed into a beta hub (all members must take part again)
     int hmax;                      // heights >= hmax are treated as unreachable
 };
 
@@ -254,7 +258,9 @@ PGX_HD void mf_body_bfs_reset(const MfView& v)
     v.flags[0] = 0;
     v.flags[1] = 0;
     v.flags[3] = 0;
+    v.flags[6] = 0;
     v.flags[7] = 0;
+    v.acnt[0] = v.acnt[1] = 0;
 }
 
 // level 1: sites with residual capacity to t.  Returns true iff the site was labelled.
@@ -321,6 +327,24 @@ PGX_HD bool mf_body_count_active(const MfView& v, int64_t u)
 {
     return v.labels[u] != v.alpha && mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf;
 }
+
+// ---- work lists ---------------------------------------------------------------------------------------------------
+// A site belongs on the list while it can still act: it holds excess and reaches t, or it lent flow to the alpha hub
+// (its height then takes part in the hub's height).  Appending is idempotent per list through the stamp in mark[].
+PGX_HD bool mf_listed(const MfView& v, int64_t u)
+{
+    if (v.labels[u] == v.alpha || mf_load32(&v.d[u]) == kMfInf) return false;
+    return mf_load64(&v.ex[u]) > 0 || (v.has_alpha_hub[0] && mf_load64(&v.g[u]) > 0);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool mf_claim(int* mark, int stamp) { return atomicExch(mark, stamp) != stamp; }
+#else
+inline bool mf_claim(int* mark, int stamp) { const bool fresh = *mark != stamp; *mark = stamp; return fresh; }
+#endif
+
+// (host/device wrappers: kernels may only call PGX_HD functions, the two variants above are picked inside them)
+PGX_HD bool mf_list_claim(const MfView& v, int site, int stamp) { return mf_claim(&v.mark[site], stamp); }
+PGX_HD void mf_list_append(const MfView& v, int which, int site, bool want) { mf_append(&v.acnt[which], v.act[which], site, want); }
 
 // ---- wave pass --------------------------------------------------------------------------------------------------
 // Right after a global relabel the heights are exact distances and `order` lists the sites level by level.  Visiting
@@ -407,7 +431,10 @@ PGX_HD long long mf_body_pull_want(const MfView& v, int64_t u, int prev)
 // ---- one push-relabel step for site u ------------------------------------------------------------------------------
 // prev/cur/next: rotating slots of the hub height scans (read prev, accumulate cur, clear next).
 // returns true iff this site did or still has work (the caller latches flags[1])
-PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, long long granted)
+// list_mode: only the sites on a work list are visited (maxflow_driver.inl), so beta-hub height scans are skipped (the
+// epilogue carries the published heights forward) and *pushed_to names the site that received flow, if any.
+PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, long long granted,
+                          bool list_mode = false, int* pushed_to = nullptr)
 {
     const int lu = v.labels[u];
     if (lu == v.alpha) return false;
@@ -418,7 +445,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
     // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
     if (granted > 0) { v.f[u] += granted; mf_add64(&v.ex[u], granted); work = true; }  // y_beta -> u (mf_body_pull_want)
-    const bool scan_b = hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
+    const bool scan_b = !list_mode && hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
     if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
     int du = v.d[u];
     // hub heights as published by the previous scan
@@ -462,6 +489,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                         mf_add64(&v.cap[v.rev[best_a]], dl);
                         mf_add64(&v.ex[u], -dl);
                         mf_add64(&v.ex[v.idx[best_a]], dl);
+                        if (pushed_to) *pushed_to = v.idx[best_a];
                         work = true;
                     } else if (kind == 2) {
                         const bool elected = mf_elect(true);  // one contender per wave and sweep on the hub words
@@ -476,6 +504,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                                 mf_add64(&v.g[u], got);
                                 mf_add64(&v.ex[u], -got);
                                 mf_add64(&v.ex[ha_site], got);
+                                if (pushed_to) *pushed_to = ha_site;
                                 work = true;
                             }
                         }
@@ -484,6 +513,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                         v.f[u] -= dl;
                         mf_add64(&v.ex[u], -dl);
                         mf_add64(&v.hub_e[lu], dl);
+                        if (list_mode) mf_store32(&v.flags[6], 1);
                         work = true;
                     }
                 } else {
@@ -505,13 +535,14 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
 }
 
 // one thread per sweep: clear the slot the NEXT sweep will accumulate into; latch the work-left flag
-PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next)
+// consumed: parity of the work list the sweep just read (list mode), -1 for a sweep over all sites
+PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next, int consumed = -1)
 {
     int act = v.flags[1];
     const int prev = (cur + 2) % 3;
     for (int l = 0; l < v.L; ++l) {
         // no scan was requested for this hub in this sweep: keep its last known height
-        if (v.hub_exists[l] && v.hub_e[l] <= 0 && v.hub_min[cur * v.L + l] == kMfInf)
+        if (v.hub_exists[l] && (consumed >= 0 || v.hub_e[l] <= 0) && v.hub_min[cur * v.L + l] == kMfInf)
             v.hub_min[cur * v.L + l] = v.hub_min[prev * v.L + l];
         v.hub_min[next * v.L + l] = kMfInf;
         if (v.hub_exists[l] && v.hub_e[l] > 0 && v.hub_min[cur * v.L + l] != kMfInf) act = 1;
@@ -519,6 +550,7 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next)
     v.hubA_min[next] = ~0ull;
     v.flags[4] = act;
     v.flags[1] = 0;
+    if (consumed >= 0) v.acnt[consumed] = 0;
 }
 
 // ---- apply the cut ---------------------------------------------------------------------------------------------

@@ -17,6 +17,8 @@ struct MfTuning {
     int max_relabels = 4096;  // hard cap on global relabels per move
     int debug = 0;            // PGX_MF_DEBUG=1: one stderr line per global relabel
     int wave = 1;             // run the level-ordered wave pass after each global relabel
+    int list_div = 8;         // sweeps visit a work list instead of all sites when <= n / list_div sites are active (0 = never)
+    int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
 };
 
 // returns 0 on success, 1 if the cap on global relabels was hit
@@ -57,14 +59,30 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             for (int k = level; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
         }
-        // ---- push-relabel sweeps
-        for (int s = 0; s < tune.sweeps_per_relabel; ++s) {
+        // ---- push-relabel sweeps: over all sites, or over a work list while few sites are active and no beta hub can
+        // deliver (a hub that receives excess back needs every member again: flags[6] ends list mode for the round)
+        bool list_mode = tune.list_div > 0 && v.off != nullptr && fl[7] == 0 && (int64_t)fl[3] * tune.list_div <= v.n;
+        const int budget = list_mode ? tune.sweeps_list : tune.sweeps_per_relabel;
+        const int stamp = be.take_stamps(v, budget + 2);
+        if (list_mode) be.build_list(v, stamp);
+        int parity = 0;
+        for (int s = 0; s < budget; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
-            be.sweep(v, prev, cur);
-            be.sweep_epilogue(v, cur, next);
+            if (list_mode) {
+                be.sweep_list(v, prev, cur, parity, stamp + 1 + s);
+                be.sweep_epilogue(v, cur, next, parity);
+                parity ^= 1;
+                stats[6] += 1;
+            } else {
+                be.sweep(v, prev, cur);
+                be.sweep_epilogue(v, cur, next, -1);
+            }
             ++sweep_id;
             stats[1] += 1;
-            if ((s + 1) % tune.sweep_check == 0 && be.read_flag(v, 4) == 0) break;
+            if ((s + 1) % tune.sweep_check != 0) continue;
+            be.read_flags(v, fl);
+            if (fl[4] == 0) break;
+            if (list_mode && fl[6] != 0) list_mode = false;
         }
     }
     if (!converged) return 1;

@@ -67,6 +67,26 @@ struct EmuBackend {
     void debug_dump(const MfView&, int) {}
     void bfs_finish(const MfView& v, int slot, int last_level) { mf_body_bfs_finish(v, slot, last_level); }
     void count_active(const MfView& v) { each([&](int64_t u) { if (mf_body_count_active(v, u)) v.flags[1] = 1; }); dump(v, "after bfs"); }
+    int next_stamp = 1;
+    int take_stamps(const MfView&, int count) { const int s = next_stamp; next_stamp += count; return s; }
+    void build_list(const MfView& v, int stamp)
+    {
+        v.acnt[0] = v.acnt[1] = 0;
+        each([&](int64_t u) { if (mf_listed(v, u) && mf_claim(&v.mark[u], stamp)) v.act[0][v.acnt[0]++] = (int)u; });
+    }
+    void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
+    {
+        std::vector<int> lst(v.act[parity], v.act[parity] + v.acnt[parity]);
+        if (shuffle) std::shuffle(lst.begin(), lst.end(), rng);
+        int* out = v.act[1 - parity];
+        int* oc = &v.acnt[1 - parity];
+        for (int u : lst) {
+            int pushed = -1;
+            if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, 0, true, &pushed)) v.flags[1] = 1;
+            if (mf_listed(v, u) && mf_claim(&v.mark[u], stamp)) out[(*oc)++] = u;
+            if (pushed >= 0 && mf_claim(&v.mark[pushed], stamp)) out[(*oc)++] = pushed;
+        }
+    }
     void sweep(const MfView& v, int prev, int cur)
     {
         each([&](int64_t u) {
@@ -87,7 +107,7 @@ struct EmuBackend {
             std::fprintf(stderr, "  u=%lld l=%d d=%d ex=%lld rt=%lld f=%lld g=%lld\n", (long long)u, v.labels[u], v.d[u], (long long)v.ex[u],
                          (long long)v.rt[u], (long long)v.f[u], (long long)v.g[u]);
     }
-    void sweep_epilogue(const MfView& v, int cur, int next) { mf_body_sweep_epilogue(v, cur, next); dump(v, "after sweep"); }
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { mf_body_sweep_epilogue(v, cur, next, consumed); dump(v, "after sweep"); }
     void apply(const MfView& v) { each([&](int64_t u) { if (mf_body_apply(v, u)) v.flags[2] += 1; }); }
 };
 
@@ -141,7 +161,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
-        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 32)), fcount(3), flags(8);
+        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 32)), fcount(3), flags(8), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
     std::vector<unsigned long long> hubA_min(3);
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
@@ -152,11 +172,12 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.bfs_hub_d = bfs_hub_d.data();
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
     v.flags = flags.data();
-    v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data();
+    v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data(); v.act[0] = act0.data(); v.act[1] = act1.data(); v.acnt = acnt.data(); v.mark = mark.data();
     v.hmax = (int)(n + L + 3);
     EmuBackend be(n, order_seed);
     MfTuning tune;
-    if (sweeps_per_relabel > 0) { tune.sweeps_per_relabel = sweeps_per_relabel; tune.sweep_check = 1; }
+    if (sweeps_per_relabel > 0) { tune.sweeps_per_relabel = tune.sweeps_list = sweeps_per_relabel; tune.sweep_check = 1; }
+    if (const char* e = std::getenv("MF_EMU_LIST_DIV")) tune.list_div = std::atoi(e);
     int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int r = mf_expand_alpha(be, v, tune, changed, st);
     if (stats) for (int k = 0; k < 8; ++k) stats[k] = st[k];

@@ -226,7 +226,14 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-def test_energy_and_moves_random_small(gpu_ctx, oracle):
+@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave"])
+def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
+    # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
+    if forced == "list_sweeps":
+        monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
+    if forced == "no_wave":
+        monkeypatch.setenv("PGX_MF_WAVE", "0")
+        monkeypatch.setenv("PGX_MF_LIST_DIV", "0")
     rng = np.random.default_rng(2024)
     for trial in range(60):
         n = int(rng.integers(2, 300))
@@ -254,8 +261,10 @@ def test_energy_and_moves_random_small(gpu_ctx, oracle):
             labels = ref
 
 
+@pytest.mark.parametrize("list_div", ["8", "1"])
 @pytest.mark.parametrize("n,lam,h", [(3000, 0.3, 10.0), (3000, 0.0, 10.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0)])
-def test_full_expansion_matches_oracle(gpu_ctx, oracle, n, lam, h):
+def test_full_expansion_matches_oracle(gpu_ctx, oracle, n, lam, h, list_div, monkeypatch):
+    monkeypatch.setenv("PGX_MF_LIST_DIV", list_div)
     Dq, graph = realistic_labeling_problem(n, L=6, lam=lam, seed=n)
     lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
     labels0 = np.zeros(n, dtype=np.int32)
