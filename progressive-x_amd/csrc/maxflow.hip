@@ -103,38 +103,81 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     }
 }
 
-// One push-relabel sweep: (1) beta-hub pull requests, summed per label in LDS; (2) one reservation per (workgroup, label)
-// on the hub's excess word; (3) the grant is split in LDS arrival order and every site runs its discharge step.
-__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
+// One push-relabel step of a workgroup's sites: (1) hub pull requests, summed per hub in LDS (slot kMfMaxLabels is the
+// alpha hub); (2) one reservation per (workgroup, hub) on the hub's excess word; (3) the grant is split in LDS arrival
+// order and every site runs its discharge step.  `u` < 0 marks an idle lane.  All threads of the workgroup call it.
+struct SweepLds {
+    int min[kMfMaxLabels];
+    unsigned long long want[kMfMaxLabels + 1];
+    long long got[kMfMaxLabels + 1];
+    unsigned long long pushA;
+};
+
+__device__ __forceinline__ void sweep_lds_init(SweepLds& s)
 {
-    __shared__ int s_min[kMfMaxLabels];
-    __shared__ unsigned long long s_want[kMfMaxLabels];
-    __shared__ long long s_got[kMfMaxLabels];
-    if (threadIdx.x < kMfMaxLabels) { s_min[threadIdx.x] = kMfInf; s_want[threadIdx.x] = 0; s_got[threadIdx.x] = 0; }
+    if (threadIdx.x < kMfMaxLabels) s.min[threadIdx.x] = kMfInf;
+    if (threadIdx.x <= kMfMaxLabels) { s.want[threadIdx.x] = 0; s.got[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s.pushA = 0;
     __syncthreads();
-    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+}
+
+__device__ __forceinline__ bool mf_sweep_step(const MfView& v, int64_t u, int prev, int cur, bool list_mode, SweepLds& s, int* pushed_to)
+{
+    MfSweepIo io;
+    io.list_mode = list_mode;
     long long want = 0, before = 0;
-    int lu = 0;
-    if (u < v.n) {
-        want = mf_body_pull_want(v, u, prev);
-        if (want > 0) { lu = v.labels[u]; before = (long long)atomicAdd(&s_want[lu], (unsigned long long)want); }
+    int slot = 0;
+    if (u >= 0) {
+        want = mf_body_pull_want(v, u, prev, &io.which);
+        if (io.which != 0) {
+            slot = io.which == 1 ? v.labels[u] : kMfMaxLabels;
+            before = (long long)atomicAdd(&s.want[slot], (unsigned long long)want);
+        }
     }
     __syncthreads();
-    if ((int)threadIdx.x < v.L && s_want[threadIdx.x] > 0)
-        s_got[threadIdx.x] = mf_reserve(&v.hub_e[threadIdx.x], (long long)s_want[threadIdx.x]);
+    if ((int)threadIdx.x <= kMfMaxLabels && s.want[threadIdx.x] > 0) {
+        const long long w = (long long)s.want[threadIdx.x];
+        if ((int)threadIdx.x == kMfMaxLabels) {
+            s.got[threadIdx.x] = mf_reserve(v.hubA_e, w);
+            atomicAdd((unsigned long long*)&v.hubA_want[cur], (unsigned long long)w);
+        } else {
+            s.got[threadIdx.x] = mf_reserve(&v.hub_e[threadIdx.x], w);
+        }
+        s.want[threadIdx.x] = 0;
+    }
     __syncthreads();
     bool r = false;
-    if (u < v.n) {
-        long long got = 0;
-        if (want > 0) {
-            got = s_got[lu] - before;
-            got = got < 0 ? 0 : (got > want ? want : got);
+    if (u >= 0) {
+        if (io.which != 0) {
+            const long long g = s.got[slot] - before;
+            io.granted = g < 0 ? 0 : (g > want ? want : g);
         }
-        r = mf_body_sweep(v, u, prev, cur, s_min, got);
+        r = mf_body_sweep(v, u, prev, cur, s.min, &io);
+        if (io.pushedA > 0) atomicAdd(&s.pushA, (unsigned long long)io.pushedA);
+        if (pushed_to) *pushed_to = io.pushed_to;
     }
-    const int count = __syncthreads_count(r ? 1 : 0);
-    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.hub_min[cur * v.L + threadIdx.x], s_min[threadIdx.x]);
-    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+
+__device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool list_mode, SweepLds& s, bool any)
+{
+    const int count = __syncthreads_count(any ? 1 : 0);
+    if (!list_mode && (int)threadIdx.x < v.L && s.min[threadIdx.x] != kMfInf)
+        atomicMin(&v.hub_min[cur * v.L + threadIdx.x], s.min[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (s.pushA > 0) atomicAdd((unsigned long long*)v.hubA_e, s.pushA);
+        if (count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// sweep over all sites
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
+{
+    __shared__ SweepLds s;
+    sweep_lds_init(s);
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    const bool r = mf_sweep_step(v, u < v.n ? u : -1, prev, cur, false, s, nullptr);
+    mf_sweep_flush(v, cur, false, s, r);
 }
 
 // ---- list-mode sweeps (maxflow_driver.inl): only the sites that can act are visited ------------------------------------
@@ -148,29 +191,23 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_build_list(MfView v, int stamp,
 
 __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp)
 {
-    __shared__ int s_min[kMfMaxLabels];  // unused in list mode (no beta-hub scans); the body wants an accumulator
-    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
-    __syncthreads();
+    __shared__ SweepLds s;
+    sweep_lds_init(s);
     const int cnt = v.acnt[parity];
     const int* __restrict__ in = v.act[parity];
     bool any = false;
     const int stride = (int)(gridDim.x * kMfBlock);
-    const int rounded = (cnt + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole workgroups iterate together (convergent appends)
+    const int rounded = (cnt + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole workgroups iterate together (barriers, appends)
     for (int i = (int)(blockIdx.x * kMfBlock + threadIdx.x); i < rounded; i += stride) {
+        const int u = i < cnt ? in[i] : -1;
         int pushed = -1;
-        bool again = false;
-        int u = -1;
-        if (i < cnt) {
-            u = in[i];
-            any |= mf_body_sweep(v, u, prev, cur, s_min, 0, true, &pushed);
-            again = mf_listed(v, u) && mf_list_claim(v, u, stamp);
-        }
+        any |= mf_sweep_step(v, u, prev, cur, true, s, &pushed);
+        const bool again = u >= 0 && mf_listed(v, u) && mf_list_claim(v, u, stamp);
         mf_list_append(v, 1 - parity, u, again);
         const bool fresh = pushed >= 0 && mf_list_claim(v, pushed, stamp);
         mf_list_append(v, 1 - parity, pushed, fresh);
     }
-    const int count = __syncthreads_count(any ? 1 : 0);
-    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mf_sweep_flush(v, cur, true, s, any);
 }
 
 // ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
@@ -481,7 +518,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
         st->mark_n = n;
         st->next_stamp = 1;
     }
-    const size_t small_bytes = (size_t)(L + 1 + 3) * 8 + (size_t)(9 * L + 2 + 3 + 8 + 2) * 4 + 64;
+    const size_t small_bytes = (size_t)(L + 1 + 3 + 4) * 8 + (size_t)(9 * L + 2 + 3 + 8 + 2) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
     MfView v;
@@ -495,6 +532,8 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.hub_e = (long long*)sp; sp += (size_t)L * 8;
     v.hubA_rt = (long long*)sp; sp += 8;
     v.hubA_min = (unsigned long long*)sp; sp += 24;
+    v.hubA_e = (long long*)sp; sp += 8;
+    v.hubA_want = (long long*)sp; sp += 24;
     v.cnt = (int*)sp; sp += (size_t)L * 4;
     v.hub_exists = (int*)sp; sp += (size_t)L * 4;
     v.bfs_hub_d = (int*)sp; sp += (size_t)L * 4;

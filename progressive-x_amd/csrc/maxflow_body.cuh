@@ -59,6 +59,8 @@ struct MfView {
     long long* hub_e;              // [L] beta hub excess
     int* has_alpha_hub;            // [1]
     long long* hubA_rt;            // [1] residual y_alpha -> t
+    long long* hubA_e;             // [1] excess held by y_alpha
+    long long* hubA_want;          // [3] rotating: what the alpha hub's members asked for in a sweep (a hint for pushers)
     int* bfs_hub_d;                // [L] BFS distance of beta hubs
     int* bfs_hubA_d;               // [1]
     int* hub_min;                  // [3][L] rotating: min member height of each beta hub
@@ -184,6 +186,8 @@ PGX_HD void mf_body_hub_setup(const MfView& v)
     const bool ha = lc && v.cnt[v.alpha] == 0;
     v.has_alpha_hub[0] = ha ? 1 : 0;
     v.hubA_rt[0] = ha ? v.h_q : 0;
+    v.hubA_e[0] = 0;
+    v.hubA_want[0] = v.hubA_want[1] = v.hubA_want[2] = 0;
     v.bfs_hubA_d[0] = kMfInf;
     for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
     for (int k = 0; k < 8; ++k) v.flags[k] = 0;
@@ -318,8 +322,9 @@ PGX_HD void mf_body_bfs_finish(const MfView& v, int slot, int last_level)
         if (v.hub_exists[l] && v.hub_e[l] > 0 && hd != kMfInf) { v.flags[1] = 1; v.flags[7] = 1; }  // [7]: a hub can still deliver
     }
     const unsigned long long pk = v.hubA_min[0];
-    for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
+    for (int r = 0; r < 3; ++r) { v.hubA_min[r] = ~0ull; v.hubA_want[r] = 0; }
     v.hubA_min[slot] = pk;
+    if (v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.bfs_hubA_d[0] != kMfInf) v.flags[1] = 1;  // the hub can still deliver
 }
 
 // After a global relabel: does site u hold excess that can reach t?
@@ -378,49 +383,62 @@ PGX_HD void mf_body_wave(const MfView& v, int64_t u, int k)
     }
 }
 
-// ---- beta-hub pulls ------------------------------------------------------------------------------------------------
-// The arc y_beta -> u is admissible when the hub sits one above u.  What u asks for is what it can pass on at once:
-// its own residual to t, or else the residual of its admissible n-links.  (Measured at N = 1e6, h = 5000: when one
-// elected member per wave pulled and members without a t residual asked for "everything visible", a single stale-height
-// member hoarded the whole label cost and dribbled it back over several global relabels: 13-19 ms per steady-state
-// move, ~16 deliveries per sweep per hub.)  A member that is eligible but can pass nothing on has a stale height: it is
-// lifted instead (relabelling a node without an admissible residual arc is valid whether or not it holds excess), which
-// is what lets the hub height rise to the members that can deliver.
-// The requests of a workgroup are summed per label in LDS and reserved with one atomic per (workgroup, label);
-// the grant is split in LDS arrival order (maxflow.hip mf_k_sweep).  The sequential emulation reserves per site.
-PGX_HD long long mf_body_pull_want(const MfView& v, int64_t u, int prev)
+// ---- hub pulls -----------------------------------------------------------------------------------------------------
+// Flow leaves a hub by being PULLED: the arc hub -> u is admissible when the hub sits one above u, and what u asks for
+// is what it can pass on at once (its own residual to t, or else the residual of its admissible arcs).
+//  * beta hub (s -> y_beta -> members): measured at N = 1e6, h = 5000: when one elected member per wave pulled and
+//    members without a t residual asked for "everything visible", a single stale-height member hoarded the whole label
+//    cost and dribbled it back over several global relabels (13-19 ms per steady-state move, ~16 deliveries per sweep).
+//  * alpha hub (sites -> y_alpha -> t, and back out through the members that lent it flow, g > 0): pushing "through"
+//    the saturated hub into its single lowest member moved one member's g per sweep, ~3 units of flow per global
+//    relabel in the moves that hand a new instance its ~5e4 points (75-240 relabels per move).  The hub now holds
+//    excess like any node and all members one below it pull concurrently.
+// A member that is eligible but can pass nothing on has a stale height: it is lifted instead (relabelling a node without
+// an admissible residual arc is valid whether or not it holds excess), which lets the hub rise to members that deliver.
+// The requests of a workgroup are summed per hub in LDS and reserved with one atomic per (workgroup, hub); the grant is
+// split in LDS arrival order (maxflow.hip mf_sweep_step).  The sequential emulation reserves per site.
+PGX_HD int mf_hubA_height(const MfView& v, int prev)
 {
-    const int lu = v.labels[u];
-    if (lu == v.alpha || !v.hub_exists[lu] || v.hub_e[lu] <= 0) return 0;  // plain (cached) reads: gates only
-    const int du = v.d[u];
-    if (du == kMfInf) return 0;
-    const int m = v.hub_min[prev * v.L + lu];
-    if (m != du) return 0;  // hub height m + 1 must be exactly one above u
-    const long long e = mf_load64(&v.ex[u]);
+    if (v.hubA_rt[0] > 0) return 1;  // plain read (gate)
+    const unsigned long long pk = v.hubA_min[prev];
+    return pk == ~0ull ? kMfInf : (int)(pk >> 32) + 1;
+}
+
+PGX_HD long long mf_passable(const MfView& v, int64_t u, int du, int prev, long long e)
+{
     if (v.rt[u] > 0) return v.rt[u] > e ? v.rt[u] - e : 0;
     if (e > 0) return 0;  // already holds excess it has not placed yet
+    const int lu = v.labels[u];
     long long adm = 0;
-    int best_h = v.f[u] > 0 ? du + 1 : kMfInf;  // residual u -> y_beta, hub height du + 1
-    if (v.has_alpha_hub[0]) {                   // u -> y_alpha (inf), then y_alpha -> t or y_alpha -> its lowest member
-        int ha = kMfInf;
-        long long room = 0;
-        if (v.hubA_rt[0] > 0) { ha = 1; room = v.hubA_rt[0]; }
-        else {
-            const unsigned long long pk = v.hubA_min[prev];
-            const int site = (int)(pk & 0xffffffffu);
-            if (pk != ~0ull && site != (int)u) { ha = (int)(pk >> 32) + 1; room = mf_load64(&v.g[site]); }
-        }
+    int best_h = kMfInf;
+    if (v.hub_exists[lu] && v.f[u] > 0) {  // residual u -> y_beta
+        const int m = v.hub_min[prev * v.L + lu];
+        if (m != kMfInf) best_h = m + 1;
+        if (best_h < du) adm += v.f[u];
+    }
+    if (v.has_alpha_hub[0]) {             // u -> y_alpha (inf)
+        const int ha = mf_hubA_height(v, prev);
         if (ha < best_h) best_h = ha;
+        const long long room = v.hubA_rt[0] > 0 ? v.hubA_rt[0] : v.hubA_want[prev];
         if (ha < du && room > 0) adm += room;
     }
-    if (v.off)
-        for (int a = v.off[u]; a < v.off[u + 1]; ++a) {
-            const long long c = mf_load64(&v.cap[a]);
-            if (c <= 0) continue;
-            const int h = mf_load32(&v.d[v.idx[a]]);
-            if (h < best_h) best_h = h;
-            if (h < du) adm += c;
+    if (v.off) {
+        const int end = v.off[u + 1];
+        for (int a0 = v.off[u]; a0 < end; a0 += 8) {  // batched loads, see mf_body_sweep
+            long long c[8];
+            int w[8], h[8];
+            for (int j = 0; j < 8; ++j) {
+                const bool in = a0 + j < end;
+                c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
+                w[j] = in ? v.idx[a0 + j] : 0;
+            }
+            for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
+            for (int j = 0; j < 8; ++j) {
+                if (h[j] < best_h) best_h = h[j];
+                if (h[j] < du) adm += c[j];
+            }
         }
+    }
     if (adm > 0) return adm;
     int nd = best_h == kMfInf ? kMfInf : best_h + 1;
     if (nd >= v.hmax) nd = kMfInf;
@@ -428,14 +446,48 @@ PGX_HD long long mf_body_pull_want(const MfView& v, int64_t u, int prev)
     return 0;
 }
 
+// *which: 0 nothing, 1 pull from the site's beta hub, 2 pull from the alpha hub
+PGX_HD long long mf_body_pull_want(const MfView& v, int64_t u, int prev, int* which)
+{
+    *which = 0;
+    const int lu = v.labels[u];
+    if (lu == v.alpha) return 0;
+    const bool b = v.hub_exists[lu] && v.hub_e[lu] > 0;                           // plain (cached) reads: gates only
+    const bool a = v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.hubA_rt[0] <= 0;
+    if (!a && !b) return 0;
+    const int du = v.d[u];
+    if (du == kMfInf) return 0;
+    int from = 0;
+    long long cap = 0;
+    if (b && v.hub_min[prev * v.L + lu] == du) from = 1;  // hub height m + 1 must be exactly one above u
+    else if (a) {
+        const unsigned long long pk = v.hubA_min[prev];
+        cap = mf_load64(&v.g[u]);
+        if (pk != ~0ull && (int)(pk >> 32) == du && cap > 0) from = 2;
+    }
+    if (from == 0) return 0;
+    long long want = mf_passable(v, u, du, prev, mf_load64(&v.ex[u]));
+    if (from == 2 && want > cap) want = cap;  // y_alpha -> u has residual g[u]
+    if (want > 0) *which = from;
+    return want;
+}
+
 // ---- one push-relabel step for site u ------------------------------------------------------------------------------
 // prev/cur/next: rotating slots of the hub height scans (read prev, accumulate cur, clear next).
 // returns true iff this site did or still has work (the caller latches flags[1])
 // list_mode: only the sites on a work list are visited (maxflow_driver.inl), so beta-hub height scans are skipped (the
 // epilogue carries the published heights forward) and *pushed_to names the site that received flow, if any.
-PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, long long granted,
-                          bool list_mode = false, int* pushed_to = nullptr)
+struct MfSweepIo {
+    long long granted = 0;   // in: flow granted by the pull phase ...
+    int which = 0;           //     ... from the beta hub (1) or the alpha hub (2)
+    bool list_mode = false;  // in
+    int pushed_to = -1;      // out: site that received flow along an n-link
+    long long pushedA = 0;   // out: flow pushed into the alpha hub (the caller adds it to hubA_e)
+};
+
+PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, MfSweepIo* io)
 {
+    const bool list_mode = io->list_mode;
     const int lu = v.labels[u];
     if (lu == v.alpha) return false;
     bool work = false;
@@ -444,21 +496,19 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     // A hub's height is rescanned only while it holds excess (members pull); otherwise the last known height is carried
     // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
     // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
-    if (granted > 0) { v.f[u] += granted; mf_add64(&v.ex[u], granted); work = true; }  // y_beta -> u (mf_body_pull_want)
+    if (io->granted > 0) {  // hub -> u (mf_body_pull_want)
+        if (io->which == 1) v.f[u] += io->granted;
+        else mf_add64(&v.g[u], -io->granted);
+        mf_add64(&v.ex[u], io->granted);
+        work = true;
+    }
     const bool scan_b = !list_mode && hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
     if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
     int du = v.d[u];
     // hub heights as published by the previous scan
     int hb = kMfInf;
     if (hub_b) { const int m = v.hub_min[prev * v.L + lu]; hb = m == kMfInf ? kMfInf : m + 1; }
-    int ha = kMfInf, ha_site = -1;
-    if (hub_a) {
-        if (v.hubA_rt[0] > 0) ha = 1;  // plain read (gate); the reservation below is atomic
-        else {
-            const unsigned long long pk = v.hubA_min[prev];
-            if (pk != ~0ull) { ha = (int)(pk >> 32) + 1; ha_site = (int)(pk & 0xffffffffu); }
-        }
-    }
+    const int ha = hub_a ? mf_hubA_height(v, prev) : kMfInf;
     if (du != kMfInf) {
         long long e = mf_load64(&v.ex[u]);
         if (e > 0) {
@@ -470,13 +520,25 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
             }
             if (e > 0) {
                 int best_h = kMfInf, best_a = -1, kind = 0;  // kind 1 n-link, 2 alpha hub, 3 beta hub
-                if (v.off)
-                    for (int a = v.off[u]; a < v.off[u + 1]; ++a)
-                        if (mf_load64(&v.cap[a]) > 0) {
-                            const int h = mf_load32(&v.d[v.idx[a]]);
-                            if (h < best_h) { best_h = h; best_a = a; kind = 1; }
+                if (v.off) {
+                    // lowest residual neighbour.  Loads are issued in batches of eight arcs (capacities and heads, then
+                    // the heads' heights): one arc at a time is a chain of ~2 memory round trips per arc, which is what
+                    // a sweep over a short work list spends its time on.
+                    const int end = v.off[u + 1];
+                    for (int a0 = v.off[u]; a0 < end; a0 += 8) {
+                        long long c[8];
+                        int w[8], h[8];
+                        for (int j = 0; j < 8; ++j) {
+                            const bool in = a0 + j < end;
+                            c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
+                            w[j] = in ? v.idx[a0 + j] : 0;
                         }
-                if (hub_a && ha < best_h && ha_site != (int)u) { best_h = ha; kind = 2; }
+                        for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
+                        for (int j = 0; j < 8; ++j)
+                            if (h[j] < best_h) { best_h = h[j]; best_a = a0 + j; kind = 1; }
+                    }
+                }
+                if (hub_a && ha < best_h) { best_h = ha; kind = 2; }
                 if (hub_b && v.f[u] > 0 && hb < best_h) { best_h = hb; kind = 3; }
                 if (kind == 0 || best_h == kMfInf) {
                     du = kMfInf;  // no residual arc leads anywhere that reaches t
@@ -489,24 +551,21 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                         mf_add64(&v.cap[v.rev[best_a]], dl);
                         mf_add64(&v.ex[u], -dl);
                         mf_add64(&v.ex[v.idx[best_a]], dl);
-                        if (pushed_to) *pushed_to = v.idx[best_a];
+                        io->pushed_to = v.idx[best_a];
                         work = true;
                     } else if (kind == 2) {
-                        const bool elected = mf_elect(true);  // one contender per wave and sweep on the hub words
-                        if (!elected) {
-                            work = true;
-                        } else if (ha_site < 0) {  // budget y_alpha -> t still open
-                            const long long got = mf_reserve(v.hubA_rt, e);
-                            if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); work = true; }
-                        } else {            // through the saturated hub into its lowest member: u -> y_alpha -> p*
-                            const long long got = mf_reserve(&v.g[ha_site], e);
-                            if (got > 0) {
-                                mf_add64(&v.g[u], got);
-                                mf_add64(&v.ex[u], -got);
-                                mf_add64(&v.ex[ha_site], got);
-                                if (pushed_to) *pushed_to = ha_site;
+                        if (ha == 1 && v.hubA_rt[0] > 0) {  // budget y_alpha -> t still open: one contender per wave
+                            if (!mf_elect(true)) work = true;
+                            else {
+                                const long long got = mf_reserve(v.hubA_rt, e);
+                                if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); }
                                 work = true;
                             }
+                        } else {                            // into the hub; members one below it pull it out again
+                            mf_add64(&v.g[u], e);
+                            mf_add64(&v.ex[u], -e);
+                            io->pushedA += e;
+                            work = true;
                         }
                     } else {  // back into the beta hub
                         const long long dl = e < v.f[u] ? e : v.f[u];
@@ -547,7 +606,9 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next, int consu
         v.hub_min[next * v.L + l] = kMfInf;
         if (v.hub_exists[l] && v.hub_e[l] > 0 && v.hub_min[cur * v.L + l] != kMfInf) act = 1;
     }
+    if (v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.hubA_min[cur] != ~0ull) act = 1;
     v.hubA_min[next] = ~0ull;
+    v.hubA_want[next] = 0;
     v.flags[4] = act;
     v.flags[1] = 0;
     if (consumed >= 0) v.acnt[consumed] = 0;

@@ -74,6 +74,18 @@ struct EmuBackend {
         v.acnt[0] = v.acnt[1] = 0;
         each([&](int64_t u) { if (mf_listed(v, u) && mf_claim(&v.mark[u], stamp)) v.act[0][v.acnt[0]++] = (int)u; });
     }
+    bool step(const MfView& v, int64_t u, int prev, int cur, bool list_mode, int* pushed)
+    {
+        MfSweepIo io;
+        io.list_mode = list_mode;
+        const long long want = mf_body_pull_want(v, u, prev, &io.which);
+        if (io.which == 1) io.granted = mf_reserve(&v.hub_e[v.labels[u]], want);
+        if (io.which == 2) { io.granted = mf_reserve(v.hubA_e, want); v.hubA_want[cur] += want; }
+        const bool r = mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, &io);
+        v.hubA_e[0] += io.pushedA;
+        if (pushed) *pushed = io.pushed_to;
+        return r;
+    }
     void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
     {
         std::vector<int> lst(v.act[parity], v.act[parity] + v.acnt[parity]);
@@ -82,24 +94,20 @@ struct EmuBackend {
         int* oc = &v.acnt[1 - parity];
         for (int u : lst) {
             int pushed = -1;
-            if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, 0, true, &pushed)) v.flags[1] = 1;
+            if (step(v, u, prev, cur, true, &pushed)) v.flags[1] = 1;
             if (mf_listed(v, u) && mf_claim(&v.mark[u], stamp)) out[(*oc)++] = u;
             if (pushed >= 0 && mf_claim(&v.mark[pushed], stamp)) out[(*oc)++] = pushed;
         }
     }
     void sweep(const MfView& v, int prev, int cur)
     {
-        each([&](int64_t u) {
-            const long long want = mf_body_pull_want(v, u, prev);
-            const long long got = want > 0 ? mf_reserve(&v.hub_e[v.labels[u]], want) : 0;
-            if (mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, got)) v.flags[1] = 1;
-        });
+        each([&](int64_t u) { if (step(v, u, prev, cur, false, nullptr)) v.flags[1] = 1; });
     }
     void dump(const MfView& v, const char* tag)
     {
         if (!std::getenv("MF_EMU_DEBUG")) return;
-        std::fprintf(stderr, "%s flags=[%d %d %d %d %d] hubA_rt=%lld hubA_d=%d\n", tag, v.flags[0], v.flags[1], v.flags[2],
-                     v.flags[3], v.flags[4], (long long)v.hubA_rt[0], v.bfs_hubA_d[0]);
+        std::fprintf(stderr, "%s flags=[%d %d %d %d %d] hubA_rt=%lld hubA_e=%lld hubA_d=%d\n", tag, v.flags[0], v.flags[1], v.flags[2],
+                     v.flags[3], v.flags[4], (long long)v.hubA_rt[0], (long long)v.hubA_e[0], v.bfs_hubA_d[0]);
         for (int l = 0; l < v.L; ++l)
             if (v.hub_exists[l]) std::fprintf(stderr, "  hub %d e=%lld bfs_d=%d min=[%d %d %d]\n", l, (long long)v.hub_e[l], v.bfs_hub_d[l],
                 v.hub_min[l], v.hub_min[v.L + l], v.hub_min[2 * v.L + l]);
@@ -159,7 +167,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
                 rev[a] = r;
             }
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
-        hub_e((size_t)L), hubA_rt(1);
+        hub_e((size_t)L), hubA_rt(1), hubA_e(1), hubA_want(3);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
         bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 32)), fcount(3), flags(8), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
     std::vector<unsigned long long> hubA_min(3);
@@ -169,7 +177,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.off = pair ? off : nullptr; v.idx = idx; v.mult = mult; v.rev = rev.data();
     v.cap = cap.data(); v.ex = ex.data(); v.rt = rt.data(); v.d = d.data(); v.f = f.data(); v.g = g.data();
     v.cnt = cnt.data(); v.hub_exists = hub_exists.data(); v.hub_e = hub_e.data();
-    v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.bfs_hub_d = bfs_hub_d.data();
+    v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.hubA_e = hubA_e.data(); v.hubA_want = hubA_want.data(); v.bfs_hub_d = bfs_hub_d.data();
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
     v.flags = flags.data();
     v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data(); v.act[0] = act0.data(); v.act[1] = act1.data(); v.acnt = acnt.data(); v.mark = mark.data();
