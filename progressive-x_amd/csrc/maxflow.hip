@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_init(MfView v, int, int)
 
 // Kernels whose per-site body reports a boolean and/or accumulates per-label minima: both are aggregated per block in
 // LDS and flushed with at most (L + 1) global operations per block.
-enum { kBfsInit = 0, kBfsLevel = 1, kCountActive = 2, kApply = 4 };
+enum { kBfsInit = 0, kCountActive = 2, kApply = 4 };
 
 template <int WHAT>
 __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
@@ -64,35 +64,10 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
         else if (WHAT == kCountActive) r = mf_body_count_active(v, u);
         else if (WHAT == kApply) r = mf_body_apply(v, u);
     }
-    if (WHAT == kBfsLevel) {
-        // frontier part: sites labelled a0-1, then the hub part if a hub received distance a0-1
-        // Eight lanes share one frontier site and stride over its arcs ("virtual warp"): a lane-per-site loop is a
-        // chain of ~5 dependent gathers per arc (measured ~45 us per level for frontiers of a few thousand sites).
-        const int F = v.fcount[(a0 - 1) % 3];
-        const int* __restrict__ fin = v.order + v.lvl[a0 - 1];
-        const int sub = (int)(threadIdx.x & 7);
-        const int64_t ngroups = ((int64_t)gridDim.x * kMfBlock) >> 3;
-        for (int64_t q = ((int64_t)blockIdx.x * kMfBlock + threadIdx.x) >> 3; v.off != nullptr && q < F; q += ngroups) {
-            const int w = fin[q];
-            for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
-                const int uu = v.idx[a];
-                const bool want = v.labels[uu] != v.alpha &&
-                                  __hip_atomic_load(&v.cap[v.rev[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
-                                  __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
-                r |= mf_bfs_label(v, uu, a0, s_min, want);
-            }
-        }
-        const int ev = mf_bfs_hub_events(v, a0);
-        if (ev != 0 && u < v.n) r |= mf_body_bfs_hubpass(v, u, a0, (ev & 1) != 0, s_min);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            v.lvl[a0] = mf_level_base(v, a0);
-            v.fcount[(a0 + 1) % 3] = 0;  // slot of the level after this one
-        }
-    }
     const int count = __syncthreads_count(r ? 1 : 0);
-    if (WHAT == kBfsInit || WHAT == kBfsLevel) {
+    if (WHAT == kBfsInit) {
         if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
-        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], WHAT == kBfsInit ? 1 : a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (WHAT == kCountActive) {
         if (threadIdx.x == 0 && count > 0) {
             __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -253,6 +228,49 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply(const long long* __res
     if (threadIdx.x == 0 && c > 0) atomicAdd(changed, c);
 }
 
+// ---- one BFS level: the sites labelled k-1 label their residual in-neighbours k; then the hub part if a hub received
+// distance k-1.  A fixed, small grid with grid-stride loops: deep searches run hundreds of levels of a few thousand
+// sites each (the relay sites of a new-instance move at N = 1e6), and a grid sized for all sites cost ~54 us per level.
+// Eight lanes share one frontier site and stride over its arcs ("virtual warp"): a lane-per-site loop is a chain of
+// ~5 dependent gathers per arc (measured ~45 us per level for frontiers of a few thousand sites).
+constexpr int kBfsLevelBlocks = 256;
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    __syncthreads();
+    bool r = false;
+    const int F = v.fcount[(k - 1) % 3];
+    const int* __restrict__ fin = v.order + v.lvl[k - 1];
+    const int sub = (int)(threadIdx.x & 7);
+    const int64_t nthreads = (int64_t)gridDim.x * kMfBlock;
+    const int64_t gtid = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    for (int64_t q = gtid >> 3; v.off != nullptr && q < F; q += nthreads >> 3) {
+        const int w = fin[q];
+        for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
+            const int uu = v.idx[a];
+            const bool want = v.labels[uu] != v.alpha &&
+                              __hip_atomic_load(&v.cap[v.rev[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                              __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
+            r |= mf_bfs_label(v, uu, k, s_min, want);
+        }
+    }
+    const int ev = mf_bfs_hub_events(v, k);
+    if (ev != 0) {
+        const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole waves call the aggregated append
+        for (int64_t u = gtid; u < rounded; u += nthreads)
+            r |= u < v.n ? mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, s_min) : mf_bfs_label(v, 0, k, s_min, false);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        v.lvl[k] = mf_level_base(v, k);
+        v.fcount[(k + 1) % 3] = 0;  // slot of the level after this one
+    }
+    const int count = __syncthreads_count(r ? 1 : 0);
+    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- wave pass: the sites of BFS level k push into level k-1 (maxflow_body.cuh mf_body_wave) -------------------------
 constexpr int kWaveBlocks = 256;
 
@@ -351,7 +369,12 @@ struct HipBackend {
     void init_sites(const MfView& v) { site(mf_k_init, v); }
     void bfs_reset(const MfView& v) { single(v, 1); }
     void bfs_init(const MfView& v) { site(mf_k_agg<kBfsInit>, v); }
-    void bfs_level(const MfView& v, int k) { site(mf_k_agg<kBfsLevel>, v, k); }
+    void bfs_level(const MfView& v, int k)
+    {
+        const unsigned g = blocks < (unsigned)kBfsLevelBlocks ? blocks : (unsigned)kBfsLevelBlocks;
+        hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k);
+        check();
+    }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
     void read_flags(const MfView& v, int out[8])
     {
@@ -378,7 +401,15 @@ struct HipBackend {
             if (peek(v.hub_exists + l))
                 std::fprintf(stderr, "    hub %d: e=%lld d=%d cnt=%d\n", l, peek(v.hub_e + l), peek(v.bfs_hub_d + l), peek(v.cnt + l));
         if (peek(v.has_alpha_hub)) std::fprintf(stderr, "    hubA: rt=%lld d=%d\n", peek(v.hubA_rt), peek(v.bfs_hubA_d));
-        (void)nact;
+        if (ctx_debug_level() == 4) {  // level sizes of the BFS that just ran (nact carries the last level)
+            std::vector<int> lv((size_t)nact + 2);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(lv.data(), v.lvl, sizeof(int) * lv.size(), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "    level sizes:");
+            for (int k = 1; k <= nact; ++k) std::fprintf(stderr, " %d", lv[(size_t)k + 1] - lv[(size_t)k]);
+            std::fprintf(stderr, "\n");
+            return;
+        }
         if (ctx_debug_level() < 3) return;
         std::vector<long long> ex((size_t)v.n), rt((size_t)v.n);
         std::vector<int> d((size_t)v.n), lab((size_t)v.n);
@@ -510,7 +541,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     PGX_TRY(ensure(ctx, st->d, (size_t)n * sizeof(int)));
     // small state: hub_e[L] i64 | hubA_rt i64 | hubA_min[3] u64 | cnt[L] | hub_exists[L] | bfs_hub_d[L] | hub_min[3L] |
     //              has_alpha_hub | bfs_hubA_d | flags[8]
-    PGX_TRY(ensure(ctx, st->front, (size_t)(2 * n + L + 32) * sizeof(int)));  // order[n] | lvl[n + L + 32]
+    PGX_TRY(ensure(ctx, st->front, (size_t)(2 * n + L + 160) * sizeof(int)));  // order[n] | lvl[n + L + 160]
     if (st->mark_n != n) {  // act[2][n] | mark[n]; stamps restart with a zeroed mark array
         PGX_TRY(ensure(ctx, st->lists, (size_t)3 * n * sizeof(int)));
         if (hipMemsetAsync(st->lists.as<int>() + 2 * n, 0, sizeof(int) * (size_t)n, ctx->stream) != hipSuccess)

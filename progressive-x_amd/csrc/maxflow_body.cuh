@@ -66,7 +66,7 @@ struct MfView {
     int* hub_min;                  // [3][L] rotating: min member height of each beta hub
     unsigned long long* hubA_min;  // [3] rotating: (height << 32 | site) of the lowest member with g > 0
     int* order;                    // [n] sites in BFS order: level k occupies order[lvl[k] .. lvl[k] + fcount[k % 3])
-    int* lvl;                      // [hmax + 16] start of each level in `order` (lvl[k + 1] is written by level k + 1)
+    int* lvl;                      // [hmax + 144] start of each level in `order` (lvl[k + 1] is written by level k + 1)
     int* fcount;                   // [3] level sizes, rotating by level % 3
     int* act[2];                   // [n] each: work lists of the list-mode sweeps (read one, write the other)
     int* acnt;                     // [2] their sizes
@@ -235,7 +235,8 @@ PGX_HD int mf_level_base(const MfView& v, int k) { return k <= 1 ? 0 : v.lvl[k -
 
 // Labels site u with BFS distance k (if still unlabelled), records what that implies for the hubs and appends u to the
 // frontier of level k.  Must be called convergently by all active lanes (wave-aggregated append); `want` selects lanes.
-PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want)
+// base: start of level k in `order`, or -1 to look it up (mf_level_base; only valid across kernel boundaries).
+PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want, int base = -1)
 {
     bool mine = false;
     if (want) mine = mf_cas32(&v.d[u], kMfInf, k);
@@ -247,7 +248,7 @@ PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool w
             mf_min32(&v.bfs_hubA_d[0], k + 1);
         }
     }
-    mf_append(&v.fcount[k % 3], v.order + mf_level_base(v, k), (int)u, mine);
+    mf_append(&v.fcount[k % 3], v.order + (base >= 0 ? base : mf_level_base(v, k)), (int)u, mine);
     return mine;
 }
 

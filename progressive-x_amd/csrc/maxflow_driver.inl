@@ -38,8 +38,8 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         be.bfs_reset(v);
         be.bfs_init(v);
         int level = 1;
-        for (;;) {
-            for (int b = 0; b < tune.bfs_batch; ++b) be.bfs_level(v, ++level);
+        for (int batch = tune.bfs_batch;; batch = batch < 64 ? 2 * batch : 64) {  // deep searches: fewer read-backs
+            for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
             const int last = be.read_flag(v, 0);
             if (last <= level - 2 || level >= v.hmax) break;
         }
@@ -53,7 +53,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         if (fl[1] == 0) { converged = true; break; }
         if (tune.debug)
             std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d\n", v.alpha, it, level, fl[3], fl[7]);
-        if (tune.debug > 1) be.debug_dump(v, fl[3]);
+        if (tune.debug > 1) be.debug_dump(v, tune.debug == 4 ? level : fl[3]);
         // ---- wave pass over the BFS levels, farthest first
         if (tune.wave && v.off != nullptr) {
             for (int k = level; k >= 1; --k) be.wave(v, k);

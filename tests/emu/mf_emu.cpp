@@ -169,7 +169,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1), hubA_e(1), hubA_want(3);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
-        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 32)), fcount(3), flags(8), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
+        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 160)), fcount(3), flags(8), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
     std::vector<unsigned long long> hubA_min(3);
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
