@@ -23,9 +23,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "progressive-x_amd"))
 
-# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v3_locality.txt):
-# FETCH_SIZE 629472 KiB x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE 78160 KiB
-PMC_TRAFFIC_DEFAULT = int((2 * 629471.8 + 78160.0) * 1024)
+# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v4_xcd.txt):
+# FETCH_SIZE 79137.5 KiB x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE 78160 KiB
+# (the writes are the per-chunk partial sums of the over-decomposed grid: 2048 chunks x 2048 hypotheses x 20 B)
+PMC_TRAFFIC_DEFAULT = int((2 * 79137.5 + 78160.0) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
 FLOPS_PER_PAIR_PNP = 25        # 9 mul + 9 add (3x4 projection) + 2 div + 2 sub + 2 mul + 1 add
@@ -150,7 +151,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_DEFAULT if (n == 1000000 and M == 2048) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v3_locality.txt",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v4_xcd.txt",
                          "kernel": "pgx::score_kernel<PnP> (+ score_reduce_kernel)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "FP64-VALU bound by construction (~0.02 algorithmic B/pair); see valu_fp64"},

@@ -100,6 +100,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_NO_XCD")) ctx->score_xcd_map = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
     *out = ctx;
     return PGX_OK;

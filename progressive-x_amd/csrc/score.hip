@@ -173,12 +173,24 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
     const double* __restrict__ pmax, double guard, const float* __restrict__ pts32, double guard32,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
+    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int chunks, int xcd_map)
 {
     using R = Residual<MT>;
-    const int m = blockIdx.x * kScoreBlock + threadIdx.x;
+    // (hypothesis group, point chunk) of this block.  Workgroups are handed to the 8 XCDs round-robin by linear id and
+    // every XCD has its own L2: with the plain 2-D grid (group fastest, 8 groups) XCD x ran group x over ALL chunks,
+    // i.e. every XCD streamed the whole point set from HBM (PMC: ~1.3 GB fetched per launch for ~0.09 GB of inputs).
+    // The 1-D mapping below gives each XCD its own chunks and runs the groups of one chunk back to back on it.
+    int gx = (int)blockIdx.x, gy = (int)blockIdx.y;
+    if (xcd_map) {
+        const int groups = Mpad / kScoreBlock;
+        const int slot = (int)(blockIdx.x >> 3);
+        gx = slot % groups;
+        gy = (int)(blockIdx.x & 7u) + 8 * (slot / groups);
+        if (gy >= chunks) return;
+    }
+    const int m = gx * kScoreBlock + threadIdx.x;
     const bool live = m < M;
-    const int64_t i0 = (int64_t)blockIdx.y * chunk;
+    const int64_t i0 = (int64_t)gy * chunk;
     const int64_t i1 = (i0 + chunk < n) ? (i0 + chunk) : n;
 
     double mdl[R::P];
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
         }
         step(i, pt, (FILT == 1 && F::enabled) ? pmax[i] : 1.0, p32);
     }
-    const int64_t o = (int64_t)blockIdx.y * Mpad + m;
+    const int64_t o = (int64_t)gy * Mpad + m;
     pcnt[o] = cnt;
     pval[o] = val;
     psh[o] = sh;
@@ -411,13 +423,15 @@ static void score_launch_deferred(pgx_ctx* ctx, double T2, int has_compound, dou
 template <int MT, bool MASK, int FILT>
 static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double guard, double guard32 = 0.0)
 {
-    dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
+    const unsigned groups = (unsigned)(ctx->Mpad / kScoreBlock);
+    dim3 grid(groups, (unsigned)ctx->chunks);
+    if (ctx->score_xcd_map) grid = dim3(groups * (((unsigned)ctx->chunks + 7u) / 8u * 8u), 1);
     hipLaunchKernelGGL((score_kernel<MT, MASK, FILT>), grid, dim3(kScoreBlock), 0, ctx->stream, ctx->pts.as<double>(),
                        ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
                        ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pts32.as<float>(), guard32,
                        ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
                        ctx->psh.as<double>(), MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr,
-                       ctx->words, ctx->perm.as<int>());
+                       ctx->words, ctx->perm.as<int>(), ctx->chunks, ctx->score_xcd_map);
 }
 
 template <int MT>
