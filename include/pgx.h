@@ -101,6 +101,19 @@ int pgx_set_unary_q(pgx_ctx *ctx, const int64_t *Dq, int64_t n, int L);   /* tes
  * (= number of directed entries in the raw getNeighbors lists; a symmetric raw list gives 2, U-6). */
 int pgx_set_graph(pgx_ctx *ctx, int64_t n, const int32_t *off, const int32_t *idx, const int32_t *mult);
 
+/* ---- a20 (SURVEY 8f "next", rank 2): the graph itself.  Replaces FlannNeighborhoodGraph(&points, radius) +
+ * getNeighbors(i) (progressivex_python.cpp:104,207,339,458,571) and the setNeighbors loop (PEARL.h:532-536); the FLANN
+ * code is absent from the snapshot [U-7], so the lists are restated deterministically:
+ *   PGX_GRAPH_KNN_IN_BALL  the k nearest neighbours with squared distance <= radius^2 (drop-in default, k = 5)
+ *   PGX_GRAPH_KNN          the k nearest neighbours (radius ignored)
+ * points: n x d doubles (d = 2..5, the data space the reference hands to FLANN), ranking by (squared distance, index),
+ * squared distance summed in dimension order without contraction.  The symmetric CSR (multiplicity = number of
+ * directed list entries of the pair, U-6) stays resident exactly as after pgx_set_graph; pgx_graph_fetch copies it
+ * out (off[n+1]; idx/mult[arcs], may be NULL). */
+enum { PGX_GRAPH_KNN_IN_BALL = 0, PGX_GRAPH_KNN = 2 };
+int pgx_graph_build(pgx_ctx *ctx, const double *points, int64_t n, int d, int kind, double radius, int k, int64_t *arcs);
+int pgx_graph_fetch(pgx_ctx *ctx, int32_t *off, int32_t *idx, int32_t *mult);
+
 /* ---- a8/a19: GCoptimizationGeneralGraph::{setLabel, expansion, whatLabel} as used by PEARL::labeling
  * (PEARL.h:507-551).  lambda = spatial coherence weight of ONE directed neighbour entry (PEARL.h:76-78),
  * label_cost = model_complexity_weight (PEARL.h:144,529).  Energies are returned both as the exact fixed-point

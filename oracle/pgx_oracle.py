@@ -213,3 +213,87 @@ def residual_sum(model_type, pts, model, labels, label):
     pts = _f64(pts); model = _f64(model); labels = _i32(labels)
     return lib().pgxo_residual_sum(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]),
                                    _p(model, C.c_double), _p(labels, C.c_int32), C.c_int(label))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# neighbourhood graph — numpy restatement of the deterministic lists the build defines for
+# FlannNeighborhoodGraph [U-7] (/root/reference/src/pyprogressivex/src/progressivex_python.cpp:104,207,339,458,571) and of
+# the setNeighbors multiplicities (/root/reference/src/pyprogressivex/include/PEARL.h:532-536) [U-6].
+# ---------------------------------------------------------------------------------------------------------------------
+def _sqdist_rows(a, b):
+    """squared distances of row a against rows b, summed in dimension order (the contract of graph.hip)"""
+    s = (a[0] - b[:, 0]) * (a[0] - b[:, 0])
+    for j in range(1, b.shape[1]):
+        df = a[j] - b[:, j]
+        s = s + df * df
+    return s
+
+
+def graph_lists(points, k, radius=None, rows=None):
+    """[n,k] int32 (or [len(rows),k] for the listed query rows), -1 padded: the k nearest neighbours ranked by (squared distance, index), inside the ball when
+    `radius` is given (squared distance <= radius*radius).  Candidates come from a kd-tree with a safety margin, the
+    ranking itself is recomputed with the exact arithmetic; brute force for small n."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    k = min(k, n - 1)
+    rows = np.arange(n) if rows is None else np.asarray(rows)
+    out = np.full((len(rows), max(k, 0)), -1, dtype=np.int32)
+    if k <= 0:
+        return out
+    r2 = np.inf if radius is None else float(radius) * float(radius)
+    if n <= 4000:   # brute force: the whole distance matrix, ranking by a stable sort (ties -> lower index)
+        S = (pts[rows, 0][:, None] - pts[None, :, 0]) * (pts[rows, 0][:, None] - pts[None, :, 0])
+        for j in range(1, pts.shape[1]):
+            df = pts[rows, j][:, None] - pts[None, :, j]
+            S = S + df * df
+        S[np.arange(len(rows)), rows] = np.inf
+        S[~(S <= r2)] = np.inf
+        order = np.argsort(S, axis=1, kind="stable")[:, :k]
+        ok = np.take_along_axis(S, order, axis=1) < np.inf
+        out[:] = np.where(ok, order, -1)
+        return out
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pts)
+    kk = min(n, k + 17)
+    if radius is None:
+        _, cands = tree.query(pts[rows], k=kk)
+    else:
+        _, cands = tree.query(pts[rows], k=kk, distance_upper_bound=float(radius) * (1.0 + 1e-9))
+    for r, i in enumerate(rows):
+        cand = np.asarray(cands[r])
+        cand = cand[(cand < n) & (cand != i)]
+        s = _sqdist_rows(pts[i], pts[cand])
+        keep = s <= r2
+        cand, s = cand[keep], s[keep]
+        full = np.lexsort((cand, s))
+        order = full[:k]
+        if len(order) == k and len(cand) >= kk - 1:
+            # all candidates tied with the k-th must be inside the margin for the ranking to be decided here
+            assert s[full[-1]] > s[order[-1]], "tie margin exhausted: raise the candidate margin"
+        out[r, :len(order)] = cand[order]
+    return out
+
+
+def graph_from_lists(lists):
+    """directed lists -> symmetric CSR (off, idx, mult) with rows sorted; multiplicity = number of directed entries"""
+    n, k = lists.shape
+    src = np.repeat(np.arange(n, dtype=np.int64), k)
+    dst = lists.reshape(-1).astype(np.int64)
+    ok = dst >= 0
+    src, dst = src[ok], dst[ok]
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    key, cnt = np.unique(lo * n + hi, return_counts=True)
+    a = np.concatenate([key // n, key % n])
+    b = np.concatenate([key % n, key // n])
+    m = np.concatenate([cnt, cnt])
+    o = np.lexsort((b, a))
+    a, b, m = a[o], b[o], m[o]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(off, a + 1, 1)
+    return np.cumsum(off).astype(np.int32), b.astype(np.int32), m.astype(np.int32)
+
+
+def graph_build(points, kind, radius=0.0, k=5):
+    """kind 0: k nearest inside the ball; kind 2: plain k-NN (the constants of include/pgx.h)"""
+    lists = graph_lists(points, k, radius if kind == 0 else None)
+    return graph_from_lists(lists)

@@ -528,6 +528,18 @@ int pgx_set_graph(pgx_ctx* ctx, int64_t n, const int32_t* off, const int32_t* id
     return graph_build_reverse(ctx);
 }
 
+int pgx_graph_build(pgx_ctx* ctx, const double* points, int64_t n, int d, int kind, double radius, int k, int64_t* arcs)
+{
+    CTX_GUARD(ctx);
+    return graph_build_launch(ctx, points, n, d, kind, radius, k, arcs);
+}
+
+int pgx_graph_fetch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult)
+{
+    CTX_GUARD(ctx);
+    return graph_fetch_launch(ctx, off, idx, mult);
+}
+
 static int flow_params(pgx_ctx* ctx, double lambda, double label_cost, int64_t* lambda_q, int64_t* h_q)
 {
     if (!(lambda >= 0.0) || !(label_cost >= 0.0))

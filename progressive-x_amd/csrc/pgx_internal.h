@@ -110,6 +110,8 @@ int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* su
 int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
 int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
 int graph_build_reverse(pgx_ctx* ctx);
+int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
+int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
 void maxflow_free(pgx_ctx* ctx);
 void comm_free(pgx_ctx* ctx);

@@ -65,13 +65,15 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         return [], np.zeros(n, dtype=np.int32), None
     ctx = _context()
     rng = np.random.default_rng(seed)
-    # FlannNeighborhoodGraph(&points, radius) [U-7]
+    # FlannNeighborhoodGraph(&points, radius) [U-7]: built on the GPU (pgx_graph_build) and left resident there; the
+    # CSR comes back for the neighbourhood samplers.  Only the exhaustive ball variant is still a host construction.
+    resident = True
     if neighborhood == "radius":
-        graph = _graph.radius_graph(graph_points, radius)
+        graph, resident = _graph.radius_graph(graph_points, radius), False
     elif str(neighborhood).startswith("knn:"):
-        graph = _graph.knn_graph(graph_points, int(str(neighborhood)[4:]))
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN, k=int(str(neighborhood)[4:]))
     else:
-        graph = _graph.flann_like_graph(graph_points, radius)
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN_IN_BALL, radius=radius, k=5)
     sampler = sampler_factory(n, rng, graph)
     s = _engine.MultiModelSettings()
     s.minimum_number_of_inliers = int(minimum_point_number)          # progressivex_python.cpp:261
@@ -85,7 +87,7 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     s.point_weights = weights
     s.max_outer_iterations = int(max_outer_iterations)
     px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
-                              do_logging=do_logging)
+                              do_logging=do_logging, graph_resident=resident)
     models, stats = px.run()
     labeling = np.asarray(stats.labeling, dtype=np.int64).astype(np.int32)     # bindings.cpp:152-156
     return models, labeling, stats

@@ -189,8 +189,9 @@ class Pearl:
 # ---------------------------------------------------------------------------------------------------------------------
 class ProgressiveX:
     def __init__(self, ctx, estimator, pts, graph, sampler, settings, scoring_exponent=2, do_logging=False,
-                 exchange=None):
+                 exchange=None, graph_resident=False):
         self.ctx, self.est, self.pts, self.graph = ctx, estimator, pts, graph
+        self.graph_resident = graph_resident   # built by ctx.graph_build: already on the device
         self.sampler, self.settings = sampler, settings
         self.scoring_exponent = int(scoring_exponent)   # setExponent(const int) truncates (scoring_function...h:39)
         self.do_logging = do_logging
@@ -210,7 +211,7 @@ class ProgressiveX:
         self.statistics.labeling = np.zeros(self.n, dtype=np.int64)                          # :522
         self.T2 = 9.0 / 4.0 * s.inlier_outlier_threshold * s.inlier_outlier_threshold        # :523
         self.ctx.set_points(self.est.model_type, self.pts)                                   # compound := 0 (:524)
-        if self.graph is not None and s.spatial_coherence_weight > 0.0:
+        if self.graph is not None and s.spatial_coherence_weight > 0.0 and not self.graph_resident:
             self.ctx.set_graph(*self.graph)
         self.pearl = Pearl(self.ctx, self.est, self.pts, s.inlier_outlier_threshold, s.spatial_coherence_weight,
                            s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging)   # :527-534

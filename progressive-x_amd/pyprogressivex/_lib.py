@@ -24,12 +24,15 @@ ABI_SYMBOLS = [
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
-    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph",
+    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
 ]
+
+
+GRAPH_KNN_IN_BALL, GRAPH_KNN = 0, 2
 
 
 class PgxError(RuntimeError):
@@ -258,6 +261,22 @@ class Context:
             mult = np.ones(1, dtype=np.int32)
         self._ck(self._lib.pgx_set_graph(self._h, C.c_int64(off.shape[0] - 1), _ptr(off, C.c_int32),
                                          _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)), "pgx_set_graph")
+
+    def graph_build(self, points, kind, radius=0.0, k=5, fetch=True):
+        """Neighbourhood graph on the GPU (pgx_graph_build); leaves it resident and returns the CSR when `fetch`."""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        arcs = C.c_int64()
+        self._ck(self._lib.pgx_graph_build(self._h, _ptr(pts, C.c_double), C.c_int64(pts.shape[0]), C.c_int(pts.shape[1]),
+                                           C.c_int(int(kind)), C.c_double(float(radius)), C.c_int(int(k)), C.byref(arcs)),
+                 "pgx_graph_build")
+        if not fetch:
+            return arcs.value
+        off = np.empty(pts.shape[0] + 1, dtype=np.int32)
+        idx = np.empty(max(arcs.value, 1), dtype=np.int32)
+        mult = np.empty(max(arcs.value, 1), dtype=np.int32)
+        self._ck(self._lib.pgx_graph_fetch(self._h, _ptr(off, C.c_int32), _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)),
+                 "pgx_graph_fetch")
+        return off, idx[:arcs.value], mult[:arcs.value]
 
     def set_labels(self, labels):
         lab = _i32(labels)

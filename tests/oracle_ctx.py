@@ -75,6 +75,10 @@ class OracleContext:
     def set_graph(self, off, idx, mult):
         self.graph = (np.asarray(off, np.int32), np.asarray(idx, np.int32), np.asarray(mult, np.int32))
 
+    def graph_build(self, points, kind, radius=0.0, k=5, fetch=True):
+        self.graph = O.graph_build(points, kind, radius=radius, k=k)
+        return self.graph if fetch else len(self.graph[1])
+
     def set_labels(self, labels):
         self.labels = np.asarray(labels, dtype=np.int32).copy()
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import (MODEL_CASES, make_case, random_sym_graph, realistic_labeling_problem)
+from pyprogressivex import _lib, datasets
 
 pytestmark = pytest.mark.gpu
 
@@ -295,6 +296,95 @@ def test_expansion_energy_never_increases(gpu_ctx, oracle):
             cur, _ = gpu_ctx.energy(lam, h)
             assert cur <= prev
             prev = cur
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a20: neighbourhood graph built on the GPU — index work, bit-exact against the oracle's lists
+# ----------------------------------------------------------------------------------------------------------------------
+def _graph_case(rng, n, d, style):
+    if style == "uniform":
+        return rng.random((n, d)) * 100.0
+    if style == "integer":      # many exact ties: ranking by (squared distance, index) decides
+        return rng.integers(0, 12, (n, d)).astype(np.float64)
+    if style == "clustered":
+        c = rng.random((8, d)) * 1000.0
+        return c[rng.integers(0, 8, n)] + rng.normal(0, 3.0, (n, d))
+    raise ValueError(style)
+
+
+@pytest.mark.parametrize("style", ["uniform", "integer", "clustered"])
+@pytest.mark.parametrize("n,d,k", [(1, 2, 5), (2, 4, 5), (7, 5, 5), (300, 2, 8), (2500, 4, 5), (2500, 5, 16), (3000, 3, 1)])
+def test_graph_build_matches_oracle(gpu_ctx, oracle, style, n, d, k):
+    rng = np.random.default_rng(n * 31 + d * 7 + k)
+    pts = _graph_case(rng, n, d, style)
+    for kind, radius in ((_lib.GRAPH_KNN_IN_BALL, 0.5), (_lib.GRAPH_KNN_IN_BALL, 9.0), (_lib.GRAPH_KNN_IN_BALL, 1e4),
+                         (_lib.GRAPH_KNN, 0.0)):
+        ref = oracle.graph_build(pts, kind, radius=radius, k=k)
+        got = gpu_ctx.graph_build(pts, kind, radius=radius, k=k)
+        for name, a, b in zip(("off", "idx", "mult"), got, ref):
+            assert np.array_equal(a, b), f"{style} n={n} d={d} k={k} kind={kind} r={radius}: {name} differs"
+
+
+def test_graph_build_feeds_the_expansion(gpu_ctx, oracle):
+    # the resident graph of pgx_graph_build is the one the moves run on: same labels as with pgx_set_graph(oracle CSR)
+    rng = np.random.default_rng(5)
+    n, L = 4000, 4
+    pts = rng.random((n, 4)) * 50.0
+    Dq = (rng.integers(0, 1 << 20, (n, L)) << 12).astype(np.int64)
+    lam, h = 0.2, 0.5
+    ref_graph = oracle.graph_build(pts, _lib.GRAPH_KNN_IN_BALL, radius=4.0, k=5)
+    ref_labels, _, _ = oracle.expansion(Dq, ref_graph, oracle.quantize_lambda(lam), oracle.quantize(h), np.zeros(n, np.int32))
+    gpu_ctx.set_unary_q(Dq)
+    gpu_ctx.graph_build(pts, _lib.GRAPH_KNN_IN_BALL, radius=4.0, k=5, fetch=False)
+    gpu_ctx.set_labels(np.zeros(n, np.int32))
+    gpu_ctx.expansion(lam, h)
+    assert np.array_equal(gpu_ctx.get_labels(), ref_labels)
+
+
+def test_graph_build_c4_size_properties(gpu_ctx, oracle):
+    x1, x2, K, gt, _ = datasets.make_poses(seed=0)
+    pts = np.column_stack([x1, x2])                      # the un-normalised 5-D rows the reference hands to FLANN
+    n = pts.shape[0]
+    off, idx, mult = gpu_ctx.graph_build(pts, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5)
+    deg = np.diff(off)
+    assert off[0] == 0 and off[-1] == idx.size and deg.min() >= 0
+    rows = np.repeat(np.arange(n), deg)
+    assert (idx != rows).all() and ((mult == 1) | (mult == 2)).all()
+    assert (np.diff(idx.astype(np.int64) + rows * n) > 0).all()                       # rows sorted, no duplicates
+    key_fwd = np.sort(rows * n + idx)
+    key_bwd = np.sort(idx.astype(np.int64) * n + rows)
+    assert np.array_equal(key_fwd, key_bwd)                                           # symmetric
+    # every directed list entry is counted once: sum of multiplicities = 2 * number of list entries
+    sample = np.random.default_rng(0).choice(n, 2000, replace=False)
+    lists = oracle.graph_lists(pts, 5, radius=20.0, rows=sample)
+    back = {}
+    for r, i in enumerate(sample):
+        mine = [int(j) for j in lists[r] if j >= 0]
+        row = idx[off[i]:off[i + 1]].tolist()
+        assert set(mine) <= set(row)                                                   # own list is part of the row
+        back[int(i)] = (mine, row, mult[off[i]:off[i + 1]].tolist())
+    # multiplicities: 2 iff both lists hold the pair (checked on the neighbours' own lists)
+    others = sorted({j for mine, row, _ in back.values() for j in row})
+    olists = dict(zip(others, oracle.graph_lists(pts, 5, radius=20.0, rows=np.array(others)).tolist()))
+    for i, (mine, row, ms) in back.items():
+        for j, m in zip(row, ms):
+            assert m == int(j in mine) + int(i in olists[j])
+
+
+def test_graph_build_error_paths(gpu_ctx):
+    pts = np.random.default_rng(0).random((10, 4))
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.graph_build(pts, 7, radius=1.0, k=5)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.graph_build(pts, _lib.GRAPH_KNN_IN_BALL, radius=0.0, k=5)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.graph_build(pts, _lib.GRAPH_KNN, k=17)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.graph_build(np.random.default_rng(0).random((10, 6)), _lib.GRAPH_KNN, k=3)
+    bad = pts.copy()
+    bad[3, 0] = np.nan
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.graph_build(bad, _lib.GRAPH_KNN, k=3)
 
 
 def test_asymmetric_graph_is_rejected(gpu_ctx):
