@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
 for path in sys.argv[1:]:
