@@ -128,6 +128,23 @@ int pgx_expansion(pgx_ctx *ctx, double lambda, double label_cost, int max_cycles
  * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves, [5]=wave passes */
 int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 
+/* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by
+ * PEARL::parameterEstimation (PEARL.h:374-380) and by the proposal engine's local optimisation.  The device accumulates
+ *   out = sum_i W_i * sum_{rows a of point i} a a^T     (upper triangle of the q x q matrix, row-major, q(q+1)/2 values)
+ * over the selected resident points; the small dense solve stays with the caller.  W_i = weights[i]^weight_power
+ * (weights may be NULL).  Rows by kind (points as given to pgx_set_points):
+ *   PGX_GRAM_AFFINE   a = (1, p_0 .. p_{d-1})                                         q = d+1   (means, covariances)
+ *   PGX_GRAM_DLT_H    the two DLT rows of a correspondence, params = (s1,cx1,cy1,s2,cx2,cy2)    q = 9
+ *   PGX_GRAM_EPI_F    the epipolar row (x2x1,x2y1,x2,y2x1,y2y1,y2,x1,y1,1), same params         q = 9
+ *   PGX_GRAM_VP       solver_vanishing_point_two_lines.h:212-217                               q = 3
+ *   PGX_GRAM_PNP_GN   Gauss-Newton rows (J_u, r_u), (J_v, r_v) at the pose params = [R|t] 3x4  q = 7
+ * Selection: PGX_SEL_INDEX (index[m], host) or PGX_SEL_LABEL (label == `label` on the resident labelling).
+ * count = selected points, bad = points skipped because the row is undefined (PnP: depth ~ 0). */
+enum { PGX_GRAM_AFFINE = 0, PGX_GRAM_DLT_H = 1, PGX_GRAM_EPI_F = 2, PGX_GRAM_VP = 3, PGX_GRAM_PNP_GN = 4 };
+enum { PGX_SEL_INDEX = 0, PGX_SEL_LABEL = 1 };
+int pgx_gram(pgx_ctx *ctx, int kind, const double *params, int nparams, int sel, const int32_t *index, int64_t m,
+             int label, const double *weights, int weight_power, double *out, int64_t *count, int64_t *bad);
+
 /* ---- a9: PEARL::parameterEstimation bookkeeping (PEARL.h:342-352, 369-371, 388-390) */
 int pgx_bucket(pgx_ctx *ctx, int L, int64_t *counts, int32_t *order);     /* order optional: stable, ascending index */
 int pgx_residual_sum(pgx_ctx *ctx, const double *model, int label, double *sum);

@@ -297,3 +297,63 @@ def graph_build(points, kind, radius=0.0, k=5):
     """kind 0: k nearest inside the ball; kind 2: plain k-NN (the constants of include/pgx.h)"""
     lists = graph_lists(points, k, radius if kind == 0 else None)
     return graph_from_lists(lists)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gram matrices of the non-minimal refits (SURVEY 8f rank 3) — numpy restatement of include/pgx.h pgx_gram.
+# Row definitions: vanishing point = /root/reference/src/pyprogressivex/include/solver_vanishing_point_two_lines.h:212-217;
+# the other estimators' solvers are absent from the snapshot (graph-cut-ransac submodule) and restated from the
+# literature: normalised DLT / 8-point rows, Gauss-Newton rows of the reprojection error at [R|t].
+# ---------------------------------------------------------------------------------------------------------------------
+GRAM_AFFINE, GRAM_DLT_H, GRAM_EPI_F, GRAM_VP, GRAM_PNP_GN = 0, 1, 2, 3, 4
+
+
+def gram_rows(kind, p, params=None):
+    """list of row blocks [m,q] (one per row of a point) and a `bad` mask"""
+    bad = np.zeros(p.shape[0], dtype=bool)
+    one = np.ones(p.shape[0])
+    if kind == GRAM_AFFINE:
+        return [np.column_stack([one, p])], bad
+    if kind in (GRAM_DLT_H, GRAM_EPI_F):
+        s1, cx1, cy1, s2, cx2, cy2 = [float(v) for v in params]
+        x1, y1 = (p[:, 0] - cx1) * s1, (p[:, 1] - cy1) * s1
+        x2, y2 = (p[:, 2] - cx2) * s2, (p[:, 3] - cy2) * s2
+        z = np.zeros_like(x1)
+        if kind == GRAM_DLT_H:
+            return [np.column_stack([-x1, -y1, -one, z, z, z, x2 * x1, x2 * y1, x2]),
+                    np.column_stack([z, z, z, -x1, -y1, -one, y2 * x1, y2 * y1, y2])], bad
+        return [np.column_stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, one])], bad
+    if kind == GRAM_VP:
+        x0, y0, x1, y1 = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+        mx, my, mz = (x0 + x1) / 2.0, (y0 + y1) / 2.0, 1.0
+        return [np.column_stack([y0 * mz - my, mx - x0 * mz, x0 * my - y0 * mx])], bad
+    if kind == GRAM_PNP_GN:
+        P = np.asarray(params, dtype=np.float64).reshape(3, 4)
+        Xr = p[:, 2:] @ P[:, :3].T
+        Xc = Xr + P[:, 3]
+        bad = ~(np.abs(Xc[:, 2]) >= 1e-12)
+        zc = np.where(bad, 1.0, Xc[:, 2])
+        inv = 1.0 / zc
+        du, dv = Xc[:, 0] * inv - p[:, 0], Xc[:, 1] * inv - p[:, 1]
+        a, b, c = inv, -Xc[:, 0] * inv * inv, -Xc[:, 1] * inv * inv
+        rx, ry, rz = Xr[:, 0], Xr[:, 1], Xr[:, 2]
+        z = np.zeros_like(a)
+        ju = np.column_stack([b * ry, a * rz - b * rx, -a * ry, a, z, b, du])
+        jv = np.column_stack([-a * rz + c * ry, -c * rx, a * rx, z, a, c, dv])
+        return [ju, jv], bad
+    raise ValueError(kind)
+
+
+def gram(kind, pts, index, params=None, weights=None, wpow=2):
+    """(G [q,q], count, bad) over pts[index]"""
+    index = np.asarray(index, dtype=np.int64)
+    p = np.ascontiguousarray(pts, dtype=np.float64)[index]
+    blocks, bad = gram_rows(kind, p, params)
+    w = np.ones(len(index)) if weights is None or len(weights) == 0 else np.asarray(weights, dtype=np.float64)[index] ** wpow
+    w = np.where(bad, 0.0, w)
+    q = blocks[0].shape[1]
+    G = np.zeros((q, q))
+    for A in blocks:
+        A = np.where(bad[:, None], 0.0, A)
+        G = G + (A * w[:, None]).T @ A
+    return G, int(len(index)), int(bad.sum())

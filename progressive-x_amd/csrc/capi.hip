@@ -116,7 +116,7 @@ void pgx_destroy(pgx_ctx* ctx)
     DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->perm, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
-                      &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch};
+                      &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -526,6 +526,13 @@ int pgx_set_graph(pgx_ctx* ctx, int64_t n, const int32_t* off, const int32_t* id
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gn = n; ctx->gE = E; ctx->max_degree = maxdeg; ctx->max_row_mult = max_row;
     return graph_build_reverse(ctx);
+}
+
+int pgx_gram(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m, int label,
+             const double* weights, int weight_power, double* out, int64_t* count, int64_t* bad)
+{
+    CTX_GUARD(ctx);
+    return gram_launch(ctx, kind, params, nparams, sel, index, m, label, weights, weight_power, out, count, bad);
 }
 
 int pgx_graph_build(pgx_ctx* ctx, const double* points, int64_t n, int d, int kind, double radius, int k, int64_t* arcs)

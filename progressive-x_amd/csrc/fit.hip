@@ -1,0 +1,279 @@
+// fit.hip — accumulation pass of the non-minimal refits: weighted Gram matrices of per-point
+// design rows over a subset of the resident points.  The small dense solve (2x2 .. 9x9 eigen / 6x6 linear) stays on the
+// host, as SURVEY a9 prescribes ("GPU does bucketing + sums, CPU does the solve").
+//
+// Replaces the data pass of estimator.estimateModelNonminimal(...) as called by
+//   pearl::PEARL::parameterEstimation   /root/reference/src/pyprogressivex/include/PEARL.h:374-380
+//   GC-RANSAC's local optimisation      (graph-cut-ransac submodule, absent from the snapshot)
+// for the five estimators of progressivex_python.cpp:119,252,343,489,616.  Only the vanishing-point rows have an in-tree
+// specification (solver_vanishing_point_two_lines.h:212-218: A = [y0*mz-my, mx-x0*mz, x0*my-y0*mx] * w); the other
+// solvers are absent upstream and restated from the literature (normalised DLT, normalised 8-point, total least squares
+// line, Gauss-Newton on the reprojection error) — DESIGN.md §3.
+//
+//   out = sum over selected points i of  W_i * sum over the rows a of point i of  a a^T      (upper triangle, row-major)
+//   W_i = w_i^wpow (weights optional).  Selection: an uploaded index list, or label == k on the resident labelling.
+// Fixed reduction tree (lanes -> waves -> per-block partials -> one final block): bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+namespace {
+
+constexpr int kFitBlock = 256;
+
+struct FitParams {
+    double v[12];
+};
+
+template <int Q>
+struct Acc {
+    double s[Q * (Q + 1) / 2];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int k = 0; k < Q * (Q + 1) / 2; ++k) s[k] = 0.0;
+    }
+    __device__ __forceinline__ void add(const double (&a)[Q], double w)
+    {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < Q; ++r) {
+            const double wa = w * a[r];
+#pragma unroll
+            for (int c = r; c < Q; ++c) s[k++] += wa * a[c];
+        }
+    }
+};
+
+// row generators: Q = row length, emit(pt, prm, acc, w, bad)
+struct GenAffine2 { static constexpr int Q = 3, D = 2; };
+struct GenAffine4 { static constexpr int Q = 5, D = 4; };
+struct GenAffine5 { static constexpr int Q = 6, D = 5; };
+struct GenDltH { static constexpr int Q = 9, D = 4; };
+struct GenEpiF { static constexpr int Q = 9, D = 4; };
+struct GenVp { static constexpr int Q = 3, D = 4; };
+struct GenPnpGn { static constexpr int Q = 7, D = 5; };
+
+template <class G>
+__device__ __forceinline__ void emit(const double* pt, const FitParams& prm, Acc<G::Q>& acc, double w, int& bad);
+
+template <>
+__device__ __forceinline__ void emit<GenAffine2>(const double* pt, const FitParams&, Acc<3>& acc, double w, int&)
+{
+    const double a[3] = {1.0, pt[0], pt[1]};
+    acc.add(a, w);
+}
+template <>
+__device__ __forceinline__ void emit<GenAffine4>(const double* pt, const FitParams&, Acc<5>& acc, double w, int&)
+{
+    const double a[5] = {1.0, pt[0], pt[1], pt[2], pt[3]};
+    acc.add(a, w);
+}
+template <>
+__device__ __forceinline__ void emit<GenAffine5>(const double* pt, const FitParams&, Acc<6>& acc, double w, int&)
+{
+    const double a[6] = {1.0, pt[0], pt[1], pt[2], pt[3], pt[4]};
+    acc.add(a, w);
+}
+// prm = (s1, cx1, cy1, s2, cx2, cy2): Hartley-normalised coordinates
+template <>
+__device__ __forceinline__ void emit<GenDltH>(const double* pt, const FitParams& prm, Acc<9>& acc, double w, int&)
+{
+    const double x1 = (pt[0] - prm.v[1]) * prm.v[0], y1 = (pt[1] - prm.v[2]) * prm.v[0];
+    const double x2 = (pt[2] - prm.v[4]) * prm.v[3], y2 = (pt[3] - prm.v[5]) * prm.v[3];
+    const double r1[9] = {-x1, -y1, -1.0, 0.0, 0.0, 0.0, x2 * x1, x2 * y1, x2};
+    const double r2[9] = {0.0, 0.0, 0.0, -x1, -y1, -1.0, y2 * x1, y2 * y1, y2};
+    acc.add(r1, w);
+    acc.add(r2, w);
+}
+template <>
+__device__ __forceinline__ void emit<GenEpiF>(const double* pt, const FitParams& prm, Acc<9>& acc, double w, int&)
+{
+    const double x1 = (pt[0] - prm.v[1]) * prm.v[0], y1 = (pt[1] - prm.v[2]) * prm.v[0];
+    const double x2 = (pt[2] - prm.v[4]) * prm.v[3], y2 = (pt[3] - prm.v[5]) * prm.v[3];
+    const double a[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+    acc.add(a, w);
+}
+// solver_vanishing_point_two_lines.h:212-217
+template <>
+__device__ __forceinline__ void emit<GenVp>(const double* pt, const FitParams&, Acc<3>& acc, double w, int&)
+{
+    const double x0 = pt[0], y0 = pt[1], x1 = pt[2], y1 = pt[3];
+    const double mx = (x0 + x1) / 2.0, my = (y0 + y1) / 2.0, mz = 1.0;
+    const double a[3] = {y0 * mz - my, mx - x0 * mz, x0 * my - y0 * mx};
+    acc.add(a, w);
+}
+// prm = P = [R | t] row-major 3x4; rows (J_u, r_u), (J_v, r_v) with J = d proj / d (omega, t) at omega = 0
+template <>
+__device__ __forceinline__ void emit<GenPnpGn>(const double* pt, const FitParams& prm, Acc<7>& acc, double w, int& bad)
+{
+    const double* P = prm.v;
+    const double X = pt[2], Y = pt[3], Z = pt[4];
+    const double rx = P[0] * X + P[1] * Y + P[2] * Z, ry = P[4] * X + P[5] * Y + P[6] * Z, rz = P[8] * X + P[9] * Y + P[10] * Z;
+    const double xc = rx + P[3], yc = ry + P[7], zc = rz + P[11];
+    if (!(fabs(zc) >= 1e-12)) { bad = 1; return; }
+    const double inv = 1.0 / zc;
+    const double du = xc * inv - pt[0], dv = yc * inv - pt[1];
+    // d proj / d Xc = [[inv, 0, -xc inv^2], [0, inv, -yc inv^2]];  d Xc / d omega = -[R X]_x, d Xc / d t = I
+    const double a = inv, b = -xc * inv * inv, c = -yc * inv * inv;
+    // skew(RX) as used by the host restatement: rows (0, rz, -ry), (-rz, 0, rx), (ry, -rx, 0)
+    const double ju[7] = {b * ry, a * rz + b * (-rx), a * (-ry), a, 0.0, b, du};
+    const double jv[7] = {a * (-rz) + c * ry, c * (-rx), a * rx, 0.0, a, c, dv};
+    acc.add(ju, w);
+    acc.add(jv, w);
+}
+
+template <class G>
+__global__ __launch_bounds__(kFitBlock) void gram_kernel(const double* __restrict__ pts, int64_t n, FitParams prm,
+                                                         const int* __restrict__ index, int64_t m,
+                                                         const int* __restrict__ labels, int label,
+                                                         const double* __restrict__ weights, int wpow,
+                                                         double* __restrict__ partials, int* __restrict__ counters)
+{
+    constexpr int Q = G::Q, NV = Q * (Q + 1) / 2;
+    __shared__ double lds[(kFitBlock / 64) * NV];
+    __shared__ int s_cnt, s_bad;
+    if (threadIdx.x == 0) { s_cnt = 0; s_bad = 0; }
+    __syncthreads();
+    Acc<Q> acc;
+    acc.zero();
+    const int64_t t = (int64_t)blockIdx.x * kFitBlock + threadIdx.x;
+    int64_t i = -1;
+    if (index != nullptr) { if (t < m) i = index[t]; }
+    else if (t < n && labels[t] == label) i = t;
+    int bad = 0;
+    if (i >= 0) {
+        double pt[G::D];
+#pragma unroll
+        for (int k = 0; k < G::D; ++k) pt[k] = pts[i * G::D + k];
+        double w = 1.0;
+        if (weights != nullptr) { w = weights[i]; if (wpow == 2) w = w * w; }
+        emit<G>(pt, prm, acc, w, bad);
+        atomicAdd(&s_cnt, 1);
+        if (bad) atomicAdd(&s_bad, 1);
+    }
+    // fixed tree: lanes (shuffle), then waves in order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = acc.s[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) lds[wave * NV + k] = x;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += kFitBlock) {
+        double s = lds[k];
+        for (int w2 = 1; w2 < kFitBlock / 64; ++w2) s += lds[w2 * NV + k];
+        partials[(int64_t)blockIdx.x * NV + k] = s;
+    }
+    if (threadIdx.x == 0) {
+        if (s_cnt) atomicAdd(&counters[0], s_cnt);
+        if (s_bad) atomicAdd(&counters[1], s_bad);
+    }
+}
+
+// one block: value k is summed over the blocks in order by one thread
+__global__ __launch_bounds__(64) void gram_final_kernel(const double* __restrict__ partials, int blocks, int nv,
+                                                        double* __restrict__ out)
+{
+    const int k = (int)threadIdx.x;
+    if (k >= nv) return;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * nv + k];
+    out[k] = s;
+}
+
+template <class G>
+void launch(pgx_ctx* ctx, const FitParams& prm, const int* index, int64_t m, int label, const double* weights, int wpow,
+            int blocks, double* partials, int* counters)
+{
+    hipLaunchKernelGGL((gram_kernel<G>), dim3((unsigned)blocks), dim3(kFitBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
+                       prm, index, m, ctx->labels.as<int>(), label, weights, wpow, partials, counters);
+}
+
+}  // namespace
+
+int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
+                int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: points not set");
+    if (wpow != 1 && wpow != 2) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: weight power must be 1 or 2");
+    if (nparams < 0 || nparams > 12 || (nparams > 0 && !params)) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: bad parameter block");
+    if (!out) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: out is NULL");
+    int q = 0;
+    const int D = ctx->D;
+    switch (kind) {
+    case PGX_GRAM_AFFINE: q = D + 1; if (D != 2 && D != 4 && D != 5) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: affine rows need 2-, 4- or 5-D points"); break;
+    case PGX_GRAM_DLT_H: case PGX_GRAM_EPI_F: q = 9; if (D != 4 || nparams != 6) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: needs 4-D correspondences and 6 normalisation parameters"); break;
+    case PGX_GRAM_VP: q = 3; if (D != 4) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: needs 4-D segments"); break;
+    case PGX_GRAM_PNP_GN: q = 7; if (D != 5 || nparams != 12) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: needs 5-D 2D-3D rows and a 3x4 pose"); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "pgx_gram: unknown row kind %d", kind);
+    }
+    const int nv = q * (q + 1) / 2;
+    int64_t work = 0;
+    if (sel == PGX_SEL_INDEX) {
+        if (m < 0 || (m > 0 && !index)) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: index list missing");
+        for (int64_t t = 0; t < m; ++t)
+            if (index[t] < 0 || index[t] >= ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: index %d out of range", index[t]);
+        work = m;
+    } else if (sel == PGX_SEL_LABEL) {
+        if (ctx->labels_n != ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: labels not set");
+        work = ctx->n;
+    } else {
+        return fail(ctx, PGX_ERR_INVALID, "pgx_gram: unknown selection %d", sel);
+    }
+    FitParams prm;
+    for (int k = 0; k < 12; ++k) prm.v[k] = k < nparams ? params[k] : 0.0;
+    const int blocks = (int)((work + kFitBlock - 1) / kFitBlock);
+    if (blocks == 0) {
+        for (int k = 0; k < nv; ++k) out[k] = 0.0;
+        if (count) *count = 0;
+        if (bad) *bad = 0;
+        return PGX_OK;
+    }
+    // scratch: partials | out | counters | index | weights
+    const size_t part_bytes = (size_t)blocks * nv * sizeof(double);
+    const size_t idx_bytes = sel == PGX_SEL_INDEX ? (size_t)m * sizeof(int32_t) : 0;
+    const size_t w_bytes = weights ? (size_t)ctx->n * sizeof(double) : 0;
+    const size_t total = part_bytes + 64 * sizeof(double) + 64 + ((idx_bytes + 7) & ~(size_t)7) + w_bytes;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, total));
+    char* base = (char*)ctx->fit_scratch.p;
+    double* d_part = (double*)base;
+    double* d_out = (double*)(base + part_bytes);
+    int* d_cnt = (int*)(base + part_bytes + 64 * sizeof(double));
+    int* d_idx = (int*)(base + part_bytes + 64 * sizeof(double) + 64);
+    double* d_w = (double*)(base + part_bytes + 64 * sizeof(double) + 64 + ((idx_bytes + 7) & ~(size_t)7));
+    PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    if (idx_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, weights, w_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int* ix = sel == PGX_SEL_INDEX ? d_idx : nullptr;
+    const double* ww = weights ? d_w : nullptr;
+    switch (kind) {
+    case PGX_GRAM_AFFINE:
+        if (D == 2) launch<GenAffine2>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt);
+        else if (D == 4) launch<GenAffine4>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt);
+        else launch<GenAffine5>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt);
+        break;
+    case PGX_GRAM_DLT_H: launch<GenDltH>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt); break;
+    case PGX_GRAM_EPI_F: launch<GenEpiF>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt); break;
+    case PGX_GRAM_VP: launch<GenVp>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt); break;
+    default: launch<GenPnpGn>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt); break;
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(gram_final_kernel, dim3(1), dim3(64), 0, ctx->stream, d_part, blocks, nv, d_out);
+    PGX_HIP(ctx, hipGetLastError());
+    int cnt[2] = {0, 0};
+    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) *count = cnt[0];
+    if (bad) *bad = cnt[1];
+    return PGX_OK;
+}
+
+}  // namespace pgx

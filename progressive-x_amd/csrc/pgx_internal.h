@@ -73,6 +73,7 @@ struct pgx_ctx {
     pgx::MaxflowState* mf = nullptr;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
+    pgx::DevBuf fit_scratch;  // pgx_gram: partials | result | counters | index list | weights
 
     pgx::CommState* comm = nullptr;
 };
@@ -112,6 +113,8 @@ int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
+int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
+                int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
 void maxflow_free(pgx_ctx* ctx);
 void comm_free(pgx_ctx* ctx);

@@ -128,7 +128,7 @@ class Pearl:
             if len(inl) < self.est.nonminimal_sample_size:            # :365
                 continue
             before = self.ctx.residual_sum(models[k].descriptor, k)   # :369-371
-            fits = self.est.nonminimal(self.pts, inl, self.point_weights, init=models[k].descriptor)   # :375-380
+            fits = self.est.nonminimal(self.ctx, ("label", k), self.point_weights, init=models[k].descriptor)   # :375-380
             if len(fits) != 1:                                        # :384
                 continue
             after = self.ctx.residual_sum(fits[0], k)                 # :388-390

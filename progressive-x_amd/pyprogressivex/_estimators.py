@@ -24,8 +24,10 @@ class Estimator:
         """samples [S, m] -> (models [H, P], sample_of_model [H]); several or zero solutions per sample allowed."""
         raise NotImplementedError
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        """Least-squares fit to pts[idx] -> list of models (the reference accepts the refit only if exactly 1)."""
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        """Least-squares fit to the selected resident points -> list of models (the reference accepts the refit only
+        if exactly 1).  sel = ("index", indices) or ("label", k); the data pass runs on the device (ctx.gram =
+        pgx_gram: weighted Gram matrix of the design rows), the small dense solve here."""
         raise NotImplementedError
 
     def descriptor(self, model):
@@ -53,14 +55,13 @@ class LineEstimator(Estimator):
         models = np.column_stack([nrm, c])
         return models[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        p = pts[idx]
-        w = np.ones(len(idx)) if weights is None else np.asarray(weights)[idx]
-        if w.sum() <= 0:
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        G, cnt, _ = ctx.gram(_lib.GRAM_AFFINE, sel, weights=weights, wpow=1)   # sum w [1,x,y][1,x,y]^T
+        W = G[0, 0]
+        if cnt < 2 or not W > 0:
             return []
-        mean = (p * w[:, None]).sum(axis=0) / w.sum()
-        q = (p - mean) * np.sqrt(w)[:, None]
-        evals, evecs = np.linalg.eigh(q.T @ q)
+        mean = G[0, 1:] / W
+        evals, evecs = np.linalg.eigh(G[1:, 1:] - W * np.outer(mean, mean))     # weighted scatter about the mean
         nrm = evecs[:, 0]
         return [np.array([nrm[0], nrm[1], -nrm @ mean])]
 
@@ -88,14 +89,12 @@ class VanishingPointEstimator(Estimator):
         v = v / np.where(ok, ln, 1.0)[:, None]
         return v[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        p = pts[idx]
-        x0, y0, x1, y1 = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
-        mx, my, mz = (x0 + x1) / 2.0, (y0 + y1) / 2.0, 1.0                       # :212-215
-        A = np.column_stack([y0 * mz - my, mx - x0 * mz, x0 * my - y0 * mx])     # :217
-        if weights is not None and len(weights) > 0:
-            A = A * np.asarray(weights)[idx][:, None]                             # :218
-        evals, evecs = np.linalg.eigh(A.T @ A)                                    # :227 SelfAdjointEigenSolver
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        # rows A = [y0*mz-my, mx-x0*mz, x0*my-y0*mx] * w (:212-218) are generated and accumulated on the device
+        AtA, cnt, _ = ctx.gram(_lib.GRAM_VP, sel, weights=weights, wpow=2)
+        if cnt < 2:
+            return []
+        evals, evecs = np.linalg.eigh(AtA)                                        # :227 SelfAdjointEigenSolver
         v = evecs[:, int(np.argmin(evals))]                                       # :230-233
         n = np.linalg.norm(v)
         return [v / n] if n > 0 else []
@@ -112,12 +111,26 @@ def _dlt_rows(x1, y1, x2, y2):
     return r1, r2
 
 
-def _hartley(xy):
-    c = xy.mean(axis=0)
-    d = np.sqrt(((xy - c) ** 2).sum(axis=1)).mean()
-    s = np.sqrt(2.0) / d if d > 0 else 1.0
-    T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
-    return (xy - c) * s, T
+def _hartley_from_moments(ctx, sel):
+    """Normalising similarities of both images from one pass of first/second moments (isotropic scaling to an RMS
+    distance of sqrt(2) from the centroid).  Returns (T1, T2, params for the DLT / epipolar rows, count)."""
+    G, cnt, _ = ctx.gram(_lib.GRAM_AFFINE, sel)
+    if cnt < 1:
+        return None, None, None, 0
+    c = G[0, 1:] / cnt
+    var = np.maximum(np.diag(G)[1:] / cnt - c * c, 0.0)
+    Ts, prm = [], []
+    for k in (0, 2):
+        rms = np.sqrt(var[k] + var[k + 1])
+        sc = np.sqrt(2.0) / rms if rms > 0 else 1.0
+        Ts.append(np.array([[sc, 0, -sc * c[k]], [0, sc, -sc * c[k + 1]], [0, 0, 1.0]]))
+        prm += [sc, c[k], c[k + 1]]
+    return Ts[0], Ts[1], np.array(prm), cnt
+
+
+def _smallest_eigenvector(G):
+    evals, evecs = np.linalg.eigh(G)
+    return evecs[:, 0]
 
 
 class HomographyEstimator(Estimator):
@@ -145,19 +158,12 @@ class HomographyEstimator(Estimator):
         ok &= np.isfinite(h).all(axis=1)
         return h[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        p = pts[idx]
-        if len(p) < 4:
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        T1, T2, prm, cnt = _hartley_from_moments(ctx, sel)
+        if cnt < 4:
             return []
-        a, T1 = _hartley(p[:, :2])
-        b, T2 = _hartley(p[:, 2:])
-        r1, r2 = _dlt_rows(a[:, 0], a[:, 1], b[:, 0], b[:, 1])
-        A = np.vstack([r1, r2])
-        if weights is not None and len(weights) > 0:
-            w = np.asarray(weights)[idx]
-            A = A * np.concatenate([w, w])[:, None]
-        _, _, vt = np.linalg.svd(A, full_matrices=False)
-        Hn = vt[-1].reshape(3, 3)
+        AtA, _, _ = ctx.gram(_lib.GRAM_DLT_H, sel, params=prm, weights=weights, wpow=2)   # normalised DLT rows
+        Hn = _smallest_eigenvector(AtA).reshape(3, 3)
         H = np.linalg.inv(T2) @ Hn @ T1
         if not np.isfinite(H).all() or abs(H[2, 2]) < 1e-300:
             return []
@@ -185,8 +191,8 @@ class SymmetricHomographyEstimator(HomographyEstimator):
         aug, keep = self._augment(models)
         return aug, src[keep]
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        res = super().nonminimal(pts, idx, weights, init)
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        res = super().nonminimal(ctx, sel, weights, init)
         return [m for m in self._augment(np.array(res).reshape(-1, 9))[0]]
 
     def output(self, model):
@@ -237,17 +243,12 @@ class FundamentalEstimator(Estimator):
                     src.append(s)
         return np.array(models).reshape(-1, 9), np.array(src, dtype=np.int64)
 
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        p = pts[idx]
-        if len(p) < 8:
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        T1, T2, prm, cnt = _hartley_from_moments(ctx, sel)
+        if cnt < 8:
             return []
-        a, T1 = _hartley(p[:, :2])
-        b, T2 = _hartley(p[:, 2:])
-        A = self._rows(np.column_stack([a, b]))
-        if weights is not None and len(weights) > 0:
-            A = A * np.asarray(weights)[idx][:, None]
-        _, _, vt = np.linalg.svd(A, full_matrices=False)
-        F = vt[-1].reshape(3, 3)
+        AtA, _, _ = ctx.gram(_lib.GRAM_EPI_F, sel, params=prm, weights=weights, wpow=2)   # normalised 8-point rows
+        F = _smallest_eigenvector(AtA).reshape(3, 3)
         u, s, v = np.linalg.svd(F)
         F = u @ np.diag([s[0], s[1], 0.0]) @ v
         F = T2.T @ F @ T1
@@ -353,57 +354,20 @@ class PnPEstimator(Estimator):
         o = np.argsort(src, kind="stable")
         return models[o], src[o]
 
-    @staticmethod
-    def _dlt(p):
-        u, v, X = p[:, 0], p[:, 1], p[:, 2:]
-        Xh = np.column_stack([X, np.ones(len(p))])
-        z = np.zeros_like(Xh)
-        A = np.vstack([np.column_stack([Xh, z, -u[:, None] * Xh]), np.column_stack([z, Xh, -v[:, None] * Xh])])
-        _, _, vt = np.linalg.svd(A, full_matrices=False)
-        P = vt[-1].reshape(3, 4)
-        if np.linalg.det(P[:, :3]) < 0:
-            P = -P
-        U, s, Vt = np.linalg.svd(P[:, :3])
-        R = U @ Vt
-        return np.column_stack([R, P[:, 3] / s.mean()])
-
-    def nonminimal(self, pts, idx, weights=None, init=None):
-        p = pts[idx]
-        if len(p) < 4:
+    def nonminimal(self, ctx, sel, weights=None, init=None):
+        """Gauss-Newton on the reprojection error from `init` (PEARL and the local optimisation always have one; the
+        DLT start of an un-initialised fit is not needed on this path).  Per iteration the device accumulates the
+        normal equations  sum (J,r)^T (J,r)  (rows in fit.hip GenPnpGn), the 6x6 solve and the pose update run here."""
+        if init is None:
             return []
-        if init is not None:
-            P = np.asarray(init, dtype=np.float64).reshape(3, 4).copy()
-        elif len(p) >= 6:
-            P = self._dlt(p)
-        else:
-            return []
-        w = np.ones(len(p)) if weights is None or len(weights) == 0 else np.asarray(weights)[idx]
+        P = np.asarray(init, dtype=np.float64).reshape(3, 4).copy()
         R, t = P[:, :3], P[:, 3]
-        for _ in range(10):                                  # Gauss-Newton on the reprojection error
-            Xc = p[:, 2:] @ R.T + t
-            z = Xc[:, 2]
-            if np.any(np.abs(z) < 1e-12):
+        for _ in range(10):
+            G, cnt, bad = ctx.gram(_lib.GRAM_PNP_GN, sel, params=np.column_stack([R, t]).reshape(-1), weights=weights, wpow=2)
+            if cnt < 4 or bad > 0:
                 return []
-            proj = Xc[:, :2] / z[:, None]
-            res = (proj - p[:, :2])
-            J = np.zeros((len(p), 2, 6))
-            inv = 1.0 / z
-            dpdX = np.zeros((len(p), 2, 3))
-            dpdX[:, 0, 0] = inv
-            dpdX[:, 1, 1] = inv
-            dpdX[:, 0, 2] = -Xc[:, 0] * inv * inv
-            dpdX[:, 1, 2] = -Xc[:, 1] * inv * inv
-            Xr = Xc - t                                      # R X
-            skew = np.zeros((len(p), 3, 3))
-            skew[:, 0, 1], skew[:, 0, 2] = Xr[:, 2], -Xr[:, 1]
-            skew[:, 1, 0], skew[:, 1, 2] = -Xr[:, 2], Xr[:, 0]
-            skew[:, 2, 0], skew[:, 2, 1] = Xr[:, 1], -Xr[:, 0]
-            J[:, :, :3] = dpdX @ skew                         # d(exp([w]_x) R X)/dw = -[R X]_x (= skew)
-            J[:, :, 3:] = dpdX
-            Jw = (J * w[:, None, None]).reshape(-1, 6)
-            rw = (res * w[:, None]).reshape(-1)
             try:
-                delta = np.linalg.lstsq(Jw, -rw, rcond=None)[0]
+                delta = np.linalg.lstsq(G[:6, :6], -G[:6, 6], rcond=None)[0]
             except np.linalg.LinAlgError:
                 return []
             om = delta[:3]

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
-    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch",
+    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
@@ -33,6 +33,15 @@ ABI_SYMBOLS = [
 
 
 GRAPH_KNN_IN_BALL, GRAPH_KNN = 0, 2
+GRAM_AFFINE, GRAM_DLT_H, GRAM_EPI_F, GRAM_VP, GRAM_PNP_GN = 0, 1, 2, 3, 4
+GRAM_Q = {GRAM_DLT_H: 9, GRAM_EPI_F: 9, GRAM_VP: 3, GRAM_PNP_GN: 7}   # GRAM_AFFINE: point dimension + 1
+
+
+def tri_to_sym(tri, q):
+    """upper triangle (row-major) -> full symmetric q x q matrix"""
+    G = np.zeros((q, q))
+    G[np.triu_indices(q)] = tri
+    return G + np.triu(G, 1).T
 
 
 class PgxError(RuntimeError):
@@ -277,6 +286,24 @@ class Context:
         self._ck(self._lib.pgx_graph_fetch(self._h, _ptr(off, C.c_int32), _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)),
                  "pgx_graph_fetch")
         return off, idx[:arcs.value], mult[:arcs.value]
+
+    def gram(self, kind, sel, params=None, weights=None, wpow=2):
+        """pgx_gram: weighted Gram matrix of the design rows of the selected resident points.
+        sel = ("index", int array) or ("label", k).  Returns (G [q,q] symmetric, count, bad)."""
+        q = GRAM_Q.get(kind, POINT_DIM[self.model_type] + 1)
+        out = np.zeros(q * (q + 1) // 2, dtype=np.float64)
+        prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        w = None if weights is None or len(weights) == 0 else np.ascontiguousarray(weights, dtype=np.float64)
+        cnt, bad = C.c_int64(), C.c_int64()
+        if sel[0] == "index":
+            idx = _i32(sel[1])
+            mode, iptr, m, label = 0, _ptr(idx, C.c_int32) if idx.size else None, idx.size, 0
+        else:
+            mode, iptr, m, label = 1, None, 0, int(sel[1])
+        self._ck(self._lib.pgx_gram(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double), C.c_int(0 if prm is None else prm.size),
+                                    C.c_int(mode), iptr, C.c_int64(m), C.c_int(label), _ptr(w, C.c_double),
+                                    C.c_int(int(wpow)), _ptr(out, C.c_double), C.byref(cnt), C.byref(bad)), "pgx_gram")
+        return tri_to_sym(out, q), cnt.value, bad.value
 
     def set_labels(self, labels):
         lab = _i32(labels)

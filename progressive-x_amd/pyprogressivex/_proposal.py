@@ -181,7 +181,7 @@ class ProposalEngine:
             inl = mask_to_indices(one["masks"][0], self.n)
             if len(inl) < est.nonminimal_sample_size:
                 break
-            fits = est.nonminimal(self.pts, inl, weights, init=model)
+            fits = est.nonminimal(self.ctx, ("index", inl), weights, init=model)
             if len(fits) != 1:
                 break
             cand = self.ctx.score(fits[0][None, :], T2, has_compound=has_compound, exponent=exponent)

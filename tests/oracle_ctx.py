@@ -75,6 +75,10 @@ class OracleContext:
     def set_graph(self, off, idx, mult):
         self.graph = (np.asarray(off, np.int32), np.asarray(idx, np.int32), np.asarray(mult, np.int32))
 
+    def gram(self, kind, sel, params=None, weights=None, wpow=2):
+        index = np.asarray(sel[1], dtype=np.int64) if sel[0] == "index" else np.nonzero(self.labels == int(sel[1]))[0]
+        return O.gram(kind, self.pts, index, params=params, weights=weights, wpow=wpow)
+
     def graph_build(self, points, kind, radius=0.0, k=5, fetch=True):
         self.graph = O.graph_build(points, kind, radius=radius, k=k)
         return self.graph if fetch else len(self.graph[1])

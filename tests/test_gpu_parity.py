@@ -387,6 +387,56 @@ def test_graph_build_error_paths(gpu_ctx):
         gpu_ctx.graph_build(bad, _lib.GRAPH_KNN, k=3)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# a9: Gram pass of the non-minimal refits — floating-point sums, 1e-9 relative to the matrix scale
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("n", [1, 257, 20011])
+def test_gram_matches_oracle(gpu_ctx, oracle, name, n):
+    mt, pts, models, thr = make_case(name, n, 2, seed=n + 11)
+    rng = np.random.default_rng(n)
+    gpu_ctx.set_points(mt, pts)
+    labels = rng.integers(0, 3, n).astype(np.int32)
+    gpu_ctx.set_labels(labels)
+    weights = rng.random(n) + 0.5
+    kinds = {"line": [(_lib.GRAM_AFFINE, None)],
+             "vanishing_point": [(_lib.GRAM_VP, None), (_lib.GRAM_AFFINE, None)],
+             "homography": [(_lib.GRAM_AFFINE, None), (_lib.GRAM_DLT_H, np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0]))],
+             "homography_sym": [(_lib.GRAM_DLT_H, np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0]))],
+             "fundamental": [(_lib.GRAM_EPI_F, np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0]))],
+             "pnp": [(_lib.GRAM_AFFINE, None), (_lib.GRAM_PNP_GN, models[0][:12])]}[name]
+    index = rng.permutation(n)[: max(1, n // 2)]
+    for kind, prm in kinds:
+        for sel, ref_index in ((("index", index), index), (("label", 1), np.nonzero(labels == 1)[0])):
+            for w, wpow in ((None, 2), (weights, 1), (weights, 2)):
+                G, cnt, bad = gpu_ctx.gram(kind, sel, params=prm, weights=w, wpow=wpow)
+                Gr, cntr, badr = oracle.gram(kind, pts, ref_index, params=prm, weights=w, wpow=wpow)
+                assert (cnt, bad) == (cntr, badr)
+                scale = max(np.abs(Gr).max(), 1e-300)
+                assert np.abs(G - Gr).max() <= REL * scale, f"{name} kind {kind} sel {sel[0]} wpow {wpow}"
+                assert np.array_equal(G, G.T)
+    # reproducible run to run (fixed reduction tree)
+    kind, prm = kinds[-1]
+    a = gpu_ctx.gram(kind, ("label", 1), params=prm, weights=weights)[0]
+    b = gpu_ctx.gram(kind, ("label", 1), params=prm, weights=weights)[0]
+    assert np.array_equal(a, b)
+
+
+def test_gram_error_paths_and_empty_selection(gpu_ctx):
+    mt, pts, models, thr = make_case("homography", 100, 1, seed=1)
+    gpu_ctx.set_points(mt, pts)
+    G, cnt, bad = gpu_ctx.gram(_lib.GRAM_AFFINE, ("index", np.zeros(0, np.int32)))
+    assert cnt == 0 and not G.any()
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.gram(_lib.GRAM_AFFINE, ("index", np.array([100], np.int32)))
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.gram(_lib.GRAM_DLT_H, ("index", np.array([1], np.int32)), params=np.ones(5))
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.gram(_lib.GRAM_VP + 9, ("index", np.array([1], np.int32)))
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.gram(_lib.GRAM_AFFINE, ("index", np.array([1], np.int32)), weights=np.ones(100), wpow=3)
+
+
 def test_asymmetric_graph_is_rejected(gpu_ctx):
     from pyprogressivex._lib import PgxError
     off = np.array([0, 1, 1], dtype=np.int32)

@@ -90,3 +90,58 @@ def test_reference_quirks(oracle_backend):
     s = _engine.MultiModelSettings()
     assert (s.minimum_number_of_inliers, s.max_proposal_number_without_change, s.max_iteration_number,
             s.max_local_optimization_number, s.max_outer_iterations) == (20, 10, 5000, 50, 10)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# non-minimal refits: the algebra around the device's Gram pass (ctx.gram), here on the oracle-backed context
+# ----------------------------------------------------------------------------------------------------------------------
+def _octx(model_type, pts):
+    from oracle_ctx import OracleContext
+    ctx = OracleContext()
+    ctx.set_points(model_type, pts)
+    return ctx
+
+
+def test_refits_recover_the_generating_models():
+    from pyprogressivex import _estimators, _lib, datasets
+    rng = np.random.default_rng(3)
+    # line: total least squares
+    t = rng.random(300) * 100
+    pts = np.column_stack([t, 0.5 * t + 7.0]) + rng.normal(0, 1e-3, (300, 2))
+    m = _estimators.LineEstimator().nonminimal(_octx(_lib.LINE2D, pts), ("index", np.arange(300)))[0]
+    assert abs(abs(m[0] * 2 + m[1] * (-1)) / np.hypot(2, -1) - 0) < 1e-3 or abs(m[0] / m[1] + 0.5) < 1e-4
+    assert np.abs(pts @ m[:2] + m[2]).max() < 1e-2
+    # homography: exact correspondences -> H up to scale
+    H = np.array([[1.1, 0.05, 20.0], [-0.03, 0.95, -12.0], [1e-5, -2e-5, 1.0]])
+    a = rng.random((200, 2)) * 800
+    b = np.column_stack([a, np.ones(200)]) @ H.T
+    corr = np.column_stack([a, b[:, :2] / b[:, 2:]])
+    ctx = _octx(_lib.HOMOGRAPHY, corr)
+    ctx.set_labels(np.where(np.arange(200) < 150, 0, 1))
+    h = _estimators.HomographyEstimator().nonminimal(ctx, ("label", 0))[0].reshape(3, 3)
+    assert np.abs(h - H / H[2, 2]).max() < 1e-6 * np.abs(H).max()
+    # fundamental matrix: x2^T F x1 = 0 on noise-free data
+    pts2, gt2, _ = datasets.make_two_view_motions(seed=1)
+    sel = np.nonzero(gt2 == 1)[0][:500]
+    F = _estimators.FundamentalEstimator().nonminimal(_octx(_lib.FUNDAMENTAL, pts2), ("index", sel))[0].reshape(3, 3)
+    x1 = np.column_stack([pts2[sel, :2], np.ones(len(sel))])
+    x2 = np.column_stack([pts2[sel, 2:], np.ones(len(sel))])
+    alg = np.abs(np.einsum("ij,jk,ik->i", x2, F, x1))
+    assert np.median(alg) < 5e-3 and abs(np.linalg.det(F)) < 1e-9
+    # PnP: Gauss-Newton from a perturbed pose converges back
+    x1p, x2p, K, gtp, poses = datasets.make_poses(n_per_object=400, n_objects=2, n_outliers=0, seed=2)
+    norm, f = datasets.normalize_pnp(x1p, x2p, K)
+    sel = np.nonzero(gtp == 1)[0]
+    P0 = poses[0].reshape(3, 4).copy()
+    P0[:, 3] += np.array([2.0, -1.5, 4.0])
+    est = _estimators.PnPEstimator()
+    fit = est.nonminimal(_octx(_lib.PNP, norm), ("index", sel), init=P0.reshape(-1))[0].reshape(3, 4)
+    assert np.abs(fit - poses[0].reshape(3, 4)).max() < 0.5      # mm-level on a 50 mm object at 600-900 mm, 1 px noise
+    assert est.nonminimal(_octx(_lib.PNP, norm), ("index", sel), init=None) == []
+    # vanishing point: segments through a common point
+    vp = np.array([1500.0, -700.0])
+    mid = rng.random((300, 2)) * 1000
+    d = (vp - mid) / np.linalg.norm(vp - mid, axis=1, keepdims=True)
+    segs = np.column_stack([mid - 30 * d, mid + 30 * d])
+    v = _estimators.VanishingPointEstimator().nonminimal(_octx(_lib.VANISHING_POINT, segs), ("index", np.arange(300)))[0]
+    assert abs(v[2]) > 0 and np.abs(v[:2] / v[2] - vp).max() < 1e-3
