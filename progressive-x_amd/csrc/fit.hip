@@ -177,15 +177,17 @@ __global__ __launch_bounds__(kFitBlock) void gram_kernel(const double* __restric
     }
 }
 
-// one block: value k is summed over the blocks in order by one thread
-__global__ __launch_bounds__(64) void gram_final_kernel(const double* __restrict__ partials, int blocks, int nv,
-                                                        double* __restrict__ out)
+// one block: value k is summed by 16 lanes (lane j takes the blocks b = j mod 16 in order), then a fixed xor tree
+__global__ __launch_bounds__(1024) void gram_final_kernel(const double* __restrict__ partials, int blocks, int nv,
+                                                          double* __restrict__ out)
 {
-    const int k = (int)threadIdx.x;
-    if (k >= nv) return;
+    const int k = (int)threadIdx.x >> 4, j = (int)threadIdx.x & 15;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * nv + k];
-    out[k] = s;
+    if (k < nv)
+        for (int b = j; b < blocks; b += 16) s += partials[(int64_t)b * nv + k];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (k < nv && j == 0) out[k] = s;
 }
 
 template <class G>
@@ -265,7 +267,7 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
     default: launch<GenPnpGn>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt); break;
     }
     PGX_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(gram_final_kernel, dim3(1), dim3(64), 0, ctx->stream, d_part, blocks, nv, d_out);
+    hipLaunchKernelGGL(gram_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_part, blocks, nv, d_out);
     PGX_HIP(ctx, hipGetLastError());
     int cnt[2] = {0, 0};
     PGX_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -221,26 +221,44 @@ class FundamentalEstimator(Estimator):
         A = self._rows(p / scale)                      # [S,7,9], isotropic pre-scaling for conditioning
         _, _, vt = np.linalg.svd(A, full_matrices=True)
         F1, F2 = vt[:, 7].reshape(-1, 3, 3), vt[:, 8].reshape(-1, 3, 3)
-        models, src = [], []
         # det(l F1 + (1-l) F2) is a cubic in l: interpolate it at 4 nodes
         ls = np.array([0.0, 1.0, -1.0, 2.0])
         vals = np.stack([np.linalg.det(l * F1 + (1 - l) * F2) for l in ls], axis=1)
         V = np.vander(ls, 4)
         coef = np.linalg.solve(V, vals.T).T            # [S,4] highest power first
         D = np.diag([1 / scale, 1 / scale, 1.0])
-        for s in range(len(samples)):
-            c = coef[s]
-            if not np.isfinite(c).all():
-                continue
-            roots = np.roots(c) if abs(c[0]) > 1e-14 * np.abs(c).max() else np.roots(c[1:])
-            for r in roots:
-                if abs(r.imag) > 1e-9 * max(1.0, abs(r.real)):
-                    continue
-                F = D @ (r.real * F1[s] + (1 - r.real) * F2[s]) @ D
-                nrm = np.linalg.norm(F)
-                if nrm > 0 and np.isfinite(nrm):
-                    models.append((F / nrm).reshape(-1))
-                    src.append(s)
+        # roots of all cubics at once: eigenvalues of the stacked companion matrices (np.roots does the same one by
+        # one); samples with a vanishing leading coefficient (a quadratic) take the slow path
+        finite = np.isfinite(coef).all(axis=1)
+        lead = np.abs(coef[:, 0]) > 1e-14 * np.abs(coef).max(axis=1)
+        reg = np.nonzero(finite & lead)[0]
+        sidx, roots = [], []
+        if len(reg):
+            comp = np.zeros((len(reg), 3, 3))
+            comp[:, 0, :] = -coef[reg, 1:] / coef[reg, :1]
+            comp[:, 1, 0] = 1.0
+            comp[:, 2, 1] = 1.0
+            ev = np.linalg.eigvals(comp)                                   # [R,3]
+            real = np.abs(ev.imag) <= 1e-9 * np.maximum(1.0, np.abs(ev.real))
+            rr, cc = np.nonzero(real)
+            sidx.append(reg[rr])
+            roots.append(ev.real[rr, cc])
+        for s in np.nonzero(finite & ~lead)[0]:
+            for r in np.roots(coef[s, 1:]):
+                if abs(r.imag) <= 1e-9 * max(1.0, abs(r.real)):
+                    sidx.append(np.array([s]))
+                    roots.append(np.array([r.real]))
+        if not sidx:
+            return np.zeros((0, 9)), np.zeros(0, dtype=np.int64)
+        sidx, roots = np.concatenate(sidx), np.concatenate(roots)
+        o = np.argsort(sidx, kind="stable")                                # by sample; roots keep LAPACK's order (as np.roots)
+        sidx, roots = sidx[o], roots[o]
+        F = D @ (roots[:, None, None] * F1[sidx] + (1.0 - roots)[:, None, None] * F2[sidx]) @ D
+        nrm = np.sqrt((F * F).sum(axis=(1, 2)))
+        ok = (nrm > 0) & np.isfinite(nrm)
+        models = (F[ok] / nrm[ok][:, None, None]).reshape(-1, 9)
+        return models, sidx[ok].astype(np.int64)
+
         return np.array(models).reshape(-1, 9), np.array(src, dtype=np.int64)
 
     def nonminimal(self, ctx, sel, weights=None, init=None):
