@@ -100,6 +100,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_NO_XCD")) ctx->score_xcd_map = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
     *out = ctx;
@@ -116,7 +117,8 @@ void pgx_destroy(pgx_ctx* ctx)
     DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->perm, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
-                      &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch};
+                      &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
+                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -213,6 +215,10 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
     ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
+    ctx->point_sort = 0;
+    ctx->comp_dirty = 1;
+    if (obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(umax))
+        PGX_TRY(score_sort_points(ctx, points, p32.data(), pmax.data()));
     for (DevBuf& b : ctx->slots) release(b);
     ctx->slots.clear();
     return PGX_OK;
@@ -227,6 +233,7 @@ int pgx_set_compound(pgx_ctx* ctx, const double* compound)
     else
         PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)ctx->n * sizeof(double), ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->comp_dirty = 1;
     return PGX_OK;
 }
 

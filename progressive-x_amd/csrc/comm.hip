@@ -190,6 +190,7 @@ int pgx_compound_allreduce_max(pgx_ctx* ctx)
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     PGX_NCCL(ctx, g_rccl.AllReduce(ctx->comp.p, ctx->comp.p, (size_t)ctx->n, ncclFloat64, ncclMax, ctx->comm->comm, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->comp_dirty = 1;
     return PGX_OK;
 }
 

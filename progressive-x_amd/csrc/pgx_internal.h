@@ -41,6 +41,12 @@ struct pgx_ctx {
     int filter_enabled = 1;  // PGX_NO_FILTER: 1 = no rejection filter, 2 = FP64 filter only (A/B, debugging)
     int last_score_filtered = 0;
     int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)
+    // spatially sorted copies for the score kernel (group-level rejection); aliases of the originals
+    // when point_sort is off
+    int point_sort = 0;          // 1: pts_s / pts32_s / pmax_s / comp_s hold the points in Morton order, pperm maps back
+    int group_filter = 1;        // PGX_NO_GROUP=1 disables the sorted copies and the group test (A/B)
+    int comp_dirty = 0;          // comp changed since comp_s was gathered
+    pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     int score_xcd_map = 1;       // XCD-aware block mapping of the score kernel (PGX_SCORE_NO_XCD=1 disables)
     int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)
 
@@ -104,6 +110,7 @@ inline int64_t quantize_lambda(double lambda) { return 2 * (int64_t)__builtin_ne
 
 // launchers implemented in the .hip translation units
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
+int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, const double* pmax);  // builds the sorted copies
 int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pref, double out3[3]);
 int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K);
 int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda);

@@ -171,6 +171,7 @@ int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K)
     hipLaunchKernelGGL(compound_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, a, K, ctx->n,
                        ctx->comp.as<double>());
     PGX_HIP(ctx, hipGetLastError());
+    ctx->comp_dirty = 1;
     return PGX_OK;
 }
 

@@ -107,15 +107,32 @@ template <int MT> struct Filter32 {
     struct Lane {};
     template <class MD> static __device__ __forceinline__ Lane prep(const MD&, double) { return {}; }
     static __device__ __forceinline__ bool reject(const float*, const Lane&, float) { return false; }
+    static __device__ __forceinline__ bool group_reject(const float*, const Lane&, float) { return false; }
 };
+
+// ---- group-level rejection ---------------------------------------------------------------------------
+// The points are kept in Morton order of all their coordinates, so 64 consecutive points form a compact group: centre c
+// and radius rho of the part the projective map multiplies, centre (ub, vb) and half extents (ru, rv) of the observed
+// part.  For every point of the group |z_i - z_c| <= ||p_z|| rho =: dz (likewise dx, dy), hence
+//   |u_i z_i - x_i| >= |ub z_c - x_c| - (ru (|z_c| + dz) + |ub| dz + dx)      and      T |z_i| <= T (|z_c| + dz),
+// and an inlier needs |u_i z_i - x_i| < T |z_i| in both coordinates: if either lower bound exceeds the upper bound no
+// point of the group is an inlier of this hypothesis.  Evaluated in f32 at the centre under the point filter's trust
+// test (centre errors <= a few tau T |z_c|), radii and norms stored rounded up by 1e-5, T inflated by 2^-6.  A wave
+// skips the 64 points when all of its 64 hypotheses reject the group (the batch is in locality order, so a wave's
+// hypotheses look at the same image region): 74 % of the (wave, group) pairs of the metric batch.
+constexpr double kGroupInflate = 1.00001;
+constexpr int kGroupRow = 12;  // floats per group: c[3], rho, ub, vb, ru, rv, scale, pad[3]
 
 template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;
-    struct Lane { float m[12]; float c1, c0; };
+    struct Lane { float m[12]; float c1, c0; float n0, n1, n2; };
     template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard32) {
         Lane ln;
 #pragma unroll
         for (int k = 0; k < 12; ++k) ln.m[k] = (float)m[k];
+        ln.n0 = (float)(sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * kGroupInflate);
+        ln.n1 = (float)(sqrt(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) * kGroupInflate);
+        ln.n2 = (float)(sqrt(m[8] * m[8] + m[9] * m[9] + m[10] * m[10]) * kGroupInflate);
         const double l3 = fmax(fabs(m[0]) + fabs(m[1]) + fabs(m[2]),
                                fmax(fabs(m[4]) + fabs(m[5]) + fabs(m[6]), fabs(m[8]) + fabs(m[9]) + fabs(m[10])));
         const double t = fmax(fabs(m[3]), fmax(fabs(m[7]), fabs(m[11])));
@@ -136,15 +153,34 @@ template <> struct Filter32<kPnP> {
         const bool trust = __builtin_fmaf(ln.c1, p[5], ln.c0) <= fabsf(pz);  // false on NaN
         return trust && (lhs > rhs);                                         // false on NaN
     }
+    // g = (cX, cY, cZ, rho, ub, vb, ru, rv, scale, -, -, -)
+    static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float Tup) {
+        const float* m = ln.m;
+        const float cx = __builtin_fmaf(m[0], g[0], __builtin_fmaf(m[1], g[1], __builtin_fmaf(m[2], g[2], m[3])));
+        const float cy = __builtin_fmaf(m[4], g[0], __builtin_fmaf(m[5], g[1], __builtin_fmaf(m[6], g[2], m[7])));
+        const float cz = __builtin_fmaf(m[8], g[0], __builtin_fmaf(m[9], g[1], __builtin_fmaf(m[10], g[2], m[11])));
+        if (!(cz == cz)) return true;  // NaN hypothesis: its residuals are NaN, never an inlier
+        const bool trust = __builtin_fmaf(ln.c1, g[8], ln.c0) <= fabsf(cz);
+        const float dz = ln.n2 * g[3], dx = ln.n0 * g[3], dy = ln.n1 * g[3];
+        const float zs = fabsf(cz) + dz;
+        const float ex = fabsf(__builtin_fmaf(g[4], cz, -cx)), ey = fabsf(__builtin_fmaf(g[5], cz, -cy));
+        const float mx = __builtin_fmaf(g[6], zs, __builtin_fmaf(fabsf(g[4]), dz, dx));
+        const float my = __builtin_fmaf(g[7], zs, __builtin_fmaf(fabsf(g[5]), dz, dy));
+        const float tol = Tup * zs;
+        return trust && ((ex - mx > tol) || (ey - my > tol));  // false on NaN/inf arithmetic
+    }
 };
 
 template <> struct Filter32<kHomography> {
     static constexpr bool enabled = true;
-    struct Lane { float m[9]; float c1, c0; };
+    struct Lane { float m[9]; float c1, c0; float n0, n1, n2; };
     template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32) {
         Lane ln;
 #pragma unroll
         for (int k = 0; k < 9; ++k) ln.m[k] = (float)h[k];
+        ln.n0 = (float)(sqrt(h[0] * h[0] + h[1] * h[1]) * kGroupInflate);
+        ln.n1 = (float)(sqrt(h[3] * h[3] + h[4] * h[4]) * kGroupInflate);
+        ln.n2 = (float)(sqrt(h[6] * h[6] + h[7] * h[7]) * kGroupInflate);
         const double l2 = fmax(fabs(h[0]) + fabs(h[1]), fmax(fabs(h[3]) + fabs(h[4]), fabs(h[6]) + fabs(h[7])));
         const double t = fmax(fabs(h[2]), fmax(fabs(h[5]), fabs(h[8])));
         ln.c1 = f32_up(guard32 * l2);
@@ -164,6 +200,22 @@ template <> struct Filter32<kHomography> {
         const bool trust = __builtin_fmaf(ln.c1, p[5], ln.c0) <= fabsf(t3);
         return trust && (lhs > rhs);
     }
+    // g = (c1x, c1y, 0, rho, x2b, y2b, r2x, r2y, scale, -, -, -)
+    static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float Tup) {
+        const float* h = ln.m;
+        const float cx = __builtin_fmaf(h[0], g[0], __builtin_fmaf(h[1], g[1], h[2]));
+        const float cy = __builtin_fmaf(h[3], g[0], __builtin_fmaf(h[4], g[1], h[5]));
+        const float cz = __builtin_fmaf(h[6], g[0], __builtin_fmaf(h[7], g[1], h[8]));
+        if (!(cz == cz)) return true;
+        const bool trust = __builtin_fmaf(ln.c1, g[8], ln.c0) <= fabsf(cz);
+        const float dz = ln.n2 * g[3], dx = ln.n0 * g[3], dy = ln.n1 * g[3];
+        const float zs = fabsf(cz) + dz;
+        const float ex = fabsf(__builtin_fmaf(g[4], cz, -cx)), ey = fabsf(__builtin_fmaf(g[5], cz, -cy));
+        const float mx = __builtin_fmaf(g[6], zs, __builtin_fmaf(fabsf(g[4]), dz, dx));
+        const float my = __builtin_fmaf(g[7], zs, __builtin_fmaf(fabsf(g[5]), dz, dy));
+        const float tol = Tup * zs;
+        return trust && ((ex - mx > tol) || (ey - my > tol));
+    }
 };
 
 // FILT: 0 = no filter, 1 = FP64 filter, 2 = FP32 pre-filter
@@ -173,7 +225,8 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
     const double* __restrict__ pmax, double guard, const float* __restrict__ pts32, double guard32,
     unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int chunks, int xcd_map)
+    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int chunks, int xcd_map,
+    const float* __restrict__ gbounds)
 {
     using R = Residual<MT>;
     // (hypothesis group, point chunk) of this block.  Workgroups are handed to the 8 XCDs round-robin by linear id and
@@ -204,6 +257,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     const typename F32::Lane flane32 = F32::prep(mdl, guard32);
     const double T2d = T2 * (1.0 + kFilterDelta);
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
+    const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));  // group test
 
     unsigned cnt = 0;
     double val = 0.0, sh = 0.0;
@@ -237,35 +291,51 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     };
     constexpr int kUnroll = 4;
     int64_t i = i0;
-    for (; i + kUnroll <= i1; i += kUnroll) {
-        const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
-        double pt[kUnroll][R::D];
-        double pm[kUnroll];
-        float p32[kUnroll][8];
+    while (i < i1) {
+        // one 64-point group at a time (chunks start at multiples of 64)
+        const int64_t gend = ((i | 63) + 1 < i1) ? (i | 63) + 1 : i1;
+        if (FILT == 2 && F32::enabled && gbounds != nullptr) {
+            const float* __restrict__ g = gbounds + (i >> 6) * kGroupRow;  // wave-uniform -> scalar loads
+            float gr[kGroupRow];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-            for (int k = 0; k < R::D; ++k) pt[u][k] = prow[u * R::D + k];
-            pm[u] = (FILT == 1 && F::enabled) ? pmax[i + u] : 1.0;
-            if (FILT == 2 && F32::enabled) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) p32[u][k] = pts32[(i + u) * 8 + k];
+            for (int k = 0; k < 9; ++k) gr[k] = g[k];
+            const bool keep = live && !F32::group_reject(gr, flane32, Tup32);
+            if (__ballot(keep) == 0) {  // none of this wave's hypotheses can have an inlier in the group
+                if (MASK && live) masks[(int64_t)perm[m] * words + (i >> 6)] = 0;
+                i = gend;
+                continue;
             }
         }
+        for (; i + kUnroll <= gend; i += kUnroll) {
+            const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
+            double pt[kUnroll][R::D];
+            double pm[kUnroll];
+            float p32[kUnroll][8];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], pm[u], p32[u]);
-    }
-    for (; i < i1; ++i) {
-        const double* __restrict__ prow = pts + i * R::D;
-        double pt[R::D];
-        float p32[8];
+            for (int u = 0; u < kUnroll; ++u) {
 #pragma unroll
-        for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
-        if (FILT == 2 && F32::enabled) {
+                for (int k = 0; k < R::D; ++k) pt[u][k] = prow[u * R::D + k];
+                pm[u] = (FILT == 1 && F::enabled) ? pmax[i + u] : 1.0;
+                if (FILT == 2 && F32::enabled) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) p32[k] = pts32[i * 8 + k];
+                    for (int k = 0; k < 8; ++k) p32[u][k] = pts32[(i + u) * 8 + k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], pm[u], p32[u]);
         }
-        step(i, pt, (FILT == 1 && F::enabled) ? pmax[i] : 1.0, p32);
+        for (; i < gend; ++i) {
+            const double* __restrict__ prow = pts + i * R::D;
+            double pt[R::D];
+            float p32[8];
+#pragma unroll
+            for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
+            if (FILT == 2 && F32::enabled) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p32[k] = pts32[i * 8 + k];
+            }
+            step(i, pt, (FILT == 1 && F::enabled) ? pmax[i] : 1.0, p32);
+        }
     }
     const int64_t o = (int64_t)gy * Mpad + m;
     pcnt[o] = cnt;
@@ -412,11 +482,13 @@ template <int MT, bool MASK>
 static void score_launch_deferred(pgx_ctx* ctx, double T2, int has_compound, double guard)
 {
     dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
+    const bool srt = ctx->point_sort != 0;
     hipLaunchKernelGGL((score_kernel_deferred<MT, MASK>), grid, dim3(kScoreBlock), 0, ctx->stream,
-                       ctx->pts.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
-                       ctx->comp.as<double>(), has_compound, ctx->chunk, ctx->pmax.as<double>(), guard,
+                       (srt ? ctx->pts_s : ctx->pts).as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
+                       (srt ? ctx->comp_s : ctx->comp).as<double>(), has_compound, ctx->chunk,
+                       (srt ? ctx->pmax_s : ctx->pmax).as<double>(), guard,
                        ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                       MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words,
+                       MASK ? (srt ? ctx->masks_s : ctx->masks).as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words,
                        ctx->perm.as<int>());
 }
 
@@ -426,12 +498,15 @@ static void score_launch_one(pgx_ctx* ctx, double T2, int has_compound, double g
     const unsigned groups = (unsigned)(ctx->Mpad / kScoreBlock);
     dim3 grid(groups, (unsigned)ctx->chunks);
     if (ctx->score_xcd_map) grid = dim3(groups * (((unsigned)ctx->chunks + 7u) / 8u * 8u), 1);
-    hipLaunchKernelGGL((score_kernel<MT, MASK, FILT>), grid, dim3(kScoreBlock), 0, ctx->stream, ctx->pts.as<double>(),
-                       ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2, ctx->comp.as<double>(), has_compound,
-                       ctx->chunk, ctx->pmax.as<double>(), guard, ctx->pts32.as<float>(), guard32,
-                       ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(),
-                       ctx->psh.as<double>(), MASK ? ctx->masks.as<unsigned long long>() : (unsigned long long*)nullptr,
-                       ctx->words, ctx->perm.as<int>(), ctx->chunks, ctx->score_xcd_map);
+    const bool srt = ctx->point_sort != 0;  // spatially sorted copies (score_sort_points); masks come out in sorted bit order
+    hipLaunchKernelGGL((score_kernel<MT, MASK, FILT>), grid, dim3(kScoreBlock), 0, ctx->stream,
+                       (srt ? ctx->pts_s : ctx->pts).as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
+                       (srt ? ctx->comp_s : ctx->comp).as<double>(), has_compound, ctx->chunk,
+                       (srt ? ctx->pmax_s : ctx->pmax).as<double>(), guard, (srt ? ctx->pts32_s : ctx->pts32).as<float>(), guard32,
+                       ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
+                       MASK ? (srt ? ctx->masks_s : ctx->masks).as<unsigned long long>() : (unsigned long long*)nullptr,
+                       ctx->words, ctx->perm.as<int>(), ctx->chunks, ctx->score_xcd_map,
+                       (srt && FILT == 2) ? ctx->gbounds.as<float>() : (const float*)nullptr);
 }
 
 template <int MT>
@@ -482,6 +557,139 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     return PGX_OK;
 }
 
+// ---- spatially sorted copies of the point data (group test) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_f64_kernel(const double* __restrict__ src, const int* __restrict__ pperm, int64_t n,
+                                                         double* __restrict__ dst)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n) dst[j] = src[pperm[j]];
+}
+
+// masks written in sorted bit order -> the caller's point order: one thread per (row, sorted word), set bits scattered
+__global__ __launch_bounds__(256) void mask_unpermute_kernel(const unsigned long long* __restrict__ ms, const int* __restrict__ pperm,
+                                                             int64_t n, int64_t words, int M, unsigned long long* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * words) return;
+    const int64_t row = t / words, w = t % words;
+    unsigned long long bits = ms[t];
+    while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const int64_t j = w * 64 + b;
+        if (j < n) {
+            const int i = pperm[j];
+            atomicOr(&out[row * words + (i >> 6)], 1ull << (i & 63));
+        }
+    }
+}
+
+// Host: Morton order of all coordinates, sorted copies, per-group bounds (rows of kGroupRow floats, see above).
+int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, const double* pmax)
+{
+    const int64_t n = ctx->n;
+    const int d = ctx->D;
+    const int bits = 30 / d;
+    std::vector<double> lo((size_t)d), inv((size_t)d);
+    for (int k = 0; k < d; ++k) {
+        double a = points[k], b = points[k];
+        for (int64_t i = 1; i < n; ++i) { const double v = points[i * d + k]; if (v < a) a = v; if (v > b) b = v; }
+        if (!std::isfinite(a) || !std::isfinite(b)) return PGX_OK;  // non-finite data: no sorted copies, no group test
+        lo[(size_t)k] = a;
+        inv[(size_t)k] = b > a ? (double)(1u << bits) / (b - a) : 0.0;
+    }
+    std::vector<uint64_t> kv((size_t)n), tmp((size_t)n);
+    const uint32_t qmax = (1u << bits) - 1u;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t q[8];
+        for (int k = 0; k < d; ++k) {
+            const double t = (points[i * d + k] - lo[(size_t)k]) * inv[(size_t)k];
+            uint32_t v = t > 0.0 ? (uint32_t)t : 0u;
+            q[k] = v > qmax ? qmax : v;
+        }
+        uint32_t key = 0;
+        for (int b = bits - 1; b >= 0; --b)
+            for (int k = 0; k < d; ++k) key = (key << 1) | ((q[k] >> b) & 1u);
+        kv[(size_t)i] = ((uint64_t)key << 32) | (uint32_t)i;
+    }
+    for (int pass = 0; pass < 4; ++pass) {  // LSD radix sort on the key's four bytes (stable: ties keep index order)
+        size_t cnt[257] = {0};
+        const int sh = 32 + 8 * pass;
+        for (int64_t i = 0; i < n; ++i) ++cnt[((kv[(size_t)i] >> sh) & 0xff) + 1];
+        for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < n; ++i) tmp[cnt[(kv[(size_t)i] >> sh) & 0xff]++] = kv[(size_t)i];
+        kv.swap(tmp);
+    }
+    const int64_t groups = (n + 63) / 64;
+    std::vector<int> pperm((size_t)n);
+    std::vector<double> sp((size_t)n * d), spm((size_t)n);
+    std::vector<float> sp32((size_t)n * 8), gb((size_t)groups * kGroupRow, 0.0f);
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t i = (int64_t)(uint32_t)kv[(size_t)j];
+        pperm[(size_t)j] = (int)i;
+        for (int k = 0; k < d; ++k) sp[(size_t)j * d + k] = points[i * d + k];
+        for (int k = 0; k < 8; ++k) sp32[(size_t)j * 8 + k] = p32[i * 8 + k];
+        spm[(size_t)j] = pmax[i];
+    }
+    // which coordinates the projective map multiplies / which are observed (as in pgx_set_points)
+    int in0, in1, ob0;
+    if (ctx->model_type == kPnP) { in0 = 2; in1 = 4; ob0 = 0; }
+    else { in0 = 0; in1 = 1; ob0 = 2; }
+    for (int64_t g = 0; g < groups; ++g) {
+        const int64_t a = g * 64, b = a + 64 < n ? a + 64 : n;
+        float* row = gb.data() + (size_t)g * kGroupRow;
+        // centre = box centre of the f32 rows (the values the kernel's per-point filter sees are not needed here: the
+        // bound is about the exact f64 points; extents are inflated below)
+        double cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, omin[2], omax[2];
+        for (int k = in0; k <= in1; ++k) { cmin[k - in0] = cmax[k - in0] = sp[(size_t)a * d + k]; }
+        for (int k = 0; k < 2; ++k) omin[k] = omax[k] = sp[(size_t)a * d + ob0 + k];
+        for (int64_t j = a; j < b; ++j) {
+            for (int k = in0; k <= in1; ++k) { const double v = sp[(size_t)j * d + k]; if (v < cmin[k - in0]) cmin[k - in0] = v; if (v > cmax[k - in0]) cmax[k - in0] = v; }
+            for (int k = 0; k < 2; ++k) { const double v = sp[(size_t)j * d + ob0 + k]; if (v < omin[k]) omin[k] = v; if (v > omax[k]) omax[k] = v; }
+        }
+        float cf[3] = {0, 0, 0};
+        double scale = 1.0;
+        for (int k = 0; k <= in1 - in0; ++k) { cf[k] = (float)(0.5 * (cmin[k] + cmax[k])); if (std::fabs((double)cf[k]) > scale) scale = std::fabs((double)cf[k]); }
+        double rho2 = 0.0;  // radius about the f32 centre actually stored
+        for (int64_t j = a; j < b; ++j) {
+            double s2 = 0.0;
+            for (int k = in0; k <= in1; ++k) { const double df = sp[(size_t)j * d + k] - (double)cf[k - in0]; s2 += df * df; }
+            if (s2 > rho2) rho2 = s2;
+        }
+        const float ub = (float)(0.5 * (omin[0] + omax[0])), vb = (float)(0.5 * (omin[1] + omax[1]));
+        double ru = 0.0, rv = 0.0;
+        for (int64_t j = a; j < b; ++j) {
+            const double du = std::fabs(sp[(size_t)j * d + ob0] - (double)ub), dv = std::fabs(sp[(size_t)j * d + ob0 + 1] - (double)vb);
+            if (du > ru) ru = du;
+            if (dv > rv) rv = dv;
+        }
+        row[0] = cf[0]; row[1] = cf[1]; row[2] = cf[2];
+        row[3] = (float)(std::sqrt(rho2) * kGroupInflate + 1e-30);
+        row[4] = ub; row[5] = vb;
+        row[6] = (float)(ru * kGroupInflate + 1e-30);
+        row[7] = (float)(rv * kGroupInflate + 1e-30);
+        row[8] = (float)(scale * 1.000001);
+    }
+    PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->comp_s, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pperm, (size_t)n * sizeof(int)));
+    PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)groups * kGroupRow * sizeof(float)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pts_s.p, sp.data(), (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pts32_s.p, sp32.data(), (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pmax_s.p, spm.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pperm.p, pperm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->gbounds.p, gb.data(), (size_t)groups * kGroupRow * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemsetAsync(ctx->comp_s.p, 0, (size_t)n * sizeof(double), ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->point_sort = 1;
+    ctx->comp_dirty = 1;
+    return PGX_OK;
+}
+
+static int score_launch_typed(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
+
 // Chooses the point chunking so that the grid has >= ~8 blocks per CU (all 32 wave slots of every CU filled)
 // while chunks stay multiples of 64 points (mask words never straddle blocks).
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
@@ -515,6 +723,29 @@ int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
     PGX_TRY(ensure(ctx, ctx->shared, (size_t)ctx->Mpad * sizeof(double)));
     if (want_masks) PGX_TRY(ensure(ctx, ctx->masks, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t)));
     ctx->have_masks = want_masks != 0;
+    if (ctx->point_sort) {
+        if (has_compound && ctx->comp_dirty) {  // the kernel reads the compound vector in sorted point order
+            hipLaunchKernelGGL(gather_f64_kernel, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->comp.as<double>(), ctx->pperm.as<int>(), ctx->n, ctx->comp_s.as<double>());
+            PGX_HIP(ctx, hipGetLastError());
+            ctx->comp_dirty = 0;
+        }
+        if (want_masks) PGX_TRY(ensure(ctx, ctx->masks_s, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t)));
+    }
+    const int rc = score_launch_typed(ctx, T2, has_compound, want_masks);
+    if (rc == PGX_OK && ctx->point_sort && want_masks) {
+        const int64_t total = (int64_t)ctx->M * ctx->words;
+        PGX_HIP(ctx, hipMemsetAsync(ctx->masks.p, 0, (size_t)total * sizeof(uint64_t), ctx->stream));
+        hipLaunchKernelGGL(mask_unpermute_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->masks_s.as<unsigned long long>(), ctx->pperm.as<int>(), ctx->n, ctx->words, ctx->M,
+                           ctx->masks.as<unsigned long long>());
+        PGX_HIP(ctx, hipGetLastError());
+    }
+    return rc;
+}
+
+static int score_launch_typed(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
+{
     switch (ctx->model_type) {
     case kLine2D: return score_dispatch<kLine2D>(ctx, T2, has_compound, want_masks);
     case kHomography: return score_dispatch<kHomography>(ctx, T2, has_compound, want_masks);
