@@ -343,6 +343,143 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     psh[o] = sh;
 }
 
+// ---- cull, then score --------------------------------------------------------------------------------
+// Skipping rejected groups inside the chunked kernel leaves the surviving work badly distributed: 3/4 of the (wave,
+// group) pairs disappear, the waves that still have work are few per SIMD and stall on their scalar loads (measured:
+// instructions 39 %, time 65 %, average resident waves 38 -> 21).  Two kernels instead:
+//   score_cull_kernel      one wave per (64 hypotheses, segment of groups): the group test, survivors appended in order
+//                          to that (wave, segment)'s list
+//   score_survivor_kernel  one wave per (64 hypotheses, slice b): scores survivors b, b+B, b+2B, ... of its hypotheses'
+//                          lists (cyclic distribution => balanced by construction, dense work in every wave), one
+//                          partial per (slice, hypothesis), added up in slice order by score_reduce_kernel as before
+// so every sum is still taken in a fixed order (bit-reproducible run to run).
+constexpr int kCullSegs = 64;      // segments per hypothesis wave (one count per lane in the survivor kernel)
+constexpr int kSurvivorSlices = 256;
+
+template <int MT>
+__global__ __launch_bounds__(64) void score_cull_kernel(
+    const double* __restrict__ models, int M, double T2, double guard32, const float* __restrict__ gbounds, int groups,
+    int gps /* groups per segment */, int* __restrict__ lists, int* __restrict__ counts)
+{
+    using R = Residual<MT>;
+    using F32 = Filter32<MT>;
+    const int w = (int)blockIdx.x, seg = (int)blockIdx.y;
+    const int m = w * 64 + (int)threadIdx.x;
+    const bool live = m < M;
+    double mdl[R::P];
+#pragma unroll
+    for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
+    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
+    const int g0 = seg * gps, g1 = g0 + gps < groups ? g0 + gps : groups;
+    int* __restrict__ out = lists + ((int64_t)w * kCullSegs + seg) * gps;
+    int cnt = 0;
+    constexpr int kU = 4;  // bounds of four groups per scalar-memory round trip
+    int g = g0;
+    for (; g + kU <= g1; g += kU) {
+        float gr[kU][9];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) gr[u][k] = gbounds[(int64_t)(g + u) * kGroupRow + k];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const bool keep = live && !F32::group_reject(gr[u], flane32, Tup32);
+            if (__ballot(keep) != 0) { if (threadIdx.x == 0) out[cnt] = g + u; ++cnt; }
+        }
+    }
+    for (; g < g1; ++g) {
+        float gr[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gr[k] = gbounds[(int64_t)g * kGroupRow + k];
+        const bool keep = live && !F32::group_reject(gr, flane32, Tup32);
+        if (__ballot(keep) != 0) { if (threadIdx.x == 0) out[cnt] = g; ++cnt; }
+    }
+    if (threadIdx.x == 0) counts[w * kCullSegs + seg] = cnt;
+}
+
+template <int MT, bool MASK>
+__global__ __launch_bounds__(64) void score_survivor_kernel(
+    const double* __restrict__ pts, int64_t n, const double* __restrict__ models, int M, int Mpad,
+    double T2, const double* __restrict__ comp, int has_comp, const float* __restrict__ pts32, double guard32,
+    const int* __restrict__ lists, const int* __restrict__ counts, int gps,
+    unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
+    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
+{
+    using R = Residual<MT>;
+    using F32 = Filter32<MT>;
+    const int w = (int)blockIdx.x, b = (int)blockIdx.y, lane = (int)threadIdx.x;
+    const int m = w * 64 + lane;
+    const bool live = m < M;
+    double mdl[R::P];
+#pragma unroll
+    for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
+    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
+    // survivor k of this hypothesis wave lives in segment seg(k) = #{segments whose inclusive prefix <= k}
+    const int my_cnt = counts[w * kCullSegs + lane];
+    int incl = my_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    const int excl = incl - my_cnt;
+
+    unsigned cnt = 0;
+    double val = 0.0, sh = 0.0;
+    constexpr int kUnroll = 4;
+    for (int k = b; k < total; k += (int)gridDim.y) {
+        // wave-uniform by construction; readfirstlane tells the compiler, so that the point rows stay scalar loads
+        const int seg = __popcll(__ballot(incl <= k));
+        const int off = __builtin_amdgcn_readfirstlane(k - __shfl(excl, seg, 64));
+        const int g = __builtin_amdgcn_readfirstlane(lists[((int64_t)w * kCullSegs + seg) * gps + off]);
+        const int64_t i0 = (int64_t)g * 64, i1 = i0 + 64 < n ? i0 + 64 : n;
+        unsigned long long word = 0;
+        auto step = [&](int64_t i, const double (&pt)[R::D], const float* p32) {
+            bool inl = false;
+            if (live && !F32::reject(p32, flane32, T2d32)) {  // exact path: oracle operation order, no contraction
+                const double sq = R::squared(pt, mdl);
+                inl = sq < T2;
+                if (inl) {
+                    ++cnt;
+                    const double sc = cv_max(0.0, 1.0 - sq / T2);
+                    val += sc;
+                    if (has_comp) sh += cv_min(comp[i], sc);
+                }
+            }
+            if (MASK) word |= (unsigned long long)(inl ? 1 : 0) << (i & 63);
+        };
+        int64_t i = i0;
+        for (; i + kUnroll <= i1; i += kUnroll) {
+            const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
+            double pt[kUnroll][R::D];
+            float p32[kUnroll][8];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+                for (int q = 0; q < R::D; ++q) pt[u][q] = prow[u * R::D + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) p32[u][q] = pts32[(i + u) * 8 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], p32[u]);
+        }
+        for (; i < i1; ++i) {
+            double pt[R::D];
+            float p32[8];
+#pragma unroll
+            for (int q = 0; q < R::D; ++q) pt[q] = pts[i * R::D + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p32[q] = pts32[i * 8 + q];
+            step(i, pt, p32);
+        }
+        if (MASK && live) masks[(int64_t)perm[m] * words + g] = word;  // rows start zeroed: culled groups stay 0
+    }
+    const int64_t o = (int64_t)b * Mpad + m;
+    pcnt[o] = cnt;
+    pval[o] = val;
+    psh[o] = sh;
+}
+
 // ---- filtered variant with deferred exact evaluation ------------------------------------------------
 // The filter leaves only a few candidate pairs per lane, but a wave pays for the exact path whenever ANY of its 64
 // hypotheses has a candidate at the current point (the union over lanes).  Here a lane instead appends the point index
@@ -532,6 +669,47 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
     // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).
     const bool deferred = filt && ctx->score_deferred;
+    if constexpr (Filter32<MT>::enabled) {
+        if (filt32 && !deferred && ctx->point_sort && ctx->score_cull) {
+            // ---- cull, then score the survivors
+            const int groups = (int)((ctx->n + 63) / 64);
+            const int gps = (groups + kCullSegs - 1) / kCullSegs;
+            const int waves = ctx->Mpad / 64;
+            PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)waves * kCullSegs * gps * sizeof(int)));
+            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)waves * kCullSegs * sizeof(int)));
+            const size_t np = (size_t)kSurvivorSlices * (size_t)ctx->Mpad;
+            PGX_TRY(ensure(ctx, ctx->pcnt, np * sizeof(unsigned)));
+            PGX_TRY(ensure(ctx, ctx->pval, np * sizeof(double)));
+            PGX_TRY(ensure(ctx, ctx->psh, np * sizeof(double)));
+            hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)waves, kCullSegs), dim3(64), 0, ctx->stream,
+                               ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps,
+                               ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>());
+            PGX_HIP(ctx, hipGetLastError());
+            if (want_masks) {
+                PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
+                hipLaunchKernelGGL((score_survivor_kernel<MT, true>), dim3((unsigned)waves, kSurvivorSlices), dim3(64), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
+                                   ctx->comp_s.as<double>(), has_compound, ctx->pts32_s.as<float>(), guard32,
+                                   ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>(), gps, ctx->pcnt.as<unsigned>(),
+                                   ctx->pval.as<double>(), ctx->psh.as<double>(), ctx->masks_s.as<unsigned long long>(),
+                                   ctx->words, ctx->perm.as<int>());
+            } else {
+                hipLaunchKernelGGL((score_survivor_kernel<MT, false>), dim3((unsigned)waves, kSurvivorSlices), dim3(64), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
+                                   ctx->comp_s.as<double>(), has_compound, ctx->pts32_s.as<float>(), guard32,
+                                   ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>(), gps, ctx->pcnt.as<unsigned>(),
+                                   ctx->pval.as<double>(), ctx->psh.as<double>(), (unsigned long long*)nullptr,
+                                   ctx->words, ctx->perm.as<int>());
+            }
+            PGX_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
+                               ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
+                               kSurvivorSlices, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
+                               ctx->values.as<double>(), ctx->shared.as<double>());
+            PGX_HIP(ctx, hipGetLastError());
+            return PGX_OK;
+        }
+    }
     if constexpr (Filter<MT>::enabled) {
         if (want_masks) {
             if (deferred) score_launch_deferred<MT, true>(ctx, T2, has_compound, guard);
