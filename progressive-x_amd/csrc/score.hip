@@ -343,23 +343,47 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     psh[o] = sh;
 }
 
-// ---- cull, then score --------------------------------------------------------------------------------
-// Skipping rejected groups inside the chunked kernel leaves the surviving work badly distributed: 3/4 of the (wave,
-// group) pairs disappear, the waves that still have work are few per SIMD and stall on their scalar loads (measured:
-// instructions 39 %, time 65 %, average resident waves 38 -> 21).  Two kernels instead:
-//   score_cull_kernel      one wave per (64 hypotheses, segment of groups): the group test, survivors appended in order
-//                          to that (wave, segment)'s list
-//   score_survivor_kernel  one wave per (64 hypotheses, slice b): scores survivors b, b+B, b+2B, ... of its hypotheses'
-//                          lists (cyclic distribution => balanced by construction, dense work in every wave), one
-//                          partial per (slice, hypothesis), added up in slice order by score_reduce_kernel as before
-// so every sum is still taken in a fixed order (bit-reproducible run to run).
-constexpr int kCullSegs = 64;      // segments per hypothesis wave (one count per lane in the survivor kernel)
-constexpr int kSurvivorSlices = 256;
+// ---- cull, then score group-major ------------------------------------------------------------------
+// Skipping rejected groups inside the chunked kernel needs a whole wave of 64 hypotheses to agree (74 % of the (wave,
+// group) pairs) although 93 % of the (hypothesis, group) pairs are rejected, and leaves the surviving work badly
+// distributed (instructions 39 %, time 65 %); scoring the survivors hypothesis-major still runs the pre-filter for 64
+// hypotheses at a time and the FP64 exact path with ~3 of 64 lanes busy (the union of the wave's candidates).  So the
+// surviving pairs are scored the other way round:
+//   score_cull_kernel   one wave per (64 hypotheses, segment of groups): the group test; bit h of keep[g][w] = hypothesis
+//                       64 w + h may have inliers in group g.  Also stores every hypothesis' f32 filter constants.
+//   score_group_kernel  one wave per GROUP, one point per lane (rows loaded once, coalesced); the surviving hypotheses
+//                       stream through the scalar unit: 17-op pre-filter for 64 points, then the exact FP64 path with
+//                       the group's actual candidates as active lanes; per (hypothesis, group): count = popcount, the
+//                       two sums by a fixed shuffle tree, added to the hypothesis' accumulators as integers (count) and
+//                       as 2^-q fixed point (sums) with integer atomics: exact and order-free, so results are
+//                       bit-reproducible although the accumulation order is not fixed.  q = 62 - ceil(log2 n): the
+//                       quantisation error of a sum is < (#groups with inliers) * 2^-(q+1), ~1e-13 relative.
+//   score_finish_kernel accumulators -> counts / values / shared in the caller's hypothesis order.
+constexpr int kCullSegs = 64;  // segments of groups per hypothesis wave in the cull kernel
+constexpr int kHypRow = 20;    // floats per hypothesis: Filter32<MT>::Lane, padded
+
+template <class LaneT>
+__device__ __forceinline__ void lane_store(const LaneT& ln, float* __restrict__ row)
+{
+    static_assert(sizeof(LaneT) % 4 == 0 && sizeof(LaneT) / 4 <= kHypRow, "Filter32 lane constants must fit a row");
+    const float* src = reinterpret_cast<const float*>(&ln);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(LaneT) / 4); ++k) row[k] = src[k];
+}
+template <class LaneT>
+__device__ __forceinline__ LaneT lane_load(const float* __restrict__ row)
+{
+    LaneT ln;
+    float* dst = reinterpret_cast<float*>(&ln);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(LaneT) / 4); ++k) dst[k] = row[k];
+    return ln;
+}
 
 template <int MT>
 __global__ __launch_bounds__(64) void score_cull_kernel(
     const double* __restrict__ models, int M, double T2, double guard32, const float* __restrict__ gbounds, int groups,
-    int gps /* groups per segment */, int* __restrict__ lists, int* __restrict__ counts)
+    int gps /* groups per segment */, int W, unsigned long long* __restrict__ keep, float* __restrict__ hyp32)
 {
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
@@ -370,10 +394,9 @@ __global__ __launch_bounds__(64) void score_cull_kernel(
 #pragma unroll
     for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
     const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    if (seg == 0) lane_store(flane32, hyp32 + (int64_t)m * kHypRow);
     const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
     const int g0 = seg * gps, g1 = g0 + gps < groups ? g0 + gps : groups;
-    int* __restrict__ out = lists + ((int64_t)w * kCullSegs + seg) * gps;
-    int cnt = 0;
     constexpr int kU = 4;  // bounds of four groups per scalar-memory round trip
     int g = g0;
     for (; g + kU <= g1; g += kU) {
@@ -384,100 +407,94 @@ __global__ __launch_bounds__(64) void score_cull_kernel(
             for (int k = 0; k < 9; ++k) gr[u][k] = gbounds[(int64_t)(g + u) * kGroupRow + k];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-            const bool keep = live && !F32::group_reject(gr[u], flane32, Tup32);
-            if (__ballot(keep) != 0) { if (threadIdx.x == 0) out[cnt] = g + u; ++cnt; }
+            const unsigned long long bm = __ballot(live && !F32::group_reject(gr[u], flane32, Tup32));
+            if (threadIdx.x == 0) keep[(int64_t)(g + u) * W + w] = bm;
         }
     }
     for (; g < g1; ++g) {
         float gr[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) gr[k] = gbounds[(int64_t)g * kGroupRow + k];
-        const bool keep = live && !F32::group_reject(gr, flane32, Tup32);
-        if (__ballot(keep) != 0) { if (threadIdx.x == 0) out[cnt] = g; ++cnt; }
+        const unsigned long long bm = __ballot(live && !F32::group_reject(gr, flane32, Tup32));
+        if (threadIdx.x == 0) keep[(int64_t)g * W + w] = bm;
     }
-    if (threadIdx.x == 0) counts[w * kCullSegs + seg] = cnt;
 }
 
+constexpr int kGroupWaves = 4;  // groups per workgroup of the group-major kernel
+
 template <int MT, bool MASK>
-__global__ __launch_bounds__(64) void score_survivor_kernel(
-    const double* __restrict__ pts, int64_t n, const double* __restrict__ models, int M, int Mpad,
-    double T2, const double* __restrict__ comp, int has_comp, const float* __restrict__ pts32, double guard32,
-    const int* __restrict__ lists, const int* __restrict__ counts, int gps,
-    unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
+__global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
+    const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
+    const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
+    const float* __restrict__ hyp32, double qscale, unsigned long long* __restrict__ acc /* [3][Mpad]: count, value, shared */,
+    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
 {
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
-    const int w = (int)blockIdx.x, b = (int)blockIdx.y, lane = (int)threadIdx.x;
-    const int m = w * 64 + lane;
-    const bool live = m < M;
-    double mdl[R::P];
+    using LaneT = typename F32::Lane;
+    const int lane = (int)(threadIdx.x & 63);
+    const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kGroupWaves + (int)(threadIdx.x >> 6));
+    if (g >= groups) return;
+    const int64_t j = (int64_t)g * 64 + lane;
+    const bool valid = j < n;
+    const int64_t jj = valid ? j : n - 1;
+    double pt[R::D];
+    float p32[8];
 #pragma unroll
-    for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
-    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    for (int q = 0; q < R::D; ++q) pt[q] = pts[jj * R::D + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p32[q] = pts32[jj * 8 + q];
+    const double cmp = has_comp ? comp[jj] : 0.0;
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
-    // survivor k of this hypothesis wave lives in segment seg(k) = #{segments whose inclusive prefix <= k}
-    const int my_cnt = counts[w * kCullSegs + lane];
-    int incl = my_cnt;
+    for (int w = 0; w < W; ++w) {
+        unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
+        while (todo != 0) {
+            const int h = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int m = w * 64 + h;
+            const LaneT ln = lane_load<LaneT>(hyp32 + (int64_t)m * kHypRow);  // uniform: SGPR operands of the filter
+            const bool cand = valid && !F32::reject(p32, ln, T2d32);
+            if (__ballot(cand) == 0) continue;
+            double mdl[R::P];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const int total = __shfl(incl, 63, 64);
-    const int excl = incl - my_cnt;
-
-    unsigned cnt = 0;
-    double val = 0.0, sh = 0.0;
-    constexpr int kUnroll = 4;
-    for (int k = b; k < total; k += (int)gridDim.y) {
-        // wave-uniform by construction; readfirstlane tells the compiler, so that the point rows stay scalar loads
-        const int seg = __popcll(__ballot(incl <= k));
-        const int off = __builtin_amdgcn_readfirstlane(k - __shfl(excl, seg, 64));
-        const int g = __builtin_amdgcn_readfirstlane(lists[((int64_t)w * kCullSegs + seg) * gps + off]);
-        const int64_t i0 = (int64_t)g * 64, i1 = i0 + 64 < n ? i0 + 64 : n;
-        unsigned long long word = 0;
-        auto step = [&](int64_t i, const double (&pt)[R::D], const float* p32) {
+            for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
+            double sc = 0.0, shv = 0.0;
             bool inl = false;
-            if (live && !F32::reject(p32, flane32, T2d32)) {  // exact path: oracle operation order, no contraction
+            if (cand) {  // exact path: oracle operation order, no contraction
                 const double sq = R::squared(pt, mdl);
-                inl = sq < T2;
+                inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
                 if (inl) {
-                    ++cnt;
-                    const double sc = cv_max(0.0, 1.0 - sq / T2);
-                    val += sc;
-                    if (has_comp) sh += cv_min(comp[i], sc);
+                    sc = cv_max(0.0, 1.0 - sq / T2);      // :94
+                    if (has_comp) shv = cv_min(cmp, sc);  // :115-117
                 }
             }
-            if (MASK) word |= (unsigned long long)(inl ? 1 : 0) << (i & 63);
-        };
-        int64_t i = i0;
-        for (; i + kUnroll <= i1; i += kUnroll) {
-            const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
-            double pt[kUnroll][R::D];
-            float p32[kUnroll][8];
+            const unsigned long long bm = __ballot(inl);
+            if (bm == 0) continue;
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-                for (int q = 0; q < R::D; ++q) pt[u][q] = prow[u * R::D + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) p32[u][q] = pts32[(i + u) * 8 + q];
+            for (int off = 32; off > 0; off >>= 1) {  // fixed tree: the partial of (hypothesis, group) is deterministic
+                sc += __shfl_down(sc, off, 64);
+                shv += __shfl_down(shv, off, 64);
             }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) step(i + u, pt[u], p32[u]);
+            if (lane == 0) {
+                atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
+                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)__double2ll_rn(sc * qscale));
+                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)__double2ll_rn(shv * qscale));
+                if (MASK) masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
+            }
         }
-        for (; i < i1; ++i) {
-            double pt[R::D];
-            float p32[8];
-#pragma unroll
-            for (int q = 0; q < R::D; ++q) pt[q] = pts[i * R::D + q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) p32[q] = pts32[i * 8 + q];
-            step(i, pt, p32);
-        }
-        if (MASK && live) masks[(int64_t)perm[m] * words + g] = word;  // rows start zeroed: culled groups stay 0
     }
-    const int64_t o = (int64_t)b * Mpad + m;
-    pcnt[o] = cnt;
-    pval[o] = val;
-    psh[o] = sh;
+}
+
+__global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long long* __restrict__ acc, int M, int Mpad, double qscale,
+                                                           const int* __restrict__ perm, long long* __restrict__ counts,
+                                                           double* __restrict__ values, double* __restrict__ shared)
+{
+    const int m = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (m >= M) return;
+    const int o = perm[m];  // hypotheses were scored in locality order: results go back to the caller's order
+    counts[o] = (long long)acc[m];
+    values[o] = (double)(long long)acc[(int64_t)Mpad + m] / qscale;
+    shared[o] = (double)(long long)acc[2 * (int64_t)Mpad + m] / qscale;
 }
 
 // ---- filtered variant with deferred exact evaluation ------------------------------------------------
@@ -671,41 +688,39 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     const bool deferred = filt && ctx->score_deferred;
     if constexpr (Filter32<MT>::enabled) {
         if (filt32 && !deferred && ctx->point_sort && ctx->score_cull) {
-            // ---- cull, then score the survivors
+            // ---- cull, then score group-major
             const int groups = (int)((ctx->n + 63) / 64);
             const int gps = (groups + kCullSegs - 1) / kCullSegs;
-            const int waves = ctx->Mpad / 64;
-            PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)waves * kCullSegs * gps * sizeof(int)));
-            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)waves * kCullSegs * sizeof(int)));
-            const size_t np = (size_t)kSurvivorSlices * (size_t)ctx->Mpad;
-            PGX_TRY(ensure(ctx, ctx->pcnt, np * sizeof(unsigned)));
-            PGX_TRY(ensure(ctx, ctx->pval, np * sizeof(double)));
-            PGX_TRY(ensure(ctx, ctx->psh, np * sizeof(double)));
-            hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)waves, kCullSegs), dim3(64), 0, ctx->stream,
-                               ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps,
-                               ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>());
+            const int W = ctx->Mpad / 64;
+            PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)groups * W * sizeof(unsigned long long)));             // keep[g][w]
+            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + 3 * sizeof(long long))));  // hyp32 | acc
+            float* hyp32 = ctx->cull_counts.as<float>();
+            unsigned long long* acc = (unsigned long long*)(ctx->cull_counts.as<char>() + (size_t)ctx->Mpad * kHypRow * sizeof(float));
+            int lg = 0;
+            while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
+            const double qscale = std::ldexp(1.0, 62 - lg);  // every sum is <= n < 2^lg
+            PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
+            hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)W, kCullSegs), dim3(64), 0, ctx->stream,
+                               ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
+                               ctx->cull_lists.as<unsigned long long>(), hyp32);
             PGX_HIP(ctx, hipGetLastError());
+            const unsigned gblocks = (unsigned)((groups + kGroupWaves - 1) / kGroupWaves);
             if (want_masks) {
                 PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
-                hipLaunchKernelGGL((score_survivor_kernel<MT, true>), dim3((unsigned)waves, kSurvivorSlices), dim3(64), 0, ctx->stream,
-                                   ctx->pts_s.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
-                                   ctx->comp_s.as<double>(), has_compound, ctx->pts32_s.as<float>(), guard32,
-                                   ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>(), gps, ctx->pcnt.as<unsigned>(),
-                                   ctx->pval.as<double>(), ctx->psh.as<double>(), ctx->masks_s.as<unsigned long long>(),
-                                   ctx->words, ctx->perm.as<int>());
+                hipLaunchKernelGGL((score_group_kernel<MT, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
+                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>());
             } else {
-                hipLaunchKernelGGL((score_survivor_kernel<MT, false>), dim3((unsigned)waves, kSurvivorSlices), dim3(64), 0, ctx->stream,
-                                   ctx->pts_s.as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
-                                   ctx->comp_s.as<double>(), has_compound, ctx->pts32_s.as<float>(), guard32,
-                                   ctx->cull_lists.as<int>(), ctx->cull_counts.as<int>(), gps, ctx->pcnt.as<unsigned>(),
-                                   ctx->pval.as<double>(), ctx->psh.as<double>(), (unsigned long long*)nullptr,
-                                   ctx->words, ctx->perm.as<int>());
+                hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
+                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>());
             }
             PGX_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
-                               ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                               kSurvivorSlices, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
-                               ctx->values.as<double>(), ctx->shared.as<double>());
+            hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
+                               ctx->Mpad, qscale, ctx->perm.as<int>(), ctx->counts.as<long long>(), ctx->values.as<double>(),
+                               ctx->shared.as<double>());
             PGX_HIP(ctx, hipGetLastError());
             return PGX_OK;
         }
