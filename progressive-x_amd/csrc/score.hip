@@ -446,21 +446,38 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     for (int q = 0; q < 8; ++q) p32[q] = pts32[jj * 8 + q];
     const double cmp = has_comp ? comp[jj] : 0.0;
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
+    // The constants of a word's surviving hypotheses are staged in LDS by the lanes that own them (one vector-load round
+    // trip per 64 hypotheses) and read back as broadcasts: one scalar-memory round trip per hypothesis (~1 us when the
+    // scalar cache misses) made the kernel latency-bound (measured: 37 % VALU utilisation, 471 us).
+    // The f32 constants of a word's surviving hypotheses are staged in LDS by the lanes that own them (one vector-load
+    // round trip per 64 hypotheses) and read back as broadcasts: one scalar-memory round trip per hypothesis (~1 us
+    // when the scalar cache misses) left the kernel latency-bound (37 % VALU utilisation).  The f64 model is fetched
+    // only by pairs that have candidates (staging it as well costs occupancy or compaction work: measured slower).
+    __shared__ float s_h32[kGroupWaves][64][kHypRow];
+    const int wv = (int)(threadIdx.x >> 6);
     for (int w = 0; w < W; ++w) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
+        if (todo == 0) continue;
+        __builtin_amdgcn_wave_barrier();  // the previous word's reads are done (LDS ops of a wave execute in order)
+        if ((todo >> lane) & 1ull) {
+            const int64_t ml = (int64_t)w * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < kHypRow; ++k) s_h32[wv][lane][k] = hyp32[ml * kHypRow + k];
+        }
+        __builtin_amdgcn_wave_barrier();
         while (todo != 0) {
             const int h = __builtin_ctzll(todo);
             todo &= todo - 1;
             const int m = w * 64 + h;
-            const LaneT ln = lane_load<LaneT>(hyp32 + (int64_t)m * kHypRow);  // uniform: SGPR operands of the filter
+            const LaneT ln = lane_load<LaneT>(&s_h32[wv][h][0]);  // same address in every lane: LDS broadcast
             const bool cand = valid && !F32::reject(p32, ln, T2d32);
             if (__ballot(cand) == 0) continue;
-            double mdl[R::P];
-#pragma unroll
-            for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
             double sc = 0.0, shv = 0.0;
             bool inl = false;
             if (cand) {  // exact path: oracle operation order, no contraction
+                double mdl[R::P];
+#pragma unroll
+                for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
                 const double sq = R::squared(pt, mdl);
                 inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
                 if (inl) {
