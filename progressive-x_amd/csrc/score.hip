@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
 //                       bit-reproducible although the accumulation order is not fixed.  q = 62 - ceil(log2 n): the
 //                       quantisation error of a sum is < (#groups with inliers) * 2^-(q+1), ~1e-13 relative.
 //   score_finish_kernel accumulators -> counts / values / shared in the caller's hypothesis order.
-constexpr int kCullSegs = 64;  // segments of groups per hypothesis wave in the cull kernel
+constexpr int kCullSegs = 256;  // segments of groups per hypothesis wave in the cull kernel (8192 waves at M = 2048)
 constexpr int kHypRow = 20;    // floats per hypothesis: Filter32<MT>::Lane, padded
 
 template <class LaneT>
