@@ -122,6 +122,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
+    if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -348,21 +349,29 @@ int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values,
     CTX_GUARD(ctx);
     const int M = ctx->M;
     if (M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: nothing launched");
-    std::vector<double> v((size_t)M), s((size_t)M);
-    std::vector<int64_t> c((size_t)M);
-    PGX_HIP(ctx, hipMemcpyAsync(c.data(), ctx->counts.p, (size_t)M * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(v.data(), ctx->values.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(s.data(), ctx->shared.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t need = (size_t)M * 24;
+    if (ctx->h_res_cap < need) {
+        if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+        ctx->h_res = nullptr; ctx->h_res_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&ctx->h_res, need * 2, hipHostMallocDefault));
+        ctx->h_res_cap = need * 2;
+    }
+    int64_t* c = (int64_t*)ctx->h_res;
+    double* v = (double*)ctx->h_res + M;
+    double* s = (double*)ctx->h_res + 2 * (size_t)M;
+    PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, (size_t)M * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(v, ctx->values.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(s, ctx->shared.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (masks) {
         if (!ctx->have_masks) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: masks were not requested at launch");
         PGX_HIP(ctx, hipMemcpyAsync(masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t),
                                     hipMemcpyDeviceToHost, ctx->stream));
     }
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts) memcpy(counts, c.data(), (size_t)M * sizeof(int64_t));
-    if (values) memcpy(values, v.data(), (size_t)M * sizeof(double));
-    if (shared) memcpy(shared, s.data(), (size_t)M * sizeof(double));
-    finish_scores(M, ctx->score_has_compound, exponent, v.data(), s.data(), scores);
+    if (counts) memcpy(counts, c, (size_t)M * sizeof(int64_t));
+    if (values) memcpy(values, v, (size_t)M * sizeof(double));
+    if (shared) memcpy(shared, s, (size_t)M * sizeof(double));
+    finish_scores(M, ctx->score_has_compound, exponent, v, s, scores);
     return PGX_OK;
 }
 

@@ -81,6 +81,8 @@ struct pgx_ctx {
     pgx::MaxflowState* mf = nullptr;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
+    void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
+    size_t h_res_cap = 0;
     pgx::DevBuf fit_scratch;  // pgx_gram: partials | result | counters | index list | weights
 
     pgx::CommState* comm = nullptr;
