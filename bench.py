@@ -23,10 +23,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "progressive-x_amd"))
 
-# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v4_xcd.txt):
-# FETCH_SIZE 79137.5 KiB x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE 78160 KiB
-# (the writes are the per-chunk partial sums of the over-decomposed grid: 2048 chunks x 2048 hypotheses x 20 B)
-PMC_TRAFFIC_DEFAULT = int((2 * 79137.5 + 78160.0) * 1024)
+# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v5_groupmajor.txt),
+# summed over the three kernels of one launch (cull, group-major score, finish): FETCH_SIZE 45259.3 + 5998.4 + 40.5 KiB,
+# x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM), + WRITE_SIZE 32581.3 + 15789.1 + 158.8 KiB
+# (the writes are the survivor bit masks of the cull pass and the accumulator atomics)
+PMC_TRAFFIC_DEFAULT = int((2 * (45259.3 + 5998.4 + 40.5) + 32581.3 + 15789.1 + 158.8) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
 FLOPS_PER_PAIR_PNP = 25        # 9 mul + 9 add (3x4 projection) + 2 div + 2 sub + 2 mul + 1 add
@@ -151,14 +152,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_DEFAULT if (n == 1000000 and M == 2048) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v4_xcd.txt",
-                         "kernel": "pgx::score_kernel<PnP> (+ score_reduce_kernel)", "kernel_ms": k_ms,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v5_groupmajor.txt",
+                         "kernel": "pgx::score_group_kernel<PnP> (+ score_cull_kernel, score_finish_kernel)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "FP64-VALU bound by construction (~0.02 algorithmic B/pair); see valu_fp64"},
-            "valu_fp64": {"achieved_tflops": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12,
+                         "note": "arithmetic bound by construction (~0.04 algorithmic B/pair); 93 % of the (hypothesis, 64-point group) pairs are culled by a bound test, see valu_fp64"},
+            "valu_fp64": {"effective_tflops": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12,
                           "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS, "peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
-                          "frac_of_no_fma_peak": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS / 2),
-                          "flops_per_pair": FLOPS_PER_PAIR_PNP, "pairs_per_launch": pairs},
+                          "effective_over_no_fma_peak": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS / 2),
+                          "flops_per_pair": FLOPS_PER_PAIR_PNP, "pairs_per_launch": pairs,
+                          "note": "effective = what evaluating every pair exactly would cost; the kernels evaluate ~7 % of the "
+                                  "pairs with the f32 pre-filter and ~0.3 % exactly (DESIGN.md 5.2c), so the ratio may exceed 1"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pts, hyps, T2, comp)
