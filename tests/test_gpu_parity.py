@@ -159,6 +159,42 @@ def test_score_filter_adversarial(gpu_ctx, oracle, name):
     assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["masks"], ref["masks"])
 
 
+@pytest.mark.parametrize("name", ["pnp", "homography"])
+def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
+    # The group-major path (Morton-sorted points, bound test per 64-point group, fixed-point accumulation) against the
+    # plain chunked kernel on data built to stress the bound: wide magnitude ranges, duplicated points, groups of one,
+    # garbage hypotheses (points behind the camera, vanishing denominators), tiny and huge thresholds.
+    monkeypatch.setenv("PGX_NO_GROUP", "1")
+    plain = _lib.Context(0)
+    monkeypatch.delenv("PGX_NO_GROUP")
+    culled = _lib.Context(0)
+    rng = np.random.default_rng(77)
+    try:
+        for trial in range(12):
+            n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 30011]))
+            mt, pts, models, thr = make_case(name, n, 96, seed=1000 + trial)
+            if trial % 3 == 1:                       # clustered duplicates: zero-radius groups
+                pts = pts[rng.integers(0, max(1, n // 50), n)]
+            if trial % 4 == 2:                       # wide magnitude range in the multiplied coordinates
+                pts = pts.copy()
+                pts[:, -3 if name == "pnp" else 0] *= rng.choice([1e-3, 1.0, 1e3], n)
+            garbage = rng.normal(0, 1, models.shape) * rng.choice([1e-3, 1.0, 1e2], (models.shape[0], 1))
+            hyps = np.vstack([models, garbage, models * (1 + 1e-9 * rng.normal(0, 1, models.shape))])
+            T2 = (9.0 / 4.0 * thr * thr) * float(rng.choice([1e-6, 1.0, 1.0, 25.0, 1e6]))
+            for ctx in (plain, culled):
+                ctx.set_points(mt, pts)
+            a = plain.score(hyps, T2, want_masks=True)
+            b = culled.score(hyps, T2, want_masks=True)
+            assert np.array_equal(a["counts"], b["counts"]), f"trial {trial}: counts differ"
+            assert np.array_equal(a["masks"], b["masks"]), f"trial {trial}: masks differ"
+            assert _rel(a["values"], b["values"]) < REL
+            ref = oracle.score(mt, pts, hyps, T2)
+            assert np.array_equal(b["counts"], ref["counts"])
+    finally:
+        plain.close()
+        culled.close()
+
+
 def test_score_early_exit_predicate_is_order_free(oracle):
     # scoring_function_with_compound_model.h:105-106 fires iff count + 1 < best: pure function of the full count,
     # which is why the batched kernel needs no point ordering (checked on the oracle itself; host logic applies it).
