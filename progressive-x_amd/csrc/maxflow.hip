@@ -47,9 +47,33 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_init(MfView v, int, int)
     if (u < v.n) mf_body_init_site(v, u);
 }
 
+// Workgroup-local staging of BFS appends (see mf_bfs_label): an LDS list, moved to the level's segment of `order` with one
+// atomic on the level counter per flush.  All threads of the workgroup call stage_flush.
+constexpr int kStageCap = 4096;
+
+struct Stage {
+    int list[kStageCap];
+    int count;
+    int base;
+};
+
+__device__ __forceinline__ void stage_flush(const MfView& v, Stage& st, int k)
+{
+    __syncthreads();
+    const int n = st.count;
+    if (n > 0) {
+        if (threadIdx.x == 0) st.base = mf_level_base(v, k) + atomicAdd(&v.fcount[k % 3], n);
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) v.order[st.base + i] = st.list[i];
+        __syncthreads();
+        if (threadIdx.x == 0) st.count = 0;
+    }
+    __syncthreads();
+}
+
 // Kernels whose per-site body reports a boolean and/or accumulates per-label minima: both are aggregated per block in
 // LDS and flushed with at most (L + 1) global operations per block.
-enum { kBfsInit = 0, kCountActive = 2, kApply = 4 };
+enum { kCountActive = 2, kApply = 4 };
 
 template <int WHAT>
 __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
@@ -60,15 +84,11 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
     bool r = false;
     if (u < v.n) {
-        if (WHAT == kBfsInit) r = mf_body_bfs_init(v, u, s_min);
-        else if (WHAT == kCountActive) r = mf_body_count_active(v, u);
+        if (WHAT == kCountActive) r = mf_body_count_active(v, u);
         else if (WHAT == kApply) r = mf_body_apply(v, u);
     }
     const int count = __syncthreads_count(r ? 1 : 0);
-    if (WHAT == kBfsInit) {
-        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
-        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (WHAT == kCountActive) {
+    if (WHAT == kCountActive) {
         if (threadIdx.x == 0 && count > 0) {
             __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&v.flags[3], count);  // number of active sites after this global relabel (diagnostics)
@@ -235,10 +255,30 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply(const long long* __res
 // ~5 dependent gathers per arc (measured ~45 us per level for frontiers of a few thousand sites).
 constexpr int kBfsLevelBlocks = 256;
 
-__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k)
+// level 1: every site with residual capacity to t
+__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_init(MfView v, int, int)
 {
     __shared__ int s_min[kMfMaxLabels];
+    __shared__ Stage s_stage;
     if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    if (threadIdx.x == 0) s_stage.count = 0;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    bool r = false;
+    if (u < v.n) r = mf_body_bfs_init(v, u, s_min, &s_stage.count, s_stage.list);
+    stage_flush(v, s_stage, 1);
+    const int count = __syncthreads_count(r ? 1 : 0);
+    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// stage_margin: the most one pass can append (256 threads x arcs per thread); 0 = append straight to `order`
+__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int stage_margin)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    __shared__ Stage s_stage;
+    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    if (threadIdx.x == 0) s_stage.count = 0;
     __syncthreads();
     bool r = false;
     const int F = v.fcount[(k - 1) % 3];
@@ -246,22 +286,35 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k)
     const int sub = (int)(threadIdx.x & 7);
     const int64_t nthreads = (int64_t)gridDim.x * kMfBlock;
     const int64_t gtid = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
-    for (int64_t q = gtid >> 3; v.off != nullptr && q < F; q += nthreads >> 3) {
-        const int w = fin[q];
-        for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
-            const int uu = v.idx[a];
-            const bool want = v.labels[uu] != v.alpha &&
-                              __hip_atomic_load(&v.cap[v.rev[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
-                              __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
-            r |= mf_bfs_label(v, uu, k, s_min, want);
+    int* const scnt = stage_margin > 0 ? &s_stage.count : nullptr;
+    int* const slist = stage_margin > 0 ? s_stage.list : nullptr;
+    const int full = kStageCap - (stage_margin > 256 ? stage_margin : 256);
+    // workgroup-uniform loops (stage_flush has barriers): every pass handles nthreads / 8 frontier sites
+    for (int64_t q0 = 0; v.off != nullptr && q0 < F; q0 += nthreads >> 3) {
+        const int64_t q = q0 + (gtid >> 3);
+        if (q < F) {
+            const int w = fin[q];
+            for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
+                const int uu = v.idx[a];
+                const bool want = v.labels[uu] != v.alpha &&
+                                  __hip_atomic_load(&v.cap[v.rev[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                                  __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
+                r |= mf_bfs_label(v, uu, k, s_min, want, -1, scnt, slist);
+            }
         }
+        if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k);
     }
     const int ev = mf_bfs_hub_events(v, k);
     if (ev != 0) {
-        const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole waves call the aggregated append
-        for (int64_t u = gtid; u < rounded; u += nthreads)
-            r |= u < v.n ? mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, s_min) : mf_bfs_label(v, 0, k, s_min, false);
+        const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole workgroups iterate together
+        for (int64_t u0 = (int64_t)blockIdx.x * kMfBlock; u0 < rounded; u0 += nthreads) {
+            const int64_t u = u0 + threadIdx.x;
+            r |= u < v.n ? mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, s_min, scnt, slist)
+                         : mf_bfs_label(v, 0, k, s_min, false, -1, scnt, slist);
+            if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k);
+        }
     }
+    stage_flush(v, s_stage, k);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         v.lvl[k] = mf_level_base(v, k);
         v.fcount[(k + 1) % 3] = 0;  // slot of the level after this one
@@ -368,11 +421,14 @@ struct HipBackend {
     int read_count(const MfView& v, int l) { return read_int(v.cnt + l); }
     void init_sites(const MfView& v) { site(mf_k_init, v); }
     void bfs_reset(const MfView& v) { single(v, 1); }
-    void bfs_init(const MfView& v) { site(mf_k_agg<kBfsInit>, v); }
+    void bfs_init(const MfView& v) { site(mf_k_bfs_init, v); }
     void bfs_level(const MfView& v, int k)
     {
         const unsigned g = blocks < (unsigned)kBfsLevelBlocks ? blocks : (unsigned)kBfsLevelBlocks;
-        hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k);
+        // staging needs room for everything one pass can append: 256 threads x ceil(max degree / 8) arcs each
+        const int per_pass = kMfBlock * ((ctx->max_degree + 7) / 8);
+        const int margin = per_pass <= kStageCap / 2 ? (per_pass > 0 ? per_pass : kMfBlock) : 0;
+        hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k, margin);
         check();
     }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
