@@ -572,3 +572,48 @@ double pgxo_residual_sum(int model_type, const double *pts, int64_t n, const dou
         if (labels[i] == label) s += pgxo_residual(model_type, pts + i * d, model);
     return s;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Minimal solvers (first slice).  models_out[s*3 .. s*3+2]; NaN for a degenerate sample.
+ *   vanishing point from two segments: /root/reference/src/pyprogressivex/include/solver_vanishing_point_two_lines.h
+ *     :174-179 l_i = endpoint_0 x endpoint_1 (homogeneous, w = 1), :180-182 v = l_0 x l_1, :123-131 vec_norm,
+ *     cross product formula :106-121.
+ *   2D line through two points: Default2DLineEstimator's solver is absent upstream [U-4]; restated as the unit normal
+ *     (-dy, dx)/|d| with offset c = -(n . a).
+ * ---------------------------------------------------------------------------------------- */
+static void cross3(double a1, double b1, double c1, double a2, double b2, double c2, double *o)
+{
+    o[0] = b1 * c2 - c1 * b2;
+    o[1] = -(a1 * c2 - c1 * a2);
+    o[2] = a1 * b2 - b1 * a2;
+}
+
+int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out)
+{
+    if (model_type != PGXO_LINE2D && model_type != PGXO_VANISHING_POINT) return -1;
+    for (int s = 0; s < S; ++s) {
+        const int32_t i0 = samples[2 * s], i1 = samples[2 * s + 1];
+        double *m = models_out + (size_t)s * 3;
+        m[0] = m[1] = m[2] = NAN;
+        if (i0 < 0 || i1 < 0 || i0 >= n || i1 >= n) continue;
+        if (model_type == PGXO_LINE2D) {
+            const double ax = pts[(size_t)i0 * 2], ay = pts[(size_t)i0 * 2 + 1];
+            const double dx = pts[(size_t)i1 * 2] - ax, dy = pts[(size_t)i1 * 2 + 1] - ay;
+            const double ln = sqrt(dx * dx + dy * dy);
+            if (ln > 0.0) {
+                m[0] = -dy / ln;
+                m[1] = dx / ln;
+                m[2] = -(m[0] * ax + m[1] * ay);
+            }
+        } else {
+            const double *a = pts + (size_t)i0 * 4, *b = pts + (size_t)i1 * 4;
+            double l0[3], l1[3], v[3];
+            cross3(a[0], a[1], 1.0, a[2], a[3], 1.0, l0);
+            cross3(b[0], b[1], 1.0, b[2], b[3], 1.0, l1);
+            cross3(l0[0], l0[1], l0[2], l1[0], l1[1], l1[2], v);
+            const double ln = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            if (ln > 0.0) { m[0] = v[0] / ln; m[1] = v[1] / ln; m[2] = v[2] / ln; }
+        }
+    }
+    return 0;
+}

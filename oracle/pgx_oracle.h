@@ -93,6 +93,9 @@ void pgxo_bucket(const int32_t *labels, int64_t n, int L, int64_t *counts, int32
 double pgxo_residual_sum(int model_type, const double *pts, int64_t n, const double *model,
                          const int32_t *labels, int label);
 
+/* minimal solvers: 2-point line, 2-segment vanishing point; NaN model for a degenerate sample */
+int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out);
+
 #ifdef __cplusplus
 }
 #endif

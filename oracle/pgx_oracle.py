@@ -215,6 +215,17 @@ def residual_sum(model_type, pts, model, labels, label):
                                    _p(model, C.c_double), _p(labels, C.c_int32), C.c_int(label))
 
 
+def solve_minimal(model_type, pts, samples):
+    """[S,3] models of the 2-point line / 2-segment vanishing point solvers (NaN rows for degenerate samples)"""
+    pts = _f64(pts); samples = _i32(samples)
+    out = np.empty((samples.shape[0], 3), dtype=np.float64)
+    r = lib().pgxo_solve_minimal(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]), _p(samples, C.c_int32),
+                                 C.c_int(samples.shape[0]), _p(out, C.c_double))
+    if r != 0:
+        raise ValueError("solve_minimal: model type without a device solver")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # neighbourhood graph (SURVEY 8f rank 2) — numpy restatement of the deterministic lists the build defines for
 # FlannNeighborhoodGraph [U-7] (/root/reference/src/pyprogressivex/src/progressivex_python.cpp:104,207,339,458,571) and of

@@ -325,6 +325,12 @@ int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
     return PGX_OK;
 }
 
+int pgx_solve_minimal(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out)
+{
+    CTX_GUARD(ctx);
+    return solve_minimal_launch(ctx, samples, S, models_out);
+}
+
 int pgx_score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
 {
     CTX_GUARD(ctx);

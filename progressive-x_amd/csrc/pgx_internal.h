@@ -124,6 +124,7 @@ int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
+int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out);
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);

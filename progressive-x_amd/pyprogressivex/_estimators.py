@@ -17,6 +17,7 @@ class Estimator:
     model_type = None
     sample_size = 0
     nonminimal_sample_size = 0
+    device_minimal = False     # True: ctx.solve_minimal(samples) replaces minimal() in the proposal engine
     rows_per_model = 1       # rows of the returned model array per instance (3 for 3x3 / 3x4 matrices)
     cols = 3
 
@@ -44,6 +45,7 @@ class LineEstimator(Estimator):
     model_type = _lib.LINE2D
     sample_size = 2
     nonminimal_sample_size = 2
+    device_minimal = True      # pgx_solve_minimal generates the hypotheses on the GPU (same formulas as minimal())
 
     def minimal(self, pts, samples):
         a, b = pts[samples[:, 0]], pts[samples[:, 1]]
@@ -73,6 +75,7 @@ class VanishingPointEstimator(Estimator):
     model_type = _lib.VANISHING_POINT
     sample_size = 2            # solver_vanishing_point_two_lines.h:70-73
     nonminimal_sample_size = 2  # the same solver class is used for both (progressivex_python.cpp:343-346)
+    device_minimal = True      # pgx_solve_minimal generates the hypotheses on the GPU (same formulas as minimal())
 
     @staticmethod
     def _cross(a1, b1, c1, a2, b2, c2):  # :106-121

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
-    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram",
+    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
@@ -286,6 +286,19 @@ class Context:
         self._ck(self._lib.pgx_graph_fetch(self._h, _ptr(off, C.c_int32), _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)),
                  "pgx_graph_fetch")
         return off, idx[:arcs.value], mult[:arcs.value]
+
+    def solve_minimal(self, samples, fetch=True):
+        """pgx_solve_minimal: hypotheses of the 2-point line / 2-segment vanishing point solvers, generated from the
+        resident points straight into the resident hypothesis buffer (score_launch can follow).  NaN rows mark
+        degenerate samples."""
+        smp = _i32(samples)
+        if smp.ndim != 2 or smp.shape[1] != 2:
+            raise ValueError("samples must be [S,2]")
+        out = np.empty((smp.shape[0], 3), dtype=np.float64) if fetch else None
+        self._ck(self._lib.pgx_solve_minimal(self._h, _ptr(smp, C.c_int32), C.c_int(smp.shape[0]), _ptr(out, C.c_double)),
+                 "pgx_solve_minimal")
+        self.M = smp.shape[0]
+        return out
 
     def gram(self, kind, sel, params=None, weights=None, wpow=2):
         """pgx_gram: weighted Gram matrix of the design rows of the selected resident points.

@@ -164,10 +164,19 @@ class ProposalEngine:
         samples = self.sampler.draw(int(s.max_iteration_number), est.sample_size)
         if len(samples) == 0:
             return None
-        models, src = est.minimal(self.pts, samples)
-        if len(models) == 0:
-            return dict(model=None, inliers=np.zeros(0, np.int64), iterations=len(samples))
-        table = self._score(models, T2, has_compound, exponent)
+        on_device = est.device_minimal and (self.exchange is None or self.exchange.world == 1)
+        if on_device:
+            # hypotheses generated on the GPU from the resident points and scored where they are (no model upload);
+            # a degenerate sample is a NaN model: never an inlier, never the winner
+            models = self.ctx.solve_minimal(samples)
+            src = np.arange(len(samples), dtype=np.int64)
+            self.ctx.score_launch(T2, has_compound=has_compound)
+            table = self.ctx.score_fetch(exponent)
+        else:
+            models, src = est.minimal(self.pts, samples)
+            if len(models) == 0:
+                return dict(model=None, inliers=np.zeros(0, np.int64), iterations=len(samples))
+            table = self._score(models, T2, has_compound, exponent)
         best, iters, history = replay_sequential(table["counts"], table["scores"], src, self.n, est.sample_size,
                                                  s.confidence, s.max_iteration_number)
         if best < 0:

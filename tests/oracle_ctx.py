@@ -75,6 +75,21 @@ class OracleContext:
     def set_graph(self, off, idx, mult):
         self.graph = (np.asarray(off, np.int32), np.asarray(idx, np.int32), np.asarray(mult, np.int32))
 
+    def solve_minimal(self, samples, fetch=True):
+        self.models = O.solve_minimal(self.model_type, self.pts, samples)
+        self.M = len(self.models)
+        return self.models.copy() if fetch else None
+
+    def score_launch(self, T2, has_compound=False, want_masks=False):
+        self._launched = O.score(self.model_type, self.pts, self.models, T2, compound=self.comp, has_compound=has_compound,
+                                 exponent=2, want_masks=want_masks)
+        self._launch_has_compound = has_compound
+
+    def score_fetch(self, exponent=2, want_masks=False):
+        r = dict(self._launched)
+        r["scores"] = r["values"] - np.power(r["shared"], float(exponent)) if self._launch_has_compound else r["values"].copy()
+        return r
+
     def gram(self, kind, sel, params=None, weights=None, wpow=2):
         index = np.asarray(sel[1], dtype=np.int64) if sel[0] == "index" else np.nonzero(self.labels == int(sel[1]))[0]
         return O.gram(kind, self.pts, index, params=params, weights=weights, wpow=wpow)

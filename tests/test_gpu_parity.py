@@ -424,6 +424,42 @@ def test_graph_build_error_paths(gpu_ctx):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f rank 1 (first slice): minimal solvers on the GPU — bit-exact models, then scored where they are
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["line", "vanishing_point"])
+def test_solve_minimal_matches_oracle_and_scores_in_place(gpu_ctx, oracle, name):
+    mt, pts, models, thr = make_case(name, 5000, 4, seed=9)
+    rng = np.random.default_rng(4)
+    samples = rng.integers(0, 5000, (3000, 2)).astype(np.int32)
+    samples[:40, 1] = samples[:40, 0]                      # degenerate: the same point / segment twice
+    gpu_ctx.set_points(mt, pts)
+    got = gpu_ctx.solve_minimal(samples)
+    ref = oracle.solve_minimal(mt, pts, samples)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[:40]).all()
+    ok = ~np.isnan(ref[:, 0])
+    assert np.array_equal(got[ok], ref[ok]), "generated hypotheses must be bit-identical to the oracle's"
+    T2 = 9.0 / 4.0 * thr * thr
+    gpu_ctx.score_launch(T2)                              # scores the resident, device-generated batch
+    a = gpu_ctx.score_fetch()
+    b = oracle.score(mt, pts, np.where(np.isnan(ref), np.nan, ref), T2)
+    assert np.array_equal(a["counts"], b["counts"]) and a["counts"][:40].max() == 0
+    assert _rel(a["values"], b["values"]) < REL
+    up = gpu_ctx.score(ref[ok], T2)                       # the same models through the upload path
+    assert np.array_equal(up["counts"], a["counts"][ok])
+
+
+def test_solve_minimal_error_paths(gpu_ctx):
+    mt, pts, models, thr = make_case("homography", 100, 1, seed=1)
+    gpu_ctx.set_points(mt, pts)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.solve_minimal(np.zeros((4, 2), np.int32))          # no device solver for homographies yet
+    mt, pts, models, thr = make_case("line", 100, 1, seed=1)
+    gpu_ctx.set_points(mt, pts)
+    out = gpu_ctx.solve_minimal(np.array([[0, 1], [5, 100], [-1, 2]], np.int32))
+    assert np.isfinite(out[0]).all() and np.isnan(out[1]).all() and np.isnan(out[2]).all()   # out-of-range index -> no model
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # a9: Gram pass of the non-minimal refits — floating-point sums, 1e-9 relative to the matrix scale
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", list(MODEL_CASES))

@@ -253,3 +253,23 @@ def test_golden_expansion(oracle):
     lab, e, cyc = oracle.expansion(g["exp_Dq"], graph, int(g["exp_lq"][0]), int(g["exp_hq"][0]),
                                    np.zeros(400, np.int32))
     assert np.array_equal(lab, g["exp_labels"]) and e == int(g["exp_energy"][0]) and cyc == int(g["exp_cycles"][0])
+
+
+def test_minimal_solvers_agree_with_the_host_formulas():
+    """oracle C restatement of the 2-point line / 2-segment vanishing point solvers vs the numpy estimators"""
+    import pgx_oracle as O
+    from pyprogressivex import _estimators, datasets
+    rng = np.random.default_rng(0)
+    pts, _, _ = datasets.make_lines(seed=2)
+    smp = rng.integers(0, len(pts), (500, 2)).astype(np.int32)
+    smp[:10, 1] = smp[:10, 0]
+    ref, src = _estimators.LineEstimator().minimal(pts, smp)
+    got = O.solve_minimal(O.LINE2D, pts, smp)
+    assert np.isnan(got[:10]).all() and np.array_equal(np.nonzero(~np.isnan(got[:, 0]))[0], src)
+    assert np.abs(got[src] - ref).max() < 1e-12
+    segs, _, _ = datasets.make_vanishing_points(n_inliers=600, n_vps=3, n_outliers=200, seed=1)
+    smp = rng.integers(0, len(segs), (500, 2)).astype(np.int32)
+    ref, src = _estimators.VanishingPointEstimator().minimal(segs, smp)
+    got = O.solve_minimal(O.VANISHING_POINT, segs, smp)
+    assert np.array_equal(np.nonzero(~np.isnan(got[:, 0]))[0], src)
+    assert np.abs(got[src] - ref).max() < 1e-12
