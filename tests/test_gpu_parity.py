@@ -407,6 +407,28 @@ def test_graph_build_c4_size_properties(gpu_ctx, oracle):
             assert m == int(j in mine) + int(i in olists[j])
 
 
+def test_next_rows_against_committed_vectors(gpu_ctx):
+    # the GPU against tests/golden/kat_next_v1.npz directly (no oracle in the loop)
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_next_v1.npz"))
+    for d in (2, 4, 5):
+        for tag, kind, radius, k in (("ball", _lib.GRAPH_KNN_IN_BALL, 6.0, 5), ("knn", _lib.GRAPH_KNN, 0.0, 8)):
+            got = gpu_ctx.graph_build(g[f"g{d}_pts"], kind, radius=radius, k=k)
+            for name, a in zip(("off", "idx", "mult"), got):
+                assert np.array_equal(a, g[f"g{d}_{tag}_{name}"]), (d, tag, name)
+    for name in ("line", "vanishing_point"):
+        gpu_ctx.set_points(MODEL_CASES[name], g[f"s_{name}_pts"])
+        assert np.array_equal(gpu_ctx.solve_minimal(g[f"s_{name}_samples"]), g[f"s_{name}_models"], equal_nan=True)
+    prm = np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0])
+    for name, kind, p in (("vanishing_point", _lib.GRAM_VP, None), ("homography", _lib.GRAM_DLT_H, prm),
+                          ("fundamental", _lib.GRAM_EPI_F, prm), ("pnp", _lib.GRAM_PNP_GN, "model")):
+        gpu_ctx.set_points(MODEL_CASES[name], g[f"m_{name}_pts"])
+        p = g[f"m_{name}_model"][:12] if isinstance(p, str) else p
+        G, cnt, bad = gpu_ctx.gram(kind, ("index", g[f"m_{name}_idx"]), params=p, weights=g[f"m_{name}_w"], wpow=2)
+        ref = g[f"m_{name}_G{kind}"]
+        assert cnt == 120 and bad == 0 and np.abs(G - ref).max() <= REL * np.abs(ref).max()
+
+
 def test_graph_build_error_paths(gpu_ctx):
     pts = np.random.default_rng(0).random((10, 4))
     with pytest.raises(_lib.PgxError):

@@ -273,3 +273,52 @@ def test_minimal_solvers_agree_with_the_host_formulas():
     got = O.solve_minimal(O.VANISHING_POINT, segs, smp)
     assert np.array_equal(np.nonzero(~np.isnan(got[:, 0]))[0], src)
     assert np.abs(got[src] - ref).max() < 1e-12
+
+
+# ---- committed vectors + hand-checkable cases ------------------------------------------------------------
+GOLDEN_NEXT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_next_v1.npz")
+
+
+def test_golden_next_rows(oracle):
+    g = np.load(GOLDEN_NEXT)
+    for d in (2, 4, 5):
+        for tag, kind, radius, k in (("ball", 0, 6.0, 5), ("knn", 2, 0.0, 8)):
+            got = oracle.graph_build(g[f"g{d}_pts"], kind, radius=radius, k=k)
+            for name, a in zip(("off", "idx", "mult"), got):
+                assert np.array_equal(a, g[f"g{d}_{tag}_{name}"]), (d, tag, name)
+    prm = np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0])
+    for name, kinds in (("line", [(oracle.GRAM_AFFINE, None)]), ("vanishing_point", [(oracle.GRAM_VP, None)]),
+                        ("homography", [(oracle.GRAM_AFFINE, None), (oracle.GRAM_DLT_H, prm)]),
+                        ("fundamental", [(oracle.GRAM_EPI_F, prm)]), ("pnp", [(oracle.GRAM_PNP_GN, "model")])):
+        for kind, p in kinds:
+            p = g[f"m_{name}_model"][:12] if isinstance(p, str) else p
+            G, cnt, bad = oracle.gram(kind, g[f"m_{name}_pts"], g[f"m_{name}_idx"], params=p, weights=g[f"m_{name}_w"], wpow=2)
+            ref = g[f"m_{name}_G{kind}"]
+            assert cnt == 120 and bad == 0 and np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max()
+    for name in ("line", "vanishing_point"):
+        got = oracle.solve_minimal(MODEL_CASES[name], g[f"s_{name}_pts"], g[f"s_{name}_samples"])
+        assert np.array_equal(got, g[f"s_{name}_models"], equal_nan=True)
+
+
+def test_graph_lists_hand_checked(oracle):
+    # five collinear points at 0, 1, 2, 4, 8: the lists can be read off
+    pts = np.array([[0.0, 0], [1, 0], [2, 0], [4, 0], [8, 0]])
+    lists = oracle.graph_lists(pts, 2)
+    assert lists.tolist() == [[1, 2], [0, 2], [1, 0], [2, 1], [3, 2]]     # ties (|2-1| = |2-... ) broken by index
+    ball = oracle.graph_lists(pts, 2, radius=2.0)
+    assert ball.tolist() == [[1, 2], [0, 2], [1, 0], [2, -1], [-1, -1]]   # squared distance <= 4
+    off, idx, mult = oracle.graph_from_lists(ball)
+    assert off.tolist() == [0, 2, 4, 7, 8, 8] and idx.tolist() == [1, 2, 0, 2, 0, 1, 3, 2]
+    assert mult.tolist() == [2, 2, 2, 2, 2, 2, 1, 1]                      # 3 lists 2, 2 does not list 3
+
+
+def test_gram_and_solvers_hand_checked(oracle):
+    pts = np.array([[0.0, 0.0], [2.0, 0.0], [2.0, 2.0]])
+    G, cnt, bad = oracle.gram(oracle.GRAM_AFFINE, pts, [0, 1, 2])
+    assert cnt == 3 and bad == 0 and G.tolist() == [[3.0, 4.0, 2.0], [4.0, 8.0, 4.0], [2.0, 4.0, 4.0]]
+    m = oracle.solve_minimal(oracle.LINE2D, pts, np.array([[0, 1], [1, 2], [0, 0]], np.int32))
+    assert m[0].tolist() == [-0.0, 1.0, -0.0] or m[0].tolist() == [0.0, 1.0, 0.0]   # the x axis: normal (0, 1), c = 0
+    assert m[1].tolist() == [-1.0, 0.0, 2.0] and np.isnan(m[2]).all()              # x = 2
+    segs = np.array([[0.0, 0, 1, 1], [0.0, 2, 1, 1], [0.0, 0, 2, 2]])               # two segments meeting at (1, 1)
+    v = oracle.solve_minimal(oracle.VANISHING_POINT, segs, np.array([[0, 1], [0, 2]], np.int32))
+    assert np.allclose(v[0, :2] / v[0, 2], [1.0, 1.0]) and np.isnan(v[1]).all()     # collinear segments: no model
