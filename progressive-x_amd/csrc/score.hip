@@ -810,16 +810,21 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
     }
     std::vector<uint64_t> kv((size_t)n), tmp((size_t)n);
     const uint32_t qmax = (1u << bits) - 1u;
+    // spread[k][v]: the bits of v placed where coordinate k's bits sit in the interleaved key (bit b -> b*d + d-1-k)
+    std::vector<std::vector<uint32_t>> spread((size_t)d, std::vector<uint32_t>((size_t)qmax + 1));
+    for (int k = 0; k < d; ++k)
+        for (uint32_t v = 0; v <= qmax; ++v) {
+            uint32_t out = 0;
+            for (int b = 0; b < bits; ++b) out |= ((v >> b) & 1u) << (b * d + d - 1 - k);
+            spread[(size_t)k][v] = out;
+        }
     for (int64_t i = 0; i < n; ++i) {
-        uint32_t q[8];
+        uint32_t key = 0;
         for (int k = 0; k < d; ++k) {
             const double t = (points[i * d + k] - lo[(size_t)k]) * inv[(size_t)k];
             uint32_t v = t > 0.0 ? (uint32_t)t : 0u;
-            q[k] = v > qmax ? qmax : v;
+            key |= spread[(size_t)k][v > qmax ? qmax : v];
         }
-        uint32_t key = 0;
-        for (int b = bits - 1; b >= 0; --b)
-            for (int k = 0; k < d; ++k) key = (key << 1) | ((q[k] >> b) & 1u);
         kv[(size_t)i] = ((uint64_t)key << 32) | (uint32_t)i;
     }
     for (int pass = 0; pass < 4; ++pass) {  // LSD radix sort on the key's four bytes (stable: ties keep index order)
