@@ -324,6 +324,21 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
     if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// stranded excess of the sites (maxflow_body.cuh mf_body_stuck_excess): per-workgroup sum, one atomic per workgroup
+__global__ __launch_bounds__(kMfBlock) void mf_k_stuck(MfView v, unsigned long long* __restrict__ out, int)
+{
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    long long e = u < v.n ? mf_body_stuck_excess(v, u) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
+    if ((threadIdx.x & 63) == 0 && e > 0) atomicAdd(&s_sum, (unsigned long long)e);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum > 0) atomicAdd(out, s_sum);
+}
+
 // ---- wave pass: the sites of BFS level k push into level k-1 (maxflow_body.cuh mf_body_wave) -------------------------
 constexpr int kWaveBlocks = 256;
 
@@ -506,6 +521,19 @@ struct HipBackend {
         hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
         check();
     }
+    long long stuck_excess(const MfView& v)
+    {
+        // sites: device reduction into the first word of the (free after the BFS) histogram-sized scratch in `lists`
+        unsigned long long* d_sum = (unsigned long long*)v.hubA_want;  // 3 x 8 B, unused while the alpha hub is gated off
+        hipError_t e = hipMemsetAsync(d_sum, 0, 8, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        hipLaunchKernelGGL(mf_k_stuck, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, d_sum, 0);
+        check();
+        long long total = (long long)peek((const long long*)d_sum);
+        for (int l = 0; l < v.L; ++l)
+            if (peek(v.hub_exists + l)) { const long long he = peek(v.hub_e + l); if (he > 0) total += he; }
+        return total;
+    }
     void apply(const MfView& v) { site(mf_k_agg<kApply>, v); }
 };
 
@@ -634,6 +662,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
+    v.gate = std::getenv("PGX_MF_NO_GATE") ? 0 : 1;
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
     MfTuning tune;

@@ -13,6 +13,12 @@
 //   label costs (Delong et al., IJCV 2012; one "hub" node per label):
 //             beta in use, beta != alpha :  s -> y_beta (h),  y_beta -> p (inf) for every p with l_p = beta
 //             alpha unused               :  p -> y_alpha (inf) for every site, y_alpha -> t (h)
+//   The alpha hub is not materialised (gate = 1): a minimum cut either cuts y_alpha -> t (pay h, the sites are free) or
+//   keeps y_alpha with t, which drags every site to the sink side (nobody switches).  So the move is solved WITHOUT the
+//   hub and applied iff the excess left stranded at convergence (= source capacity - max flow = what switching gains)
+//   is >= h; ties switch, as the minimal sink side demands (with exactly h stranded the hub is saturated by sites that
+//   cannot reach t otherwise).  With the hub every site is adjacent to every other through it, and the moves that hand a
+//   new instance its points (the label is unused until then) needed 10-14 global relabels of ~55 levels each.
 // All capacities are int64 multiples of 2^-32, so the maximum flow is exact and the minimal sink side
 // {v : v reaches t in the residual graph} is unique => labels are bit-identical to the CPU oracle's Dinic solver and to
 // BK's what_segment(default = SOURCE), independent of push order, atomics and scheduling.
@@ -75,6 +81,7 @@ struct MfView {
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep,
                                    //      6 a list-mode sweep pushed into a beta hub (all members must take part again)
     int hmax;                      // heights >= hmax are treated as unreachable
+    int gate;                      // 1: an unused alpha is handled by the stuck-excess test instead of a hub (see below)
 };
 
 // ---- atomics ---------------------------------------------------------------------------------------------------
@@ -183,7 +190,7 @@ PGX_HD void mf_body_hub_setup(const MfView& v)
         v.bfs_hub_d[l] = kMfInf;
         for (int r = 0; r < 3; ++r) v.hub_min[r * v.L + l] = kMfInf;
     }
-    const bool ha = lc && v.cnt[v.alpha] == 0;
+    const bool ha = lc && v.cnt[v.alpha] == 0 && !v.gate;
     v.has_alpha_hub[0] = ha ? 1 : 0;
     v.hubA_rt[0] = ha ? v.h_q : 0;
     v.hubA_e[0] = 0;
@@ -620,6 +627,14 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next, int consu
     v.flags[4] = act;
     v.flags[1] = 0;
     if (consumed >= 0) v.acnt[consumed] = 0;
+}
+
+// excess that cannot reach t any more (valid after the last global relabel): the gain of the move
+PGX_HD long long mf_body_stuck_excess(const MfView& v, int64_t u)
+{
+    if (v.labels[u] == v.alpha || v.d[u] != kMfInf) return 0;
+    const long long e = mf_load64(&v.ex[u]);
+    return e > 0 ? e : 0;
 }
 
 // ---- apply the cut ---------------------------------------------------------------------------------------------

@@ -86,6 +86,10 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         }
     }
     if (!converged) return 1;
+    if (v.gate && cnt_alpha == 0 && v.h_q > 0) {
+        // alpha is not in use: taking it costs h once.  Worth it iff the stranded excess (sites + hubs) reaches h.
+        if (be.stuck_excess(v) < v.h_q) return 0;
+    }
     be.apply(v);
     *changed = be.read_flag(v, 2);
     stats[4] += *changed;

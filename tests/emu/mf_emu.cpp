@@ -116,6 +116,13 @@ struct EmuBackend {
                          (long long)v.rt[u], (long long)v.f[u], (long long)v.g[u]);
     }
     void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { mf_body_sweep_epilogue(v, cur, next, consumed); dump(v, "after sweep"); }
+    long long stuck_excess(const MfView& v)
+    {
+        long long s = 0;
+        for (int64_t u = 0; u < v.n; ++u) s += mf_body_stuck_excess(v, u);
+        for (int l = 0; l < v.L; ++l) if (v.hub_exists[l] && v.hub_e[l] > 0) s += v.hub_e[l];
+        return s;
+    }
     void apply(const MfView& v) { each([&](int64_t u) { if (mf_body_apply(v, u)) v.flags[2] += 1; }); }
 };
 
@@ -182,6 +189,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.flags = flags.data();
     v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data(); v.act[0] = act0.data(); v.act[1] = act1.data(); v.acnt = acnt.data(); v.mark = mark.data();
     v.hmax = (int)(n + L + 3);
+    v.gate = std::getenv("MF_EMU_NO_GATE") ? 0 : 1;
     EmuBackend be(n, order_seed);
     MfTuning tune;
     if (sweeps_per_relabel > 0) { tune.sweeps_per_relabel = tune.sweeps_list = sweeps_per_relabel; tune.sweep_check = 1; }
