@@ -588,8 +588,123 @@ static void cross3(double a1, double b1, double c1, double a2, double b2, double
     o[2] = a1 * b2 - b1 * a2;
 }
 
+/* 7-point fundamental matrix (DefaultFundamentalMatrixEstimator's minimal solver is absent upstream; restated from the
+ * literature): rows (x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1) of the correspondences divided by `scale`; null space by
+ * Gauss-Jordan elimination with full pivoting (first maximum in row-major order; rank test 1e-12); det(F2 + l (F1-F2)) as
+ * a cubic; one real root by 200 bisection steps inside the Cauchy bound, the other two from the quadratic factor; every
+ * root gives F = l F1 + (1-l) F2, un-scaled and normalised to unit Frobenius norm.  out = 3 slots x 9, NaN = no model. */
+static double det3(const double *a)
+{
+    return a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+}
+
+static void solve_f7(const double *pts, int64_t n, const int32_t *smp, double scale, double *out)
+{
+    for (int k = 0; k < 27; ++k) out[k] = NAN;
+    double M[7][9];
+    for (int r = 0; r < 7; ++r) {
+        const int32_t i = smp[r];
+        if (i < 0 || i >= n) return;
+        const double x1 = pts[(size_t)i * 4] / scale, y1 = pts[(size_t)i * 4 + 1] / scale;
+        const double x2 = pts[(size_t)i * 4 + 2] / scale, y2 = pts[(size_t)i * 4 + 3] / scale;
+        M[r][0] = x2 * x1; M[r][1] = x2 * y1; M[r][2] = x2;
+        M[r][3] = y2 * x1; M[r][4] = y2 * y1; M[r][5] = y2;
+        M[r][6] = x1; M[r][7] = y1; M[r][8] = 1.0;
+    }
+    int col[9];
+    for (int j = 0; j < 9; ++j) col[j] = j;
+    for (int r = 0; r < 7; ++r) {
+        int pr = r, pc = r;
+        double best = -1.0;
+        for (int i = r; i < 7; ++i)
+            for (int j = r; j < 9; ++j) {
+                const double a = fabs(M[i][j]);
+                if (a > best) { best = a; pr = i; pc = j; }
+            }
+        if (!(best >= 1e-12)) return;
+        if (pr != r) for (int j = 0; j < 9; ++j) { const double t = M[r][j]; M[r][j] = M[pr][j]; M[pr][j] = t; }
+        if (pc != r) {
+            for (int i = 0; i < 7; ++i) { const double t = M[i][r]; M[i][r] = M[i][pc]; M[i][pc] = t; }
+            const int t = col[r]; col[r] = col[pc]; col[pc] = t;
+        }
+        const double piv = M[r][r];
+        for (int j = r; j < 9; ++j) M[r][j] = M[r][j] / piv;
+        for (int i = 0; i < 7; ++i) {
+            if (i == r) continue;
+            const double f = M[i][r];
+            for (int j = r; j < 9; ++j) M[i][j] = M[i][j] - f * M[r][j];
+        }
+    }
+    double F1[9], F2[9], D[9], T[9];
+    for (int k = 0; k < 7; ++k) { F1[col[k]] = -M[k][7]; F2[col[k]] = -M[k][8]; }
+    F1[col[7]] = 1.0; F1[col[8]] = 0.0;
+    F2[col[7]] = 0.0; F2[col[8]] = 1.0;
+    for (int k = 0; k < 9; ++k) D[k] = F1[k] - F2[k];
+    const double c0 = det3(F2), c3 = det3(D);
+    double c1 = 0.0, c2 = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 9; ++k) T[k] = F2[k];
+        for (int k = 0; k < 3; ++k) T[3 * r + k] = D[3 * r + k];
+        c1 = c1 + det3(T);
+        for (int k = 0; k < 9; ++k) T[k] = D[k];
+        for (int k = 0; k < 3; ++k) T[3 * r + k] = F2[3 * r + k];
+        c2 = c2 + det3(T);
+    }
+    double roots[3] = {NAN, NAN, NAN};
+    const double cm = fmax(fmax(fabs(c0), fabs(c1)), fmax(fabs(c2), fabs(c3)));
+    if (!(cm > 0.0) || !(cm < 1e300)) return;
+    if (fabs(c3) > 1e-14 * cm) {
+        const double a = c2 / c3, b = c1 / c3, c = c0 / c3;
+        double lo = -(1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)))), hi = -lo;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            const double pv = ((mid + a) * mid + b) * mid + c;
+            if (pv < 0.0) lo = mid; else hi = mid;
+        }
+        const double l0 = 0.5 * (lo + hi);
+        roots[0] = l0;
+        const double qb = a + l0, qc = b + qb * l0;
+        const double disc = qb * qb - 4.0 * qc;
+        if (disc >= 0.0) {
+            const double sq = sqrt(disc);
+            roots[1] = (-qb - sq) / 2.0;
+            roots[2] = (-qb + sq) / 2.0;
+        }
+    } else if (fabs(c2) > 1e-14 * cm) {
+        const double disc = c1 * c1 - 4.0 * c2 * c0;
+        if (disc >= 0.0) {
+            const double sq = sqrt(disc);
+            roots[0] = (-c1 - sq) / (2.0 * c2);
+            roots[1] = (-c1 + sq) / (2.0 * c2);
+        }
+    } else if (fabs(c1) > 1e-14 * cm) {
+        roots[0] = -c0 / c1;
+    }
+    const double s1 = scale, s2 = scale * scale;
+    for (int q = 0; q < 3; ++q) {
+        const double l = roots[q];
+        if (!(l == l)) continue;
+        double F[9];
+        for (int k = 0; k < 9; ++k) F[k] = l * F1[k] + (1.0 - l) * F2[k];
+        F[0] = F[0] / s2; F[1] = F[1] / s2; F[2] = F[2] / s1;
+        F[3] = F[3] / s2; F[4] = F[4] / s2; F[5] = F[5] / s1;
+        F[6] = F[6] / s1; F[7] = F[7] / s1;
+        double nn = 0.0;
+        for (int k = 0; k < 9; ++k) nn = nn + F[k] * F[k];
+        const double nrm = sqrt(nn);
+        if (!(nrm > 0.0) || !(nrm < 1e300)) continue;
+        for (int k = 0; k < 9; ++k) out[9 * q + k] = F[k] / nrm;
+    }
+}
+
 int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out)
 {
+    if (model_type == PGXO_FUNDAMENTAL) {
+        double scale = 1.0;
+        for (int64_t i = 0; i < n * 4; ++i) { const double a = fabs(pts[i]); if (a > scale) scale = a; }
+        for (int s = 0; s < S; ++s) solve_f7(pts, n, samples + (size_t)s * 7, scale, models_out + (size_t)s * 27);
+        return 0;
+    }
     if (model_type != PGXO_LINE2D && model_type != PGXO_VANISHING_POINT) return -1;
     for (int s = 0; s < S; ++s) {
         const int32_t i0 = samples[2 * s], i1 = samples[2 * s + 1];

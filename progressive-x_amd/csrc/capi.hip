@@ -209,6 +209,11 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
             q[5] = (float)(pm * 1.000001);
         }
     ctx->umax = umax;
+    {
+        double fs = 1.0;
+        for (int64_t i = 0; i < n * d; ++i) { const double a = std::fabs(points[i]); if (a > fs) fs = a; }
+        ctx->fscale = fs;   // NaN coordinates leave it at what the finite ones give; the solvers then produce NaN models
+    }
     PGX_TRY(ensure(ctx, ctx->pts32, (size_t)n * 8 * sizeof(float)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts32.p, p32.data(), (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts.p, points, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

@@ -38,6 +38,7 @@ struct pgx_ctx {
     pgx::DevBuf pmax;        // per point max(|coords the filter scales by|, 1)  (score filter)
     pgx::DevBuf pts32;       // N x 8 f32: coordinates + filter scale (FP32 pre-filter)
     double umax = 0.0;       // max |observed image coordinate| over all points
+    double fscale = 0.0;     // max(1, max |coordinate|) over all points: isotropic pre-scaling of the minimal solvers
     int filter_enabled = 1;  // PGX_NO_FILTER: 1 = no rejection filter, 2 = FP64 filter only (A/B, debugging)
     int last_score_filtered = 0;
     int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)

@@ -18,6 +18,7 @@ class Estimator:
     sample_size = 0
     nonminimal_sample_size = 0
     device_minimal = False     # True: ctx.solve_minimal(samples) replaces minimal() in the proposal engine
+    device_slots = 1           # hypotheses the device solver emits per sample (NaN = none)
     rows_per_model = 1       # rows of the returned model array per instance (3 for 3x3 / 3x4 matrices)
     cols = 3
 
@@ -211,6 +212,8 @@ class FundamentalEstimator(Estimator):
     sample_size = 7
     nonminimal_sample_size = 8
     rows_per_model = 3
+    device_minimal = True      # pgx_solve_minimal: Gauss-Jordan null space + cubic by bisection, three slots per sample
+    device_slots = 3
 
     @staticmethod
     def _rows(p):

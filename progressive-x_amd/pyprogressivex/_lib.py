@@ -292,12 +292,14 @@ class Context:
         resident points straight into the resident hypothesis buffer (score_launch can follow).  NaN rows mark
         degenerate samples."""
         smp = _i32(samples)
-        if smp.ndim != 2 or smp.shape[1] != 2:
-            raise ValueError("samples must be [S,2]")
-        out = np.empty((smp.shape[0], 3), dtype=np.float64) if fetch else None
+        want = 7 if self.model_type == FUNDAMENTAL else 2
+        if smp.ndim != 2 or smp.shape[1] != want:
+            raise ValueError(f"samples must be [S,{want}]")
+        rows = smp.shape[0] * 3 if self.model_type == FUNDAMENTAL else smp.shape[0]   # three root slots per 7-point sample
+        out = np.empty((rows, PARAM_DIM[self.model_type]), dtype=np.float64) if fetch else None
         self._ck(self._lib.pgx_solve_minimal(self._h, _ptr(smp, C.c_int32), C.c_int(smp.shape[0]), _ptr(out, C.c_double)),
                  "pgx_solve_minimal")
-        self.M = smp.shape[0]
+        self.M = rows
         return out
 
     def gram(self, kind, sel, params=None, weights=None, wpow=2):

@@ -169,7 +169,7 @@ class ProposalEngine:
             # hypotheses generated on the GPU from the resident points and scored where they are (no model upload);
             # a degenerate sample is a NaN model: never an inlier, never the winner
             models = self.ctx.solve_minimal(samples)
-            src = np.arange(len(samples), dtype=np.int64)
+            src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)
             self.ctx.score_launch(T2, has_compound=has_compound)
             table = self.ctx.score_fetch(exponent)
         else:

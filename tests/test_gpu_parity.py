@@ -448,23 +448,29 @@ def test_graph_build_error_paths(gpu_ctx):
 # ----------------------------------------------------------------------------------------------------------------------
 # SURVEY 8f rank 1 (first slice): minimal solvers on the GPU — bit-exact models, then scored where they are
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["line", "vanishing_point"])
+@pytest.mark.parametrize("name", ["line", "vanishing_point", "fundamental"])
 def test_solve_minimal_matches_oracle_and_scores_in_place(gpu_ctx, oracle, name):
     mt, pts, models, thr = make_case(name, 5000, 4, seed=9)
     rng = np.random.default_rng(4)
-    samples = rng.integers(0, 5000, (3000, 2)).astype(np.int32)
+    m = 7 if name == "fundamental" else 2
+    slots = 3 if name == "fundamental" else 1
+    samples = rng.integers(0, 5000, (3000, m)).astype(np.int32)
+    if name == "fundamental":                              # some all-inlier samples of one motion as well
+        for s in range(100, 400):
+            samples[s] = rng.choice(np.nonzero(np.arange(5000) % 5 == s % 3)[0], 7, replace=False)
     samples[:40, 1] = samples[:40, 0]                      # degenerate: the same point / segment twice
     gpu_ctx.set_points(mt, pts)
     got = gpu_ctx.solve_minimal(samples)
     ref = oracle.solve_minimal(mt, pts, samples)
-    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[:40]).all()
+    assert got.shape == ref.shape == (3000 * slots, 9 if name == "fundamental" else 3)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[:40 * slots]).all()
     ok = ~np.isnan(ref[:, 0])
     assert np.array_equal(got[ok], ref[ok]), "generated hypotheses must be bit-identical to the oracle's"
     T2 = 9.0 / 4.0 * thr * thr
     gpu_ctx.score_launch(T2)                              # scores the resident, device-generated batch
     a = gpu_ctx.score_fetch()
     b = oracle.score(mt, pts, np.where(np.isnan(ref), np.nan, ref), T2)
-    assert np.array_equal(a["counts"], b["counts"]) and a["counts"][:40].max() == 0
+    assert np.array_equal(a["counts"], b["counts"]) and a["counts"][:40 * slots].max() == 0
     assert _rel(a["values"], b["values"]) < REL
     up = gpu_ctx.score(ref[ok], T2)                       # the same models through the upload path
     assert np.array_equal(up["counts"], a["counts"][ok])

@@ -45,11 +45,13 @@ def test_homography_pipeline_and_single_model_convention(oracle_backend):
 
 
 def test_two_view_motion_pipeline(oracle_backend):
-    pts, gt, _ = datasets.make_two_view_motions(n_per_motion=150, n_motions=2, n_outliers=60, seed=0)
-    F, lab = px.findTwoViewMotions(pts, 1000, 1000, 1000, 1000, threshold=1.0, conf=0.99, sampler_id=0, seed=1,
-                                   minimum_point_number=20, max_iters=1500)
-    assert F.shape[1] == 3 and F.shape[0] % 3 == 0 and F.shape[0] >= 6
-    assert _me(lab, F.shape[0] // 3, gt) < 0.3     # epipolar constraint is weak: uniform outliers often fit
+    # the epipolar constraint is weak (uniform outliers often fit, small spurious instances survive): few outliers and
+    # a minimum instance size of 80 make the outcome stable across seeds (ME 0.08-0.15 for seeds 1-5)
+    pts, gt, _ = datasets.make_two_view_motions(n_per_motion=150, n_motions=2, n_outliers=20, seed=0)
+    F, lab = px.findTwoViewMotions(pts, 1000, 1000, 1000, 1000, threshold=0.5, conf=0.99, sampler_id=0, seed=1,
+                                   minimum_point_number=80, max_iters=1500)
+    assert F.shape == (6, 3)
+    assert _me(lab, 2, gt) < 0.25
 
 
 def test_pose_pipeline(oracle_backend, capsys):
