@@ -697,8 +697,53 @@ static void solve_f7(const double *pts, int64_t n, const int32_t *smp, double sc
     }
 }
 
+/* 4-point homography (DefaultHomographyEstimator's minimal solver is absent upstream; restated): h33 = 1, the 8x8 DLT
+ * system (x-equations of the four points, then their y-equations) of the points divided by `scale`, Gaussian
+ * elimination with partial pivoting (first maximum; rank test 1e-12), back substitution, scaling undone. */
+static void solve_h4(const double *pts, int64_t n, const int32_t *smp, double scale, double *out)
+{
+    for (int k = 0; k < 9; ++k) out[k] = NAN;
+    double M[8][9];
+    for (int r = 0; r < 4; ++r) {
+        const int32_t i = smp[r];
+        if (i < 0 || i >= n) return;
+        const double x1 = pts[(size_t)i * 4] / scale, y1 = pts[(size_t)i * 4 + 1] / scale;
+        const double x2 = pts[(size_t)i * 4 + 2] / scale, y2 = pts[(size_t)i * 4 + 3] / scale;
+        double *a = M[r], *b = M[r + 4];
+        a[0] = -x1; a[1] = -y1; a[2] = -1.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; a[6] = x2 * x1; a[7] = x2 * y1; a[8] = -x2;
+        b[0] = 0.0; b[1] = 0.0; b[2] = 0.0; b[3] = -x1; b[4] = -y1; b[5] = -1.0; b[6] = y2 * x1; b[7] = y2 * y1; b[8] = -y2;
+    }
+    for (int c = 0; c < 8; ++c) {
+        int pr = c;
+        double best = fabs(M[c][c]);
+        for (int i = c + 1; i < 8; ++i) { const double a = fabs(M[i][c]); if (a > best) { best = a; pr = i; } }
+        if (!(best >= 1e-12)) return;
+        if (pr != c) for (int j = c; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[pr][j]; M[pr][j] = t; }
+        for (int i = c + 1; i < 8; ++i) {
+            const double f = M[i][c] / M[c][c];
+            for (int j = c; j < 9; ++j) M[i][j] = M[i][j] - f * M[c][j];
+        }
+    }
+    double h[9];
+    for (int c = 7; c >= 0; --c) {
+        double acc = M[c][8];
+        for (int j = c + 1; j < 8; ++j) acc = acc - M[c][j] * h[j];
+        h[c] = acc / M[c][c];
+    }
+    h[8] = 1.0;
+    h[2] = h[2] * scale; h[5] = h[5] * scale; h[6] = h[6] / scale; h[7] = h[7] / scale;
+    for (int k = 0; k < 9; ++k) if (!(fabs(h[k]) < 1e300)) return;
+    for (int k = 0; k < 9; ++k) out[k] = h[k];
+}
+
 int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out)
 {
+    if (model_type == PGXO_HOMOGRAPHY) {
+        double scale = 1.0;
+        for (int64_t i = 0; i < n * 4; ++i) { const double a = fabs(pts[i]); if (a > scale) scale = a; }
+        for (int s = 0; s < S; ++s) solve_h4(pts, n, samples + (size_t)s * 4, scale, models_out + (size_t)s * 9);
+        return 0;
+    }
     if (model_type == PGXO_FUNDAMENTAL) {
         double scale = 1.0;
         for (int64_t i = 0; i < n * 4; ++i) { const double a = fabs(pts[i]); if (a > scale) scale = a; }

@@ -12,6 +12,9 @@
 //                                       full pivoting, det(l F1 + (1-l) F2) = 0 as a cubic, real roots by bisection of
 //                                       one root + the quadratic factor (only + - * / sqrt: identical on CPU and GPU),
 //                                       up to three models per sample (three slots, NaN = no root)
+//   homography from 4 correspondences   DefaultHomographyEstimator's minimal solver (progressivex_python.cpp:252), absent
+//                                       upstream: h33 = 1, the 8x8 DLT system of the isotropically scaled points by
+//                                       Gaussian elimination with partial pivoting (rank test 1e-12), scaling undone
 // Operation order is the contract (bit-exact against the oracle's C restatement, no contraction, IEEE sqrt and divide).
 // A degenerate sample (coincident points / parallel or identical lines) yields a NaN model, which can never have an
 // inlier; the caller drops it (the reference's solvers return "no model").
@@ -71,6 +74,51 @@ __global__ __launch_bounds__(kSolveBlock) void solve_kernel(const double* __rest
     models[(int64_t)s * 3] = m[0];
     models[(int64_t)s * 3 + 1] = m[1];
     models[(int64_t)s * 3 + 2] = m[2];
+}
+
+// ---- 4-point homography -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void solve_h4_kernel(const double* __restrict__ pts, int64_t n, const int* __restrict__ samples,
+                                                      int S, double scale, double* __restrict__ models, int* __restrict__ perm,
+                                                      int Mpad)
+{
+    const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+    for (int t = s; t < Mpad; t += (int)(gridDim.x * 64)) perm[t] = t < S ? t : 0;
+    if (s >= S) return;
+    const double nan = __builtin_nan("");
+    double* out = models + (int64_t)s * 9;
+    for (int k = 0; k < 9; ++k) out[k] = nan;
+    double M[8][9];  // rows 0..3: x-equations of the four points, rows 4..7: y-equations; column 8 = right-hand side
+    for (int r = 0; r < 4; ++r) {
+        const int i = samples[4 * s + r];
+        if (i < 0 || i >= n) return;
+        const double x1 = pts[(int64_t)i * 4] / scale, y1 = pts[(int64_t)i * 4 + 1] / scale;
+        const double x2 = pts[(int64_t)i * 4 + 2] / scale, y2 = pts[(int64_t)i * 4 + 3] / scale;
+        double* a = M[r];
+        double* b = M[r + 4];
+        a[0] = -x1; a[1] = -y1; a[2] = -1.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; a[6] = x2 * x1; a[7] = x2 * y1; a[8] = -x2;
+        b[0] = 0.0; b[1] = 0.0; b[2] = 0.0; b[3] = -x1; b[4] = -y1; b[5] = -1.0; b[6] = y2 * x1; b[7] = y2 * y1; b[8] = -y2;
+    }
+    for (int c = 0; c < 8; ++c) {
+        int pr = c;
+        double best = fabs(M[c][c]);
+        for (int i = c + 1; i < 8; ++i) { const double a = fabs(M[i][c]); if (a > best) { best = a; pr = i; } }
+        if (!(best >= 1e-12)) return;  // degenerate sample (three collinear points, repeated point) or NaN
+        if (pr != c) for (int j = c; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[pr][j]; M[pr][j] = t; }
+        for (int i = c + 1; i < 8; ++i) {
+            const double f = M[i][c] / M[c][c];
+            for (int j = c; j < 9; ++j) M[i][j] = M[i][j] - f * M[c][j];
+        }
+    }
+    double h[9];
+    for (int c = 7; c >= 0; --c) {
+        double acc = M[c][8];
+        for (int j = c + 1; j < 8; ++j) acc = acc - M[c][j] * h[j];
+        h[c] = acc / M[c][c];
+    }
+    h[8] = 1.0;
+    h[2] = h[2] * scale; h[5] = h[5] * scale; h[6] = h[6] / scale; h[7] = h[7] / scale;  // H = S^-1 Hn S, S = diag(1/s, 1/s, 1)
+    for (int k = 0; k < 9; ++k) if (!(fabs(h[k]) < 1e300)) return;
+    for (int k = 0; k < 9; ++k) out[k] = h[k];
 }
 
 // ---- 7-point fundamental matrix -------------------------------------------------------------------------------------
@@ -214,8 +262,24 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->M = Mtot;
         return PGX_OK;
     }
+    if (ctx->model_type == kHomography) {
+        if (!(ctx->fscale >= 1.0)) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: coordinate scale not available");
+        ctx->Mpad = ((S + 255) / 256) * 256;
+        PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 9 * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
+        PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * 4 * sizeof(int32_t)));
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, samples, (size_t)S * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(solve_h4_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
+                           ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
+        PGX_HIP(ctx, hipGetLastError());
+        if (models_out)
+            PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->M = S;
+        return PGX_OK;
+    }
     if (ctx->model_type != kLine2D && ctx->model_type != kVanishingPoint)
-        return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: no device solver for model type %d yet (built: 2-point line, 2-segment vanishing point, 7-point fundamental matrix)", ctx->model_type);
+        return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: no device solver for model type %d yet (built: 2-point line, 2-segment vanishing point, 4-point homography, 7-point fundamental matrix)", ctx->model_type);
     ctx->Mpad = ((S + 255) / 256) * 256;
     PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 3 * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));

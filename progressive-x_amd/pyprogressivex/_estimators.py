@@ -142,6 +142,7 @@ class HomographyEstimator(Estimator):
     sample_size = 4
     nonminimal_sample_size = 4
     rows_per_model = 3
+    device_minimal = True      # pgx_solve_minimal: 8x8 Gaussian elimination per sample on the GPU
 
     def minimal(self, pts, samples):
         scale = max(1.0, float(np.abs(pts).max()))     # isotropic pre-scaling: coordinates O(1) for the 8x8 solve
@@ -177,6 +178,7 @@ class HomographyEstimator(Estimator):
 class SymmetricHomographyEstimator(HomographyEstimator):
     """Same solvers; the model carried to the kernels is [H | H^-1] (symmetric transfer error switch)."""
     model_type = _lib.HOMOGRAPHY_SYM
+    device_minimal = False     # 18-parameter models: generated on the host
 
     @staticmethod
     def _augment(models):

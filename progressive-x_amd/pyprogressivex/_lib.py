@@ -292,7 +292,7 @@ class Context:
         resident points straight into the resident hypothesis buffer (score_launch can follow).  NaN rows mark
         degenerate samples."""
         smp = _i32(samples)
-        want = 7 if self.model_type == FUNDAMENTAL else 2
+        want = {FUNDAMENTAL: 7, HOMOGRAPHY: 4}.get(self.model_type, 2)
         if smp.ndim != 2 or smp.shape[1] != want:
             raise ValueError(f"samples must be [S,{want}]")
         rows = smp.shape[0] * 3 if self.model_type == FUNDAMENTAL else smp.shape[0]   # three root slots per 7-point sample

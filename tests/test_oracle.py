@@ -295,7 +295,7 @@ def test_golden_next_rows(oracle):
             G, cnt, bad = oracle.gram(kind, g[f"m_{name}_pts"], g[f"m_{name}_idx"], params=p, weights=g[f"m_{name}_w"], wpow=2)
             ref = g[f"m_{name}_G{kind}"]
             assert cnt == 120 and bad == 0 and np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max()
-    for name in ("line", "vanishing_point"):
+    for name in ("line", "vanishing_point", "homography", "fundamental"):
         got = oracle.solve_minimal(MODEL_CASES[name], g[f"s_{name}_pts"], g[f"s_{name}_samples"])
         assert np.array_equal(got, g[f"s_{name}_models"], equal_nan=True)
 
