@@ -82,7 +82,8 @@ int pgx_score_upload(pgx_ctx *ctx, const double *models, int M);
  * Built: the 2-segment vanishing point solver (solver_vanishing_point_two_lines.h:147-185) and the 2-point line solver
  * [U-4] (samples[S][2], S x 3 models), the 4-point homography solver (samples[S][4], S x 9, h33 = 1,
  * DefaultHomographyEstimator progressivex_python.cpp:252, absent upstream), the 7-point fundamental matrix solver (samples[S][7], THREE model slots per
- * sample: 3S x 9, DefaultFundamentalMatrixEstimator progressivex_python.cpp:616, absent upstream); a degenerate sample
+ * sample: 3S x 9, DefaultFundamentalMatrixEstimator progressivex_python.cpp:616, absent upstream), P3P (samples[S][3],
+ * FOUR slots per sample: 4S x 12 [R|t], DefaultPnPEstimator progressivex_python.cpp:119, absent upstream); a degenerate sample
  * or an absent root yields a NaN model (never an inlier).  Other model types: PGX_ERR_INVALID. */
 int pgx_solve_minimal(pgx_ctx *ctx, const int32_t *samples, int S, double *models_out);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */

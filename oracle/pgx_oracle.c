@@ -697,6 +697,140 @@ static void solve_f7(const double *pts, int64_t n, const int32_t *smp, double sc
     }
 }
 
+/* monic cubic x^3 + a x^2 + b x + c: one real root by 200 bisection steps inside the Cauchy bound, the other two from the
+ * quadratic factor (NaN when complex).  Only + - * / sqrt. */
+static void cubic_roots(double a, double b, double c, double *r)
+{
+    r[0] = r[1] = r[2] = NAN;
+    double lo = -(1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)))), hi = -lo;
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const double pv = ((mid + a) * mid + b) * mid + c;
+        if (pv < 0.0) lo = mid; else hi = mid;
+    }
+    const double l0 = 0.5 * (lo + hi);
+    r[0] = l0;
+    const double qb = a + l0, qc = b + qb * l0;
+    const double disc = qb * qb - 4.0 * qc;
+    if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        r[1] = (-qb - sq) / 2.0;
+        r[2] = (-qb + sq) / 2.0;
+    }
+}
+
+static double quartic_eval(const double *m, double x) { return (((x + m[3]) * x + m[2]) * x + m[1]) * x + m[0]; }
+
+/* P3P (Grunert's quartic in v = s3/s1 as in Fischler-Bolles; DefaultPnPEstimator's minimal solver is absent upstream):
+ * rows (u, v, X, Y, Z) in normalised image coordinates; positive real roots of the quartic by bisection between the
+ * critical points (roots of the derivative cubic) inside (0, Cauchy bound); depths from the two remaining constraints
+ * (consistency 1e-6); pose from the orthonormal frames of the two congruent triangles.  out = 4 slots x 12 ([R|t]
+ * row-major), NaN = no solution. */
+static void solve_p3p(const double *pts, int64_t n, const int32_t *smp, double *out)
+{
+    for (int k = 0; k < 48; ++k) out[k] = NAN;
+    double f[3][3], X[3][3];
+    for (int r = 0; r < 3; ++r) {
+        const int32_t i = smp[r];
+        if (i < 0 || i >= n) return;
+        const double u = pts[(size_t)i * 5], v = pts[(size_t)i * 5 + 1];
+        const double ln = sqrt(u * u + v * v + 1.0);
+        f[r][0] = u / ln; f[r][1] = v / ln; f[r][2] = 1.0 / ln;
+        X[r][0] = pts[(size_t)i * 5 + 2]; X[r][1] = pts[(size_t)i * 5 + 3]; X[r][2] = pts[(size_t)i * 5 + 4];
+    }
+    double d12[3], d02[3], d01[3];
+    for (int k = 0; k < 3; ++k) { d12[k] = X[1][k] - X[2][k]; d02[k] = X[0][k] - X[2][k]; d01[k] = X[0][k] - X[1][k]; }
+    const double a2 = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
+    const double b2 = d02[0] * d02[0] + d02[1] * d02[1] + d02[2] * d02[2];
+    const double c2 = d01[0] * d01[0] + d01[1] * d01[1] + d01[2] * d01[2];
+    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return;
+    const double ca = f[1][0] * f[2][0] + f[1][1] * f[2][1] + f[1][2] * f[2][2];
+    const double cb = f[0][0] * f[2][0] + f[0][1] * f[2][1] + f[0][2] * f[2][2];
+    const double cg = f[0][0] * f[1][0] + f[0][1] * f[1][1] + f[0][2] * f[1][2];
+    const double q = (a2 - c2) / b2, rr = (a2 + c2) / b2;
+    const double A4 = (q - 1.0) * (q - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (q * (1.0 - q) * cb - (1.0 - rr) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (q * q - 1.0 + 2.0 * q * q * cb * cb + 2.0 * (b2 - c2) / b2 * ca * ca - 4.0 * rr * ca * cb * cg +
+                             2.0 * (b2 - a2) / b2 * cg * cg);
+    const double A1 = 4.0 * (-q * (1.0 + q) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - rr) * ca * cg);
+    const double A0 = (1.0 + q) * (1.0 + q) - 4.0 * a2 / b2 * cg * cg;
+    if (!(fabs(A4) > 1e-14) || !(fabs(A4) < 1e300)) return;
+    double m[4] = {A0 / A4, A1 / A4, A2 / A4, A3 / A4};  /* monic: x^4 + m3 x^3 + m2 x^2 + m1 x + m0 */
+    for (int k = 0; k < 4; ++k) if (!(fabs(m[k]) < 1e300)) return;
+    const double B = 1.0 + fmax(fmax(fabs(m[0]), fabs(m[1])), fmax(fabs(m[2]), fabs(m[3])));
+    double crit[3];
+    cubic_roots(0.75 * m[3], 0.5 * m[2], 0.25 * m[1], crit);
+    /* break points of (0, B): the positive critical points in ascending order */
+    double bp[5];
+    int nb = 0;
+    bp[nb++] = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {          /* selection in ascending order (at most three values) */
+        double best = B;
+        for (int k = 0; k < 3; ++k)
+            if (crit[k] == crit[k] && crit[k] > bp[nb - 1] && crit[k] < best) best = crit[k];
+        if (best < B) bp[nb++] = best; else break;
+    }
+    bp[nb++] = B;
+    int slot = 0;
+    for (int s = 0; s + 1 < nb && slot < 4; ++s) {
+        double lo = bp[s], hi = bp[s + 1];
+        const double plo = quartic_eval(m, lo), phi = quartic_eval(m, hi);
+        if (!((plo < 0.0 && phi >= 0.0) || (plo >= 0.0 && phi < 0.0))) continue;
+        const int rising = plo < 0.0;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            const double pv = quartic_eval(m, mid);
+            if ((pv < 0.0) == rising) lo = mid; else hi = mid;
+        }
+        const double v = 0.5 * (lo + hi);
+        if (!(v > 0.0)) continue;
+        const double den = 2.0 * (cg - v * ca);
+        const double u = ((-1.0 + q) * v * v - 2.0 * q * cb * v + 1.0 + q) / den;
+        const double s1 = sqrt(b2 / (1.0 + v * v - 2.0 * v * cb));
+        const double s2 = u * s1, s3 = v * s1;
+        if (!(s1 > 0.0) || !(s2 > 0.0) || !(s3 > 0.0) || !(s1 < 1e300) || !(s2 < 1e300) || !(s3 < 1e300)) continue;
+        const double e1 = s1 * s1 + s2 * s2 - 2.0 * s1 * s2 * cg - c2;
+        const double e2 = s2 * s2 + s3 * s3 - 2.0 * s2 * s3 * ca - a2;
+        if (!(fabs(e1) < 1e-6 * c2) || !(fabs(e2) < 1e-6 * a2)) continue;
+        /* camera-frame points and the two orthonormal frames */
+        const double dep[3] = {s1, s2, s3};
+        double Y[3][3];
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Y[r][k] = f[r][k] * dep[r];
+        double EX[3][3], EY[3][3];
+        int okf = 1;
+        for (int w = 0; w < 2; ++w) {
+            double (*P)[3] = w == 0 ? X : Y;
+            double (*E)[3] = w == 0 ? EX : EY;
+            double p1[3], p2[3];
+            for (int k = 0; k < 3; ++k) { p1[k] = P[1][k] - P[0][k]; p2[k] = P[2][k] - P[0][k]; }
+            const double n1 = sqrt(p1[0] * p1[0] + p1[1] * p1[1] + p1[2] * p1[2]);
+            if (!(n1 > 0.0)) { okf = 0; break; }
+            for (int k = 0; k < 3; ++k) E[0][k] = p1[k] / n1;
+            double cr[3] = {E[0][1] * p2[2] - E[0][2] * p2[1], E[0][2] * p2[0] - E[0][0] * p2[2], E[0][0] * p2[1] - E[0][1] * p2[0]};
+            const double n3 = sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+            if (!(n3 > 0.0)) { okf = 0; break; }
+            for (int k = 0; k < 3; ++k) E[2][k] = cr[k] / n3;
+            E[1][0] = E[2][1] * E[0][2] - E[2][2] * E[0][1];
+            E[1][1] = E[2][2] * E[0][0] - E[2][0] * E[0][2];
+            E[1][2] = E[2][0] * E[0][1] - E[2][1] * E[0][0];
+        }
+        if (!okf) continue;
+        double *P = out + 12 * slot;
+        double R[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i][j] = EY[0][i] * EX[0][j] + EY[1][i] * EX[1][j] + EY[2][i] * EX[2][j];
+        int fin = 1;
+        for (int i = 0; i < 3; ++i) {
+            const double t = Y[0][i] - (R[i][0] * X[0][0] + R[i][1] * X[0][1] + R[i][2] * X[0][2]);
+            if (!(fabs(t) < 1e300)) fin = 0;
+            for (int j = 0; j < 3; ++j) { if (!(fabs(R[i][j]) < 1e300)) fin = 0; P[4 * i + j] = R[i][j]; }
+            P[4 * i + 3] = t;
+        }
+        if (!fin) { for (int k = 0; k < 12; ++k) P[k] = NAN; continue; }
+        ++slot;
+    }
+}
+
 /* 4-point homography (DefaultHomographyEstimator's minimal solver is absent upstream; restated): h33 = 1, the 8x8 DLT
  * system (x-equations of the four points, then their y-equations) of the points divided by `scale`, Gaussian
  * elimination with partial pivoting (first maximum; rank test 1e-12), back substitution, scaling undone. */
@@ -738,6 +872,10 @@ static void solve_h4(const double *pts, int64_t n, const int32_t *smp, double sc
 
 int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out)
 {
+    if (model_type == PGXO_PNP) {
+        for (int s = 0; s < S; ++s) solve_p3p(pts, n, samples + (size_t)s * 3, models_out + (size_t)s * 48);
+        return 0;
+    }
     if (model_type == PGXO_HOMOGRAPHY) {
         double scale = 1.0;
         for (int64_t i = 0; i < n * 4; ++i) { const double a = fabs(pts[i]); if (a > scale) scale = a; }

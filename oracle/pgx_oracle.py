@@ -219,7 +219,8 @@ def solve_minimal(model_type, pts, samples):
     """[S,3] models of the 2-point line / 2-segment vanishing point solvers, [3S,9] (three slots per sample) of the
     7-point fundamental matrix solver; NaN rows = no model"""
     pts = _f64(pts); samples = _i32(samples)
-    shape = {FUNDAMENTAL: (samples.shape[0] * 3, 9), HOMOGRAPHY: (samples.shape[0], 9)}.get(model_type, (samples.shape[0], 3))
+    shape = {FUNDAMENTAL: (samples.shape[0] * 3, 9), HOMOGRAPHY: (samples.shape[0], 9),
+             PNP: (samples.shape[0] * 4, 12)}.get(model_type, (samples.shape[0], 3))
     out = np.empty(shape, dtype=np.float64)
     r = lib().pgxo_solve_minimal(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]), _p(samples, C.c_int32),
                                  C.c_int(samples.shape[0]), _p(out, C.c_double))

@@ -309,6 +309,8 @@ class PnPEstimator(Estimator):
     nonminimal_sample_size = 6
     rows_per_model = 3
     cols = 4
+    device_minimal = True      # pgx_solve_minimal: Grunert's quartic by bisection, pose from the triangle frames; 4 slots
+    device_slots = 4
 
     def minimal(self, pts, samples):
         p = pts[samples]                                     # [S,3,5]

@@ -292,10 +292,10 @@ class Context:
         resident points straight into the resident hypothesis buffer (score_launch can follow).  NaN rows mark
         degenerate samples."""
         smp = _i32(samples)
-        want = {FUNDAMENTAL: 7, HOMOGRAPHY: 4}.get(self.model_type, 2)
+        want = {FUNDAMENTAL: 7, HOMOGRAPHY: 4, PNP: 3}.get(self.model_type, 2)
         if smp.ndim != 2 or smp.shape[1] != want:
             raise ValueError(f"samples must be [S,{want}]")
-        rows = smp.shape[0] * 3 if self.model_type == FUNDAMENTAL else smp.shape[0]   # three root slots per 7-point sample
+        rows = smp.shape[0] * {FUNDAMENTAL: 3, PNP: 4}.get(self.model_type, 1)   # root slots per 7-point / P3P sample
         out = np.empty((rows, PARAM_DIM[self.model_type]), dtype=np.float64) if fetch else None
         self._ck(self._lib.pgx_solve_minimal(self._h, _ptr(smp, C.c_int32), C.c_int(smp.shape[0]), _ptr(out, C.c_double)),
                  "pgx_solve_minimal")

@@ -33,9 +33,9 @@ for name, kinds in (("line", [(O.GRAM_AFFINE, None)]), ("vanishing_point", [(O.G
         p = models[0][:12] if isinstance(p, str) else p
         G, cnt, bad = O.gram(kind, pts, idx, params=p, weights=w, wpow=2)
         out[f"m_{name}_G{kind}"] = G
-for name in ("line", "vanishing_point", "homography", "fundamental"):
+for name in ("line", "vanishing_point", "homography", "fundamental", "pnp"):
     mt, pts, models, thr = make_case(name, 200, 2, seed=31)
-    smp = rng.integers(0, 200, (64, {"homography": 4, "fundamental": 7}.get(name, 2))).astype(np.int32)
+    smp = rng.integers(0, 200, (64, {"homography": 4, "fundamental": 7, "pnp": 3}.get(name, 2))).astype(np.int32)
     smp[:4, 1] = smp[:4, 0]
     out[f"s_{name}_pts"], out[f"s_{name}_samples"] = pts, smp
     out[f"s_{name}_models"] = O.solve_minimal(mt, pts, smp)

@@ -416,7 +416,7 @@ def test_next_rows_against_committed_vectors(gpu_ctx):
             got = gpu_ctx.graph_build(g[f"g{d}_pts"], kind, radius=radius, k=k)
             for name, a in zip(("off", "idx", "mult"), got):
                 assert np.array_equal(a, g[f"g{d}_{tag}_{name}"]), (d, tag, name)
-    for name in ("line", "vanishing_point", "homography", "fundamental"):
+    for name in ("line", "vanishing_point", "homography", "fundamental", "pnp"):
         gpu_ctx.set_points(MODEL_CASES[name], g[f"s_{name}_pts"])
         assert np.array_equal(gpu_ctx.solve_minimal(g[f"s_{name}_samples"]), g[f"s_{name}_models"], equal_nan=True)
     prm = np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0])
@@ -448,21 +448,21 @@ def test_graph_build_error_paths(gpu_ctx):
 # ----------------------------------------------------------------------------------------------------------------------
 # SURVEY 8f rank 1 (first slice): minimal solvers on the GPU — bit-exact models, then scored where they are
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["line", "vanishing_point", "homography", "fundamental"])
+@pytest.mark.parametrize("name", ["line", "vanishing_point", "homography", "fundamental", "pnp"])
 def test_solve_minimal_matches_oracle_and_scores_in_place(gpu_ctx, oracle, name):
     mt, pts, models, thr = make_case(name, 5000, 4, seed=9)
     rng = np.random.default_rng(4)
-    m = {"fundamental": 7, "homography": 4}.get(name, 2)
-    slots = 3 if name == "fundamental" else 1
+    m = {"fundamental": 7, "homography": 4, "pnp": 3}.get(name, 2)
+    slots = {"fundamental": 3, "pnp": 4}.get(name, 1)
     samples = rng.integers(0, 5000, (3000, m)).astype(np.int32)
-    if name == "fundamental":                              # some all-inlier samples of one motion as well
+    if name in ("fundamental", "pnp"):                      # some all-inlier samples of one structure as well
         for s in range(100, 400):
-            samples[s] = rng.choice(np.nonzero(np.arange(5000) % 5 == s % 3)[0], 7, replace=False)
+            samples[s] = rng.choice(np.nonzero(np.arange(5000) % 5 == s % 3)[0], m, replace=False)
     samples[:40, 1] = samples[:40, 0]                      # degenerate: the same point / segment twice
     gpu_ctx.set_points(mt, pts)
     got = gpu_ctx.solve_minimal(samples)
     ref = oracle.solve_minimal(mt, pts, samples)
-    assert got.shape == ref.shape == (3000 * slots, 9 if name in ("fundamental", "homography") else 3)
+    assert got.shape == ref.shape == (3000 * slots, {"fundamental": 9, "homography": 9, "pnp": 12}.get(name, 3))
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[:40 * slots]).all()
     ok = ~np.isnan(ref[:, 0])
     assert np.array_equal(got[ok], ref[ok]), "generated hypotheses must be bit-identical to the oracle's"
@@ -477,10 +477,10 @@ def test_solve_minimal_matches_oracle_and_scores_in_place(gpu_ctx, oracle, name)
 
 
 def test_solve_minimal_error_paths(gpu_ctx):
-    mt, pts, models, thr = make_case("pnp", 100, 1, seed=1)
+    mt, pts, models, thr = make_case("homography_sym", 100, 1, seed=1)
     gpu_ctx.set_points(mt, pts)
     with pytest.raises(_lib.PgxError):
-        gpu_ctx.solve_minimal(np.zeros((4, 2), np.int32))          # no device solver for P3P yet
+        gpu_ctx.solve_minimal(np.zeros((4, 2), np.int32))          # 18-parameter models are generated on the host
     mt, pts, models, thr = make_case("line", 100, 1, seed=1)
     gpu_ctx.set_points(mt, pts)
     out = gpu_ctx.solve_minimal(np.array([[0, 1], [5, 100], [-1, 2]], np.int32))

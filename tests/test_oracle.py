@@ -295,7 +295,7 @@ def test_golden_next_rows(oracle):
             G, cnt, bad = oracle.gram(kind, g[f"m_{name}_pts"], g[f"m_{name}_idx"], params=p, weights=g[f"m_{name}_w"], wpow=2)
             ref = g[f"m_{name}_G{kind}"]
             assert cnt == 120 and bad == 0 and np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max()
-    for name in ("line", "vanishing_point", "homography", "fundamental"):
+    for name in ("line", "vanishing_point", "homography", "fundamental", "pnp"):
         got = oracle.solve_minimal(MODEL_CASES[name], g[f"s_{name}_pts"], g[f"s_{name}_samples"])
         assert np.array_equal(got, g[f"s_{name}_models"], equal_nan=True)
 
@@ -322,3 +322,51 @@ def test_gram_and_solvers_hand_checked(oracle):
     segs = np.array([[0.0, 0, 1, 1], [0.0, 2, 1, 1], [0.0, 0, 2, 2]])               # two segments meeting at (1, 1)
     v = oracle.solve_minimal(oracle.VANISHING_POINT, segs, np.array([[0, 1], [0, 2]], np.int32))
     assert np.allclose(v[0, :2] / v[0, 2], [1.0, 1.0]) and np.isnan(v[1]).all()     # collinear segments: no model
+
+
+def test_device_solvers_agree_with_independent_numpy_solvers(oracle):
+    """The C restatements the GPU is held to (elimination / bisection, no library calls) against the host numpy solvers
+    that use different methods (LAPACK solve, SVD null space + companion eigenvalues, Kabsch alignment): same solution
+    sets up to the methods' own accuracy."""
+    from pyprogressivex import _estimators, datasets
+    rng = np.random.default_rng(0)
+    pts, gt, _ = datasets.make_homographies(seed=0)
+    smp = rng.integers(0, len(pts), (300, 4)).astype(np.int32)
+    m = oracle.solve_minimal(oracle.HOMOGRAPHY, pts, smp)
+    ref, src = _estimators.HomographyEstimator().minimal(pts, smp)
+    ok = np.nonzero(~np.isnan(m[:, 0]))[0]
+    assert abs(len(ok) - len(src)) <= 2
+    for i in np.intersect1d(ok, src):
+        r = ref[np.nonzero(src == i)[0][0]]
+        assert np.abs(m[i] - r).max() <= 1e-9 * max(1.0, np.abs(r).max())
+    pts, gt, _ = datasets.make_two_view_motions(seed=0)
+    sel = np.nonzero(gt == 1)[0]
+    smp = np.stack([rng.choice(sel, 7, replace=False) for _ in range(200)]).astype(np.int32)
+    m = oracle.solve_minimal(oracle.FUNDAMENTAL, pts, smp)
+    ref, src = _estimators.FundamentalEstimator().minimal(pts, smp)
+    for s in range(len(smp)):
+        A = [ref[i] for i in np.nonzero(src == s)[0]]
+        B = [m[3 * s + q] for q in range(3) if not np.isnan(m[3 * s + q, 0])]
+        assert len(A) == len(B)
+        for a in A:
+            assert min(min(np.abs(a - b).max(), np.abs(a + b).max()) for b in B) < 1e-8
+    x1, x2, K, gtp, poses = datasets.make_poses(n_per_object=400, n_objects=3, n_outliers=300, seed=0)
+    pp, f = datasets.normalize_pnp(x1, x2, K)
+    smp = np.stack([rng.choice(np.nonzero(gtp == 1 + s % 3)[0], 3, replace=False) for s in range(300)]).astype(np.int32)
+    m = oracle.solve_minimal(oracle.PNP, pp, smp)
+    ref, src = _estimators.PnPEstimator().minimal(pp, smp)
+    same = 0
+    for s in range(len(smp)):
+        A = [ref[i] for i in np.nonzero(src == s)[0]]
+        B = [m[4 * s + q] for q in range(4) if not np.isnan(m[4 * s + q, 0])]
+        if len(A) != len(B):
+            continue                                   # borderline roots: the consistency thresholds decide differently
+        same += 1
+        for a in A:
+            assert min(np.abs(a - b).max() / max(1.0, np.abs(a).max()) for b in B) < 1e-5
+        for b in B:                                    # a rotation, and it reprojects its three sample points
+            P = b.reshape(3, 4)
+            assert abs(np.linalg.det(P[:, :3]) - 1.0) < 1e-9
+            Xc = pp[smp[s], 2:] @ P[:, :3].T + P[:, 3]
+            assert np.abs(Xc[:, :2] / Xc[:, 2:] - pp[smp[s], :2]).max() < 1e-6
+    assert same >= 290
