@@ -100,6 +100,8 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_SPLIT")) { int v = std::atoi(b); if (v >= 1 && v <= 1024) ctx->score_split = v; }
     if (const char* b = std::getenv("PGX_SCORE_NO_CULL")) ctx->score_cull = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_NO_XCD")) ctx->score_xcd_map = std::atoi(b) ? 0 : 1;

@@ -49,6 +49,8 @@ struct pgx_ctx {
     int comp_dirty = 0;          // comp changed since comp_s was gathered
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     int score_cull = 1;          // cull + survivor kernels instead of in-kernel group skipping (PGX_SCORE_NO_CULL=1: A/B)
+    int score_group_xcd = 0;     // PGX_SCORE_GROUP_XCD=1: a group's workgroups on one XCD (less HBM fetch, slower: A/B)
+    int score_split = 16;        // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT)
     pgx::DevBuf cull_lists, cull_counts;
     int score_xcd_map = 1;       // XCD-aware block mapping of the score kernel (PGX_SCORE_NO_XCD=1 disables)
     int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)

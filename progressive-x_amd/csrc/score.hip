@@ -420,20 +420,36 @@ __global__ __launch_bounds__(64) void score_cull_kernel(
     }
 }
 
-constexpr int kGroupWaves = 4;  // groups per workgroup of the group-major kernel
+constexpr int kGroupWaves = 4;  // waves per workgroup of the group-major kernel
 
 template <int MT, bool MASK>
 __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
     const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
     const float* __restrict__ hyp32, double qscale, unsigned long long* __restrict__ acc /* [3][Mpad]: count, value, shared */,
-    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
+    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local)
 {
+    // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
     using LaneT = typename F32::Lane;
     const int lane = (int)(threadIdx.x & 63);
-    const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kGroupWaves + (int)(threadIdx.x >> 6));
+    // Which (group, part) this wave owns.  xcd_local places the workgroups of one group on the same XCD (ids go round-robin
+    // over the 8 XCDs) so that its rows are fetched from HBM once: FETCH_SIZE 165 -> 45 MiB per launch, but the kernel
+    // takes 0.51 instead of 0.36 ms (measured), so the default spreads a group over the XCDs and pays the re-fetch.
+    int g, part;
+    if (xcd_local) {
+        const int bpg = split / kGroupWaves;  // workgroups per group
+        const int slot = (int)(blockIdx.x >> 3);
+        g = (slot / bpg) * 8 + (int)(blockIdx.x & 7u);
+        part = (slot % bpg) * kGroupWaves + (int)(threadIdx.x >> 6);
+    } else {
+        const int wid = (int)blockIdx.x * kGroupWaves + (int)(threadIdx.x >> 6);
+        g = wid / split;
+        part = wid % split;
+    }
+    g = __builtin_amdgcn_readfirstlane(g);
+    part = __builtin_amdgcn_readfirstlane(part);
     if (g >= groups) return;
     const int64_t j = (int64_t)g * 64 + lane;
     const bool valid = j < n;
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // only by pairs that have candidates (staging it as well costs occupancy or compaction work: measured slower).
     __shared__ float s_h32[kGroupWaves][64][kHypRow];
     const int wv = (int)(threadIdx.x >> 6);
-    for (int w = 0; w < W; ++w) {
+    for (int w = part; w < W; w += split) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
         if (todo == 0) continue;
         __builtin_amdgcn_wave_barrier();  // the previous word's reads are done (LDS ops of a wave execute in order)
@@ -721,18 +737,22 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
                                ctx->cull_lists.as<unsigned long long>(), hyp32);
             PGX_HIP(ctx, hipGetLastError());
-            const unsigned gblocks = (unsigned)((groups + kGroupWaves - 1) / kGroupWaves);
+            const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
+            const int xcd_local = ctx->score_group_xcd && split % kGroupWaves == 0;
+            const unsigned gblocks = xcd_local
+                                         ? (unsigned)(((groups + 7) / 8) * 8 * (split / kGroupWaves))
+                                         : (unsigned)(((int64_t)groups * split + kGroupWaves - 1) / kGroupWaves);
             if (want_masks) {
                 PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
                 hipLaunchKernelGGL((score_group_kernel<MT, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>());
+                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local);
             } else {
                 hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>());
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local);
             }
             PGX_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
