@@ -102,12 +102,13 @@ def main():
     def step():
         ctx.timer_start()
         ctx.score_launch(T2, has_compound=True)
-        kernel_ms = ctx.timer_stop()     # HIP events on the stream the kernels run on
+        ctx.timer_mark()                 # HIP events on the stream the kernels run on; no host wait here
         if use_comm:
             ctx.score_allgather()
             res = ctx.score_fetch_all(exponent=2)
         else:
             res = ctx.score_fetch(exponent=2)
+        kernel_ms = ctx.timer_elapsed()  # the fetch synchronised the stream: the events are complete
         best = parallel.select_best(res["scores"], res["counts"])
         return kernel_ms, best, res
 

@@ -56,6 +56,8 @@ int pgx_model_dims(int model_type, int *point_dim, int *param_dim);
 int pgx_sync(pgx_ctx *ctx);                               /* hipStreamSynchronize on the ctx stream */
 int pgx_timer_start(pgx_ctx *ctx);                        /* hipEventRecord on the ctx stream */
 int pgx_timer_stop(pgx_ctx *ctx, float *milliseconds);    /* record + synchronize + elapsed */
+int pgx_timer_mark(pgx_ctx *ctx);                         /* record the stop event only (no host wait) */
+int pgx_timer_elapsed(pgx_ctx *ctx, float *milliseconds); /* elapsed between start and mark (waits for the mark) */
 int pgx_device_info(pgx_ctx *ctx, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
 
 /* ---- resident data ------------------------------------------------------------------------------------------

@@ -165,6 +165,23 @@ int pgx_timer_stop(pgx_ctx* ctx, float* ms)
     return PGX_OK;
 }
 
+int pgx_timer_mark(pgx_ctx* ctx)
+{
+    CTX_GUARD(ctx);
+    PGX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_timer_elapsed(pgx_ctx* ctx, float* ms)
+{
+    CTX_GUARD(ctx);
+    PGX_HIP(ctx, hipEventSynchronize(ctx->ev1));  // returns at once when the stream was synchronised after the mark
+    float t = 0.f;
+    PGX_HIP(ctx, hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+    if (ms) *ms = t;
+    return PGX_OK;
+}
+
 int pgx_device_info(pgx_ctx* ctx, char* name, int name_len, int* cu_count, int64_t* hbm_bytes)
 {
     CTX_GUARD(ctx);

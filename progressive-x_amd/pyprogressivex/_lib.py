@@ -20,7 +20,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/pgx.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "pgx_version", "pgx_device_count", "pgx_global_error", "pgx_create", "pgx_destroy", "pgx_last_error",
-    "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_device_info",
+    "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_timer_mark", "pgx_timer_elapsed", "pgx_device_info",
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
@@ -142,6 +142,14 @@ class Context:
 
     def timer_start(self):
         self._ck(self._lib.pgx_timer_start(self._h), "pgx_timer_start")
+
+    def timer_mark(self):
+        self._ck(self._lib.pgx_timer_mark(self._h), "pgx_timer_mark")
+
+    def timer_elapsed(self):
+        ms = C.c_float()
+        self._ck(self._lib.pgx_timer_elapsed(self._h, C.byref(ms)), "pgx_timer_elapsed")
+        return float(ms.value)
 
     def timer_stop(self):
         ms = C.c_float()
