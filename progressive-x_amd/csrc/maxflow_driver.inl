@@ -37,10 +37,13 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // ---- global relabel
         be.bfs_reset(v);
         be.bfs_init(v);
-        int level = 1;
-        for (int batch = tune.bfs_batch;; batch = batch < 64 ? 2 * batch : 64) {  // deep searches: fewer read-backs
+        // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
+        // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
+        int level = 1, last = 1;
+        for (int round = 0;; ++round) {
+            const int batch = round == 0 ? tune.bfs_batch : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
             for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
-            const int last = be.read_flag(v, 0);
+            last = be.read_flag(v, 0);
             if (last <= level - 2 || level >= v.hmax) break;
         }
         stats[2] += 1;
@@ -56,7 +59,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         if (tune.debug > 1) be.debug_dump(v, tune.debug == 4 ? level : fl[3]);
         // ---- wave pass over the BFS levels, farthest first
         if (tune.wave && v.off != nullptr) {
-            for (int k = level; k >= 1; --k) be.wave(v, k);
+            for (int k = (last + 1 < level ? last + 1 : level); k >= 1; --k) be.wave(v, k);  // levels beyond `last` are empty
             stats[5] += 1;
         }
         // ---- push-relabel sweeps: over all sites, or over a work list while few sites are active and no beta hub can
