@@ -157,6 +157,16 @@ enum { PGX_SEL_INDEX = 0, PGX_SEL_LABEL = 1 };
 int pgx_gram(pgx_ctx *ctx, int kind, const double *params, int nparams, int sel, const int32_t *index, int64_t m,
              int label, const double *weights, int weight_power, double *out, int64_t *count, int64_t *bad);
 
+/* ---- the inlier/outlier graph cut of GC-RANSAC's local optimisation.
+ * Replaces gcransac::GCRANSAC::labeling as reached from proposal_engine->run (progressive_x.h:294-299; settings
+ * spatial_coherence_weight / threshold at :541-545).  The graph-cut-ransac sources are absent from the snapshot, so the
+ * energy is restated from memory of upstream [U-12, DESIGN.md 5.8]: e_i = clamp(r_i^2 / T2, 0, 1);
+ *   unary: r_i^2 <= T2 ? (outlier: (1-lambda)(1-e_i), inlier: 0) : (outlier: 0, inlier: (1-lambda) e_i);
+ *   pairwise, every undirected neighbour pair of the resident graph once: both outliers lambda (e_i+e_j)/2, labels differ
+ *   lambda, both inliers 0.  One exact s-t cut on the device (terms in 2^-32 fixed point); inliers = sink segment.
+ * flags[n] (host): 1 = inlier, 0 = outlier; count = number of inliers.  Needs pgx_set_points + a graph over the points. */
+int pgx_gc_labeling(pgx_ctx *ctx, const double *model, double T2, double lambda, int32_t *flags, int64_t *count);
+
 /* ---- a9: PEARL::parameterEstimation bookkeeping (PEARL.h:342-352, 369-371, 388-390) */
 int pgx_bucket(pgx_ctx *ctx, int L, int64_t *counts, int32_t *order);     /* order optional: stable, ascending index */
 int pgx_residual_sum(pgx_ctx *ctx, const double *model, int label, double *sum);

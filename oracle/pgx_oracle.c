@@ -541,6 +541,62 @@ int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * GC-RANSAC's inlier/outlier labelling (gcransac::GCRANSAC::labeling; the graph-cut-ransac sources are
+ * absent from the snapshot - call site /root/reference/src/pyprogressivex/include/progressive_x.h:294-299 - restated
+ * from memory of upstream [U-12]).  The graph is built the way upstream builds it with Kolmogorov's Energy class:
+ *   add_term1(i, E0, E1)         -> t-links  s->i += E1, i->t += E0          (0 = SOURCE = outlier, 1 = SINK = inlier)
+ *   add_term2(i, j, A, B, C, D)  -> s->i += D, i->t += A, edge i->j = B - A, j->i = C - D
+ * with e = clamp(r^2/T2, 0, 1), E0 = (1-lambda)(1-e), E1 = 0 for r^2 <= T2, else E0 = 0, E1 = (1-lambda) e;
+ * A = lambda (e_i+e_j)/2, B = C = lambda, D = 0; every undirected pair once (i < j), self loops skipped.
+ * Terms are quantised to 2^-32 (A as 2 * Q(lambda (e_i+e_j)/4), lambda as pgxo_quantize_lambda) so that the device's
+ * re-parameterised graph represents the same integer energy.  Inliers = sites that reach t.
+ * ---------------------------------------------------------------------------------------- */
+int64_t pgxo_gc_labeling(int model_type, const double *pts, int64_t n, const double *model, double T2, double lambda,
+                         const int32_t *off, const int32_t *idx, int32_t *flags)
+{
+    int d = 0;
+    pgxo_model_dims(model_type, &d, NULL);
+    double *e = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    uint8_t *inl = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    int64_t *to_t = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+    int64_t *from_s = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+    const double oml = 1.0 - lambda;
+    const int64_t lambda_q = 2 * (int64_t)nearbyint(lambda * 2147483648.0);
+    for (int64_t i = 0; i < n; ++i) {
+        const double sq = pgxo_squared_residual(model_type, pts + i * d, model);
+        inl[i] = (sq <= T2) ? 1 : 0; /* NaN -> beyond the threshold */
+        double c = inl[i] ? sq / T2 : 1.0;
+        if (c < 0.0) c = 0.0;
+        e[i] = c;
+        if (inl[i]) to_t[i] += pgxo_quantize(oml * (1.0 - e[i]));
+        else from_s[i] += pgxo_quantize(oml * e[i]);
+    }
+    const int S = (int)n, T = (int)n + 1;
+    dinic_t g;
+    dn_init(&g, (int)n + 2, 2 * (2 * n + (off ? off[n] : 0)) + 16);
+    if (off)
+        for (int64_t i = 0; i < n; ++i)
+            for (int32_t a = off[i]; a < off[i + 1]; ++a) {
+                const int32_t j = idx[a];
+                if (j <= i) continue; /* each undirected pair once, no self loops */
+                const int64_t A = 2 * pgxo_quantize(lambda * 0.25 * (e[i] + e[j]));
+                to_t[i] += A;
+                dn_add(&g, (int)i, (int)j, lambda_q - A, lambda_q);
+            }
+    for (int64_t i = 0; i < n; ++i) {
+        dn_add(&g, S, (int)i, from_s[i], 0);
+        dn_add(&g, (int)i, T, to_t[i], 0);
+    }
+    dn_maxflow(&g, S, T);
+    uint8_t *reach = (uint8_t *)malloc((size_t)n + 2);
+    dn_sink_side(&g, T, reach);
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; ++i) { flags[i] = reach[i] ? 1 : 0; count += flags[i]; }
+    free(reach); dn_free(&g); free(from_s); free(to_t); free(inl); free(e);
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a9  PEARL.h:342-352 (bucket by label, ascending point index) ; PEARL.h:369-371 (residual sums)
  * ---------------------------------------------------------------------------------------- */
 void pgxo_bucket(const int32_t *labels, int64_t n, int L, int64_t *counts, int32_t *order)

@@ -181,6 +181,18 @@ def expand_alpha(Dq, graph, lambda_q, h_q, alpha, labels):
     return labels, int(changed), int(flow.value)
 
 
+def gc_labeling(model_type, pts, model, T2, lam, graph):
+    """GC-RANSAC's inlier/outlier cut ([U-12]): flags[n] int32, 1 = inlier"""
+    pts = _f64(pts); model = _f64(model)
+    n = pts.shape[0]
+    off, idx = _i32(graph[0]), _i32(graph[1])
+    flags = np.zeros(n, dtype=np.int32)
+    lib().pgxo_gc_labeling.restype = C.c_int64
+    lib().pgxo_gc_labeling(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(n), _p(model, C.c_double),
+                           C.c_double(T2), C.c_double(lam), _p(off, C.c_int32), _p(idx, C.c_int32), _p(flags, C.c_int32))
+    return flags
+
+
 def expansion(Dq, graph, lambda_q, h_q, labels, max_cycles=1000):
     Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels).copy()
     n, L = Dq.shape

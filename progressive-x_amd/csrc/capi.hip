@@ -121,7 +121,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
-                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts};
+                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -681,6 +681,13 @@ int pgx_residual_sum(pgx_ctx* ctx, const double* model, int label, double* sum)
     CTX_GUARD(ctx);
     if (!model || !sum) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sum: NULL argument");
     return residual_sum_launch(ctx, model, label, sum);
+}
+
+int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
+{
+    CTX_GUARD(ctx);
+    if (!model || !flags) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: NULL argument");
+    return gc_labeling_launch(ctx, model, T2, lambda, flags, count);
 }
 
 }  // extern "C"

@@ -607,10 +607,17 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
     if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
-    if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
-    const bool pair = lambda_q > 0;
-    if (!pair) return expand_alpha_l0(ctx, h_q, alpha, changed);
-    if (pair && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
+    if (lambda_q <= 0) return expand_alpha_l0(ctx, h_q, alpha, changed);
+    return expand_alpha_on(ctx, n, L, ctx->dq.as<long long>(), ctx->labels.as<int>(), nullptr, lambda_q, h_q, alpha, changed);
+}
+
+// One expansion move on caller-chosen tables: dq [L][n] label-major, labels [n], and optionally per-arc weights wq [E]
+// (used by the binary inlier/outlier cut of gclo.hip, whose pairwise weights depend on both end points).
+int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq,
+                    int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
+{
+    const bool pair = true;
+    if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();
         PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));
@@ -638,8 +645,9 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     char* sp = (char*)st->small.p;
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
-    v.dq = ctx->dq.as<long long>();
-    v.labels = ctx->labels.as<int>();
+    v.dq = dq;
+    v.labels = labels;
+    v.wq = wq;
     v.off = pair ? ctx->goff.as<int>() : nullptr;
     v.idx = ctx->gidx.as<int>(); v.mult = ctx->gmult.as<int>(); v.rev = ctx->grev.as<int>();
     v.cap = st->cap.as<long long>(); v.ex = st->ex.as<long long>(); v.rt = st->rt.as<long long>();

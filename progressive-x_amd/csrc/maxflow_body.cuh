@@ -52,6 +52,7 @@ struct MfView {
     const int* off;       // [n+1]   (nullptr => no pairwise term)
     const int* idx;       // [E]
     const int* mult;      // [E]
+    const long long* wq;  // [E] per-arc weight (symmetric: wq[a] == wq[rev[a]]) replacing lambda_q * mult[a], or nullptr
     const int* rev;       // [E] index of the reverse arc
     long long* cap;       // [E] residual capacity of arc a (row owner -> idx[a])
     long long* ex;        // [n] excess
@@ -219,7 +220,7 @@ PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
         for (int a = v.off[u]; a < v.off[u + 1]; ++a) {
             const int q = v.idx[a];
             const int lq = v.labels[q];
-            const long long w = v.lambda_q * (long long)v.mult[a];
+            const long long w = v.wq ? v.wq[a] : v.lambda_q * (long long)v.mult[a];
             if (lq == v.alpha) { keep += w; v.cap[a] = 0; }
             else if (lq == lu) v.cap[a] = w;
             else { keep += w / 2; v.cap[a] = w / 2; }

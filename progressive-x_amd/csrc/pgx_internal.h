@@ -52,6 +52,7 @@ struct pgx_ctx {
     int score_group_xcd = 0;     // PGX_SCORE_GROUP_XCD=1: a group's workgroups on one XCD (less HBM fetch, slower: A/B)
     int score_split = 16;        // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT)
     pgx::DevBuf cull_lists, cull_counts;
+    pgx::DevBuf gc;          // inlier/outlier graph cut: e[n] | dq[2][n] | wq[E] | labels[n]
     int score_xcd_map = 1;       // XCD-aware block mapping of the score kernel (PGX_SCORE_NO_XCD=1 disables)
     int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)
 
@@ -124,6 +125,7 @@ int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda);
 int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* sum);
 int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
 int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
+int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count);
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
@@ -131,6 +133,8 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
+int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq, int64_t lambda_q,
+                    int64_t h_q, int alpha, int64_t* changed);
 void maxflow_free(pgx_ctx* ctx);
 void comm_free(pgx_ctx* ctx);
 

@@ -226,6 +226,100 @@ int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda)
     return PGX_OK;
 }
 
+// ---- GC-RANSAC's inlier/outlier graph cut ---------------------------------------------------------
+// gcransac::GCRANSAC::labeling is part of the absent graph-cut-ransac submodule (call site progressive_x.h:294-299,
+// settings :541-545); restated from memory of upstream [U-12]: with e_i = clamp(r_i^2 / T^2, 0, 1),
+//   unary     r_i^2 <= T^2 : outlier costs (1 - lambda)(1 - e_i), inlier 0      else : outlier 0, inlier (1 - lambda) e_i
+//   pairwise  (each undirected neighbour pair once, self loops skipped)
+//             both outliers lambda (e_i + e_j) / 2,  labels differ lambda,  both inliers 0
+// minimised exactly by one s-t cut; inliers = the SINK segment = the sites that still reach t (ties -> outlier).
+// With o = [outlier] the pair term equals  q (o_i + o_j) + (lambda - q) [o_i != o_j],  q = lambda (e_i + e_j) / 4, i.e. a
+// unary share per end point plus a Potts edge of weight lambda - q >= lambda / 2: exactly the graph of one expansion move
+// (every site "inlier", alpha = "outlier", no label costs) with per-arc weights.  All terms are quantised to 2^-32 first
+// (q per pair, so that both end points and both arcs see the same integer), sums are int64: order-free and bit-exact.
+template <int MT>
+__global__ __launch_bounds__(kPwBlock) void gc_energy_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl, double T2,
+                                                             double* __restrict__ e)
+{
+    using R = Residual<MT>;
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    double pt[R::D];
+    load_point<MT>(pts, i, pt);
+    const double sq = R::squared(pt, mdl.v);
+    // negative = beyond the threshold (or NaN): e = 1; the sign carries the branch of the unary term
+    e[i] = (sq <= T2) ? cv_max(0.0, sq / T2) : -1.0;
+}
+
+__global__ __launch_bounds__(kPwBlock) void gc_terms_kernel(const double* __restrict__ e, int64_t n, const int* __restrict__ off,
+                                                            const int* __restrict__ idx, double lambda, long long lambda_q,
+                                                            long long* __restrict__ dq, long long* __restrict__ wq,
+                                                            int* __restrict__ labels)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    const double ei_s = e[i];
+    const bool inl = ei_s >= 0.0;
+    const double ei = inl ? ei_s : 1.0;
+    const double oml = 1.0 - lambda;
+    long long out = inl ? (long long)__builtin_nearbyint(oml * (1.0 - ei) * 4294967296.0) : 0;
+    for (int a = off[i]; a < off[i + 1]; ++a) {
+        const int j = idx[a];
+        if (j == i) { wq[a] = 0; continue; }
+        const double ej_s = e[j];
+        const double ej = ej_s >= 0.0 ? ej_s : 1.0;
+        const long long q = (long long)__builtin_nearbyint(lambda * 0.25 * (ei + ej) * 4294967296.0);
+        out += q;
+        wq[a] = lambda_q - q;
+    }
+    dq[i] = out;                                                                    // label 0 = outlier (alpha)
+    dq[n + i] = inl ? 0 : (long long)__builtin_nearbyint(oml * ei * 4294967296.0);  // label 1 = inlier
+    labels[i] = 1;
+}
+
+int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
+{
+    const int64_t n = ctx->n;
+    if (n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: points not set");
+    if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: needs a neighbourhood graph over the %lld points", (long long)n);
+    if (!(lambda > 0.0) || !(lambda < 1.0)) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: lambda must lie in (0, 1)");
+    if (!(T2 > 0.0)) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: threshold must be positive");
+    const int64_t E = ctx->gE;
+    // e[n] f64 | dq[2][n] i64 | wq[E] i64 | labels[n] i32
+    PGX_TRY(ensure(ctx, ctx->gc, (size_t)n * 8 + (size_t)2 * n * 8 + (size_t)(E > 0 ? E : 1) * 8 + (size_t)n * 4));
+    double* e = ctx->gc.as<double>();
+    long long* dq = (long long*)(e + n);
+    long long* wq = dq + 2 * n;
+    int* labels = (int*)(wq + (E > 0 ? E : 1));
+    ModelArg mdl;
+    int pd = 0, pp = 0;
+    model_dims(ctx->model_type, &pd, &pp);
+    for (int j = 0; j < 18; ++j) mdl.v[j] = j < pp ? model[j] : 0.0;
+    const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
+    dim3 g((unsigned)blocks), b(kPwBlock);
+    const double* pts = ctx->pts.as<double>();
+    switch (ctx->model_type) {
+    case kLine2D: hipLaunchKernelGGL((gc_energy_kernel<kLine2D>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    case kHomography: hipLaunchKernelGGL((gc_energy_kernel<kHomography>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    case kFundamental: hipLaunchKernelGGL((gc_energy_kernel<kFundamental>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    case kPnP: hipLaunchKernelGGL((gc_energy_kernel<kPnP>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    case kVanishingPoint: hipLaunchKernelGGL((gc_energy_kernel<kVanishingPoint>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    case kHomographySym: hipLaunchKernelGGL((gc_energy_kernel<kHomographySym>), g, b, 0, ctx->stream, pts, n, mdl, T2, e); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "bad model type");
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    const long long lambda_q = quantize_lambda(lambda);
+    hipLaunchKernelGGL(gc_terms_kernel, g, b, 0, ctx->stream, e, n, ctx->goff.as<int>(), ctx->gidx.as<int>(), lambda, lambda_q, dq,
+                       wq, labels);
+    PGX_HIP(ctx, hipGetLastError());
+    int64_t changed = 0;
+    PGX_TRY(expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, 0, &changed));
+    PGX_HIP(ctx, hipMemcpyAsync(flags, labels, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) *count = n - changed;
+    return PGX_OK;
+}
+
 // ---- a9: residual sums ---------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(kPwBlock) void residual_sum_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl,

@@ -11,6 +11,9 @@ Extensions that do not change the reference behaviour when left at their default
   neighborhood="flann_like"     U-7 switch: "flann_like" (<= 5 nearest neighbours inside the ball, what upstream's
                                 checks=6 approximate search can return at most), "radius" (all points in the ball),
                                 or "knn:<k>"
+  local_optimization="auto"     U-12 switch: "auto" = GC-RANSAC's graph-cut local optimisation whenever the spatial
+                                coherence weight is in (0, 1) (the cut runs on the GPU, pgx_gc_labeling), iterated
+                                least-squares refits otherwise; "lsq" = refits only
 """
 import sys
 
@@ -57,7 +60,8 @@ def _unknown_sampler(sampler_id):
 
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
-         do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
+         do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like",
+         local_optimization="auto"):
     n = pts.shape[0]
     if getattr(sampler_factory, "unknown", False):
         # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
@@ -86,6 +90,7 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         s.maximum_model_number = int(maximum_model_number)
     s.point_weights = weights
     s.max_outer_iterations = int(max_outer_iterations)
+    s.local_optimization = str(local_optimization)   # "auto": GC-RANSAC's graph-cut LO when 0 < lambda < 1; "lsq"
     px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
                               do_logging=do_logging, graph_resident=resident)
     models, stats = px.run()
@@ -119,7 +124,8 @@ def _sampler_factory(sampler_id, valid):
 def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-                     do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like"):
+                     do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like",
+                     local_optimization="auto"):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -137,14 +143,15 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 3), labels
 
 
 def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
-                       do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
+                       do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
+                     local_optimization="auto"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -162,7 +169,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 3), labels
 
 
@@ -172,7 +179,8 @@ findFundamentalMatrices = findTwoViewMotions   # name used by BASELINE.json's no
 def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_coherence_weight=0.0,
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
+                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
+                     local_optimization="auto"):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -189,14 +197,15 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
                              weights=_weights(weights), seed=seed, max_outer_iterations=max_outer_iterations,
-                             neighborhood=neighborhood)
+                             neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 3), labels
 
 
 def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_weight=0.0,
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
-              do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like"):
+              do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
+                     local_optimization="auto"):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -213,14 +222,15 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 3), labels
 
 
 def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_weight=0.1,
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
                 minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
-                neighborhood="flann_like"):
+                neighborhood="flann_like",
+                     local_optimization="auto"):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
     import time
     x1 = _as_f64(x1y1)
@@ -254,5 +264,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 4), labels

@@ -34,6 +34,8 @@ class MultiModelSettings:
         # proposal_engine_settings (:66-71)
         self.max_iteration_number = 5000
         self.max_local_optimization_number = 50
+        self.max_graph_cut_number = 10        # gcransac::utils::Settings default [UPSTREAM-MEMORY]
+        self.local_optimization = "auto"      # "auto": graph-cut LO when 0 < lambda < 1, else LSQ refits; "lsq": always LSQ
         # not in the reference: its outer loop is hard-capped at 10 proposals (progressive_x.h:272)
         self.max_outer_iterations = 10
 

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
-    "pgx_bucket", "pgx_residual_sum",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
 ]
@@ -378,6 +378,16 @@ class Context:
         self._ck(self._lib.pgx_residual_sum(self._h, _ptr(m, C.c_double), C.c_int(int(label)), C.byref(s)),
                  "pgx_residual_sum")
         return s.value
+
+    def gc_labeling(self, model, T2, lam):
+        """GC-RANSAC's inlier/outlier graph cut of `model` on the resident graph (include/pgx.h pgx_gc_labeling):
+        returns the int32 flags (1 = inlier)."""
+        m = _f64(model).reshape(-1)
+        flags = np.empty(self.n, dtype=np.int32)
+        cnt = C.c_int64()
+        self._ck(self._lib.pgx_gc_labeling(self._h, _ptr(m, C.c_double), C.c_double(float(T2)), C.c_double(float(lam)),
+                                           _ptr(flags, C.c_int32), C.byref(cnt)), "pgx_gc_labeling")
+        return flags
 
     # -- multi-GPU ---------------------------------------------------------------------------------------------------
     def comm_init(self, nranks, rank, unique_id):

@@ -11,9 +11,10 @@ absent from the snapshot (empty submodule), so the loop is restated [UPSTREAM-ME
     the early exit `count + 1 < best.inlier_number` (scoring_function_with_compound_model.h:105-106), "first strictly
     better score wins", and the adaptive iteration bound log(1-conf)/log(1-(inl/N)^m) — so for a given hypothesis list
     the CPU restatement and the GPU path select the same model;
-  * local optimisation = iterated least-squares refits on the inliers of a new so-far-best model (simplified stand-in
-    for GC-RANSAC's graph-cut + inner-RANSAC local optimisation, capped by max_local_optimization_number = 50,
-    progressive_x.h:68).
+  * local optimisation of the winner: GC-RANSAC's graph-cut + inner-RANSAC procedure (`_graph_cut_lo`, the cut runs on
+    the GPU: pgx_gc_labeling) when the spatial coherence weight is in (0, 1); iterated least-squares refits on the
+    inliers otherwise (with lambda = 0 the cut is plain thresholding).  Both are capped by
+    max_local_optimization_number = 50 (progressive_x.h:68).
 """
 import numpy as np
 
@@ -182,7 +183,25 @@ class ProposalEngine:
         if best < 0:
             return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iters)
         model, score = models[best].copy(), float(table["scores"][best])
-        # local optimisation: iterated LSQ refits scored with the same compound term
+        if self._use_graph_cut():
+            model, score = self._graph_cut_lo(model, score, T2, has_compound, exponent, weights)
+        else:
+            model, score = self._lsq_lo(model, score, T2, has_compound, exponent, weights)
+        final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iters,
+                    score=float(final["scores"][0]))
+
+
+    # -- local optimisation ------------------------------------------------------------------------------------------
+    def _use_graph_cut(self):
+        # "auto": the graph cut whenever it is not trivial (0 < lambda < 1); "lsq" forces the refit-only stand-in
+        lam = float(self.s.spatial_coherence_weight)
+        return getattr(self.s, "local_optimization", "auto") != "lsq" and 0.0 < lam < 1.0
+
+    def _lsq_lo(self, model, score, T2, has_compound, exponent, weights):
+        """iterated least-squares refits on the inliers, scored with the same compound term (the stand-in used when the
+        spatial coherence weight is 0 and the graph cut degenerates to thresholding)"""
+        est, s = self.est, self.s
         lo_budget = int(s.max_local_optimization_number)
         while lo_budget > 0:
             lo_budget -= 1
@@ -198,9 +217,44 @@ class ProposalEngine:
                 model, score = np.asarray(fits[0], dtype=np.float64), float(cand["scores"][0])
             else:
                 break
-        final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
-        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iters,
-                    score=float(final["scores"][0]))
+        return model, score
+
+    def _graph_cut_lo(self, model, score, T2, has_compound, exponent, weights):
+        """gcransac::GCRANSAC::graphCutLocalOptimization, restated [UPSTREAM-MEMORY, U-12] and batched:
+
+          repeat (at most max_graph_cut_number = 10 times):
+            inliers <- the inlier/outlier graph cut of the best model (one exact min-cut on the GPU, pgx_gc_labeling);
+            inner RANSAC: max_local_optimization_number samples of min(7 * sample size, |inliers|) inliers, each refitted
+            by the non-minimal solver (Gram pass on the GPU); all candidates are scored in ONE launch and then walked in
+            order - a strictly better score replaces the best model, exactly what the sequential loop would keep;
+            stop when a round brought no improvement."""
+        est, s = self.est, self.s
+        lam = float(s.spatial_coherence_weight)
+        rng = self.sampler.rng
+        limit = 7 * est.sample_size
+        trials = int(s.max_local_optimization_number)
+        for _ in range(int(getattr(s, "max_graph_cut_number", 10))):
+            flags = self.ctx.gc_labeling(model, T2, lam)
+            inl = np.nonzero(flags)[0].astype(np.int64)
+            size = min(limit, len(inl))
+            cands = []
+            if size < len(inl) and size >= est.nonminimal_sample_size:
+                for _t in range(trials):
+                    pick = np.sort(rng.choice(inl, size, replace=False))
+                    cands.extend(est.nonminimal(self.ctx, ("index", pick), weights, init=model))
+            elif est.sample_size < len(inl) and len(inl) >= est.nonminimal_sample_size:
+                cands.extend(est.nonminimal(self.ctx, ("index", inl), weights, init=model))
+            if not cands:
+                break
+            cands = np.asarray(cands, dtype=np.float64)
+            table = self.ctx.score(cands, T2, has_compound=has_compound, exponent=exponent)
+            updated = False
+            for h in range(len(cands)):
+                if int(table["counts"][h]) > 0 and float(table["scores"][h]) > score:
+                    model, score, updated = cands[h].copy(), float(table["scores"][h]), True
+            if not updated:
+                break
+        return model, score
 
 
 def mask_to_indices(mask_row, n):

@@ -29,6 +29,7 @@ def timed(name, fn, gt, rows, *args, **kw):
                      pearl_iterations=st.pearl_iterations, expansion_cycles=st.expansion_cycles, core=st.processing_time)
         return models, st
     _api._engine.ProgressiveX.run = run
+    kw.setdefault("local_optimization", os.environ.get("BENCH_LO", "auto"))   # "lsq": refit-only local optimisation
     t0 = time.perf_counter()
     models, labels = fn(*args, **kw)
     dt = time.perf_counter() - t0

@@ -181,7 +181,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
     v.dq = dq.data(); v.labels = labels;
-    v.off = pair ? off : nullptr; v.idx = idx; v.mult = mult; v.rev = rev.data();
+    v.off = pair ? off : nullptr; v.idx = idx; v.mult = mult; v.rev = rev.data(); v.wq = nullptr;
     v.cap = cap.data(); v.ex = ex.data(); v.rt = rt.data(); v.d = d.data(); v.f = f.data(); v.g = g.data();
     v.cnt = cnt.data(); v.hub_exists = hub_exists.data(); v.hub_e = hub_e.data();
     v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.hubA_e = hubA_e.data(); v.hubA_want = hubA_want.data(); v.bfs_hub_d = bfs_hub_d.data();

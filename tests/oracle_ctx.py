@@ -130,5 +130,8 @@ class OracleContext:
         counts, order = O.bucket(self.labels, L)
         return counts, (order if want_order else None)
 
+    def gc_labeling(self, model, T2, lam):
+        return O.gc_labeling(self.model_type, self.pts, model, T2, lam, self.graph)
+
     def residual_sum(self, model, label):
         return O.residual_sum(self.model_type, self.pts, model, self.labels, label)

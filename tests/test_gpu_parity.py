@@ -545,6 +545,67 @@ def test_asymmetric_graph_is_rejected(gpu_ctx):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# GC-RANSAC's inlier/outlier graph cut (pgx_gc_labeling) — flags bit-exact against the oracle, which
+# builds upstream's add_term1/add_term2 graph while the device solves the re-parameterised Potts form
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("n,lam", [(2, 0.5), (65, 0.1), (3000, 0.3), (20011, 0.14), (20011, 0.9)])
+def test_gc_labeling_matches_oracle(gpu_ctx, oracle, name, n, lam):
+    mt, pts, models, thr = make_case(name, n, 6, seed=n)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    graph = gpu_ctx.graph_build(pts, _lib.GRAPH_KNN, k=min(6, max(1, n - 1)))
+    seen = set()
+    for m in models:
+        ref = oracle.gc_labeling(mt, pts, m, T2, lam, graph)
+        got = gpu_ctx.gc_labeling(m, T2, lam)
+        assert got.dtype == np.int32 and np.array_equal(got, ref), f"{name} n={n} lam={lam}: {int((got != ref).sum())} flags differ"
+        seen.add(int(ref.sum()))
+    if n >= 3000:
+        assert max(seen) > n // 20          # the ground-truth hypotheses keep a real inlier set
+    # a degenerate (NaN) model: every residual counts as beyond the threshold (e = 1), on both sides
+    bad = np.full(models.shape[1], np.nan)
+    assert np.array_equal(gpu_ctx.gc_labeling(bad, T2, lam), oracle.gc_labeling(mt, pts, bad, T2, lam, graph))
+
+
+def test_gc_labeling_smooths_and_keeps_the_pearl_state(gpu_ctx, oracle):
+    # the pairwise term changes the outcome of plain thresholding (points just beyond the threshold inside an inlier
+    # neighbourhood are pulled in) but not wholesale; a following expansion still sees its own tables
+    rng = np.random.default_rng(2)
+    n = 20000
+    pts = np.column_stack([rng.random(n) * 1000, rng.normal(0, 2.0, n)])
+    pts[rng.random(n) < 0.3, 1] = 50.0                                       # gross outliers
+    model, T2, lam = np.array([0.0, 1.0, 0.0]), 9.0, 0.14
+    gpu_ctx.set_points(_lib.LINE2D, pts)
+    graph = gpu_ctx.graph_build(np.column_stack([pts[:, 0], np.zeros(n)]), _lib.GRAPH_KNN, k=6)   # neighbours along x
+    Dq = (rng.integers(0, 1 << 20, (n, 3)) << 12).astype(np.int64)
+    gpu_ctx.set_unary_q(Dq)
+    gpu_ctx.set_labels(np.zeros(n, np.int32))
+    flags = gpu_ctx.gc_labeling(model, T2, lam)
+    assert np.array_equal(flags, oracle.gc_labeling(_lib.LINE2D, pts, model, T2, lam, graph))
+    thr_inl = pts[:, 1] ** 2 <= T2
+    assert 0 < int((flags != thr_inl).sum()) < n // 4
+    gpu_ctx.expansion(0.2, 0.5)
+    ref, _, _ = oracle.expansion(Dq, graph, oracle.quantize_lambda(0.2), oracle.quantize(0.5), np.zeros(n, np.int32))
+    assert np.array_equal(gpu_ctx.get_labels(), ref)
+
+
+def test_gc_labeling_error_paths(gpu_ctx):
+    from pyprogressivex._lib import PgxError
+    pts = np.random.default_rng(0).random((100, 2))
+    gpu_ctx.set_points(_lib.LINE2D, pts)
+    gpu_ctx.graph_build(pts, _lib.GRAPH_KNN, k=3)
+    for lam in (0.0, 1.0, -0.1, float("nan")):
+        with pytest.raises(PgxError):
+            gpu_ctx.gc_labeling(np.array([0.0, 1.0, 0.0]), 1.0, lam)
+    with pytest.raises(PgxError):
+        gpu_ctx.gc_labeling(np.array([0.0, 1.0, 0.0]), 0.0, 0.5)
+    gpu_ctx.set_points(_lib.LINE2D, pts[:50])            # graph over 100 sites no longer matches
+    with pytest.raises(PgxError):
+        gpu_ctx.gc_labeling(np.array([0.0, 1.0, 0.0]), 1.0, 0.5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # full BASELINE size: 1e6 2D-3D correspondences x 2048 pose hypotheses, size-independent properties
 # ----------------------------------------------------------------------------------------------------------------------
 def test_metric_batch_full_size_properties(gpu_ctx, oracle):

@@ -370,3 +370,55 @@ def test_device_solvers_agree_with_independent_numpy_solvers(oracle):
             Xc = pp[smp[s], 2:] @ P[:, :3].T + P[:, 3]
             assert np.abs(Xc[:, :2] / Xc[:, 2:] - pp[smp[s], :2]).max() < 1e-6
     assert same >= 290
+
+
+def test_gc_labeling_minimises_the_restated_energy(oracle):
+    """GC-RANSAC's inlier/outlier cut [U-12]: the oracle builds the graph the way upstream's Energy::add_term1/add_term2
+    would; here the energy is written down directly (integer terms, every undirected pair once) and minimised by brute
+    force on <= 10 points of a 2-D line problem.  The cut must reach the minimum and, among the minimisers, return the
+    smallest inlier set (sink segment = sites that still reach t; ties -> outlier)."""
+    from pyprogressivex import _lib
+    rng = np.random.default_rng(5)
+    q = lambda x: int(np.rint(x * 4294967296.0))
+    hit_tie = 0
+    for trial in range(200):
+        n = int(rng.integers(2, 11))
+        pts = np.column_stack([rng.random(n) * 10, rng.normal(0, 1.0, n)])
+        if trial % 3 == 0:
+            pts[:, 1] = np.round(pts[:, 1])          # many equal residuals -> ties
+        model = np.array([0.0, 1.0, 0.0])            # the line y = 0: r = |y|
+        T2, lam = float(rng.choice([0.25, 1.0, 2.25])), float(rng.choice([0.1, 0.3, 0.5, 0.9]))
+        graph = random_sym_graph(rng, n, 0.5)
+        flags = oracle.gc_labeling(_lib.LINE2D, pts, model, T2, lam, graph)
+        sq = pts[:, 1] ** 2
+        inl = sq <= T2
+        e = np.where(inl, sq / T2, 1.0)
+        lq = 2 * int(np.rint(lam * 2147483648.0))
+        off, idx = graph[0], graph[1]
+        pairs = [(i, int(j)) for i in range(n) for j in idx[off[i]:off[i + 1]] if i < j]
+
+        def energy(x):   # x[i] = 1 inlier
+            tot = 0
+            for i in range(n):
+                if inl[i]:
+                    tot += q((1 - lam) * (1 - e[i])) if x[i] == 0 else 0
+                else:
+                    tot += q((1 - lam) * e[i]) if x[i] == 1 else 0
+            for i, j in pairs:
+                if x[i] == 0 and x[j] == 0:
+                    tot += 2 * q(lam * 0.25 * (e[i] + e[j]))
+                elif x[i] != x[j]:
+                    tot += lq
+            return tot
+
+        best, inter, nbest = None, None, 0
+        for x in itertools.product([0, 1], repeat=n):
+            en = energy(x)
+            if best is None or en < best:
+                best, inter, nbest = en, np.array(x), 1
+            elif en == best:
+                inter, nbest = inter & np.array(x), nbest + 1
+        hit_tie += nbest > 1
+        assert energy(tuple(int(f) for f in flags)) == best
+        assert np.array_equal(flags, inter)
+    assert hit_tie > 5
