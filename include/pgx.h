@@ -157,6 +157,12 @@ enum { PGX_SEL_INDEX = 0, PGX_SEL_LABEL = 1 };
 int pgx_gram(pgx_ctx *ctx, int kind, const double *params, int nparams, int sel, const int32_t *index, int64_t m,
              int label, const double *weights, int weight_power, double *out, int64_t *count, int64_t *bad);
 
+/* Batched form for the inner RANSAC of the local optimisation: B index selections of m points each (index[B][m]), one
+ * parameter block per selection (params[B][nparams]), optional per-entry weights already gathered by the caller
+ * (weights_sel[B][m]).  out[B][q(q+1)/2], bad[B] (optional).  One launch, one wave per selection. */
+int pgx_gram_batch(pgx_ctx *ctx, int kind, const double *params, int nparams, const int32_t *index, int B, int m,
+                   const double *weights_sel, int weight_power, double *out, int32_t *bad);
+
 /* ---- the inlier/outlier graph cut of GC-RANSAC's local optimisation.
  * Replaces gcransac::GCRANSAC::labeling as reached from proposal_engine->run (progressive_x.h:294-299; settings
  * spatial_coherence_weight / threshold at :541-545).  The graph-cut-ransac sources are absent from the snapshot, so the

@@ -683,6 +683,13 @@ int pgx_residual_sum(pgx_ctx* ctx, const double* model, int label, double* sum)
     return residual_sum_launch(ctx, model, label, sum);
 }
 
+int pgx_gram_batch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,
+                   const double* weights_sel, int weight_power, double* out, int32_t* bad)
+{
+    CTX_GUARD(ctx);
+    return gram_batch_launch(ctx, kind, params, nparams, index, B, m, weights_sel, weight_power, out, bad);
+}
+
 int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
 {
     CTX_GUARD(ctx);

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "pgx_internal.h"
 
@@ -198,7 +199,118 @@ void launch(pgx_ctx* ctx, const FitParams& prm, const int* index, int64_t m, int
                        prm, index, m, ctx->labels.as<int>(), label, weights, wpow, partials, counters);
 }
 
+// Batched variant for the inner RANSAC of the local optimisation: B small index selections of m points
+// each, one wave per selection (m <= 64 in practice: 7 x the minimal sample size), per-selection parameter blocks.
+// Lanes take the points t = lane, lane + 64, ..; fixed shuffle tree: bit-reproducible.
+template <class G>
+__global__ __launch_bounds__(64) void gram_batch_kernel(const double* __restrict__ pts, const double* __restrict__ prm,
+                                                        const int* __restrict__ index, int m,
+                                                        const double* __restrict__ wsel, int wpow,
+                                                        double* __restrict__ out, int* __restrict__ bad)
+{
+    constexpr int Q = G::Q, NV = Q * (Q + 1) / 2;
+    const int b = blockIdx.x;
+    FitParams p;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) p.v[k] = prm[(int64_t)b * 12 + k];
+    Acc<Q> acc;
+    acc.zero();
+    int nbad = 0;
+    for (int t = threadIdx.x; t < m; t += 64) {
+        const int64_t i = index[(int64_t)b * m + t];
+        double pt[G::D];
+#pragma unroll
+        for (int k = 0; k < G::D; ++k) pt[k] = pts[i * G::D + k];
+        double w = 1.0;
+        if (wsel != nullptr) { w = wsel[(int64_t)b * m + t]; if (wpow == 2) w = w * w; }
+        int bd = 0;
+        emit<G>(pt, p, acc, w, bd);
+        nbad += bd;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = acc.s[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (threadIdx.x == 0) out[(int64_t)b * NV + k] = x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nbad += __shfl_down(nbad, off, 64);
+    if (threadIdx.x == 0) bad[b] = nbad;
+}
+
+template <class G>
+void launch_batch(pgx_ctx* ctx, int B, const double* prm, const int* index, int m, const double* wsel, int wpow, double* out,
+                  int* bad)
+{
+    hipLaunchKernelGGL((gram_batch_kernel<G>), dim3((unsigned)B), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), prm, index, m,
+                       wsel, wpow, out, bad);
+}
+
 }  // namespace
+
+static int gram_row_length(pgx_ctx* ctx, const char* who, int kind, int nparams, int* q)
+{
+    const int D = ctx->D;
+    switch (kind) {
+    case PGX_GRAM_AFFINE: *q = D + 1; if (D != 2 && D != 4 && D != 5) return fail(ctx, PGX_ERR_INVALID, "%s: affine rows need 2-, 4- or 5-D points", who); break;
+    case PGX_GRAM_DLT_H: case PGX_GRAM_EPI_F: *q = 9; if (D != 4 || nparams != 6) return fail(ctx, PGX_ERR_INVALID, "%s: needs 4-D correspondences and 6 normalisation parameters", who); break;
+    case PGX_GRAM_VP: *q = 3; if (D != 4) return fail(ctx, PGX_ERR_INVALID, "%s: needs 4-D segments", who); break;
+    case PGX_GRAM_PNP_GN: *q = 7; if (D != 5 || nparams != 12) return fail(ctx, PGX_ERR_INVALID, "%s: needs 5-D 2D-3D rows and a 3x4 pose", who); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "%s: unknown row kind %d", who, kind);
+    }
+    return PGX_OK;
+}
+
+int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,
+                      const double* wsel, int wpow, double* out, int32_t* bad)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_batch: points not set");
+    if (wpow != 1 && wpow != 2) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_batch: weight power must be 1 or 2");
+    if (nparams < 0 || nparams > 12 || (nparams > 0 && !params)) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_batch: bad parameter block");
+    if (!out || B < 0 || m < 0 || ((int64_t)B * m > 0 && !index)) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_batch: bad argument");
+    int q = 0;
+    PGX_TRY(gram_row_length(ctx, "pgx_gram_batch", kind, nparams, &q));
+    const int nv = q * (q + 1) / 2;
+    if (B == 0) return PGX_OK;
+    const int64_t tot = (int64_t)B * m;
+    for (int64_t t = 0; t < tot; ++t)
+        if (index[t] < 0 || index[t] >= ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_batch: index %d out of range", index[t]);
+    // scratch: prm[B][12] | out[B][nv] | wsel[B][m] | index[B][m] | bad[B]
+    const size_t prm_bytes = (size_t)B * 12 * 8, out_bytes = (size_t)B * nv * 8, w_bytes = wsel ? (size_t)tot * 8 : 0;
+    const size_t idx_bytes = ((size_t)tot * 4 + 7) & ~(size_t)7, bad_bytes = (size_t)B * 4;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, prm_bytes + out_bytes + w_bytes + idx_bytes + bad_bytes + 64));
+    char* base = (char*)ctx->fit_scratch.p;
+    double* d_prm = (double*)base;
+    double* d_out = (double*)(base + prm_bytes);
+    double* d_w = (double*)(base + prm_bytes + out_bytes);
+    int* d_idx = (int*)(base + prm_bytes + out_bytes + w_bytes);
+    int* d_bad = (int*)(base + prm_bytes + out_bytes + w_bytes + idx_bytes);
+    std::vector<double> hp((size_t)B * 12, 0.0);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < nparams; ++k) hp[(size_t)b * 12 + k] = params[(size_t)b * nparams + k];
+    PGX_HIP(ctx, hipMemcpyAsync(d_prm, hp.data(), prm_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (tot > 0) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, (size_t)tot * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, wsel, w_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const double* ww = wsel ? d_w : nullptr;
+    const int D = ctx->D;
+    switch (kind) {
+    case PGX_GRAM_AFFINE:
+        if (D == 2) launch_batch<GenAffine2>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad);
+        else if (D == 4) launch_batch<GenAffine4>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad);
+        else launch_batch<GenAffine5>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad);
+        break;
+    case PGX_GRAM_DLT_H: launch_batch<GenDltH>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad); break;
+    case PGX_GRAM_EPI_F: launch_batch<GenEpiF>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad); break;
+    case PGX_GRAM_VP: launch_batch<GenVp>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad); break;
+    default: launch_batch<GenPnpGn>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad); break;
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bad) PGX_HIP(ctx, hipMemcpyAsync(bad, d_bad, bad_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
 
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad)

@@ -26,11 +26,52 @@ class Estimator:
         """samples [S, m] -> (models [H, P], sample_of_model [H]); several or zero solutions per sample allowed."""
         raise NotImplementedError
 
+    def _fit(self, init):
+        """The refit as a coroutine: yields Gram requests (kind, params, use_weights, wpow), receives (G, count, bad)
+        and returns the list of models.  Written once, driven either by one pgx_gram call per request (`nonminimal`) or
+        in lockstep over a batch of selections with one pgx_gram_batch launch per step (`nonminimal_batch`)."""
+        raise NotImplementedError
+        yield  # pragma: no cover
+
     def nonminimal(self, ctx, sel, weights=None, init=None):
         """Least-squares fit to the selected resident points -> list of models (the reference accepts the refit only
         if exactly 1).  sel = ("index", indices) or ("label", k); the data pass runs on the device (ctx.gram =
         pgx_gram: weighted Gram matrix of the design rows), the small dense solve here."""
-        raise NotImplementedError
+        gen = self._fit(init)
+        try:
+            req = next(gen)
+            while True:
+                kind, params, use_w, wpow = req
+                req = gen.send(ctx.gram(kind, sel, params=params, weights=weights if use_w else None, wpow=wpow))
+        except StopIteration as done:
+            return done.value
+
+    def nonminimal_batch(self, ctx, index, weights=None, init=None):
+        """`nonminimal` for B index selections of equal size (index [B, m]) sharing `init`: the B coroutines advance in
+        lockstep, each step is ONE pgx_gram_batch launch.  Returns a list of B model lists."""
+        index = np.asarray(index)
+        B, m = index.shape
+        gens = [self._fit(init) for _ in range(B)]
+        results, pending = [None] * B, {}
+        for b, g in enumerate(gens):
+            try:
+                pending[b] = next(g)
+            except StopIteration as done:
+                results[b] = done.value
+        while pending:
+            groups = {}
+            for b, (kind, params, use_w, wpow) in pending.items():
+                groups.setdefault((kind, bool(use_w), wpow, params is None), []).append(b)
+            for (kind, use_w, wpow, no_params), bs in groups.items():
+                prm = None if no_params else np.array([np.asarray(pending[b][1], dtype=np.float64).reshape(-1) for b in bs])
+                G, bad = ctx.gram_batch(kind, index[bs], params=prm, weights=weights if use_w else None, wpow=wpow)
+                for k, b in enumerate(bs):
+                    try:
+                        pending[b] = gens[b].send((G[k], m, int(bad[k])))
+                    except StopIteration as done:
+                        results[b] = done.value
+                        del pending[b]
+        return results
 
     def descriptor(self, model):
         return np.asarray(model, dtype=np.float64)
@@ -58,8 +99,8 @@ class LineEstimator(Estimator):
         models = np.column_stack([nrm, c])
         return models[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
-        G, cnt, _ = ctx.gram(_lib.GRAM_AFFINE, sel, weights=weights, wpow=1)   # sum w [1,x,y][1,x,y]^T
+    def _fit(self, init):
+        G, cnt, _ = yield (_lib.GRAM_AFFINE, None, True, 1)                    # sum w [1,x,y][1,x,y]^T
         W = G[0, 0]
         if cnt < 2 or not W > 0:
             return []
@@ -93,9 +134,9 @@ class VanishingPointEstimator(Estimator):
         v = v / np.where(ok, ln, 1.0)[:, None]
         return v[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
+    def _fit(self, init):
         # rows A = [y0*mz-my, mx-x0*mz, x0*my-y0*mx] * w (:212-218) are generated and accumulated on the device
-        AtA, cnt, _ = ctx.gram(_lib.GRAM_VP, sel, weights=weights, wpow=2)
+        AtA, cnt, _ = yield (_lib.GRAM_VP, None, True, 2)
         if cnt < 2:
             return []
         evals, evecs = np.linalg.eigh(AtA)                                        # :227 SelfAdjointEigenSolver
@@ -115,10 +156,10 @@ def _dlt_rows(x1, y1, x2, y2):
     return r1, r2
 
 
-def _hartley_from_moments(ctx, sel):
-    """Normalising similarities of both images from one pass of first/second moments (isotropic scaling to an RMS
-    distance of sqrt(2) from the centroid).  Returns (T1, T2, params for the DLT / epipolar rows, count)."""
-    G, cnt, _ = ctx.gram(_lib.GRAM_AFFINE, sel)
+def _hartley_from_moments(G, cnt):
+    """Normalising similarities of both images from one pass of first/second moments (the affine Gram matrix G;
+    isotropic scaling to an RMS distance of sqrt(2) from the centroid).  Returns (T1, T2, params for the DLT /
+    epipolar rows, count)."""
     if cnt < 1:
         return None, None, None, 0
     c = G[0, 1:] / cnt
@@ -163,11 +204,12 @@ class HomographyEstimator(Estimator):
         ok &= np.isfinite(h).all(axis=1)
         return h[ok], np.nonzero(ok)[0]
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
-        T1, T2, prm, cnt = _hartley_from_moments(ctx, sel)
+    def _fit(self, init):
+        G, cnt, _ = yield (_lib.GRAM_AFFINE, None, False, 2)
+        T1, T2, prm, cnt = _hartley_from_moments(G, cnt)
         if cnt < 4:
             return []
-        AtA, _, _ = ctx.gram(_lib.GRAM_DLT_H, sel, params=prm, weights=weights, wpow=2)   # normalised DLT rows
+        AtA, _, _ = yield (_lib.GRAM_DLT_H, prm, True, 2)                                  # normalised DLT rows
         Hn = _smallest_eigenvector(AtA).reshape(3, 3)
         H = np.linalg.inv(T2) @ Hn @ T1
         if not np.isfinite(H).all() or abs(H[2, 2]) < 1e-300:
@@ -197,8 +239,8 @@ class SymmetricHomographyEstimator(HomographyEstimator):
         aug, keep = self._augment(models)
         return aug, src[keep]
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
-        res = super().nonminimal(ctx, sel, weights, init)
+    def _fit(self, init):
+        res = yield from super()._fit(init)
         return [m for m in self._augment(np.array(res).reshape(-1, 9))[0]]
 
     def output(self, model):
@@ -269,11 +311,12 @@ class FundamentalEstimator(Estimator):
 
         return np.array(models).reshape(-1, 9), np.array(src, dtype=np.int64)
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
-        T1, T2, prm, cnt = _hartley_from_moments(ctx, sel)
+    def _fit(self, init):
+        G, cnt, _ = yield (_lib.GRAM_AFFINE, None, False, 2)
+        T1, T2, prm, cnt = _hartley_from_moments(G, cnt)
         if cnt < 8:
             return []
-        AtA, _, _ = ctx.gram(_lib.GRAM_EPI_F, sel, params=prm, weights=weights, wpow=2)   # normalised 8-point rows
+        AtA, _, _ = yield (_lib.GRAM_EPI_F, prm, True, 2)                                  # normalised 8-point rows
         F = _smallest_eigenvector(AtA).reshape(3, 3)
         u, s, v = np.linalg.svd(F)
         F = u @ np.diag([s[0], s[1], 0.0]) @ v
@@ -382,7 +425,7 @@ class PnPEstimator(Estimator):
         o = np.argsort(src, kind="stable")
         return models[o], src[o]
 
-    def nonminimal(self, ctx, sel, weights=None, init=None):
+    def _fit(self, init):
         """Gauss-Newton on the reprojection error from `init` (PEARL and the local optimisation always have one; the
         DLT start of an un-initialised fit is not needed on this path).  Per iteration the device accumulates the
         normal equations  sum (J,r)^T (J,r)  (rows in fit.hip GenPnpGn), the 6x6 solve and the pose update run here."""
@@ -391,7 +434,7 @@ class PnPEstimator(Estimator):
         P = np.asarray(init, dtype=np.float64).reshape(3, 4).copy()
         R, t = P[:, :3], P[:, 3]
         for _ in range(10):
-            G, cnt, bad = ctx.gram(_lib.GRAM_PNP_GN, sel, params=np.column_stack([R, t]).reshape(-1), weights=weights, wpow=2)
+            G, cnt, bad = yield (_lib.GRAM_PNP_GN, np.column_stack([R, t]).reshape(-1), True, 2)
             if cnt < 4 or bad > 0:
                 return []
             try:

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
-    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
 ]
@@ -327,6 +327,29 @@ class Context:
                                     C.c_int(mode), iptr, C.c_int64(m), C.c_int(label), _ptr(w, C.c_double),
                                     C.c_int(int(wpow)), _ptr(out, C.c_double), C.byref(cnt), C.byref(bad)), "pgx_gram")
         return tri_to_sym(out, q), cnt.value, bad.value
+
+    def gram_batch(self, kind, index, params=None, weights=None, wpow=2):
+        """pgx_gram_batch: B selections of m resident points each (index [B, m]) in one launch; params [B, np] or None;
+        weights = the full per-point weight vector (gathered here).  Returns (G [B, q, q] symmetric, bad [B])."""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        B, m = idx.shape
+        q = GRAM_Q.get(kind, POINT_DIM[self.model_type] + 1)
+        nv = q * (q + 1) // 2
+        out = np.zeros((B, nv), dtype=np.float64)
+        bad = np.zeros(B, dtype=np.int32)
+        prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(B, -1)
+        w = None
+        if weights is not None and len(weights) > 0:
+            w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)[idx])
+        self._ck(self._lib.pgx_gram_batch(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double),
+                                          C.c_int(0 if prm is None else prm.shape[1]), _ptr(idx, C.c_int32) if idx.size else None,
+                                          C.c_int(B), C.c_int(m), _ptr(w, C.c_double), C.c_int(int(wpow)),
+                                          _ptr(out, C.c_double), _ptr(bad, C.c_int32)), "pgx_gram_batch")
+        G = np.zeros((B, q, q))
+        iu = np.triu_indices(q)
+        G[:, iu[0], iu[1]] = out
+        G[:, iu[1], iu[0]] = out
+        return G, bad
 
     def set_labels(self, labels):
         lab = _i32(labels)

@@ -225,7 +225,7 @@ class ProposalEngine:
           repeat (at most max_graph_cut_number = 10 times):
             inliers <- the inlier/outlier graph cut of the best model (one exact min-cut on the GPU, pgx_gc_labeling);
             inner RANSAC: max_local_optimization_number samples of min(7 * sample size, |inliers|) inliers, each refitted
-            by the non-minimal solver (Gram pass on the GPU); all candidates are scored in ONE launch and then walked in
+            by the non-minimal solver (batched Gram pass on the GPU: pgx_gram_batch, all samples per launch); all candidates are scored in ONE launch and then walked in
             order - a strictly better score replaces the best model, exactly what the sequential loop would keep;
             stop when a round brought no improvement."""
         est, s = self.est, self.s
@@ -239,9 +239,9 @@ class ProposalEngine:
             size = min(limit, len(inl))
             cands = []
             if size < len(inl) and size >= est.nonminimal_sample_size:
-                for _t in range(trials):
-                    pick = np.sort(rng.choice(inl, size, replace=False))
-                    cands.extend(est.nonminimal(self.ctx, ("index", pick), weights, init=model))
+                picks = np.array([np.sort(rng.choice(inl, size, replace=False)) for _t in range(trials)])
+                for fits in est.nonminimal_batch(self.ctx, picks, weights, init=model):   # one launch per refit step
+                    cands.extend(fits)
             elif est.sample_size < len(inl) and len(inl) >= est.nonminimal_sample_size:
                 cands.extend(est.nonminimal(self.ctx, ("index", inl), weights, init=model))
             if not cands:

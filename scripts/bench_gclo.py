@@ -28,15 +28,17 @@ def run(name, mt, pts, gpts, model, thr, lam, est, radius):
     rng = np.random.default_rng(0)
     size = 7 * est.sample_size
     t0 = time.perf_counter()
-    cands = []
-    for _ in range(50):
-        pick = np.sort(rng.choice(inl, size, replace=False))
-        cands.extend(est.nonminimal(ctx, ("index", pick), None, init=model))
+    picks = np.array([np.sort(rng.choice(inl, size, replace=False)) for _ in range(50)])
+    cands = [m for fits in est.nonminimal_batch(ctx, picks, None, init=model) for m in fits]
     t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for b in range(50):
+        est.nonminimal(ctx, ("index", picks[b]), None, init=model)
+    t_single = time.perf_counter() - t0
     t0 = time.perf_counter()
     ctx.score(np.asarray(cands), T2, has_compound=False, exponent=2)
     t_score = time.perf_counter() - t0
-    print(f"{name}: n={len(pts)} inliers={len(inl)} cut {t_cut * 1e3:.2f} ms, 50 refits {t_fit * 1e3:.2f} ms "
+    print(f"{name}: n={len(pts)} inliers={len(inl)} cut {t_cut * 1e3:.2f} ms, 50 refits batched {t_fit * 1e3:.2f} ms / one by one {t_single * 1e3:.2f} ms "
           f"({len(cands)} candidates), scoring {t_score * 1e3:.2f} ms  stats={st}", flush=True)
     ctx.close()
 

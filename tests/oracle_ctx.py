@@ -94,6 +94,12 @@ class OracleContext:
         index = np.asarray(sel[1], dtype=np.int64) if sel[0] == "index" else np.nonzero(self.labels == int(sel[1]))[0]
         return O.gram(kind, self.pts, index, params=params, weights=weights, wpow=wpow)
 
+    def gram_batch(self, kind, index, params=None, weights=None, wpow=2):
+        index = np.asarray(index, dtype=np.int64)
+        res = [O.gram(kind, self.pts, index[b], params=None if params is None else np.asarray(params)[b], weights=weights,
+                      wpow=wpow) for b in range(index.shape[0])]
+        return np.array([r[0] for r in res]), np.array([r[2] for r in res], dtype=np.int32)
+
     def graph_build(self, points, kind, radius=0.0, k=5, fetch=True):
         self.graph = O.graph_build(points, kind, radius=radius, k=k)
         return self.graph if fetch else len(self.graph[1])

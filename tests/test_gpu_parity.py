@@ -522,6 +522,62 @@ def test_gram_matches_oracle(gpu_ctx, oracle, name, n):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("B,m", [(1, 1), (3, 14), (50, 49), (7, 64), (5, 200)])
+def test_gram_batch_matches_oracle(gpu_ctx, oracle, name, B, m):
+    """pgx_gram_batch (one wave per selection, per-selection parameter blocks) against the oracle's per-selection Gram."""
+    n = 5000
+    mt, pts, models, thr = make_case(name, n, 2, seed=B + m)
+    rng = np.random.default_rng(B * 1000 + m)
+    gpu_ctx.set_points(mt, pts)
+    weights = rng.random(n) + 0.5
+    norm = lambda: np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0]) * (1.0 + 0.1 * rng.random(6))
+    kinds = {"line": [(_lib.GRAM_AFFINE, None)],
+             "vanishing_point": [(_lib.GRAM_VP, None)],
+             "homography": [(_lib.GRAM_AFFINE, None), (_lib.GRAM_DLT_H, norm)],
+             "homography_sym": [(_lib.GRAM_DLT_H, norm)],
+             "fundamental": [(_lib.GRAM_EPI_F, norm)],
+             "pnp": [(_lib.GRAM_PNP_GN, lambda: models[0][:12] + 1e-3 * rng.random(12))]}[name]
+    index = np.array([rng.choice(n, m, replace=False) for _ in range(B)])
+    for kind, make in kinds:
+        prm = None if make is None else np.array([make() for _ in range(B)])
+        for w, wpow in ((None, 2), (weights, 1), (weights, 2)):
+            G, bad = gpu_ctx.gram_batch(kind, index, params=prm, weights=w, wpow=wpow)
+            assert G.shape[0] == B and bad.shape == (B,)
+            for b in range(B):
+                Gr, _, badr = oracle.gram(kind, pts, index[b], params=None if prm is None else prm[b], weights=w, wpow=wpow)
+                assert int(bad[b]) == badr
+                assert np.abs(G[b] - Gr).max() <= REL * max(np.abs(Gr).max(), 1e-300), f"{name} kind {kind} b={b} wpow {wpow}"
+                assert np.array_equal(G[b], G[b].T)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.gram_batch(kinds[0][0], np.full((2, 3), n, np.int32), params=None if kinds[0][1] is None else np.zeros((2, 6 if name != "pnp" else 12)))
+
+
+def test_batched_refits_equal_single_refits(gpu_ctx):
+    """Estimator.nonminimal_batch (coroutines in lockstep over pgx_gram_batch) returns what nonminimal returns per
+    selection (same algebra; only the reduction tree of the Gram pass differs: 1e-9)."""
+    from pyprogressivex import _estimators
+    rng = np.random.default_rng(4)
+    for name in ("line", "vanishing_point", "homography", "homography_sym", "fundamental", "pnp"):
+        mt, pts, models, thr = make_case(name, 4000, 1, seed=9)
+        est = _estimators.ESTIMATORS[name]()
+        gpu_ctx.set_points(mt, pts)
+        m = 7 * est.sample_size
+        one = gpu_ctx.score(models[:1], 2.25 * thr * thr, want_masks=True)
+        inl = np.nonzero(np.unpackbits(one["masks"][0].view(np.uint8), bitorder="little")[:len(pts)])[0]
+        assert len(inl) > m
+        picks = np.array([np.sort(rng.choice(inl, m, replace=False)) for _ in range(20)])
+        init = models[0] if name == "pnp" else None
+        batch = est.nonminimal_batch(gpu_ctx, picks, None, init=init)
+        for b in range(len(picks)):
+            single = est.nonminimal(gpu_ctx, ("index", picks[b]), None, init=init)
+            assert len(single) == len(batch[b]) == 1
+            a, c = np.asarray(single[0]), np.asarray(batch[b][0])
+            if np.dot(a, c) < 0 and name in ("line", "vanishing_point", "fundamental"):
+                c = -c                                             # eigenvector sign
+            assert np.abs(a - c).max() <= 1e-6 * max(1.0, np.abs(a).max()), name
+
+
 def test_gram_error_paths_and_empty_selection(gpu_ctx):
     mt, pts, models, thr = make_case("homography", 100, 1, seed=1)
     gpu_ctx.set_points(mt, pts)

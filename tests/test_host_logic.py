@@ -147,3 +147,33 @@ def test_refits_recover_the_generating_models():
     segs = np.column_stack([mid - 30 * d, mid + 30 * d])
     v = _estimators.VanishingPointEstimator().nonminimal(_octx(_lib.VANISHING_POINT, segs), ("index", np.arange(300)))[0]
     assert abs(v[2]) > 0 and np.abs(v[:2] / v[2] - vp).max() < 1e-3
+
+
+def test_batched_refits_equal_single_refits_on_the_oracle_context():
+    # the lockstep coroutine driver (nonminimal_batch) must return exactly what per-selection refits return when both
+    # are fed by the same Gram provider
+    from pyprogressivex import _estimators, _lib, datasets
+    rng = np.random.default_rng(1)
+    pts, gt, _ = datasets.make_homographies(n_per_plane=200, n_planes=2, n_outliers=50, seed=1)
+    inl = np.nonzero(gt == 1)[0]
+    picks = np.array([np.sort(rng.choice(inl, 28, replace=False)) for _ in range(6)])
+    for est, mt in ((_estimators.HomographyEstimator(), _lib.HOMOGRAPHY), (_estimators.FundamentalEstimator(), _lib.FUNDAMENTAL)):
+        ctx = _octx(mt, pts)
+        w = rng.random(len(pts)) + 0.5
+        batch = est.nonminimal_batch(ctx, picks, w)
+        for b in range(len(picks)):
+            single = est.nonminimal(ctx, ("index", picks[b]), w)
+            assert len(single) == len(batch[b]) == 1 and np.array_equal(single[0], batch[b][0])
+    # PnP: selections converge after different numbers of Gauss-Newton steps; an un-initialised fit returns nothing
+    x1p, x2p, K, gtp, poses = datasets.make_poses(n_per_object=300, n_objects=1, n_outliers=0, seed=2)
+    norm, f = datasets.normalize_pnp(x1p, x2p, K)
+    ctx = _octx(_lib.PNP, norm)
+    est = _estimators.PnPEstimator()
+    picks = np.array([np.sort(rng.choice(300, 21, replace=False)) for _ in range(5)])
+    P0 = poses[0].copy()
+    P0[[3, 7, 11]] += [1.0, -1.0, 2.0]
+    batch = est.nonminimal_batch(ctx, picks, None, init=P0)
+    for b in range(5):
+        single = est.nonminimal(ctx, ("index", picks[b]), None, init=P0)
+        assert np.array_equal(single[0], batch[b][0])
+    assert est.nonminimal_batch(ctx, picks, None, init=None) == [[]] * 5
