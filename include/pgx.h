@@ -118,11 +118,12 @@ int pgx_set_graph(pgx_ctx *ctx, int64_t n, const int32_t *off, const int32_t *id
  * code is absent from the snapshot [U-7], so the lists are restated deterministically:
  *   PGX_GRAPH_KNN_IN_BALL  the k nearest neighbours with squared distance <= radius^2 (drop-in default, k = 5)
  *   PGX_GRAPH_KNN          the k nearest neighbours (radius ignored)
+ *   PGX_GRAPH_BALL         every point with squared distance <= radius^2 (k ignored; symmetric lists: multiplicity 2)
  * points: n x d doubles (d = 2..5, the data space the reference hands to FLANN), ranking by (squared distance, index),
  * squared distance summed in dimension order without contraction.  The symmetric CSR (multiplicity = number of
  * directed list entries of the pair, U-6) stays resident exactly as after pgx_set_graph; pgx_graph_fetch copies it
  * out (off[n+1]; idx/mult[arcs], may be NULL). */
-enum { PGX_GRAPH_KNN_IN_BALL = 0, PGX_GRAPH_KNN = 2 };
+enum { PGX_GRAPH_KNN_IN_BALL = 0, PGX_GRAPH_BALL = 1, PGX_GRAPH_KNN = 2 };
 int pgx_graph_build(pgx_ctx *ctx, const double *points, int64_t n, int d, int kind, double radius, int k, int64_t *arcs);
 int pgx_graph_fetch(pgx_ctx *ctx, int32_t *off, int32_t *idx, int32_t *mult);
 

@@ -319,8 +319,40 @@ def graph_from_lists(lists):
     return np.cumsum(off).astype(np.int32), b.astype(np.int32), m.astype(np.int32)
 
 
+def graph_ball(points, radius):
+    """exhaustive ball (kind 1): every point with squared distance <= radius^2, symmetric lists -> multiplicity 2.
+    Candidate pairs from a kd-tree with a safety margin, the decision itself with the exact arithmetic."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    r2 = float(radius) * float(radius)
+    if n <= 4000:
+        S = (pts[:, 0][:, None] - pts[None, :, 0]) * (pts[:, 0][:, None] - pts[None, :, 0])
+        for j in range(1, pts.shape[1]):
+            df = pts[:, j][:, None] - pts[None, :, j]
+            S = S + df * df
+        a, b = np.nonzero((S <= r2) & ~np.eye(n, dtype=bool))
+    else:
+        from scipy.spatial import cKDTree
+        pairs = cKDTree(pts).query_pairs(r=float(radius) * (1.0 + 1e-9), output_type="ndarray")
+        i, j = pairs[:, 0], pairs[:, 1]
+        s = (pts[i, 0] - pts[j, 0]) * (pts[i, 0] - pts[j, 0])
+        for c in range(1, pts.shape[1]):
+            df = pts[i, c] - pts[j, c]
+            s = s + df * df
+        keep = s <= r2
+        a = np.concatenate([i[keep], j[keep]])
+        b = np.concatenate([j[keep], i[keep]])
+    o = np.lexsort((b, a))
+    a, b = a[o], b[o]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(off, a + 1, 1)
+    return np.cumsum(off).astype(np.int32), b.astype(np.int32), np.full(len(b), 2, dtype=np.int32)
+
+
 def graph_build(points, kind, radius=0.0, k=5):
-    """kind 0: k nearest inside the ball; kind 2: plain k-NN (the constants of include/pgx.h)"""
+    """kind 0: k nearest inside the ball; kind 1: the whole ball; kind 2: plain k-NN (the constants of include/pgx.h)"""
+    if kind == 1:
+        return graph_ball(points, radius)
     lists = graph_lists(points, k, radius if kind == 0 else None)
     return graph_from_lists(lists)
 

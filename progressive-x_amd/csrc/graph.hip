@@ -217,6 +217,81 @@ __global__ __launch_bounds__(kGBlock) void g_search_kernel(const double* __restr
     }
 }
 
+// Exhaustive ball (PGX_GRAPH_BALL): every point with squared distance <= r2, variable degree.  Same tiling as the search
+// kernel, run twice: phase 0 counts (deg[qi]), phase 1 writes the neighbours to idx[off[qi] ..] in the order met (rows
+// are sorted afterwards).  (a-b)^2 == (b-a)^2 and the sum runs over the coordinates in the same order, so the lists are
+// symmetric by construction: every arc gets multiplicity 2 (both directed entries exist, U-6).
+template <int D>
+__global__ __launch_bounds__(kGBlock) void g_ball_kernel(const double* __restrict__ spts, const int* __restrict__ sidx,
+                                                         const int* __restrict__ start, const int* __restrict__ blk_start,
+                                                         GridSpec g, int cells, double r2, int phase, int* __restrict__ deg,
+                                                         const int* __restrict__ off, int* __restrict__ idx,
+                                                         int* __restrict__ mult, unsigned long long* __restrict__ total)
+{
+    __shared__ double t_pts[kTile * D];
+    __shared__ int t_idx[kTile];
+    __shared__ int s_cell;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = cells;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+        }
+        s_cell = lo;
+    }
+    __syncthreads();
+    const int c = s_cell;
+    const int slice = (int)blockIdx.x - blk_start[c];
+    const int cs = start[c], ce = start[c + 1];
+    const int q = cs + slice * kGBlock + (int)threadIdx.x;
+    const bool live = q < ce;
+    int qi = -1;
+    double qp[D];
+    if (live) {
+        qi = sidx[q];
+#pragma unroll
+        for (int j = 0; j < D; ++j) qp[j] = spts[(int64_t)q * D + j];
+    }
+    int cnt = 0;
+    int w = (live && phase == 1) ? off[qi] : 0;
+    const int cx = c % g.W, cy = c / g.W;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= g.H) continue;
+        const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < g.W ? cx + 1 : g.W - 1;
+        const int s0 = start[yy * g.W + x0], s1 = start[yy * g.W + x1 + 1];
+        for (int t0 = s0; t0 < s1; t0 += kTile) {
+            const int m = s1 - t0 < kTile ? s1 - t0 : kTile;
+            __syncthreads();
+            for (int e = (int)threadIdx.x; e < m * D; e += kGBlock) t_pts[e] = spts[(int64_t)t0 * D + e];
+            for (int e = (int)threadIdx.x; e < m; e += kGBlock) t_idx[e] = sidx[t0 + e];
+            __syncthreads();
+            if (live)
+                for (int e = 0; e < m; ++e) {
+                    double df = qp[0] - t_pts[e * D];
+                    double s = df * df;
+#pragma unroll
+                    for (int j = 1; j < D; ++j) {
+                        df = qp[j] - t_pts[e * D + j];
+                        s = s + df * df;
+                    }
+                    const int ci = t_idx[e];
+                    if (s <= r2 && ci != qi) {
+                        if (phase == 1) { idx[w] = ci; mult[w] = 2; ++w; }
+                        ++cnt;
+                    }
+                }
+        }
+    }
+    if (phase == 0) {
+        if (live) deg[qi] = cnt;
+        unsigned long long t = (unsigned long long)cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(total, t);
+    }
+}
+
 // ---- lists -> CSR ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kGBlock) void g_recip_kernel(const int* __restrict__ nbr, int64_t n, int k,
                                                           int* __restrict__ m1, int* __restrict__ outdeg,
@@ -305,6 +380,15 @@ void launch_search(pgx_ctx* ctx, GraphScratch& gs, const GridSpec& g, int cells,
                            gs.nbr.as<int>(), pending);
 }
 
+template <int D>
+void launch_ball(pgx_ctx* ctx, GraphScratch& gs, const GridSpec& g, int cells, int nblocks, double r2, int phase, int* off,
+                 int* idx, int* mult)
+{
+    hipLaunchKernelGGL((g_ball_kernel<D>), dim3((unsigned)nblocks), dim3(kGBlock), 0, ctx->stream, gs.spts.as<double>(),
+                       gs.sidx.as<int>(), gs.start.as<int>(), gs.blk.as<int>(), g, cells, r2, phase, gs.deg.as<int>(), off, idx, mult,
+                       (unsigned long long*)(gs.small.as<int>() + 2));
+}
+
 void free_scratch(GraphScratch& gs)
 {
     DevBuf* all[] = {&gs.key, &gs.count, &gs.start, &gs.cursor, &gs.sidx, &gs.spts, &gs.blk, &gs.nbr, &gs.m1,
@@ -314,7 +398,7 @@ void free_scratch(GraphScratch& gs)
 
 // one grid pass: sort by cell of size `cell`, search.  Returns the number of pending queries (knn mode) in *pending.
 int grid_pass(pgx_ctx* ctx, GraphScratch& gs, int64_t n, int d, const double mn[2], const double mx[2], double cell,
-              double r2, int k, int knn_mode, int* pending_out)
+              double r2, int k, int knn_mode, int* pending_out, GridSpec* grid_out = nullptr, int* nblocks_out = nullptr)
 {
     GridSpec g;
     g.min0 = mn[0]; g.min1 = mn[1];
@@ -342,6 +426,12 @@ int grid_pass(pgx_ctx* ctx, GraphScratch& gs, int64_t n, int d, const double mn[
     int nblocks = 0;
     PGX_HIP(ctx, hipMemcpyAsync(&nblocks, gs.blk.as<int>() + cells, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (grid_out) {  // the caller runs its own kernels over the sorted grid (exhaustive ball)
+        *grid_out = g;
+        *nblocks_out = nblocks;
+        *pending_out = 0;
+        return PGX_OK;
+    }
     if (nblocks > 0) {
         switch (d) {
         case 2: launch_search<2>(ctx, gs, g, cells, nblocks, r2, k, knn_mode); break;
@@ -368,10 +458,11 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
     if (n <= 0 || !pts) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: no points");
     if (n >= (int64_t)1 << 30) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: too many points");
     if (d < 2 || d > 5) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: dimension %d not supported (2..5)", d);
-    if (kind != PGX_GRAPH_KNN_IN_BALL && kind != PGX_GRAPH_KNN)
+    if (kind != PGX_GRAPH_KNN_IN_BALL && kind != PGX_GRAPH_KNN && kind != PGX_GRAPH_BALL)
         return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: unknown graph kind %d", kind);
     if (k < 1 || k > 16) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: k = %d outside 1..16", k);
-    if (kind == PGX_GRAPH_KNN_IN_BALL && !(radius > 0.0) ) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: radius must be > 0");
+    if (kind == PGX_GRAPH_BALL) k = 1;  // unused
+    if (kind != PGX_GRAPH_KNN && !(radius > 0.0)) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: radius must be > 0");
     if (k > n - 1) k = (int)(n - 1);
     // extent of the two grid coordinates (host pass: the caller's buffer is in host memory anyway)
     double mn[2] = {pts[0], pts[1]}, mx[2] = {pts[0], pts[1]};
@@ -384,6 +475,51 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
         }
     GraphScratch gs;
     int rc = PGX_OK;
+    // exhaustive ball: count, scan, fill, sort rows — the lists are symmetric, the CSR is written directly
+    auto ball_csr = [&](pgx_ctx* c, GraphScratch& g_s, int64_t nn, int dd, const double* lo, const double* hi, double rad,
+                        int64_t* arcs_out) -> int {
+        GridSpec g;
+        int nblocks = 0, pend = 0;
+        const double cell = rad * (1.0 + 1e-9);
+        PGX_TRY(grid_pass(c, g_s, nn, dd, lo, hi, cell, rad * rad, 1, 0, &pend, &g, &nblocks));
+        const int cells = g.W * g.H;
+        const unsigned nb = (unsigned)((nn + kGBlock - 1) / kGBlock);
+        PGX_TRY(ensure(c, c->goff, (size_t)(nn + 1) * sizeof(int32_t)));
+        PGX_HIP(c, hipMemsetAsync(g_s.small.p, 0, 32, c->stream));
+        PGX_HIP(c, hipMemsetAsync(g_s.deg.p, 0, (size_t)nn * sizeof(int), c->stream));
+        auto run = [&](int phase, int* off, int* idx, int* mult) {
+            switch (dd) {
+            case 2: launch_ball<2>(c, g_s, g, cells, nblocks, rad * rad, phase, off, idx, mult); break;
+            case 3: launch_ball<3>(c, g_s, g, cells, nblocks, rad * rad, phase, off, idx, mult); break;
+            case 4: launch_ball<4>(c, g_s, g, cells, nblocks, rad * rad, phase, off, idx, mult); break;
+            default: launch_ball<5>(c, g_s, g, cells, nblocks, rad * rad, phase, off, idx, mult); break;
+            }
+        };
+        if (nblocks > 0) run(0, nullptr, nullptr, nullptr);
+        PGX_HIP(c, hipGetLastError());
+        unsigned long long total = 0;
+        PGX_HIP(c, hipMemcpyAsync(&total, g_s.small.as<int>() + 2, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+        PGX_HIP(c, hipStreamSynchronize(c->stream));
+        if (total >= (1ull << 31)) return fail(c, PGX_ERR_INVALID, "pgx_graph_build: %llu arcs inside the ball (limit 2^31 - 1): choose a smaller radius", total);
+        hipLaunchKernelGGL(g_scan_kernel, dim3(1), dim3(1024), 0, c->stream, g_s.deg.as<int>(), c->goff.as<int>(), nn, 0);
+        const int E = (int)total;
+        PGX_TRY(ensure(c, c->gidx, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+        PGX_TRY(ensure(c, c->gmult, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+        PGX_TRY(ensure(c, c->grev, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
+        int stats[2] = {0, 0};
+        if (E > 0) {
+            run(1, c->goff.as<int>(), c->gidx.as<int>(), c->gmult.as<int>());
+            PGX_HIP(c, hipMemsetAsync(g_s.small.p, 0, 16, c->stream));
+            hipLaunchKernelGGL(g_rowsort_kernel, dim3(nb), dim3(kGBlock), 0, c->stream, nn, c->goff.as<int>(), c->gidx.as<int>(),
+                               c->gmult.as<int>(), g_s.small.as<int>());
+            PGX_HIP(c, hipMemcpyAsync(stats, g_s.small.p, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
+            PGX_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        PGX_HIP(c, hipGetLastError());
+        c->gn = nn; c->gE = E; c->max_degree = stats[0]; c->max_row_mult = stats[1];
+        if (arcs_out) *arcs_out = E;
+        return graph_build_reverse(c);
+    };
     auto body = [&]() -> int {
         const size_t nk = (size_t)n * (size_t)(k > 0 ? k : 1);
         PGX_TRY(ensure(ctx, gs.dpts, (size_t)n * d * sizeof(double)));
@@ -401,6 +537,7 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
         PGX_HIP(ctx, hipMemsetAsync(gs.nbr.p, 0xff, nk * sizeof(int), ctx->stream));
         PGX_HIP(ctx, hipMemsetAsync(gs.done.p, 0, (size_t)n * sizeof(int), ctx->stream));
         int pend = 0;
+        if (kind == PGX_GRAPH_BALL) return ball_csr(ctx, gs, n, d, mn, mx, radius, arcs);
         if (k == 0) {
             // a single point: no neighbours
         } else if (kind == PGX_GRAPH_KNN_IN_BALL) {

@@ -19,7 +19,7 @@ import sys
 
 import numpy as np
 
-from . import _engine, _estimators, _graph, _lib, _proposal
+from . import _engine, _estimators, _lib, _proposal
 
 _ctx = None
 
@@ -70,10 +70,10 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     ctx = _context()
     rng = np.random.default_rng(seed)
     # FlannNeighborhoodGraph(&points, radius) [U-7]: built on the GPU (pgx_graph_build) and left resident there; the
-    # CSR comes back for the neighbourhood samplers.  Only the exhaustive ball variant is still a host construction.
+    # CSR comes back for the neighbourhood samplers.
     resident = True
     if neighborhood == "radius":
-        graph, resident = _graph.radius_graph(graph_points, radius), False
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_BALL, radius=radius)
     elif str(neighborhood).startswith("knn:"):
         graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN, k=int(str(neighborhood)[4:]))
     else:

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
 ]
 
 
-GRAPH_KNN_IN_BALL, GRAPH_KNN = 0, 2
+GRAPH_KNN_IN_BALL, GRAPH_BALL, GRAPH_KNN = 0, 1, 2
 GRAM_AFFINE, GRAM_DLT_H, GRAM_EPI_F, GRAM_VP, GRAM_PNP_GN = 0, 1, 2, 3, 4
 GRAM_Q = {GRAM_DLT_H: 9, GRAM_EPI_F: 9, GRAM_VP: 3, GRAM_PNP_GN: 7}   # GRAM_AFFINE: point dimension + 1
 

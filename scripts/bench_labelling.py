@@ -10,7 +10,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "progressive-x_amd"), os.path.join(ROOT, "oracle")]
-from pyprogressivex import _graph, _lib, datasets  # noqa: E402
+from pyprogressivex import _lib, datasets  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import host_graph as _graph  # noqa: E402  (scipy kd-tree reference constructions)
 import pgx_oracle as O  # noqa: E402
 
 

@@ -4,7 +4,9 @@ expanded for the first time (the move that hands a new instance its points)."""
 import os, sys, time
 sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'progressive-x_amd')]
 import numpy as np
-from pyprogressivex import _lib, _graph, datasets
+from pyprogressivex import _lib, datasets
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import host_graph as _graph
 mode = sys.argv[1] if len(sys.argv) > 1 else "steady"
 x1, x2, K, gt, poses = datasets.make_poses(seed=0)
 pts, f = datasets.normalize_pnp(x1, x2, K)

@@ -1,4 +1,5 @@
-"""Neighbourhood graph construction (host side, outside the hot path) -> the symmetric CSR that libpgx consumes.
+"""Host-side (scipy kd-tree) neighbourhood graphs — TEST / BENCH INFRASTRUCTURE ONLY: independent constructions used to
+cross-check and to time pgx_graph_build (csrc/graph.hip), which is what the package itself uses for every variant.
 
 Replaces: gcransac::neighborhood::FlannNeighborhoodGraph(&points, radius) + getNeighbors(i)
 (/root/reference/src/pyprogressivex/src/progressivex_python.cpp:104,207,339,458,571; PEARL.h:534).  The FLANN

@@ -67,7 +67,8 @@ def test_unknown_sampler_returns_zero_models_not_an_exception(capsys):
 
 
 def test_host_helpers():
-    from pyprogressivex import _engine, _graph, _proposal, parallel
+    import host_graph as _graph
+    from pyprogressivex import _engine, _proposal, parallel
     # progressive_x.h:495-513 incl. std::round semantics
     assert _engine.predicted_unseen_inliers(0.5, 4, 1000, 1, 5000) == \
         int(round((5000 - 1) * (1 - 0.5 ** (1 / 1000)) ** 0.25))

@@ -102,3 +102,15 @@ def test_bundled_tless_poses():
             ang = np.degrees(np.arccos(np.clip((np.trace(Pk[:, :3].T @ g[:, :3]) - 1) / 2, -1, 1)))
             errs.append((ang, np.linalg.norm(Pk[:, 3] - g[:, 3])))
         assert min(e[0] for e in errs) < 15.0 and min(e[1] for e in errs) < 60.0, errs
+
+
+def test_switches_ball_graph_and_refit_only_local_optimisation(monkeypatch):
+    # neighborhood="radius" -> the exhaustive ball graph (PGX_GRAPH_BALL); local_optimization="lsq" -> no graph cut
+    pts, gt, _ = datasets.make_lines(n_per_line=300, n_lines=3, n_outliers=300, seed=4)
+    kw = dict(threshold=2.0, conf=0.99, sampler_id=2, seed=3, minimum_point_number=60, spatial_coherence_weight=0.05,
+              neighborhood_ball_radius=12.0, neighborhood="radius")
+    (L, lab), (Lr, labr) = _both(monkeypatch, px.findLines, pts, np.array(0), 1000, 1000, **kw)
+    assert L.shape == (3, 3) and np.array_equal(lab, labr) and np.allclose(L, Lr, rtol=1e-9, atol=1e-12)
+    assert _me(lab, 3, gt) < 0.1
+    (L2, lab2), (L2r, lab2r) = _both(monkeypatch, px.findLines, pts, np.array(0), 1000, 1000, local_optimization="lsq", **kw)
+    assert np.array_equal(lab2, lab2r) and np.allclose(L2, L2r, rtol=1e-9, atol=1e-12) and _me(lab2, 3, gt) < 0.1

@@ -361,6 +361,27 @@ def test_graph_build_matches_oracle(gpu_ctx, oracle, style, n, d, k):
             assert np.array_equal(a, b), f"{style} n={n} d={d} k={k} kind={kind} r={radius}: {name} differs"
 
 
+@pytest.mark.parametrize("style", ["uniform", "integer", "clustered"])
+@pytest.mark.parametrize("n,d", [(1, 2), (2, 4), (300, 2), (2500, 4), (3000, 5), (30000, 3)])
+def test_graph_ball_matches_oracle(gpu_ctx, oracle, style, n, d):
+    # exhaustive ball (PGX_GRAPH_BALL): variable degree, symmetric lists, multiplicity 2 everywhere
+    rng = np.random.default_rng(n * 17 + d)
+    if n > 5000 and style == "integer":
+        pytest.skip("a 12^3 lattice with 30000 points is one dense clique: quadratic output")
+    pts = _graph_case(rng, n, d, style)
+    for radius in (0.5, 3.0, 9.0) if n <= 5000 else (0.5, 3.0):
+        ref = oracle.graph_build(pts, _lib.GRAPH_BALL, radius=radius)
+        got = gpu_ctx.graph_build(pts, _lib.GRAPH_BALL, radius=radius)
+        for name, a, b in zip(("off", "idx", "mult"), got, ref):
+            assert np.array_equal(a, b), f"{style} n={n} d={d} r={radius}: {name} differs"
+    if n == 2500:   # an independent construction: scipy's kd-tree pairs (distances well away from the radius)
+        import host_graph
+        ref = host_graph.radius_graph(pts, 3.0)
+        got = gpu_ctx.graph_build(pts, _lib.GRAPH_BALL, radius=3.0)
+        if style == "uniform":
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
 def test_graph_build_feeds_the_expansion(gpu_ctx, oracle):
     # the resident graph of pgx_graph_build is the one the moves run on: same labels as with pgx_set_graph(oracle CSR)
     rng = np.random.default_rng(5)
@@ -771,7 +792,8 @@ def test_single_move_at_c5_size_matches_oracle(gpu_ctx, oracle):
     """BASELINE config C5 shape: 2e5 line segments, 6 vanishing points, k-NN(8) graph on the midpoints; one expansion
     move from a noisy labelling must reproduce the oracle's min-cut labels exactly (the full expansion is covered at
     smaller sizes; Dinic needs ~17 s for it here)."""
-    from pyprogressivex import _graph, datasets
+    import host_graph as _graph
+    from pyprogressivex import datasets
     pts, gt, vps = datasets.make_vanishing_points(seed=0)
     n = pts.shape[0]
     graph = _graph.knn_graph(0.5 * (pts[:, :2] + pts[:, 2:]), 8)
