@@ -138,7 +138,8 @@ int pgx_expand_alpha(pgx_ctx *ctx, double lambda, double label_cost, int alpha, 
 int pgx_expansion(pgx_ctx *ctx, double lambda, double label_cost, int max_cycles,
                   int64_t *energy_q, double *energy, int *cycles);
 /* counters of the last pgx_expansion / pgx_expand_alpha: [0]=min-cuts solved, [1]=push-relabel sweeps,
- * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves, [5]=wave passes */
+ * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves, [5]=wave passes,
+ * [6]=work-list sweeps, [7]=moves skipped because the labelling had not changed since that label's last move, which relabelled nothing */
 int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by

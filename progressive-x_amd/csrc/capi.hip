@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <vector>
 #include <cmath>
 
 #include "pgx_internal.h"
@@ -643,14 +644,21 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
     PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
     int64_t old_e = new_e + 1;
     int done = 0;
+    int64_t version = 0;
+    std::vector<int64_t> noop_at((size_t)(ctx->L > 0 ? ctx->L : 1), -1);
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         if (new_e == old_e) break;
         old_e = new_e;
         int64_t changed_total = 0;
         for (int alpha = 0; alpha < ctx->L; ++alpha) {
+            // a move is a deterministic function of (labelling, alpha): one that relabelled nothing and has seen no
+            // label change since would relabel nothing again — skipped (typically the tail of the verifying cycle)
+            if (noop_at[alpha] == version) { ctx->stats[7]++; continue; }
             int64_t ch = 0;
             PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
             changed_total += ch;
+            if (ch > 0) { ++version; noop_at[alpha] = -1; }
+            else noop_at[alpha] = version;
         }
         // a cycle that relabels nothing leaves the energy unchanged by construction: skip the recomputation
         if (changed_total > 0) PGX_TRY(energy_launch(ctx, lq, hq, &new_e));

@@ -386,7 +386,7 @@ class Context:
         st = np.zeros(8, dtype=np.int64)
         self._ck(self._lib.pgx_expansion_stats(self._h, _ptr(st, C.c_int64)), "pgx_expansion_stats")
         return dict(mincuts=int(st[0]), sweeps=int(st[1]), global_relabels=int(st[2]), bfs_levels=int(st[3]),
-                    relabelled_sites=int(st[4]), wave_passes=int(st[5]))
+                    relabelled_sites=int(st[4]), wave_passes=int(st[5]), list_sweeps=int(st[6]), skipped_moves=int(st[7]))
 
     def bucket(self, L, want_order=True):
         counts = np.zeros(L, dtype=np.int64)

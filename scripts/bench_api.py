@@ -29,6 +29,18 @@ def timed(name, fn, gt, rows, *args, **kw):
                      pearl_iterations=st.pearl_iterations, expansion_cycles=st.expansion_cycles, core=st.processing_time)
         return models, st
     _api._engine.ProgressiveX.run = run
+    acc = {}
+    if os.environ.get("BENCH_MF_STATS"):   # accumulate the max-flow counters of every PEARL labelling call
+        from pyprogressivex import _lib
+        orig_exp = _lib.Context.expansion
+
+        def expansion(self, *a, **k):
+            r = orig_exp(self, *a, **k)
+            for key, val in self.expansion_stats().items():
+                acc[key] = acc.get(key, 0) + val
+            return r
+        _lib.Context.expansion = expansion
+        stats["maxflow"] = acc
     kw.setdefault("local_optimization", os.environ.get("BENCH_LO", "auto"))   # "lsq": refit-only local optimisation
     t0 = time.perf_counter()
     models, labels = fn(*args, **kw)

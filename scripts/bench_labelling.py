@@ -34,7 +34,7 @@ def run(name, mt, pts, models, thr, lam, h, graph, with_oracle=True):
     out = dict(config=name, n=n, K=len(models), arcs=int(graph[0][-1]), lam=lam, h=h, gpu_unary_ms=1e3 * t_unary,
                gpu_expansion_ms=1e3 * t_gpu, cycles=cycles, energy=e, **st,
                gpu_ms_per_mincut=1e3 * t_gpu / max(1, st["mincuts"]))
-    if with_oracle:
+    if with_oracle and "--no-oracle" not in sys.argv:
         t0 = time.perf_counter()
         Dq = O.unary_q(mt, pts, models, thr, lam)
         t_ou = time.perf_counter() - t0
@@ -48,7 +48,8 @@ def run(name, mt, pts, models, thr, lam, h, graph, with_oracle=True):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["C2", "C3", "C5", "C4"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["C2", "C3", "C5", "C4"]
+    # --no-oracle: skip the Dinic reference (minutes at C4 size)
     if "C2" in which:
         pts, gt, models = datasets.make_homographies(seed=0)
         run("C2 homography 5k/5 planes", _lib.HOMOGRAPHY, pts, models, 3.0, 0.05, 10.0, _graph.flann_like_graph(pts, 200.0))
