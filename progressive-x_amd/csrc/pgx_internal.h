@@ -50,7 +50,7 @@ struct pgx_ctx {
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     int score_cull = 1;          // cull + survivor kernels instead of in-kernel group skipping (PGX_SCORE_NO_CULL=1: A/B)
     int score_group_xcd = 0;     // PGX_SCORE_GROUP_XCD=1: a group's workgroups on one XCD (less HBM fetch, slower: A/B)
-    int score_split = 16;        // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT)
+    int score_split = 8;         // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT)
     pgx::DevBuf cull_lists, cull_counts;
     pgx::DevBuf gc;          // inlier/outlier graph cut: e[n] | dq[2][n] | wq[E] | labels[n]
     int score_xcd_map = 1;       // XCD-aware block mapping of the score kernel (PGX_SCORE_NO_XCD=1 disables)

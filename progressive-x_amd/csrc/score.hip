@@ -383,7 +383,8 @@ __device__ __forceinline__ LaneT lane_load(const float* __restrict__ row)
 template <int MT>
 __global__ __launch_bounds__(64) void score_cull_kernel(
     const double* __restrict__ models, int M, double T2, double guard32, const float* __restrict__ gbounds, int groups,
-    int gps /* groups per segment */, int W, unsigned long long* __restrict__ keep, float* __restrict__ hyp32)
+    int gps /* groups per segment */, int W, unsigned long long* __restrict__ keep, float* __restrict__ hyp32,
+    double* __restrict__ models_t /* [P][W * 64]: component-major copy for the gathers of the group kernel */)
 {
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
@@ -394,10 +395,14 @@ __global__ __launch_bounds__(64) void score_cull_kernel(
 #pragma unroll
     for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
     const typename F32::Lane flane32 = F32::prep(mdl, guard32);
-    if (seg == 0) lane_store(flane32, hyp32 + (int64_t)m * kHypRow);
+    if (seg == 0) {
+        lane_store(flane32, hyp32 + (int64_t)m * kHypRow);
+#pragma unroll
+        for (int k = 0; k < R::P; ++k) models_t[(int64_t)k * W * 64 + m] = mdl[k];
+    }
     const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
     const int g0 = seg * gps, g1 = g0 + gps < groups ? g0 + gps : groups;
-    constexpr int kU = 4;  // bounds of four groups per scalar-memory round trip
+    constexpr int kU = 4;  // bounds of four groups per scalar-memory round trip (eight: no gain)
     int g = g0;
     for (; g + kU <= g1; g += kU) {
         float gr[kU][9];
@@ -420,37 +425,43 @@ __global__ __launch_bounds__(64) void score_cull_kernel(
     }
 }
 
-constexpr int kGroupWaves = 4;  // waves per workgroup of the group-major kernel
+constexpr int kGroupWaves = 1;  // waves per workgroup of the group-major kernel
 
 template <int MT, bool MASK>
 __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
     const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
     const float* __restrict__ hyp32, double qscale, unsigned long long* __restrict__ acc /* [3][Mpad]: count, value, shared */,
-    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local)
+    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t)
 {
     // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
     using LaneT = typename F32::Lane;
     const int lane = (int)(threadIdx.x & 63);
-    // Which (group, part) this wave owns.  xcd_local places the workgroups of one group on the same XCD (ids go round-robin
-    // over the 8 XCDs) so that its rows are fetched from HBM once: FETCH_SIZE 165 -> 45 MiB per launch, but the kernel
-    // takes 0.51 instead of 0.36 ms (measured), so the default spreads a group over the XCDs and pays the re-fetch.
+    // One item (group, part) per wave, one wave per workgroup.  Measured alternatives at M = 2048, N = 1e6: 4-wave workgroups
+    // (a workgroup retires with its slowest wave; 0.32 ms), 2-wave (0.30), persistent waves striding over the items
+    // (0.31-0.38), workgroups that hand out 8-64 items to their 4 waves from an LDS counter (0.29-0.32), placing a
+    // group's workgroups on one XCD (FETCH_SIZE 165 -> 45 MiB but 0.51 ms); one wave per workgroup with 8 parts per
+    // group: 0.28 ms (16 parts: 250 k workgroups, the dispatcher limits at ~1.3 ns per workgroup).
+    const int wv = 0;
     int g, part;
-    if (xcd_local) {
-        const int bpg = split / kGroupWaves;  // workgroups per group
+    if (xcd_local) {  // workgroup ids go round-robin over the 8 XCDs: all parts of a group on one XCD (its L2 fetches the rows once)
         const int slot = (int)(blockIdx.x >> 3);
-        g = (slot / bpg) * 8 + (int)(blockIdx.x & 7u);
-        part = (slot % bpg) * kGroupWaves + (int)(threadIdx.x >> 6);
+        g = (slot / split) * 8 + (int)(blockIdx.x & 7u);
+        part = slot % split;
+        if (g >= groups) return;
     } else {
-        const int wid = (int)blockIdx.x * kGroupWaves + (int)(threadIdx.x >> 6);
-        g = wid / split;
-        part = wid % split;
+        g = (int)blockIdx.x / split;
+        part = (int)blockIdx.x % split;
     }
     g = __builtin_amdgcn_readfirstlane(g);
     part = __builtin_amdgcn_readfirstlane(part);
-    if (g >= groups) return;
+    {   // nothing survived the cull for this wave's hypotheses: leave before the point rows are requested
+        unsigned long long any = 0;
+        for (int w = part; w < W; w += split) any |= keep[(int64_t)g * W + w];
+        if (any == 0) return;
+    }
     const int64_t j = (int64_t)g * 64 + lane;
     const bool valid = j < n;
     const int64_t jj = valid ? j : n - 1;
@@ -462,15 +473,54 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     for (int q = 0; q < 8; ++q) p32[q] = pts32[jj * 8 + q];
     const double cmp = has_comp ? comp[jj] : 0.0;
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
-    // The constants of a word's surviving hypotheses are staged in LDS by the lanes that own them (one vector-load round
-    // trip per 64 hypotheses) and read back as broadcasts: one scalar-memory round trip per hypothesis (~1 us when the
-    // scalar cache misses) made the kernel latency-bound (measured: 37 % VALU utilisation, 471 us).
     // The f32 constants of a word's surviving hypotheses are staged in LDS by the lanes that own them (one vector-load
     // round trip per 64 hypotheses) and read back as broadcasts: one scalar-memory round trip per hypothesis (~1 us
     // when the scalar cache misses) left the kernel latency-bound (37 % VALU utilisation).  The f64 model is fetched
     // only by pairs that have candidates (staging it as well costs occupancy or compaction work: measured slower).
     __shared__ float s_h32[kGroupWaves][64][kHypRow];
-    const int wv = (int)(threadIdx.x >> 6);
+    __shared__ unsigned s_queue[kGroupWaves][128];
+    int qn = 0;  // queued candidate pairs of this wave (wave-uniform)
+    // Exact evaluation of up to 64 queued (hypothesis, point) pairs, one per lane.  A pair's point lives in the registers
+    // of lane `src` of this wave (shuffles), its model is gathered from global memory.  Every contribution is converted to
+    // 2^-q fixed point BEFORE any summation, so the accumulated integers do not depend on how pairs were batched:
+    // results are bit-reproducible and independent of the launch geometry.  Equal hypotheses are adjacent in the queue
+    // (pairs are appended hypothesis by hypothesis): a segmented shuffle reduction leaves one atomic set per run.
+    auto drain = [&](int c) {
+        const bool act = lane < c;
+        const unsigned e = act ? s_queue[wv][lane] : 0u;
+        const int m = act ? (int)(e >> 6) : -1 - lane;
+        const int src = act ? (int)(e & 63u) : lane;
+        double q_pt[R::D];
+#pragma unroll
+        for (int k = 0; k < R::D; ++k) q_pt[k] = __shfl(pt[k], src, 64);
+        const double q_cmp = has_comp ? __shfl(cmp, src, 64) : 0.0;
+        long long cnt = 0, val = 0, shq = 0;
+        if (act) {  // exact path: oracle operation order, no contraction
+            double mdl[R::P];
+#pragma unroll
+            for (int k = 0; k < R::P; ++k) mdl[k] = models_t[(int64_t)k * Mpad + m];  // neighbours in m share cache lines
+            const double sq = R::squared(q_pt, mdl);
+            if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
+                const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
+                cnt = 1;
+                val = __double2ll_rn(sc * qscale);
+                if (has_comp) shq = __double2ll_rn(cv_min(q_cmp, sc) * qscale);     // :115-117
+            }
+        }
+        for (int off = 1; off < 64; off <<= 1) {  // segmented sums: lane i ends with the total of i .. end of its run
+            const int mo = __shfl_down(m, off, 64);
+            const bool same = lane + off < 64 && mo == m;
+            if (__ballot(same) == 0) break;  // runs are contiguous: none reaches `off` lanes, none reaches further
+            const long long c2 = __shfl_down(cnt, off, 64), v2 = __shfl_down(val, off, 64), s2 = __shfl_down(shq, off, 64);
+            if (same) { cnt += c2; val += v2; shq += s2; }
+        }
+        const int mp = __shfl_up(m, 1, 64);
+        if (act && (lane == 0 || mp != m) && cnt > 0) {
+            atomicAdd(&acc[m], (unsigned long long)cnt);
+            atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+            if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+        }
+    };
     for (int w = part; w < W; w += split) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
         if (todo == 0) continue;
@@ -487,7 +537,25 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             const int m = w * 64 + h;
             const LaneT ln = lane_load<LaneT>(&s_h32[wv][h][0]);  // same address in every lane: LDS broadcast
             const bool cand = valid && !F32::reject(p32, ln, T2d32);
-            if (__ballot(cand) == 0) continue;
+            const unsigned long long cm = __ballot(cand);
+            if (cm == 0) continue;
+            if (!MASK) {
+                // the exact path with ~3 of 64 lanes busy per (hypothesis, group) was most of this kernel: candidates
+                // are queued instead and evaluated 64 at a time
+                if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
+                    ((unsigned)m << 6) | (unsigned)lane;
+                qn += __popcll(cm);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    drain(64);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned mv = s_queue[wv][64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    s_queue[wv][lane] = mv;
+                    qn -= 64;
+                }
+                continue;
+            }
             double sc = 0.0, shv = 0.0;
             bool inl = false;
             if (cand) {  // exact path: oracle operation order, no contraction
@@ -503,18 +571,24 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             }
             const unsigned long long bm = __ballot(inl);
             if (bm == 0) continue;
+            // per-lane fixed point first (the same integers the queued path adds up), then an exact integer tree
+            long long val = inl ? __double2ll_rn(sc * qscale) : 0, shq = (inl && has_comp) ? __double2ll_rn(shv * qscale) : 0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {  // fixed tree: the partial of (hypothesis, group) is deterministic
-                sc += __shfl_down(sc, off, 64);
-                shv += __shfl_down(shv, off, 64);
+            for (int off = 32; off > 0; off >>= 1) {
+                val += __shfl_down(val, off, 64);
+                shq += __shfl_down(shq, off, 64);
             }
             if (lane == 0) {
                 atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
-                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)__double2ll_rn(sc * qscale));
-                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)__double2ll_rn(shv * qscale));
-                if (MASK) masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
+                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+                masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
             }
         }
+    }
+    if (!MASK && qn > 0) {
+        __builtin_amdgcn_wave_barrier();
+        drain(qn);
     }
 }
 
@@ -726,33 +800,32 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             const int gps = (groups + kCullSegs - 1) / kCullSegs;
             const int W = ctx->Mpad / 64;
             PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)groups * W * sizeof(unsigned long long)));             // keep[g][w]
-            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + 3 * sizeof(long long))));  // hyp32 | acc
+            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + 3 * sizeof(long long) + Residual<MT>::P * sizeof(double))));  // hyp32 | acc | models_t
             float* hyp32 = ctx->cull_counts.as<float>();
             unsigned long long* acc = (unsigned long long*)(ctx->cull_counts.as<char>() + (size_t)ctx->Mpad * kHypRow * sizeof(float));
+            double* models_t = (double*)(acc + 3 * (size_t)ctx->Mpad);
             int lg = 0;
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg);  // every sum is <= n < 2^lg
             PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)W, kCullSegs), dim3(64), 0, ctx->stream,
                                ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
-                               ctx->cull_lists.as<unsigned long long>(), hyp32);
+                               ctx->cull_lists.as<unsigned long long>(), hyp32, models_t);
             PGX_HIP(ctx, hipGetLastError());
             const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
-            const int xcd_local = ctx->score_group_xcd && split % kGroupWaves == 0;
-            const unsigned gblocks = xcd_local
-                                         ? (unsigned)(((groups + 7) / 8) * 8 * (split / kGroupWaves))
-                                         : (unsigned)(((int64_t)groups * split + kGroupWaves - 1) / kGroupWaves);
+            const int xcd_local = ctx->score_group_xcd;
+            const unsigned gblocks = xcd_local ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
             if (want_masks) {
                 PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
                 hipLaunchKernelGGL((score_group_kernel<MT, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local);
+                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t);
             } else {
                 hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local);
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t);
             }
             PGX_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
