@@ -122,6 +122,7 @@ template <int MT> struct Filter32 {
 // hypotheses look at the same image region): 74 % of the (wave, group) pairs of the metric batch.
 constexpr double kGroupInflate = 1.00001;
 constexpr int kGroupRow = 12;  // floats per group: c[3], rho, ub, vb, ru, rv, scale, pad[3]
+constexpr int kSuper = 8;      // groups per super-group (512 points): first level of the cull kernel
 
 template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;
@@ -380,48 +381,63 @@ __device__ __forceinline__ LaneT lane_load(const float* __restrict__ row)
     return ln;
 }
 
+constexpr int kCullWaves = 4;   // hypothesis words (waves) per workgroup of the cull kernel
+constexpr int kCullTile = 64;   // group bounds staged in LDS per step
+
+// The group bounds of a segment are staged in LDS by the whole workgroup (coalesced vector loads, one round trip per 64
+// groups) and read back as broadcasts: with scalar loads a wave paid one ~1 us scalar-cache miss per four groups, and the
+// kernel — a single generation of waves — took as long as that latency chain (43 us for 27 VALU instructions per test).
 template <int MT>
-__global__ __launch_bounds__(64) void score_cull_kernel(
+__global__ __launch_bounds__(64 * kCullWaves) void score_cull_kernel(
     const double* __restrict__ models, int M, double T2, double guard32, const float* __restrict__ gbounds, int groups,
     int gps /* groups per segment */, int W, unsigned long long* __restrict__ keep, float* __restrict__ hyp32,
     double* __restrict__ models_t /* [P][W * 64]: component-major copy for the gathers of the group kernel */)
 {
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
-    const int w = (int)blockIdx.x, seg = (int)blockIdx.y;
-    const int m = w * 64 + (int)threadIdx.x;
-    const bool live = m < M;
+    __shared__ __attribute__((aligned(16))) float s_gb[kCullTile + kCullTile / kSuper][kGroupRow];  // groups | their super-groups
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = (int)blockIdx.x * kCullWaves + (int)(threadIdx.x >> 6), seg = (int)blockIdx.y;
+    const int m = w * 64 + lane;
+    const bool live = w < W && m < M;
     double mdl[R::P];
 #pragma unroll
     for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
     const typename F32::Lane flane32 = F32::prep(mdl, guard32);
-    if (seg == 0) {
+    if (seg == 0 && w < W) {
         lane_store(flane32, hyp32 + (int64_t)m * kHypRow);
 #pragma unroll
         for (int k = 0; k < R::P; ++k) models_t[(int64_t)k * W * 64 + m] = mdl[k];
     }
     const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
     const int g0 = seg * gps, g1 = g0 + gps < groups ? g0 + gps : groups;
-    constexpr int kU = 4;  // bounds of four groups per scalar-memory round trip (eight: no gain)
-    int g = g0;
-    for (; g + kU <= g1; g += kU) {
-        float gr[kU][9];
+    for (int t0 = g0; t0 < g1; t0 += kCullTile) {
+        const int cnt = g1 - t0 < kCullTile ? g1 - t0 : kCullTile;
+        __syncthreads();  // the previous tile has been read
+        const int scnt = (cnt + kSuper - 1) / kSuper;  // t0 is a multiple of kSuper (gps is)
+        for (int e = (int)threadIdx.x; e < cnt * kGroupRow; e += 64 * kCullWaves)
+            (&s_gb[0][0])[e] = gbounds[(int64_t)t0 * kGroupRow + e];
+        for (int e = (int)threadIdx.x; e < scnt * kGroupRow; e += 64 * kCullWaves)
+            (&s_gb[kCullTile][0])[e] = gbounds[((int64_t)groups + t0 / kSuper) * kGroupRow + e];
+        __syncthreads();
+        if (w >= W) continue;
+        for (int sgi = 0; sgi < scnt; ++sgi) {
+            const int i0 = sgi * kSuper, i1 = i0 + kSuper < cnt ? i0 + kSuper : cnt;
+            float sr[9];
 #pragma unroll
-        for (int u = 0; u < kU; ++u)
+            for (int k = 0; k < 9; ++k) sr[k] = s_gb[kCullTile + sgi][k];  // same address in every lane: LDS broadcast
+            if (__ballot(live && !F32::group_reject(sr, flane32, Tup32)) == 0) {  // no hypothesis of the word reaches these 512 points
+                if (lane < i1 - i0) keep[(int64_t)(t0 + i0 + lane) * W + w] = 0;
+                continue;
+            }
+            for (int i = i0; i < i1; ++i) {
+                float gr[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) gr[u][k] = gbounds[(int64_t)(g + u) * kGroupRow + k];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const unsigned long long bm = __ballot(live && !F32::group_reject(gr[u], flane32, Tup32));
-            if (threadIdx.x == 0) keep[(int64_t)(g + u) * W + w] = bm;
+                for (int k = 0; k < 9; ++k) gr[k] = s_gb[i][k];
+                const unsigned long long bm = __ballot(live && !F32::group_reject(gr, flane32, Tup32));
+                if (lane == 0) keep[(int64_t)(t0 + i) * W + w] = bm;
+            }
         }
-    }
-    for (; g < g1; ++g) {
-        float gr[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) gr[k] = gbounds[(int64_t)g * kGroupRow + k];
-        const unsigned long long bm = __ballot(live && !F32::group_reject(gr, flane32, Tup32));
-        if (threadIdx.x == 0) keep[(int64_t)g * W + w] = bm;
     }
 }
 
@@ -797,7 +813,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         if (filt32 && !deferred && ctx->point_sort && ctx->score_cull) {
             // ---- cull, then score group-major
             const int groups = (int)((ctx->n + 63) / 64);
-            const int gps = (groups + kCullSegs - 1) / kCullSegs;
+            const int gps = ((groups + kCullSegs - 1) / kCullSegs + kSuper - 1) / kSuper * kSuper;  // whole super-groups per segment
             const int W = ctx->Mpad / 64;
             PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)groups * W * sizeof(unsigned long long)));             // keep[g][w]
             PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + 3 * sizeof(long long) + Residual<MT>::P * sizeof(double))));  // hyp32 | acc | models_t
@@ -808,8 +824,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg);  // every sum is <= n < 2^lg
             PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
-            hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)W, kCullSegs), dim3(64), 0, ctx->stream,
-                               ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
+            hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
+                               ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
                                ctx->cull_lists.as<unsigned long long>(), hyp32, models_t);
             PGX_HIP(ctx, hipGetLastError());
             const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
@@ -931,7 +947,8 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
     const int64_t groups = (n + 63) / 64;
     std::vector<int> pperm((size_t)n);
     std::vector<double> sp((size_t)n * d), spm((size_t)n);
-    std::vector<float> sp32((size_t)n * 8), gb((size_t)groups * kGroupRow, 0.0f);
+    const int64_t supers = (groups + kSuper - 1) / kSuper;
+    std::vector<float> sp32((size_t)n * 8), gb((size_t)(groups + supers) * kGroupRow, 0.0f);
     for (int64_t j = 0; j < n; ++j) {
         const int64_t i = (int64_t)(uint32_t)kv[(size_t)j];
         pperm[(size_t)j] = (int)i;
@@ -943,9 +960,7 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
     int in0, in1, ob0;
     if (ctx->model_type == kPnP) { in0 = 2; in1 = 4; ob0 = 0; }
     else { in0 = 0; in1 = 1; ob0 = 2; }
-    for (int64_t g = 0; g < groups; ++g) {
-        const int64_t a = g * 64, b = a + 64 < n ? a + 64 : n;
-        float* row = gb.data() + (size_t)g * kGroupRow;
+    auto bounds = [&](int64_t a, int64_t b, float* row) {  // bounds of the sorted points [a, b)
         // centre = box centre of the f32 rows (the values the kernel's per-point filter sees are not needed here: the
         // bound is about the exact f64 points; extents are inflated below)
         double cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, omin[2], omax[2];
@@ -977,18 +992,22 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
         row[6] = (float)(ru * kGroupInflate + 1e-30);
         row[7] = (float)(rv * kGroupInflate + 1e-30);
         row[8] = (float)(scale * 1.000001);
-    }
+    };
+    for (int64_t g = 0; g < groups; ++g) bounds(g * 64, g * 64 + 64 < n ? g * 64 + 64 : n, gb.data() + (size_t)g * kGroupRow);
+    // super-groups of kSuper consecutive groups (512 points): the cull kernel tests them first; rows behind the group rows
+    for (int64_t sg = 0; sg < supers; ++sg)
+        bounds(sg * kSuper * 64, (sg + 1) * kSuper * 64 < n ? (sg + 1) * kSuper * 64 : n, gb.data() + (size_t)(groups + sg) * kGroupRow);
     PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
     PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->comp_s, (size_t)n * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pperm, (size_t)n * sizeof(int)));
-    PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)groups * kGroupRow * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)(groups + supers) * kGroupRow * sizeof(float)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts_s.p, sp.data(), (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pts32_s.p, sp32.data(), (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pmax_s.p, spm.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pperm.p, pperm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(ctx->gbounds.p, gb.data(), (size_t)groups * kGroupRow * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->gbounds.p, gb.data(), (size_t)(groups + supers) * kGroupRow * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemsetAsync(ctx->comp_s.p, 0, (size_t)n * sizeof(double), ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->point_sort = 1;
