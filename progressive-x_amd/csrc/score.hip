@@ -441,6 +441,14 @@ __global__ __launch_bounds__(64 * kCullWaves) void score_cull_kernel(
     }
 }
 
+// round-to-nearest-even of 0 <= x < 2^51 as an integer: one FP64 add against 1.5 * 2^52 and an integer subtraction (the
+// generic double -> int64 conversion is ~20 instructions and ran twice per evaluated pair)
+__device__ __forceinline__ long long to_fixed(double x)
+{
+    const double magic = 6755399441055744.0;
+    return __double_as_longlong(x + magic) - __double_as_longlong(magic);
+}
+
 constexpr int kGroupWaves = 1;  // waves per workgroup of the group-major kernel
 
 template <int MT, bool MASK>
@@ -519,8 +527,8 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
                 const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
                 cnt = 1;
-                val = __double2ll_rn(sc * qscale);
-                if (has_comp) shq = __double2ll_rn(cv_min(q_cmp, sc) * qscale);     // :115-117
+                val = to_fixed(sc * qscale);
+                if (has_comp) shq = to_fixed(cv_min(q_cmp, sc) * qscale);           // :115-117
             }
         }
         for (int off = 1; off < 64; off <<= 1) {  // segmented sums: lane i ends with the total of i .. end of its run
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             const unsigned long long bm = __ballot(inl);
             if (bm == 0) continue;
             // per-lane fixed point first (the same integers the queued path adds up), then an exact integer tree
-            long long val = inl ? __double2ll_rn(sc * qscale) : 0, shq = (inl && has_comp) ? __double2ll_rn(shv * qscale) : 0;
+            long long val = inl ? to_fixed(sc * qscale) : 0, shq = (inl && has_comp) ? to_fixed(shv * qscale) : 0;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 val += __shfl_down(val, off, 64);
@@ -822,7 +830,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             double* models_t = (double*)(acc + 3 * (size_t)ctx->Mpad);
             int lg = 0;
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
-            const double qscale = std::ldexp(1.0, 62 - lg);  // every sum is <= n < 2^lg
+            const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
             PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
