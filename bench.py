@@ -101,6 +101,8 @@ def main():
     if use_comm:
         parallel.init_rccl(ctx, rank, world)
 
+    fetch_buf = None if use_comm else ctx.score_buffers()   # reused every step (results are consumed before the next one)
+
     def step():
         ctx.timer_start()
         ctx.score_launch(T2, has_compound=True)
@@ -109,7 +111,7 @@ def main():
             ctx.score_allgather()
             res = ctx.score_fetch_all(exponent=2)
         else:
-            res = ctx.score_fetch(exponent=2)
+            res = ctx.score_fetch(exponent=2, out=fetch_buf)
         kernel_ms = ctx.timer_elapsed()  # the fetch synchronised the stream: the events are complete
         best = parallel.select_best(res["scores"], res["counts"])
         return kernel_ms, best, res

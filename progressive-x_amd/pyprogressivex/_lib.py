@@ -211,7 +211,21 @@ class Context:
         self._ck(self._lib.pgx_score_launch(self._h, C.c_double(T2), C.c_int(1 if has_compound else 0),
                                             C.c_int(1 if want_masks else 0)), "pgx_score_launch")
 
-    def score_fetch(self, exponent=2, want_masks=False):
+    def score_buffers(self):
+        """Reusable result buffers for score_fetch(out=...): a loop that fetches every step saves the four allocations and
+        pointer conversions per call (the arrays are overwritten by the next fetch)."""
+        M = self.M
+        buf = dict(counts=np.empty(M, dtype=np.int64), values=np.empty(M, dtype=np.float64),
+                   shared=np.empty(M, dtype=np.float64), scores=np.empty(M, dtype=np.float64), masks=None)
+        buf["_ptrs"] = (_ptr(buf["counts"], C.c_int64), _ptr(buf["values"], C.c_double), _ptr(buf["shared"], C.c_double),
+                        _ptr(buf["scores"], C.c_double))
+        return buf
+
+    def score_fetch(self, exponent=2, want_masks=False, out=None):
+        if out is not None and not want_masks and out["counts"].shape[0] == self.M:
+            pc, pv, ps, pq = out["_ptrs"]
+            self._ck(self._lib.pgx_score_fetch(self._h, C.c_int(int(exponent)), pc, pv, ps, pq, None), "pgx_score_fetch")
+            return out
         M = self.M
         counts = np.empty(M, dtype=np.int64)
         values = np.empty(M, dtype=np.float64)
