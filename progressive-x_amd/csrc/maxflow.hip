@@ -20,7 +20,7 @@ namespace pgx {
 constexpr int kMfBlock = 256;
 
 struct MaxflowState {
-    DevBuf cap, ex, rt, d, f, g, small, front;
+    DevBuf cap, tot, ex, rt, d, f, g, small, front;
     int* h_flags = nullptr;  // pinned host mirror for flag read-backs
     DevBuf lists;            // act[2][n] | mark[n]
     int next_stamp = 1;
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
             const int w = fin[q];
             for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
                 const int uu = v.idx[a];
-                const bool want = v.labels[uu] != v.alpha &&
-                                  __hip_atomic_load(&v.cap[v.rev[a]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+                // residual of the reverse arc uu -> w without the gather through rev[a]; label test folded into d (kMfDead)
+                const bool want = v.tot[a] - __hip_atomic_load(&v.cap[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
                                   __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
                 r |= mf_bfs_label(v, uu, k, s_min, want, -1, scnt, slist);
             }
@@ -556,7 +556,7 @@ void maxflow_free(pgx_ctx* ctx)
 {
     if (!ctx->mf) return;
     MaxflowState* st = ctx->mf;
-    release(st->cap); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
+    release(st->cap); release(st->tot); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
     release(st->small); release(st->front); release(st->lists);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
     delete st;
@@ -638,6 +638,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     MaxflowState* st = ctx->mf;
     const int64_t E = pair ? ctx->gE : 0;
     PGX_TRY(ensure(ctx, st->cap, (size_t)(E > 0 ? E : 1) * sizeof(long long)));
+    PGX_TRY(ensure(ctx, st->tot, (size_t)(E > 0 ? E : 1) * sizeof(long long)));
     PGX_TRY(ensure(ctx, st->ex, (size_t)n * sizeof(long long)));
     PGX_TRY(ensure(ctx, st->rt, (size_t)n * sizeof(long long)));
     PGX_TRY(ensure(ctx, st->f, (size_t)n * sizeof(long long)));
@@ -663,7 +664,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.wq = wq;
     v.off = pair ? ctx->goff.as<int>() : nullptr;
     v.idx = ctx->gidx.as<int>(); v.mult = ctx->gmult.as<int>(); v.rev = ctx->grev.as<int>();
-    v.cap = st->cap.as<long long>(); v.ex = st->ex.as<long long>(); v.rt = st->rt.as<long long>();
+    v.cap = st->cap.as<long long>(); v.tot = st->tot.as<long long>(); v.ex = st->ex.as<long long>(); v.rt = st->rt.as<long long>();
     v.d = st->d.as<int>(); v.f = st->f.as<long long>(); v.g = st->g.as<long long>();
     v.hub_e = (long long*)sp; sp += (size_t)L * 8;
     v.hubA_rt = (long long*)sp; sp += 8;

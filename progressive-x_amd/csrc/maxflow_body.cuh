@@ -41,6 +41,7 @@
 namespace pgx {
 
 constexpr int kMfInf = 0x3fffffff;
+constexpr int kMfDead = -1;  // height of a site that is already alpha (not part of the move's graph)
 
 struct MfView {
     int64_t n;
@@ -55,6 +56,8 @@ struct MfView {
     const long long* wq;  // [E] per-arc weight (symmetric: wq[a] == wq[rev[a]]) replacing lambda_q * mult[a], or nullptr
     const int* rev;       // [E] index of the reverse arc
     long long* cap;       // [E] residual capacity of arc a (row owner -> idx[a])
+    long long* tot;       // [E] cap[a] + cap[rev[a]], invariant under pushes: the BFS reads the reverse residual as
+                          //     tot[a] - cap[a], two sequential reads instead of a gather through rev[a]
     long long* ex;        // [n] excess
     long long* rt;        // [n] residual capacity site -> t
     int* d;               // [n] height / BFS distance to t
@@ -208,10 +211,11 @@ PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
     v.g[u] = 0;
     v.d[u] = kMfInf;
     if (lu == v.alpha) {  // inactive: already alpha
+        v.d[u] = kMfDead;  // never "unlabelled": the BFS tests d alone and skips the label gather
         v.ex[u] = 0;
         v.rt[u] = 0;
         if (v.off)
-            for (int a = v.off[u]; a < v.off[u + 1]; ++a) v.cap[a] = 0;
+            for (int a = v.off[u]; a < v.off[u + 1]; ++a) { v.cap[a] = 0; v.tot[a] = 0; }
         return;
     }
     long long keep = v.dq[(int64_t)lu * v.n + u];
@@ -221,9 +225,9 @@ PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
             const int q = v.idx[a];
             const int lq = v.labels[q];
             const long long w = v.wq ? v.wq[a] : v.lambda_q * (long long)v.mult[a];
-            if (lq == v.alpha) { keep += w; v.cap[a] = 0; }
-            else if (lq == lu) v.cap[a] = w;
-            else { keep += w / 2; v.cap[a] = w / 2; }
+            if (lq == v.alpha) { keep += w; v.cap[a] = 0; v.tot[a] = 0; }
+            else if (lq == lu) { v.cap[a] = w; v.tot[a] = 2 * w; }
+            else { keep += w / 2; v.cap[a] = w / 2; v.tot[a] = w; }  // the reverse arc gets w / 2 as well
         }
     if (keep > take) { v.ex[u] = keep - take; v.rt[u] = 0; }
     else { v.ex[u] = 0; v.rt[u] = take - keep; }
@@ -297,7 +301,7 @@ PGX_HD bool mf_body_bfs_expand(const MfView& v, int64_t w, int k, int* hub_acc)
     if (!v.off) return false;
     for (int a = v.off[w]; a < v.off[w + 1]; ++a) {
         const int u = v.idx[a];
-        const bool want = v.labels[u] != v.alpha && mf_load64(&v.cap[v.rev[a]]) > 0 && mf_load32(&v.d[u]) == kMfInf;
+        const bool want = v.tot[a] - mf_load64(&v.cap[a]) > 0 && mf_load32(&v.d[u]) == kMfInf;  // residual u -> w; inactive sites have d = kMfDead
         any |= mf_bfs_label(v, u, k, hub_acc, want);
     }
     return any;

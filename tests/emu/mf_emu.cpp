@@ -173,6 +173,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
                 if (r < 0) return -10;  // graph not symmetric
                 rev[a] = r;
             }
+    std::vector<long long> tot((size_t)(E > 0 ? E : 1));
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1), hubA_e(1), hubA_want(3);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
@@ -182,7 +183,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
     v.dq = dq.data(); v.labels = labels;
     v.off = pair ? off : nullptr; v.idx = idx; v.mult = mult; v.rev = rev.data(); v.wq = nullptr;
-    v.cap = cap.data(); v.ex = ex.data(); v.rt = rt.data(); v.d = d.data(); v.f = f.data(); v.g = g.data();
+    v.cap = cap.data(); v.tot = tot.data(); v.ex = ex.data(); v.rt = rt.data(); v.d = d.data(); v.f = f.data(); v.g = g.data();
     v.cnt = cnt.data(); v.hub_exists = hub_exists.data(); v.hub_e = hub_e.data();
     v.has_alpha_hub = has_alpha.data(); v.hubA_rt = hubA_rt.data(); v.hubA_e = hubA_e.data(); v.hubA_want = hubA_want.data(); v.bfs_hub_d = bfs_hub_d.data();
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
