@@ -190,9 +190,38 @@ def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
             assert _rel(a["values"], b["values"]) < REL
             ref = oracle.score(mt, pts, hyps, T2)
             assert np.array_equal(b["counts"], ref["counts"])
+            # without masks the candidates go through the compaction queue (64 exact evaluations per wave step): the
+            # same per-pair fixed-point integers are accumulated, so counts AND sums are bitwise those of the mask variant
+            c = culled.score(hyps, T2)
+            assert np.array_equal(c["counts"], b["counts"]), f"trial {trial}: queued path counts differ"
+            if name in ("pnp", "homography"):
+                assert np.array_equal(c["values"], b["values"]) and np.array_equal(c["shared"], b["shared"])
     finally:
         plain.close()
         culled.close()
+
+
+@pytest.mark.parametrize("name", ["pnp", "homography"])
+def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch):
+    # per-pair fixed point + integer accumulation: the results of the group-major path do not depend on how many waves share
+    # a group, on queue boundaries or on the order in which groups finish — bitwise equal across PGX_SCORE_SPLIT values
+    mt, pts, models, thr = make_case(name, 50000, 700, seed=21)
+    T2 = 2.25 * thr * thr
+    comp = np.random.default_rng(3).random(len(pts))
+    outs = []
+    for split in ("1", "3", "8", "16"):
+        monkeypatch.setenv("PGX_SCORE_SPLIT", split)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(mt, pts)
+            ctx.set_compound(comp)
+            outs.append(ctx.score(models, T2, has_compound=True, exponent=2))
+            outs.append(ctx.score(models, T2, has_compound=True, exponent=2))
+        finally:
+            ctx.close()
+    for o in outs[1:]:
+        for key in ("counts", "values", "shared", "scores"):
+            assert np.array_equal(o[key], outs[0][key]), key
 
 
 def test_score_early_exit_predicate_is_order_free(oracle):
