@@ -190,11 +190,22 @@ def main():
             cb = cpu_baseline(pts, hyps, T2, comp)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_port"] = out["value"] / cb["value"]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if use_comm:
         ctx.comm_barrier()
         ctx.comm_destroy()
     ctx.close()
+    if line is not None:
+        # libraries (RCCL's version banner) write to the C stdio buffer, which is flushed at exit, i.e. AFTER python's own
+        # buffer: flush it now so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
