@@ -124,6 +124,11 @@ def init_rccl(ctx, rank, world):
         ctx.comm_init(world, rank, uid)
         ctx.comm_barrier()
     finally:
+        try:   # the banner sits in the C stdio buffer (a pipe is block-buffered): push it out while fd 1 is still stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(saved, 1)
         os.close(saved)
     cleanup_unique_id(rank)
