@@ -119,7 +119,7 @@ void pgx_destroy(pgx_ctx* ctx)
     comm_free(ctx);
     maxflow_free(ctx);
     DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->perm, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
-                      &ctx->values, &ctx->shared, &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
+                      &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc};
@@ -380,7 +380,8 @@ int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values,
     CTX_GUARD(ctx);
     const int M = ctx->M;
     if (M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: nothing launched");
-    const size_t need = (size_t)M * 24;
+    const size_t Mp = (size_t)ctx->Mpad;
+    const size_t need = Mp * 24;
     if (ctx->h_res_cap < need) {
         if (ctx->h_res) (void)hipHostFree(ctx->h_res);
         ctx->h_res = nullptr; ctx->h_res_cap = 0;
@@ -388,11 +389,10 @@ int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values,
         ctx->h_res_cap = need * 2;
     }
     int64_t* c = (int64_t*)ctx->h_res;
-    double* v = (double*)ctx->h_res + M;
-    double* s = (double*)ctx->h_res + 2 * (size_t)M;
-    PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, (size_t)M * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(v, ctx->values.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(s, ctx->shared.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double* v = (double*)ctx->h_res + Mp;
+    double* s = (double*)ctx->h_res + 2 * Mp;
+    // counts | values | shared are one allocation of 3 x Mpad words (score_launch): one copy
+    PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
     if (masks) {
         if (!ctx->have_masks) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: masks were not requested at launch");
         PGX_HIP(ctx, hipMemcpyAsync(masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t),

@@ -1053,9 +1053,12 @@ int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
     PGX_TRY(ensure(ctx, ctx->pcnt, np * sizeof(unsigned)));
     PGX_TRY(ensure(ctx, ctx->pval, np * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->psh, np * sizeof(double)));
-    PGX_TRY(ensure(ctx, ctx->counts, (size_t)ctx->Mpad * sizeof(long long)));
-    PGX_TRY(ensure(ctx, ctx->values, (size_t)ctx->Mpad * sizeof(double)));
-    PGX_TRY(ensure(ctx, ctx->shared, (size_t)ctx->Mpad * sizeof(double)));
+    // counts | values | shared live in ONE allocation (values / shared are views into it): pgx_score_fetch brings all three
+    // back with a single copy (three small copies cost ~5 us each on the critical path of a 0.3 ms step)
+    PGX_TRY(ensure(ctx, ctx->counts, (size_t)3 * ctx->Mpad * sizeof(long long)));
+    ctx->values.p = ctx->counts.as<char>() + (size_t)ctx->Mpad * 8;
+    ctx->shared.p = ctx->counts.as<char>() + (size_t)2 * ctx->Mpad * 8;
+    ctx->values.cap = ctx->shared.cap = 0;  // not owned
     if (want_masks) PGX_TRY(ensure(ctx, ctx->masks, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t)));
     ctx->have_masks = want_masks != 0;
     if (ctx->point_sort) {
