@@ -52,7 +52,11 @@ def timed(name, fn, gt, rows, *args, **kw):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["C1", "C2", "C3", "C5", "C4"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["C1", "C2", "C3", "C5", "C4"]
+    if "--oracle" in sys.argv:   # the same host code on the single-threaded CPU port (test infrastructure) instead of libpgx
+        sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+        from oracle_ctx import OracleContext
+        _api._ctx = OracleContext()
     px.findLines(np.random.default_rng(0).random((50, 2)) * 100, np.array(0), 100, 100, sampler_id=0, seed=0)  # warm up
     if "C1" in which:
         pts, gt, _ = datasets.make_lines(seed=0)
