@@ -159,6 +159,13 @@ enum { PGX_SEL_INDEX = 0, PGX_SEL_LABEL = 1 };
 int pgx_gram(pgx_ctx *ctx, int kind, const double *params, int nparams, int sel, const int32_t *index, int64_t m,
              int label, const double *weights, int weight_power, double *out, int64_t *count, int64_t *bad);
 
+/* All instances of one PEARL iteration at once (PEARL.h:369-390 runs these per instance): Gram matrices of the points with
+ * label k under parameter block k (params[K][nparams]), k = 0..K-1, and the residual sums of model k over label k.  One
+ * launch each; out[k] / sums[k] are bit-identical to the single-label calls pgx_gram(PGX_SEL_LABEL, k) / pgx_residual_sum. */
+int pgx_gram_labels(pgx_ctx *ctx, int kind, const double *params, int nparams, int K, const double *weights,
+                    int weight_power, double *out, int64_t *count, int64_t *bad);
+int pgx_residual_sums(pgx_ctx *ctx, const double *models, int K, double *sums);
+
 /* Batched form for the inner RANSAC of the local optimisation: B index selections of m points each (index[B][m]), one
  * parameter block per selection (params[B][nparams]), optional per-entry weights already gathered by the caller
  * (weights_sel[B][m]).  out[B][q(q+1)/2], bad[B] (optional).  One launch, one wave per selection. */

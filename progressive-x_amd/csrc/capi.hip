@@ -691,6 +691,20 @@ int pgx_residual_sum(pgx_ctx* ctx, const double* model, int label, double* sum)
     return residual_sum_launch(ctx, model, label, sum);
 }
 
+int pgx_gram_labels(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int weight_power,
+                    double* out, int64_t* count, int64_t* bad)
+{
+    CTX_GUARD(ctx);
+    return gram_labels_launch(ctx, kind, params, nparams, K, weights, weight_power, out, count, bad);
+}
+
+int pgx_residual_sums(pgx_ctx* ctx, const double* models, int K, double* sums)
+{
+    CTX_GUARD(ctx);
+    if (!models || !sums) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sums: NULL argument");
+    return residual_sums_launch(ctx, models, K, sums);
+}
+
 int pgx_gram_batch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,
                    const double* weights_sel, int weight_power, double* out, int32_t* bad)
 {

@@ -199,6 +199,79 @@ void launch(pgx_ctx* ctx, const FitParams& prm, const int* index, int64_t m, int
                        prm, index, m, ctx->labels.as<int>(), label, weights, wpow, partials, counters);
 }
 
+// All labels in one launch (PEARL::parameterEstimation refits every instance per iteration): blockIdx.y = label, one
+// parameter block per label.  Per-block tree and final pass are those of gram_kernel / gram_final_kernel, so out[k] is
+// bit-identical to the single-label call with label k.
+template <class G>
+__global__ __launch_bounds__(kFitBlock) void gram_labels_kernel(const double* __restrict__ pts, int64_t n, const double* __restrict__ prm_k,
+                                                                const int* __restrict__ labels, const double* __restrict__ weights,
+                                                                int wpow, int blocks, double* __restrict__ partials,
+                                                                int* __restrict__ counters)
+{
+    constexpr int Q = G::Q, NV = Q * (Q + 1) / 2;
+    __shared__ double lds[(kFitBlock / 64) * NV];
+    __shared__ int s_cnt, s_bad;
+    if (threadIdx.x == 0) { s_cnt = 0; s_bad = 0; }
+    __syncthreads();
+    const int label = (int)blockIdx.y;
+    FitParams prm;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) prm.v[k] = prm_k[(int64_t)label * 12 + k];
+    Acc<Q> acc;
+    acc.zero();
+    const int64_t t = (int64_t)blockIdx.x * kFitBlock + threadIdx.x;
+    const int64_t i = (t < n && labels[t] == label) ? t : -1;
+    int bad = 0;
+    if (i >= 0) {
+        double pt[G::D];
+#pragma unroll
+        for (int k = 0; k < G::D; ++k) pt[k] = pts[i * G::D + k];
+        double w = 1.0;
+        if (weights != nullptr) { w = weights[i]; if (wpow == 2) w = w * w; }
+        emit<G>(pt, prm, acc, w, bad);
+        atomicAdd(&s_cnt, 1);
+        if (bad) atomicAdd(&s_bad, 1);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = acc.s[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) lds[wave * NV + k] = x;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += kFitBlock) {
+        double s = lds[k];
+        for (int w2 = 1; w2 < kFitBlock / 64; ++w2) s += lds[w2 * NV + k];
+        partials[((int64_t)label * blocks + blockIdx.x) * NV + k] = s;
+    }
+    if (threadIdx.x == 0) {
+        if (s_cnt) atomicAdd(&counters[2 * label], s_cnt);
+        if (s_bad) atomicAdd(&counters[2 * label + 1], s_bad);
+    }
+}
+
+__global__ __launch_bounds__(1024) void gram_final_labels_kernel(const double* __restrict__ partials, int blocks, int nv,
+                                                                 double* __restrict__ out)
+{
+    const double* part = partials + (int64_t)blockIdx.x * blocks * nv;
+    const int k = (int)threadIdx.x >> 4, j = (int)threadIdx.x & 15;
+    double s = 0.0;
+    if (k < nv)
+        for (int b = j; b < blocks; b += 16) s += part[(int64_t)b * nv + k];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (k < nv && j == 0) out[(int64_t)blockIdx.x * nv + k] = s;
+}
+
+template <class G>
+void launch_labels(pgx_ctx* ctx, int K, const double* prm, const double* weights, int wpow, int blocks, double* partials, int* counters)
+{
+    hipLaunchKernelGGL((gram_labels_kernel<G>), dim3((unsigned)blocks, (unsigned)K), dim3(kFitBlock), 0, ctx->stream,
+                       ctx->pts.as<double>(), ctx->n, prm, ctx->labels.as<int>(), weights, wpow, blocks, partials, counters);
+}
+
 // Batched variant for the inner RANSAC of the local optimisation: B small index selections of m points
 // each, one wave per selection (m <= 64 in practice: 7 x the minimal sample size), per-selection parameter blocks.
 // Lanes take the points t = lane, lane + 64, ..; fixed shuffle tree: bit-reproducible.
@@ -309,6 +382,61 @@ int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams,
     PGX_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (bad) PGX_HIP(ctx, hipMemcpyAsync(bad, d_bad, bad_bytes, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int wpow,
+                       double* out, int64_t* count, int64_t* bad)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: points not set");
+    if (ctx->labels_n != ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: labels not set");
+    if (wpow != 1 && wpow != 2) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: weight power must be 1 or 2");
+    if (nparams < 0 || nparams > 12 || (nparams > 0 && !params)) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: bad parameter block");
+    if (!out || K <= 0 || K > 4096) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: bad argument");
+    int q = 0;
+    PGX_TRY(gram_row_length(ctx, "pgx_gram_labels", kind, nparams, &q));
+    const int nv = q * (q + 1) / 2;
+    const int blocks = (int)((ctx->n + kFitBlock - 1) / kFitBlock);
+    // scratch: partials[K][blocks][nv] | out[K][nv] | counters[2K] | prm[K][12] | weights[n]
+    const size_t part_bytes = (size_t)K * blocks * nv * 8, out_bytes = (size_t)K * nv * 8, cnt_bytes = ((size_t)K * 8 + 15) & ~(size_t)15;
+    const size_t prm_bytes = (size_t)K * 12 * 8, w_bytes = weights ? (size_t)ctx->n * 8 : 0;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, part_bytes + out_bytes + cnt_bytes + prm_bytes + w_bytes + 64));
+    char* base = (char*)ctx->fit_scratch.p;
+    double* d_part = (double*)base;
+    double* d_out = (double*)(base + part_bytes);
+    int* d_cnt = (int*)(base + part_bytes + out_bytes);
+    double* d_prm = (double*)(base + part_bytes + out_bytes + cnt_bytes);
+    double* d_w = (double*)(base + part_bytes + out_bytes + cnt_bytes + prm_bytes);
+    std::vector<double> hp((size_t)K * 12, 0.0);
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < nparams; ++j) hp[(size_t)k * 12 + j] = params[(size_t)k * nparams + j];
+    PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(d_prm, hp.data(), prm_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, weights, w_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const double* ww = weights ? d_w : nullptr;
+    const int D = ctx->D;
+    switch (kind) {
+    case PGX_GRAM_AFFINE:
+        if (D == 2) launch_labels<GenAffine2>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt);
+        else if (D == 4) launch_labels<GenAffine4>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt);
+        else launch_labels<GenAffine5>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt);
+        break;
+    case PGX_GRAM_DLT_H: launch_labels<GenDltH>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt); break;
+    case PGX_GRAM_EPI_F: launch_labels<GenEpiF>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt); break;
+    case PGX_GRAM_VP: launch_labels<GenVp>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt); break;
+    default: launch_labels<GenPnpGn>(ctx, K, d_prm, ww, wpow, blocks, d_part, d_cnt); break;
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(gram_final_labels_kernel, dim3((unsigned)K), dim3(1024), 0, ctx->stream, d_part, blocks, nv, d_out);
+    PGX_HIP(ctx, hipGetLastError());
+    std::vector<int> cnt((size_t)2 * K, 0);
+    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)2 * K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < K; ++k) {
+        if (count) count[k] = cnt[2 * k];
+        if (bad) bad[k] = cnt[2 * k + 1];
+    }
     return PGX_OK;
 }
 

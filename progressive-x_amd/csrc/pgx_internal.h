@@ -132,6 +132,9 @@ int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out);
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad);
+int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int wpow,
+                       double* out, int64_t* count, int64_t* bad);
+int residual_sums_launch(pgx_ctx* ctx, const double* models, int K, double* sums);
 int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,
                       const double* wsel, int wpow, double* out, int32_t* bad);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);

@@ -339,6 +339,73 @@ __global__ __launch_bounds__(kPwBlock) void residual_sum_kernel(const double* __
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
+// All K labels in one launch (blockIdx.y = label, model k for label k): the same per-block tree and the same final pass as
+// the single-label kernel, so sums[k] is bit-identical to residual_sum_launch(model k, k).  PEARL::parameterEstimation
+// needs 2K such sums per iteration; one host round trip each made its loop latency-bound.
+template <int MT>
+__global__ __launch_bounds__(kPwBlock) void residual_sums_kernel(const double* __restrict__ pts, int64_t n,
+                                                                 const double* __restrict__ models,
+                                                                 const int* __restrict__ labels, int blocks,
+                                                                 double* __restrict__ partials)
+{
+    using R = Residual<MT>;
+    __shared__ double lds[4];
+    const int label = (int)blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    double acc[1] = {0.0};
+    if (i < n && labels[i] == label) {
+        double pt[R::D], mdl[R::P];
+#pragma unroll
+        for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)label * R::P + k];
+        load_point<MT>(pts, i, pt);
+        acc[0] = R::plain(pt, mdl);
+    }
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) partials[(int64_t)label * blocks + blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(kPwBlock) void final_sums_kernel(const double* __restrict__ partials, int count, double* __restrict__ out)
+{
+    __shared__ double lds[4];
+    const double* part = partials + (int64_t)blockIdx.x * count;
+    double acc[1] = {0.0};
+    for (int b = threadIdx.x; b < count; b += kPwBlock) acc[0] += part[b];
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc[0];
+}
+
+int residual_sums_launch(pgx_ctx* ctx, const double* models, int K, double* sums)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sums: points not set");
+    if (ctx->labels_n != ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sums: labels not set");
+    if (K <= 0 || K > 65535) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sums: K = %d out of range", K);
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    PGX_TRY(ensure(ctx, ctx->red_partials, (size_t)blocks * (size_t)(K > 3 ? K : 3) * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->red_out, (size_t)(K > 8 ? K : 8) * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->kmodels, (size_t)K * ctx->P * sizeof(double)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->kmodels.p, models, (size_t)K * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    dim3 g((unsigned)blocks, (unsigned)K), b(kPwBlock);
+    const double* pts = ctx->pts.as<double>();
+    const double* mdl = ctx->kmodels.as<double>();
+    const int* lab = ctx->labels.as<int>();
+    double* part = ctx->red_partials.as<double>();
+    switch (ctx->model_type) {
+    case kLine2D: hipLaunchKernelGGL((residual_sums_kernel<kLine2D>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    case kHomography: hipLaunchKernelGGL((residual_sums_kernel<kHomography>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    case kFundamental: hipLaunchKernelGGL((residual_sums_kernel<kFundamental>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    case kPnP: hipLaunchKernelGGL((residual_sums_kernel<kPnP>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    case kVanishingPoint: hipLaunchKernelGGL((residual_sums_kernel<kVanishingPoint>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    case kHomographySym: hipLaunchKernelGGL((residual_sums_kernel<kHomographySym>), g, b, 0, ctx->stream, pts, ctx->n, mdl, lab, blocks, part); break;
+    default: return fail(ctx, PGX_ERR_INVALID, "bad model type");
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(final_sums_kernel, dim3((unsigned)K), dim3(kPwBlock), 0, ctx->stream, part, blocks, ctx->red_out.as<double>());
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(sums, ctx->red_out.p, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
 int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* sum)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_residual_sum: points not set");

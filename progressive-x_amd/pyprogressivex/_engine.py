@@ -125,18 +125,28 @@ class Pearl:
         self.points_per_instance = [order[starts[k]:starts[k + 1]].astype(np.int64) for k in range(K)]
         self.outliers_number = int(counts[K])
         changed = False
+        if K == 0:
+            return False
+        # The per-instance steps of PEARL.h:365-393 run for all instances together: the sums before (:369-371), the refits
+        # (:375-380) and the sums after (:388-390) are one launch each (per refit step) instead of one per instance — the
+        # same numbers bit for bit, K times fewer host round trips.
+        small = {k for k in range(K) if len(self.points_per_instance[k]) < self.est.nonminimal_sample_size}   # :365
+        current = np.array([np.asarray(m.descriptor, dtype=np.float64).reshape(-1) for m in models])
+        before = self.ctx.residual_sums(current)
+        fits = self.est.nonminimal_labels(self.ctx, K, self.point_weights, inits=current, skip=small)
+        cand = current.copy()
+        tried = []
         for k in range(K):
-            inl = self.points_per_instance[k]
-            if len(inl) < self.est.nonminimal_sample_size:            # :365
+            if k in small or len(fits[k]) != 1:                       # :384
                 continue
-            before = self.ctx.residual_sum(models[k].descriptor, k)   # :369-371
-            fits = self.est.nonminimal(self.ctx, ("label", k), self.point_weights, init=models[k].descriptor)   # :375-380
-            if len(fits) != 1:                                        # :384
-                continue
-            after = self.ctx.residual_sum(fits[0], k)                 # :388-390
-            if after < before:                                        # :393
-                models[k].descriptor = np.asarray(fits[0], dtype=np.float64)
-                changed = True
+            cand[k] = np.asarray(fits[k][0], dtype=np.float64).reshape(-1)
+            tried.append(k)
+        if tried:
+            after = self.ctx.residual_sums(cand)
+            for k in tried:
+                if after[k] < before[k]:                              # :393
+                    models[k].descriptor = cand[k].copy()
+                    changed = True
         return changed
 
     # PEARL.h:275-315

@@ -46,6 +46,37 @@ class Estimator:
         except StopIteration as done:
             return done.value
 
+    def nonminimal_labels(self, ctx, K, weights=None, inits=None, skip=()):
+        """`nonminimal(ctx, ("label", k), weights, init=inits[k])` for k = 0..K-1 with the coroutines advancing in lockstep:
+        every step is ONE pgx_gram_labels launch for all labels (PEARL refits every instance per iteration; one host round
+        trip per instance and step made that loop latency-bound).  Labels in `skip` are not fitted.  The Gram matrices
+        are bit-identical to the single-label calls, so the results are those of K separate `nonminimal` calls."""
+        gens = {k: self._fit(None if inits is None else inits[k]) for k in range(K) if k not in skip}
+        results, pending = {k: [] for k in range(K)}, {}
+        for k, g in gens.items():
+            try:
+                pending[k] = next(g)
+            except StopIteration as done:
+                results[k] = done.value
+        while pending:
+            groups = {}
+            for k, (kind, params, use_w, wpow) in pending.items():
+                groups.setdefault((kind, bool(use_w), wpow, None if params is None else len(np.ravel(params))), []).append(k)
+            for (kind, use_w, wpow, plen), ks in groups.items():
+                prm = None
+                if plen is not None:
+                    prm = np.zeros((K, plen))
+                    for k in ks:
+                        prm[k] = np.asarray(pending[k][1], dtype=np.float64).reshape(-1)
+                G, cnt, bad = ctx.gram_labels(kind, K, params=prm, weights=weights if use_w else None, wpow=wpow)
+                for k in ks:
+                    try:
+                        pending[k] = gens[k].send((G[k], int(cnt[k]), int(bad[k])))
+                    except StopIteration as done:
+                        results[k] = done.value
+                        del pending[k]
+        return [results[k] for k in range(K)]
+
     def nonminimal_batch(self, ctx, index, weights=None, init=None):
         """`nonminimal` for B index selections of equal size (index [B, m]) sharing `init`: the B coroutines advance in
         lockstep, each step is ONE pgx_gram_batch launch.  Returns a list of B model lists."""

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
-    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
 ]
@@ -341,6 +341,33 @@ class Context:
                                     C.c_int(mode), iptr, C.c_int64(m), C.c_int(label), _ptr(w, C.c_double),
                                     C.c_int(int(wpow)), _ptr(out, C.c_double), C.byref(cnt), C.byref(bad)), "pgx_gram")
         return tri_to_sym(out, q), cnt.value, bad.value
+
+    def gram_labels(self, kind, K, params=None, weights=None, wpow=2):
+        """pgx_gram_labels: the Gram matrices of the points with label k under parameter block k, k = 0..K-1, in one launch.
+        Returns (G [K, q, q], count [K], bad [K]); G[k] is bit-identical to gram(kind, ("label", k), params[k])[0]."""
+        q = GRAM_Q.get(kind, POINT_DIM[self.model_type] + 1)
+        nv = q * (q + 1) // 2
+        out = np.zeros((K, nv), dtype=np.float64)
+        cnt = np.zeros(K, dtype=np.int64)
+        bad = np.zeros(K, dtype=np.int64)
+        prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(K, -1)
+        w = None if weights is None or len(weights) == 0 else np.ascontiguousarray(weights, dtype=np.float64)
+        self._ck(self._lib.pgx_gram_labels(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double), C.c_int(0 if prm is None else prm.shape[1]),
+                                           C.c_int(int(K)), _ptr(w, C.c_double), C.c_int(int(wpow)), _ptr(out, C.c_double),
+                                           _ptr(cnt, C.c_int64), _ptr(bad, C.c_int64)), "pgx_gram_labels")
+        G = np.zeros((K, q, q))
+        iu = np.triu_indices(q)
+        G[:, iu[0], iu[1]] = out
+        G[:, iu[1], iu[0]] = out
+        return G, cnt, bad
+
+    def residual_sums(self, models):
+        """pgx_residual_sums: sum of the unsquared residuals of model k over the points labelled k, all k in one launch."""
+        m = np.ascontiguousarray(models, dtype=np.float64)
+        K = m.shape[0]
+        out = np.zeros(K, dtype=np.float64)
+        self._ck(self._lib.pgx_residual_sums(self._h, _ptr(m, C.c_double), C.c_int(K), _ptr(out, C.c_double)), "pgx_residual_sums")
+        return out
 
     def gram_batch(self, kind, index, params=None, weights=None, wpow=2):
         """pgx_gram_batch: B selections of m resident points each (index [B, m]) in one launch; params [B, np] or None;

@@ -94,6 +94,15 @@ class OracleContext:
         index = np.asarray(sel[1], dtype=np.int64) if sel[0] == "index" else np.nonzero(self.labels == int(sel[1]))[0]
         return O.gram(kind, self.pts, index, params=params, weights=weights, wpow=wpow)
 
+    def gram_labels(self, kind, K, params=None, weights=None, wpow=2):
+        res = [self.gram(kind, ("label", k), params=None if params is None else np.asarray(params)[k], weights=weights, wpow=wpow)
+               for k in range(K)]
+        return (np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.int64),
+                np.array([r[2] for r in res], dtype=np.int64))
+
+    def residual_sums(self, models):
+        return np.array([self.residual_sum(m, k) for k, m in enumerate(np.asarray(models))])
+
     def gram_batch(self, kind, index, params=None, weights=None, wpow=2):
         index = np.asarray(index, dtype=np.int64)
         res = [O.gram(kind, self.pts, index[b], params=None if params is None else np.asarray(params)[b], weights=weights,

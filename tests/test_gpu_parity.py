@@ -628,6 +628,35 @@ def test_batched_refits_equal_single_refits(gpu_ctx):
             assert np.abs(a - c).max() <= 1e-6 * max(1.0, np.abs(a).max()), name
 
 
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_label_batched_gram_and_residual_sums_are_bitwise_the_single_label_calls(gpu_ctx, name):
+    # pgx_gram_labels / pgx_residual_sums: all instances of a PEARL iteration in one launch, same trees as the single calls
+    n, K = 30011, 5
+    mt, pts, models, thr = make_case(name, n, K, seed=4)
+    rng = np.random.default_rng(8)
+    gpu_ctx.set_points(mt, pts)
+    labels = rng.integers(0, K + 1, n).astype(np.int32)        # label K = outliers, label 3 stays empty
+    labels[labels == 3] = K
+    gpu_ctx.set_labels(labels)
+    weights = rng.random(n) + 0.5
+    sums = gpu_ctx.residual_sums(models)
+    for k in range(K):
+        assert sums[k] == gpu_ctx.residual_sum(models[k], k)
+    norm = np.array([0.01, 300.0, 200.0, 0.012, 310.0, 190.0])
+    kinds = {"line": [(_lib.GRAM_AFFINE, None)], "vanishing_point": [(_lib.GRAM_VP, None)],
+             "homography": [(_lib.GRAM_AFFINE, None), (_lib.GRAM_DLT_H, np.array([norm * (1 + 0.1 * k) for k in range(K)]))],
+             "homography_sym": [(_lib.GRAM_DLT_H, np.array([norm * (1 + 0.1 * k) for k in range(K)]))],
+             "fundamental": [(_lib.GRAM_EPI_F, np.array([norm * (1 + 0.1 * k) for k in range(K)]))],
+             "pnp": [(_lib.GRAM_PNP_GN, models[:, :12])]}[name]
+    for kind, prm in kinds:
+        for w, wpow in ((None, 2), (weights, 1), (weights, 2)):
+            G, cnt, bad = gpu_ctx.gram_labels(kind, K, params=prm, weights=w, wpow=wpow)
+            for k in range(K):
+                Gk, ck, bk = gpu_ctx.gram(kind, ("label", k), params=None if prm is None else prm[k], weights=w, wpow=wpow)
+                assert np.array_equal(G[k], Gk) and (int(cnt[k]), int(bad[k])) == (ck, bk), f"{name} kind {kind} label {k}"
+            assert cnt[3] == 0 and not G[3].any()
+
+
 def test_gram_error_paths_and_empty_selection(gpu_ctx):
     mt, pts, models, thr = make_case("homography", 100, 1, seed=1)
     gpu_ctx.set_points(mt, pts)
