@@ -650,6 +650,12 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
         if (new_e == old_e) break;
         old_e = new_e;
         int64_t changed_total = 0;
+        if (lq <= 0) {  // no pairwise term: closed-form moves, the whole cycle enqueued at once (one host round trip)
+            std::vector<int64_t> ch((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
+            std::vector<int> ev((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
+            PGX_TRY(expand_cycle_l0(ctx, hq, ch.data(), ev.data()));
+            for (int alpha = 0; alpha < ctx->L; ++alpha) changed_total += ch[(size_t)alpha];
+        } else
         for (int alpha = 0; alpha < ctx->L; ++alpha) {
             // a move is a deterministic function of (labelling, alpha): one that relabelled nothing and has seen no
             // label change since would relabel nothing again — skipped (typically the tail of the verifying cycle)

@@ -248,6 +248,36 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply(const long long* __res
     if (threadIdx.x == 0 && c > 0) atomicAdd(changed, c);
 }
 
+// The same move with the decision taken on the device (every workgroup evaluates the O(L) rule from the finished sums), so
+// that a whole cycle of L moves is enqueued without a host round trip: at lambda = 0 a PEARL iteration is ~20 moves and
+// two synchronisations per move were most of its time (C3: 324 iterations).
+__global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply_dev(const long long* __restrict__ dq, int* __restrict__ labels, int64_t n,
+                                                              int L, int alpha, long long h_q, const long long* __restrict__ sums,
+                                                              const int* __restrict__ cnt, int* __restrict__ changed,
+                                                              int* __restrict__ evaluated)
+{
+    __shared__ L0Decision s_dec;
+    __shared__ int s_live;
+    if (threadIdx.x == 0) {
+        s_live = (int64_t)cnt[alpha] != n;  // every site already carries alpha: nothing to evaluate
+        if (s_live) l0_decide(L, alpha, h_q, sums, cnt, &s_dec);
+        if (blockIdx.x == 0 && s_live) *evaluated = 1;
+    }
+    __syncthreads();
+    if (!s_live || !s_dec.switch_any) return;
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    bool sw = false;
+    if (u < n) {
+        const int lu = labels[u];
+        if (lu != alpha && l0_site_switches(dq, n, u, lu, alpha, 1, s_dec.all[lu])) {
+            labels[u] = alpha;
+            sw = true;
+        }
+    }
+    const int c = __syncthreads_count(sw ? 1 : 0);
+    if (threadIdx.x == 0 && c > 0) atomicAdd(changed, c);
+}
+
 // ---- one BFS level: the sites labelled k-1 label their residual in-neighbours k; then the hub part if a hub received
 // distance k-1.  A fixed, small grid with grid-stride loops: deep searches run hundreds of levels of a few thousand
 // sites each (the relay sites of a new-instance move at N = 1e6), and a grid sized for all sites cost ~54 us per level.
@@ -609,6 +639,52 @@ static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* change
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *changed = ch;
     ctx->stats[4] += ch;
+    return PGX_OK;
+}
+
+// One cycle over all labels at lambda = 0, enqueued back to back; one read-back at the end.  changed[alpha] = sites that
+// took alpha in move alpha, evaluated[alpha] = 0 when every site already carried alpha.
+int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
+{
+    const int64_t n = ctx->dq_n;
+    const int L = ctx->L;
+    if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: unary table not set");
+    if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
+    if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
+    if (!ctx->mf) {
+        ctx->mf = new MaxflowState();
+        PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));
+    }
+    MaxflowState* st = ctx->mf;
+    // small state: sums[2L] i64 | cnt[L] i32 (cleared before every move) | changed[L] i32 | evaluated[L] i32
+    const size_t move_bytes = (size_t)2 * L * 8 + (size_t)L * 4, res_bytes = (size_t)2 * L * 4;
+    PGX_TRY(ensure(ctx, st->small, move_bytes + res_bytes + 4096));
+    long long* d_sums = (long long*)st->small.p;
+    int* d_cnt = (int*)((char*)st->small.p + (size_t)2 * L * 8);
+    int* d_changed = d_cnt + L;
+    int* d_eval = d_changed + L;
+    PGX_HIP(ctx, hipMemsetAsync(d_changed, 0, res_bytes, ctx->stream));
+    const unsigned blocks = (unsigned)((n + kMfBlock - 1) / kMfBlock);
+    for (int alpha = 0; alpha < L; ++alpha) {
+        PGX_HIP(ctx, hipMemsetAsync(st->small.p, 0, move_bytes, ctx->stream));
+        MfView v{};
+        v.n = n; v.L = L; v.alpha = alpha; v.labels = ctx->labels.as<int>(); v.cnt = d_cnt;
+        hipLaunchKernelGGL(mf_k_count, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+        hipLaunchKernelGGL(mf_k_l0_reduce, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
+                           ctx->labels.as<int>(), n, L, alpha, d_sums);
+        hipLaunchKernelGGL(mf_k_l0_apply_dev, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
+                           ctx->labels.as<int>(), n, L, alpha, (long long)h_q, d_sums, d_cnt, d_changed + alpha, d_eval + alpha);
+    }
+    PGX_HIP(ctx, hipGetLastError());
+    std::vector<int> host((size_t)2 * L);
+    PGX_HIP(ctx, hipMemcpyAsync(host.data(), d_changed, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int alpha = 0; alpha < L; ++alpha) {
+        changed[alpha] = host[(size_t)alpha];
+        evaluated[alpha] = host[(size_t)L + alpha];
+        ctx->stats[0] += evaluated[alpha] ? 1 : 0;
+        ctx->stats[4] += changed[alpha];
+    }
     return PGX_OK;
 }
 

@@ -30,7 +30,7 @@ struct L0Decision {
 };
 
 // sums[l*2+0] = sum rt, sums[l*2+1] = sum ex over the active members of label l; cnt[l] = sites carrying label l
-inline void l0_decide(int L, int alpha, long long h_q, const long long* sums, const int* cnt, L0Decision* out)
+PGX_L0_HD void l0_decide(int L, int alpha, long long h_q, const long long* sums, const int* cnt, L0Decision* out)
 {
     long long gain = 0;
     for (int l = 0; l < L; ++l) {

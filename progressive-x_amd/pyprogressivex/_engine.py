@@ -120,9 +120,10 @@ class Pearl:
         if not self.has_engine:
             return False
         K = len(models)
-        counts, order = self.ctx.bucket(K + 1, want_order=True)       # :342-352
-        starts = np.concatenate([[0], np.cumsum(counts)])
-        self.points_per_instance = [order[starts[k]:starts[k + 1]].astype(np.int64) for k in range(K)]
+        # :342-352 buckets the points by label; only the bucket SIZES are used on the host (:365 and rejectInstances), the
+        # members themselves are selected on the device by label (pgx_gram_labels / pgx_residual_sums): no index traffic
+        counts, _ = self.ctx.bucket(K + 1, want_order=False)
+        self.points_per_instance = [int(counts[k]) for k in range(K)]
         self.outliers_number = int(counts[K])
         changed = False
         if K == 0:
@@ -130,7 +131,7 @@ class Pearl:
         # The per-instance steps of PEARL.h:365-393 run for all instances together: the sums before (:369-371), the refits
         # (:375-380) and the sums after (:388-390) are one launch each (per refit step) instead of one per instance — the
         # same numbers bit for bit, K times fewer host round trips.
-        small = {k for k in range(K) if len(self.points_per_instance[k]) < self.est.nonminimal_sample_size}   # :365
+        small = {k for k in range(K) if self.points_per_instance[k] < self.est.nonminimal_sample_size}   # :365
         current = np.array([np.asarray(m.descriptor, dtype=np.float64).reshape(-1) for m in models])
         before = self.ctx.residual_sums(current)
         fits = self.est.nonminimal_labels(self.ctx, K, self.point_weights, inits=current, skip=small)
@@ -153,7 +154,7 @@ class Pearl:
     def reject_instances(self, models):
         changed = False
         for k in range(len(models) - 1, -1, -1):
-            cnt = len(self.points_per_instance[k])
+            cnt = self.points_per_instance[k]
             if cnt < self.minimum_inlier_number:
                 self.outliers_number += cnt
                 del self.points_per_instance[k]
