@@ -23,14 +23,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "progressive-x_amd"))
 
-# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v10_compaction.txt),
-# summed over the three kernels of one launch (cull, group-major score, finish): FETCH_SIZE 344094.9 + 6002.6 + 38.5 KiB,
-# x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM), + WRITE_SIZE 27527.2 + 15979.7 + 158.8 KiB
+# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v12_final.txt),
+# summed over the three kernels of one launch (cull, group-major score, finish): FETCH_SIZE 267746.8 + 3439.0 + 36.5 KiB,
+# x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM), + WRITE_SIZE 27527.2 + 4276.5 + 158.8 KiB
 # (writes: survivor bit masks of the cull pass, accumulator atomics; fetch: the 8 waves that share a 64-point group run
 # on the 8 XCDs -- wave p of every group on XCD p, which keeps each XCD's hypotheses, their constants and their accumulator
 # atomics in its own L2 -- so every XCD's L2 fetches all rows once: 8 x 80 MB.  Co-locating a group's waves cuts the fetch
 # 8x but every XCD then updates every accumulator: measured 0.31 instead of 0.28 ms)
-PMC_TRAFFIC_DEFAULT = int((2 * (344094.9 + 6002.6 + 38.5) + 27527.2 + 15979.7 + 158.8) * 1024)
+PMC_TRAFFIC_DEFAULT = int((2 * (267746.8 + 3439.0 + 36.5) + 27527.2 + 4276.5 + 158.8) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
 FLOPS_PER_PAIR_PNP = 25        # 9 mul + 9 add (3x4 projection) + 2 div + 2 sub + 2 mul + 1 add
@@ -175,7 +175,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_DEFAULT if (n == 1000000 and M == 2048) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v10_compaction.txt",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v12_final.txt",
                          "kernel": "pgx::score_group_kernel<PnP> (+ score_cull_kernel, score_finish_kernel)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "arithmetic bound by construction (~0.04 algorithmic B/pair); 93 % of the (hypothesis, 64-point group) pairs are culled by a bound test, see valu_fp64"},
