@@ -145,8 +145,11 @@ int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by
  * PEARL::parameterEstimation (PEARL.h:374-380) and by the proposal engine's local optimisation.  The device accumulates
  *   out = sum_i W_i * sum_{rows a of point i} a a^T     (upper triangle of the q x q matrix, row-major, q(q+1)/2 values)
- * over the selected resident points; the small dense solve stays with the caller.  W_i = weights[i]^weight_power
- * (weights may be NULL).  Rows by kind (points as given to pgx_set_points):
+ * over the selected resident points; the small dense solve stays with the caller.  W_i = weights[i]^weight_power when
+ * use_weights != 0, else 1.  The per-point weights are RESIDENT: pgx_set_weights uploads them once per point set and checks
+ * len == n (a host pointer without a length used to be read for n doubles on every call; the reference has the same
+ * unchecked read at solver_vanishing_point_two_lines.h:204-207 via progressivex_python.cpp:381).  pgx_set_weights(NULL, 0)
+ * clears them; pgx_set_points invalidates them.  Rows by kind (points as given to pgx_set_points):
  *   PGX_GRAM_AFFINE   a = (1, p_0 .. p_{d-1})                                         q = d+1   (means, covariances)
  *   PGX_GRAM_DLT_H    the two DLT rows of a correspondence, params = (s1,cx1,cy1,s2,cx2,cy2)    q = 9
  *   PGX_GRAM_EPI_F    the epipolar row (x2x1,x2y1,x2,y2x1,y2y1,y2,x1,y1,1), same params         q = 9
@@ -156,13 +159,14 @@ int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
  * count = selected points, bad = points skipped because the row is undefined (PnP: depth ~ 0). */
 enum { PGX_GRAM_AFFINE = 0, PGX_GRAM_DLT_H = 1, PGX_GRAM_EPI_F = 2, PGX_GRAM_VP = 3, PGX_GRAM_PNP_GN = 4 };
 enum { PGX_SEL_INDEX = 0, PGX_SEL_LABEL = 1 };
+int pgx_set_weights(pgx_ctx *ctx, const double *weights, int64_t len);
 int pgx_gram(pgx_ctx *ctx, int kind, const double *params, int nparams, int sel, const int32_t *index, int64_t m,
-             int label, const double *weights, int weight_power, double *out, int64_t *count, int64_t *bad);
+             int label, int use_weights, int weight_power, double *out, int64_t *count, int64_t *bad);
 
 /* All instances of one PEARL iteration at once (PEARL.h:369-390 runs these per instance): Gram matrices of the points with
  * label k under parameter block k (params[K][nparams]), k = 0..K-1, and the residual sums of model k over label k.  One
  * launch each; out[k] / sums[k] are bit-identical to the single-label calls pgx_gram(PGX_SEL_LABEL, k) / pgx_residual_sum. */
-int pgx_gram_labels(pgx_ctx *ctx, int kind, const double *params, int nparams, int K, const double *weights,
+int pgx_gram_labels(pgx_ctx *ctx, int kind, const double *params, int nparams, int K, int use_weights,
                     int weight_power, double *out, int64_t *count, int64_t *bad);
 int pgx_residual_sums(pgx_ctx *ctx, const double *models, int K, double *sums);
 

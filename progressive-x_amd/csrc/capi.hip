@@ -122,7 +122,8 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
-                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc};
+                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
+                      &ctx->weights};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -244,6 +245,7 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
     ctx->point_sort = 0;
     ctx->comp_dirty = 1;
+    ctx->weights_n = 0;  // weights belong to a point set
     if (obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(umax))
         PGX_TRY(score_sort_points(ctx, points, p32.data(), pmax.data()));
     for (DevBuf& b : ctx->slots) release(b);
@@ -576,11 +578,25 @@ int pgx_set_graph(pgx_ctx* ctx, int64_t n, const int32_t* off, const int32_t* id
     return graph_build_reverse(ctx);
 }
 
-int pgx_gram(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m, int label,
-             const double* weights, int weight_power, double* out, int64_t* count, int64_t* bad)
+int pgx_set_weights(pgx_ctx* ctx, const double* weights, int64_t len)
 {
     CTX_GUARD(ctx);
-    return gram_launch(ctx, kind, params, nparams, sel, index, m, label, weights, weight_power, out, count, bad);
+    if (!weights || len == 0) { ctx->weights_n = 0; return PGX_OK; }  // clears
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_weights: points not set");
+    if (len != ctx->n)
+        return fail(ctx, PGX_ERR_INVALID, "pgx_set_weights: %lld weights for %lld points", (long long)len, (long long)ctx->n);
+    PGX_TRY(ensure(ctx, ctx->weights, (size_t)len * sizeof(double)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->weights.p, weights, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->weights_n = len;
+    return PGX_OK;
+}
+
+int pgx_gram(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m, int label,
+             int use_weights, int weight_power, double* out, int64_t* count, int64_t* bad)
+{
+    CTX_GUARD(ctx);
+    return gram_launch(ctx, kind, params, nparams, sel, index, m, label, use_weights, weight_power, out, count, bad);
 }
 
 int pgx_graph_build(pgx_ctx* ctx, const double* points, int64_t n, int d, int kind, double radius, int k, int64_t* arcs)
@@ -697,11 +713,11 @@ int pgx_residual_sum(pgx_ctx* ctx, const double* model, int label, double* sum)
     return residual_sum_launch(ctx, model, label, sum);
 }
 
-int pgx_gram_labels(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int weight_power,
+int pgx_gram_labels(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, int use_weights, int weight_power,
                     double* out, int64_t* count, int64_t* bad)
 {
     CTX_GUARD(ctx);
-    return gram_labels_launch(ctx, kind, params, nparams, K, weights, weight_power, out, count, bad);
+    return gram_labels_launch(ctx, kind, params, nparams, K, use_weights, weight_power, out, count, bad);
 }
 
 int pgx_residual_sums(pgx_ctx* ctx, const double* models, int K, double* sums)

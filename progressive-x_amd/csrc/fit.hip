@@ -385,7 +385,19 @@ int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams,
     return PGX_OK;
 }
 
-int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int wpow,
+// Per-point weights are RESIDENT (pgx_set_weights checks their length against n and uploads them once): the Gram calls only
+// say whether to use them.  (They used to take a host pointer without a length and copied n doubles from it on every call.)
+static int resident_weights(pgx_ctx* ctx, const char* who, int use_weights, const double** ww)
+{
+    *ww = nullptr;
+    if (!use_weights) return PGX_OK;
+    if (ctx->weights_n != ctx->n || !ctx->weights.p)
+        return fail(ctx, PGX_ERR_INVALID, "%s: use_weights set but no weights are resident for the current points (pgx_set_weights)", who);
+    *ww = ctx->weights.as<double>();
+    return PGX_OK;
+}
+
+int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, int use_weights, int wpow,
                        double* out, int64_t* count, int64_t* bad)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gram_labels: points not set");
@@ -397,23 +409,22 @@ int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams
     PGX_TRY(gram_row_length(ctx, "pgx_gram_labels", kind, nparams, &q));
     const int nv = q * (q + 1) / 2;
     const int blocks = (int)((ctx->n + kFitBlock - 1) / kFitBlock);
-    // scratch: partials[K][blocks][nv] | out[K][nv] | counters[2K] | prm[K][12] | weights[n]
+    const double* ww = nullptr;
+    PGX_TRY(resident_weights(ctx, "pgx_gram_labels", use_weights, &ww));
+    // scratch: partials[K][blocks][nv] | out[K][nv] | counters[2K] | prm[K][12]
     const size_t part_bytes = (size_t)K * blocks * nv * 8, out_bytes = (size_t)K * nv * 8, cnt_bytes = ((size_t)K * 8 + 15) & ~(size_t)15;
-    const size_t prm_bytes = (size_t)K * 12 * 8, w_bytes = weights ? (size_t)ctx->n * 8 : 0;
-    PGX_TRY(ensure(ctx, ctx->fit_scratch, part_bytes + out_bytes + cnt_bytes + prm_bytes + w_bytes + 64));
+    const size_t prm_bytes = (size_t)K * 12 * 8;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, part_bytes + out_bytes + cnt_bytes + prm_bytes + 64));
     char* base = (char*)ctx->fit_scratch.p;
     double* d_part = (double*)base;
     double* d_out = (double*)(base + part_bytes);
     int* d_cnt = (int*)(base + part_bytes + out_bytes);
     double* d_prm = (double*)(base + part_bytes + out_bytes + cnt_bytes);
-    double* d_w = (double*)(base + part_bytes + out_bytes + cnt_bytes + prm_bytes);
     std::vector<double> hp((size_t)K * 12, 0.0);
     for (int k = 0; k < K; ++k)
         for (int j = 0; j < nparams; ++j) hp[(size_t)k * 12 + j] = params[(size_t)k * nparams + j];
     PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
     PGX_HIP(ctx, hipMemcpyAsync(d_prm, hp.data(), prm_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, weights, w_bytes, hipMemcpyHostToDevice, ctx->stream));
-    const double* ww = weights ? d_w : nullptr;
     const int D = ctx->D;
     switch (kind) {
     case PGX_GRAM_AFFINE:
@@ -441,7 +452,7 @@ int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams
 }
 
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
-                int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad)
+                int label, int use_weights, int wpow, double* out, int64_t* count, int64_t* bad)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: points not set");
     if (wpow != 1 && wpow != 2) return fail(ctx, PGX_ERR_INVALID, "pgx_gram: weight power must be 1 or 2");
@@ -469,6 +480,8 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
     } else {
         return fail(ctx, PGX_ERR_INVALID, "pgx_gram: unknown selection %d", sel);
     }
+    const double* ww = nullptr;
+    PGX_TRY(resident_weights(ctx, "pgx_gram", use_weights, &ww));
     FitParams prm;
     for (int k = 0; k < 12; ++k) prm.v[k] = k < nparams ? params[k] : 0.0;
     const int blocks = (int)((work + kFitBlock - 1) / kFitBlock);
@@ -478,23 +491,19 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
         if (bad) *bad = 0;
         return PGX_OK;
     }
-    // scratch: partials | out | counters | index | weights
+    // scratch: partials | out | counters | index
     const size_t part_bytes = (size_t)blocks * nv * sizeof(double);
     const size_t idx_bytes = sel == PGX_SEL_INDEX ? (size_t)m * sizeof(int32_t) : 0;
-    const size_t w_bytes = weights ? (size_t)ctx->n * sizeof(double) : 0;
-    const size_t total = part_bytes + 64 * sizeof(double) + 64 + ((idx_bytes + 7) & ~(size_t)7) + w_bytes;
+    const size_t total = part_bytes + 64 * sizeof(double) + 64 + ((idx_bytes + 7) & ~(size_t)7);
     PGX_TRY(ensure(ctx, ctx->fit_scratch, total));
     char* base = (char*)ctx->fit_scratch.p;
     double* d_part = (double*)base;
     double* d_out = (double*)(base + part_bytes);
     int* d_cnt = (int*)(base + part_bytes + 64 * sizeof(double));
     int* d_idx = (int*)(base + part_bytes + 64 * sizeof(double) + 64);
-    double* d_w = (double*)(base + part_bytes + 64 * sizeof(double) + 64 + ((idx_bytes + 7) & ~(size_t)7));
     PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (idx_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, weights, w_bytes, hipMemcpyHostToDevice, ctx->stream));
     const int* ix = sel == PGX_SEL_INDEX ? d_idx : nullptr;
-    const double* ww = weights ? d_w : nullptr;
     switch (kind) {
     case PGX_GRAM_AFFINE:
         if (D == 2) launch<GenAffine2>(ctx, prm, ix, m, label, ww, wpow, blocks, d_part, d_cnt);

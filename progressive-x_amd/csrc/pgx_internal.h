@@ -87,7 +87,9 @@ struct pgx_ctx {
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
     void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
     size_t h_res_cap = 0;
-    pgx::DevBuf fit_scratch;  // pgx_gram: partials | result | counters | index list | weights
+    pgx::DevBuf fit_scratch;  // pgx_gram: partials | result | counters | index list
+    pgx::DevBuf weights;      // resident per-point weights of the weighted refits (pgx_set_weights), weights_n == n when valid
+    int64_t weights_n = 0;
 
     pgx::CommState* comm = nullptr;
 };
@@ -131,8 +133,8 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out);
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
-                int label, const double* weights, int wpow, double* out, int64_t* count, int64_t* bad);
-int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, const double* weights, int wpow,
+                int label, int use_weights, int wpow, double* out, int64_t* count, int64_t* bad);
+int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, int use_weights, int wpow,
                        double* out, int64_t* count, int64_t* bad);
 int residual_sums_launch(pgx_ctx* ctx, const double* models, int K, double* sums);
 int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,

@@ -148,29 +148,31 @@ struct SlotArg {
     const double* p[32];
 };
 
-__global__ __launch_bounds__(kPwBlock) void compound_kernel(SlotArg slots, int K, int64_t n, double* __restrict__ comp)
+__global__ __launch_bounds__(kPwBlock) void compound_kernel(SlotArg slots, int K, int64_t n, double* __restrict__ comp, int accumulate)
 {
     const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
     if (i >= n) return;
-    double c = 0.0;  // progressive_x.h:604 setConstant(0)
+    double c = accumulate ? comp[i] : 0.0;  // progressive_x.h:604 setConstant(0); later chunks of > 32 models continue the max
     for (int k = 0; k < K; ++k) c = cv_max(c, slots.p[k][i]);  // :620-621
     comp[i] = c;
 }
 
 int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K)
 {
-    if (K > 32) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: at most 32 models per call (got %d)", K);
-    SlotArg a;
-    for (int k = 0; k < 32; ++k) a.p[k] = nullptr;
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < K; ++k)
         if (slots[k] < 0 || slots[k] >= (int)ctx->slots.size() || !ctx->slots[slots[k]].p)
             return fail(ctx, PGX_ERR_INVALID, "pgx_compound_update: slot %d holds no preference vector", slots[k]);
-        a.p[k] = ctx->slots[slots[k]].as<double>();
-    }
     const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
-    hipLaunchKernelGGL(compound_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, a, K, ctx->n,
-                       ctx->comp.as<double>());
-    PGX_HIP(ctx, hipGetLastError());
+    // the kernel argument holds 32 pointers; max is associative and exact, so more models run as chunks of 32 that continue
+    // from the compound vector written by the chunk before
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int kc = K - k0 < 32 ? K - k0 : 32;
+        SlotArg a;
+        for (int k = 0; k < 32; ++k) a.p[k] = k < kc ? ctx->slots[slots[k0 + k]].as<double>() : nullptr;
+        hipLaunchKernelGGL(compound_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, a, kc, ctx->n,
+                           ctx->comp.as<double>(), k0 > 0 ? 1 : 0);
+        PGX_HIP(ctx, hipGetLastError());
+    }
     ctx->comp_dirty = 1;
     return PGX_OK;
 }

@@ -47,9 +47,16 @@ def _shape2(a):
     return a.shape[0], a.shape[1]
 
 
-def _weights(weights_):
+def _weights(weights_, n=None):
+    """bindings.cpp:200-208: a 0-d / empty array means "no weights".  The reference then reads weights[i] for every point
+    without a length check (undefined behaviour for a short array); here a length other than n is a ValueError."""
     w = np.asarray(weights_, dtype=np.float64)
-    return None if w.ndim == 0 or w.size == 0 else np.ascontiguousarray(w).reshape(-1)   # bindings.cpp:200-208
+    if w.ndim == 0 or w.size == 0:
+        return None
+    w = np.ascontiguousarray(w).reshape(-1)
+    if n is not None and w.shape[0] != n:
+        raise ValueError(f"weights should have one entry per row ({n}), got {w.shape[0]}")
+    return w
 
 
 def _unknown_sampler(sampler_id):
@@ -196,7 +203,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
-                             weights=_weights(weights), seed=seed, max_outer_iterations=max_outer_iterations,
+                             weights=_weights(weights, n), seed=seed, max_outer_iterations=max_outer_iterations,
                              neighborhood=neighborhood, local_optimization=local_optimization)
     return _stack(est, models, 3), labels
 
@@ -212,7 +219,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
     n, dim = _shape2(points)
     if dim != 2 or n < 2:
         raise ValueError("Points should be an array with dims [n,3], n>=2")          # bindings.cpp:267-270 (sic)
-    _weights(weights)
+    _weights(weights)         # parsed and unused (progressivex_python.cpp:466-482): any length is accepted, as upstream
     if do_logging and sampler_id == 1:
         print("Note: PROSAC sampler requires the points to be order by quality, e.g., SNN ratio.")
     est = _estimators.LineEstimator()

@@ -212,7 +212,6 @@ class ProgressiveX:
         self.models = []
         self.statistics = Statistics()
         self.n = pts.shape[0]
-        self._next_slot = 0
 
     def _log(self, msg):
         if self.do_logging:
@@ -235,8 +234,10 @@ class ProgressiveX:
         s = self.settings
         if inlier_number < max(self.est.sample_size, s.minimum_number_of_inliers):            # :574
             return False
-        model.slot = self._next_slot
-        self._next_slot += 1
+        # lowest preference slot no live model holds: slots of proposals that failed this test and of instances PEARL removed
+        # are reused (each is N * 8 bytes on the device)
+        used = {m.slot for m in self.models}
+        model.slot = next(k for k in range(len(used) + 1) if k not in used)
         r = self.ctx.preference(model.descriptor, self.T2, model.slot)                        # :578-579
         denom = r["pref_sqnorm"] + r["comp_sqnorm"] - r["dot"]
         tanimoto = r["dot"] / denom if denom != 0.0 else float("nan")                          # :583-585 (0/0 -> NaN)

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
-    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_gram", "pgx_solve_minimal",
+    "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
@@ -172,6 +172,28 @@ class Context:
                  "pgx_set_points")
         self.model_type = model_type
         self.n = pts.shape[0]
+        self._w_obj = None          # resident weights belong to a point set
+
+    def set_weights(self, weights):
+        """pgx_set_weights: per-point weights of the weighted refits, uploaded once and checked against n (None clears)."""
+        if weights is None or len(weights) == 0:
+            self._ck(self._lib.pgx_set_weights(self._h, None, C.c_int64(0)), "pgx_set_weights")
+            self._w_obj = None
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.shape[0] != self.n:
+            raise ValueError(f"weights must have one entry per point ({self.n}), got {w.shape[0]}")
+        self._ck(self._lib.pgx_set_weights(self._h, _ptr(w, C.c_double), C.c_int64(w.shape[0])), "pgx_set_weights")
+        self._w_obj = weights
+
+    def _use_weights(self, weights):
+        """1 when `weights` (the same array object as last time, or a new one that is uploaded now) is to be used.  The
+        arrays are treated as immutable: a caller that edits its weights in place calls set_weights again."""
+        if weights is None or len(weights) == 0:
+            return 0
+        if weights is not getattr(self, "_w_obj", None):
+            self.set_weights(weights)
+        return 1
 
     def set_compound(self, compound=None):
         c = None if compound is None else _f64(compound)
@@ -330,7 +352,7 @@ class Context:
         q = GRAM_Q.get(kind, POINT_DIM[self.model_type] + 1)
         out = np.zeros(q * (q + 1) // 2, dtype=np.float64)
         prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
-        w = None if weights is None or len(weights) == 0 else np.ascontiguousarray(weights, dtype=np.float64)
+        use_w = self._use_weights(weights)
         cnt, bad = C.c_int64(), C.c_int64()
         if sel[0] == "index":
             idx = _i32(sel[1])
@@ -338,7 +360,7 @@ class Context:
         else:
             mode, iptr, m, label = 1, None, 0, int(sel[1])
         self._ck(self._lib.pgx_gram(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double), C.c_int(0 if prm is None else prm.size),
-                                    C.c_int(mode), iptr, C.c_int64(m), C.c_int(label), _ptr(w, C.c_double),
+                                    C.c_int(mode), iptr, C.c_int64(m), C.c_int(label), C.c_int(use_w),
                                     C.c_int(int(wpow)), _ptr(out, C.c_double), C.byref(cnt), C.byref(bad)), "pgx_gram")
         return tri_to_sym(out, q), cnt.value, bad.value
 
@@ -351,9 +373,9 @@ class Context:
         cnt = np.zeros(K, dtype=np.int64)
         bad = np.zeros(K, dtype=np.int64)
         prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(K, -1)
-        w = None if weights is None or len(weights) == 0 else np.ascontiguousarray(weights, dtype=np.float64)
+        use_w = self._use_weights(weights)
         self._ck(self._lib.pgx_gram_labels(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double), C.c_int(0 if prm is None else prm.shape[1]),
-                                           C.c_int(int(K)), _ptr(w, C.c_double), C.c_int(int(wpow)), _ptr(out, C.c_double),
+                                           C.c_int(int(K)), C.c_int(use_w), C.c_int(int(wpow)), _ptr(out, C.c_double),
                                            _ptr(cnt, C.c_int64), _ptr(bad, C.c_int64)), "pgx_gram_labels")
         G = np.zeros((K, q, q))
         iu = np.triu_indices(q)
@@ -381,7 +403,10 @@ class Context:
         prm = None if params is None else np.ascontiguousarray(params, dtype=np.float64).reshape(B, -1)
         w = None
         if weights is not None and len(weights) > 0:
-            w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)[idx])
+            wf = np.asarray(weights, dtype=np.float64).reshape(-1)
+            if wf.shape[0] != self.n:
+                raise ValueError(f"weights must have one entry per point ({self.n}), got {wf.shape[0]}")
+            w = np.ascontiguousarray(wf[idx])
         self._ck(self._lib.pgx_gram_batch(self._h, C.c_int(int(kind)), _ptr(prm, C.c_double),
                                           C.c_int(0 if prm is None else prm.shape[1]), _ptr(idx, C.c_int32) if idx.size else None,
                                           C.c_int(B), C.c_int(m), _ptr(w, C.c_double), C.c_int(int(wpow)),

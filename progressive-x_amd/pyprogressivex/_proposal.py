@@ -22,6 +22,35 @@ import numpy as np
 # ---------------------------------------------------------------------------------------------------------------------
 # samplers  (ids as in progressivex_python.cpp:215-245)
 # ---------------------------------------------------------------------------------------------------------------------
+def _distinct_rows(rng, tops, m, retries=4):
+    """Rows of m DISTINCT integers, row r uniform over range(tops[r]) (tops[r] >= m).  Fast path: draw with replacement and
+    redraw the rows that hold duplicates; rows still bad after a few rounds (likely when tops[r] is close to m: the 7-point
+    solver on 7..10 points, PROSAC's first rows) get an exact draw — a partial Fisher-Yates shuffle of their range — so a
+    sample never carries repeated indices (the reference's samplers return distinct indices by construction)."""
+    tops = np.asarray(tops, dtype=np.int64)
+    count = tops.shape[0]
+    s = (rng.random((count, m)) * tops[:, None]).astype(np.int64)
+    if m < 2:
+        return s
+    dense = tops < 4 * m                      # rejection succeeds with probability < ~0.5 per round there: go exact at once
+    for _ in range(retries):
+        srt = np.sort(s, axis=1)
+        bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1) & ~dense
+        if not bad.any():
+            break
+        s[bad] = (rng.random((int(bad.sum()), m)) * tops[bad][:, None]).astype(np.int64)
+    srt = np.sort(s, axis=1)
+    bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+    for r in bad:                             # exact: m steps of Fisher-Yates on range(tops[r]) with a sparse swap table
+        top, swaps = int(tops[r]), {}
+        for j in range(m):
+            k = j + int(rng.integers(0, top - j))
+            vj, vk = swaps.get(j, j), swaps.get(k, k)
+            swaps[j], swaps[k] = vk, vj
+            s[r, j] = vk
+    return s
+
+
 class UniformSampler:
     """gcransac::sampler::UniformSampler: m distinct indices uniformly at random."""
 
@@ -34,16 +63,7 @@ class UniformSampler:
     def draw(self, count, m):
         if self.n < m:
             return np.zeros((0, m), dtype=np.int64)
-        # rejection-free: argsort of random keys on a (count, k) window would cost O(count n); use per-row choice via
-        # sorting random floats only for small m: draw with replacement and redraw rows that contain duplicates
-        s = self.rng.integers(0, self.n, (count, m))
-        for _ in range(32):
-            srt = np.sort(s, axis=1)
-            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
-            if not bad.any():
-                break
-            s[bad] = self.rng.integers(0, self.n, (int(bad.sum()), m))
-        return s
+        return _distinct_rows(self.rng, np.full(count, self.n, dtype=np.int64), m)
 
 
 class ProsacSampler(UniformSampler):
@@ -54,14 +74,7 @@ class ProsacSampler(UniformSampler):
         if self.n < m:
             return np.zeros((0, m), dtype=np.int64)
         tops = np.minimum(self.n, np.maximum(m, (m + (self.n - m) * (np.arange(count) + 1) / count).astype(np.int64)))
-        s = (self.rng.random((count, m)) * tops[:, None]).astype(np.int64)
-        for _ in range(32):
-            srt = np.sort(s, axis=1)
-            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
-            if not bad.any():
-                break
-            s[bad] = (self.rng.random((int(bad.sum()), m)) * tops[bad][:, None]).astype(np.int64)
-        return s
+        return _distinct_rows(self.rng, tops, m)
 
 
 class NapsacSampler(UniformSampler):
@@ -79,13 +92,7 @@ class NapsacSampler(UniformSampler):
         centers, deg = centers[ok], deg[ok]
         if len(centers) == 0:
             return np.zeros((0, m), dtype=np.int64)
-        pick = (self.rng.random((len(centers), m - 1)) * deg[:, None]).astype(np.int64)
-        for _ in range(32):
-            srt = np.sort(pick, axis=1)
-            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1) if m > 2 else np.zeros(len(centers), bool)
-            if not bad.any():
-                break
-            pick[bad] = (self.rng.random((int(bad.sum()), m - 1)) * deg[bad][:, None]).astype(np.int64)
+        pick = _distinct_rows(self.rng, deg, m - 1)
         nbr = self.idx[self.off[centers][:, None] + pick]
         return np.column_stack([centers, nbr])
 

@@ -76,25 +76,59 @@ def _launcher_key():
     return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
 
 
+def _rendezvous_dir():
+    """A directory only this user can write: $PGX_RDV_DIR, else $XDG_RUNTIME_DIR, else /tmp/pgx_rdv_<uid> created 0700.
+    Refuses a directory owned by somebody else or writable by group/others (another local user could pre-create the id
+    file and hang the bootstrap or join the ranks to a foreign communicator)."""
+    import stat
+    base = os.environ.get("PGX_RDV_DIR") or os.environ.get("XDG_RUNTIME_DIR")
+    if not base:
+        base = os.path.join("/tmp", f"pgx_rdv_{os.getuid()}")
+        os.makedirs(base, mode=0o700, exist_ok=True)
+    st = os.stat(base)
+    if st.st_uid != os.getuid() or (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH)):
+        raise PermissionError(f"rendezvous directory {base} must be owned by uid {os.getuid()} and not group/world writable")
+    return base
+
+
+def _launcher_start_time():
+    """Wall-clock start of the launcher (the common parent of all ranks); files older than this are stale."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/stat") as f:
+            btime = next(float(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, StopIteration, ValueError):
+        return 0.0
+
+
+def _rendezvous_path():
+    return os.path.join(_rendezvous_dir(), f"pgx_rdv_{_launcher_key()}.id")
+
+
 def exchange_unique_id(rank, world, make_id, timeout=300.0):
-    """rank 0 creates the 128-byte ncclUniqueId and publishes it through an atomically renamed file."""
+    """rank 0 creates the 128-byte ncclUniqueId and publishes it through an atomically renamed file in a private
+    directory; readers accept it only if this user wrote it after the launcher started."""
     if world == 1:
         return make_id()
-    base = os.environ.get("PGX_RDV_DIR", "/tmp")
-    path = os.path.join(base, f"pgx_rdv_{_launcher_key()}.id")
+    path = _rendezvous_path()
     if rank == 0:
         uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)
         return uid
+    not_before = _launcher_start_time() - 2.0
     t0 = time.time()
     while time.time() - t0 < timeout:
         try:
             with open(path, "rb") as f:
+                st = os.fstat(f.fileno())
                 uid = f.read()
-            if len(uid) == 128:
+            if len(uid) == 128 and st.st_uid == os.getuid() and st.st_mtime >= not_before:
                 return uid
         except OSError:
             pass
@@ -105,7 +139,7 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0):
 def cleanup_unique_id(rank):
     if rank == 0:
         try:
-            os.remove(os.path.join(os.environ.get("PGX_RDV_DIR", "/tmp"), f"pgx_rdv_{_launcher_key()}.id"))
+            os.remove(_rendezvous_path())
         except OSError:
             pass
 

@@ -87,3 +87,37 @@ def test_host_helpers():
     assert per == 3 and bounds == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert parallel.select_best([1.0, 5.0, 5.0, np.nan], [1, 2, 2, 3]) == 1
     assert parallel.select_best([1.0, 5.0], [0, 0]) == -1
+
+
+def test_weights_length_is_validated_before_anything_runs():
+    # the reference reads weights[i] for every point without a length check (solver_vanishing_point_two_lines.h:204-207):
+    # a short array is a heap over-read there, a ValueError here (raised before the GPU context is touched)
+    lines = np.random.default_rng(0).random((20, 4))
+    with pytest.raises(ValueError, match="weights should have one entry per row"):
+        px.findVanishingPoints(lines, np.ones(5), 100, 100, sampler_id=0)
+    # findLines parses the weights and never uses them (progressivex_python.cpp:466-482): any length passes, as upstream
+    L, lab = px.findLines(np.random.default_rng(0).random((50, 2)), np.ones(5), 100, 100)
+    assert L.shape == (0, 3)
+
+
+def test_samplers_return_distinct_indices_even_when_n_is_close_to_m():
+    from pyprogressivex import _proposal
+    rng = np.random.default_rng(0)
+    for n, m in ((7, 7), (8, 7), (10, 7), (4, 4), (100, 4), (2, 2)):
+        for cls in (_proposal.UniformSampler, _proposal.ProsacSampler):
+            s = cls(n, rng).draw(300, m)
+            assert s.shape == (300, m) and s.min() >= 0 and s.max() < n
+            srt = np.sort(s, axis=1)
+            assert not (srt[:, 1:] == srt[:, :-1]).any(), (cls.__name__, n, m)
+    # PROSAC's first rows draw from a prefix of exactly m points: they must be permutations of range(m)
+    s = _proposal.ProsacSampler(1000, rng).draw(2000, 4)
+    assert sorted(s[0].tolist()) == [0, 1, 2, 3]
+    # NAPSAC on a ring graph with degree 2 and m = 3: both neighbours, distinct
+    n = 50
+    off = np.arange(0, 2 * n + 1, 2)
+    idx = np.column_stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n]).reshape(-1)
+    s = _proposal.NapsacSampler(n, rng, (off, idx)).draw(200, 3)
+    assert len(s) == 200 and all(len(set(r)) == 3 for r in s.tolist())
+    # the exact fallback is uniform: every index equally likely in every column
+    s = _proposal.UniformSampler(8, rng).draw(40000, 7)
+    assert np.abs(np.bincount(s[:, 0], minlength=8) / 40000 - 0.125).max() < 0.01

@@ -670,6 +670,43 @@ def test_gram_error_paths_and_empty_selection(gpu_ctx):
         gpu_ctx.gram(_lib.GRAM_VP + 9, ("index", np.array([1], np.int32)))
     with pytest.raises(_lib.PgxError):
         gpu_ctx.gram(_lib.GRAM_AFFINE, ("index", np.array([1], np.int32)), weights=np.ones(100), wpow=3)
+    # weights are resident and length-checked (a short host array used to be read for n doubles)
+    with pytest.raises(ValueError, match="one entry per point"):
+        gpu_ctx.gram(_lib.GRAM_AFFINE, ("index", np.array([1], np.int32)), weights=np.ones(5))
+    with pytest.raises(ValueError, match="one entry per point"):
+        gpu_ctx.gram_batch(_lib.GRAM_AFFINE, np.array([[1, 2]], np.int32), weights=np.ones(5))
+    import ctypes as C
+    w = np.ones(5)
+    assert gpu_ctx._lib.pgx_set_weights(gpu_ctx._h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(5)) != 0
+    assert b"5 weights for 100 points" in gpu_ctx._lib.pgx_last_error(gpu_ctx._h)
+    out = np.zeros(15)
+    cnt, bad = C.c_int64(), C.c_int64()
+    idx = np.array([1], np.int32)
+    rc = gpu_ctx._lib.pgx_gram(gpu_ctx._h, C.c_int(_lib.GRAM_AFFINE), None, C.c_int(0), C.c_int(0),
+                               idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(1), C.c_int(0), C.c_int(1), C.c_int(2),
+                               out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(bad))
+    assert rc != 0 and b"no weights are resident" in gpu_ctx._lib.pgx_last_error(gpu_ctx._h)
+    # set_points invalidates the resident weights of the previous point set
+    gpu_ctx.set_weights(np.ones(100))
+    gpu_ctx.set_points(mt, pts[:50])
+    rc = gpu_ctx._lib.pgx_gram(gpu_ctx._h, C.c_int(_lib.GRAM_AFFINE), None, C.c_int(0), C.c_int(0),
+                               idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(1), C.c_int(0), C.c_int(1), C.c_int(2),
+                               out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(bad))
+    assert rc != 0
+
+
+def test_compound_update_takes_more_than_32_models(gpu_ctx, oracle):
+    """the 32-pointer kernel argument is chunked (max is associative and exact)."""
+    mt, pts, models, thr = make_case("line", 3000, 40, seed=2)
+    gpu_ctx.set_points(mt, pts)
+    T2 = 2.25 * thr * thr
+    prefs = []
+    for k in range(40):
+        prefs.append(gpu_ctx.preference(models[k], T2, slot=k, want_pref=True)["pref"])
+    comp = gpu_ctx.compound_update(list(range(40)), want_compound=True)
+    assert np.array_equal(comp, np.max(np.stack(prefs), axis=0))
+    comp = gpu_ctx.compound_update([39, 3, 35], want_compound=True)
+    assert np.array_equal(comp, np.max(np.stack([prefs[39], prefs[3], prefs[35]]), axis=0))
 
 
 def test_asymmetric_graph_is_rejected(gpu_ctx):

@@ -177,3 +177,25 @@ def test_batched_refits_equal_single_refits_on_the_oracle_context():
         single = est.nonminimal(ctx, ("index", picks[b]), None, init=P0)
         assert np.array_equal(single[0], batch[b][0])
     assert est.nonminimal_batch(ctx, picks, None, init=None) == [[]] * 5
+
+
+def test_preference_slots_are_recycled(oracle_backend):
+    """Rejected proposals and instances removed by PEARL give their preference slot back (each is N * 8 bytes on the
+    device): the slot index never exceeds the number of live models."""
+    from pyprogressivex import _engine
+    seen = []
+    orig = OracleContext.preference
+
+    def spy(self, model, T2, slot, **kw):
+        seen.append(int(slot))
+        return orig(self, model, T2, slot, **kw)
+    OracleContext.preference = spy
+    try:
+        pts, gt, _ = datasets.make_lines(n_per_line=120, n_lines=3, n_outliers=200, seed=3)
+        L, lab = px.findLines(pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99, sampler_id=0, seed=2,
+                              minimum_point_number=40, max_outer_iterations=25, maximum_tanimoto_similarity=1e-9)
+    finally:
+        OracleContext.preference = orig
+    # the first model is accepted (Tanimoto 0/0 -> NaN -> valid), every later proposal overlaps it a little and is rejected
+    # (until 10 rejections end the run): all of them reuse slot 1
+    assert len(L) == 1 and len(seen) >= 5 and seen[0] == 0 and set(seen[1:]) == {1}
