@@ -137,6 +137,14 @@ int pgx_energy(pgx_ctx *ctx, double lambda, double label_cost, int64_t *energy_q
 int pgx_expand_alpha(pgx_ctx *ctx, double lambda, double label_cost, int alpha, int64_t *changed);
 int pgx_expansion(pgx_ctx *ctx, double lambda, double label_cost, int max_cycles,
                   int64_t *energy_q, double *energy, int *cycles);
+/* U-8: what GCO-v3's expansion() does for an energy WITHOUT smooth costs, which is what PEARL hands it when
+ * spatial_coherence_weight == 0 (PEARL.h:523-536: no setSmoothCost, no setNeighbors; :550-551 expansion()): its
+ * solveSpecialCases() labels "data costs only" by per-site argmin and "data costs + per-label costs" by the greedy
+ * facility-location heuristic solveGreedy() instead of running alpha-expansion [UPSTREAM-MEMORY, restated in
+ * oracle/pgx_oracle.c].  Works on the resident unary table; the resident labelling is OVERWRITTEN (the heuristic
+ * ignores the starting labels).  opened = labels in use. */
+int pgx_greedy_labeling(pgx_ctx *ctx, double label_cost, int64_t *energy_q, double *energy, int *opened);
+
 /* counters of the last pgx_expansion / pgx_expand_alpha: [0]=min-cuts solved, [1]=push-relabel sweeps,
  * [2]=global relabels (BFS passes), [3]=BFS levels, [4]=sites relabelled by moves, [5]=wave passes,
  * [6]=work-list sweeps, [7]=moves skipped because the labelling had not changed since that label's last move, which relabelled nothing */

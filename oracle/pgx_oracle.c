@@ -541,6 +541,60 @@ int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * U-8  GCO-v3's special cases for an energy WITHOUT smooth costs (PEARL never calls setSmoothCost / setNeighbors when
+ * spatial_coherence_weight == 0: /root/reference/src/pyprogressivex/include/PEARL.h:523-536, and then calls
+ * expansion(): :550-551).  GCoptimization::expansion() starts with solveSpecialCases(), which for "data costs only"
+ * assigns every site its cheapest label and for "data costs + per-label costs" runs solveGreedy(): the greedy
+ * uncapacitated-facility-location heuristic.  The GCO sources are absent from the snapshot; restated from the
+ * published algorithm [UPSTREAM-MEMORY]:
+ *   every site starts unassigned at a prohibitive cost BIG; repeat: for every label not opened yet,
+ *   delta(l) = h + sum_i min(0, D[i][l] - e_i); open the label with the most negative delta (ties: lowest index) and
+ *   move to it every site it serves strictly cheaper; stop when no delta is negative.  The given labelling is ignored.
+ * Integers throughout (D, h are 2^-32 fixed point), so the decisions are exact and CPU == GPU bit for bit.
+ * h == 0: per-site argmin, first minimum.  Returns the number of labels opened; energy as pgxo_energy computes it.
+ * ---------------------------------------------------------------------------------------- */
+int pgxo_greedy_labeling(int64_t n, int L, const int64_t *Dq, int64_t h_q, int32_t *labels, int64_t *energy_q)
+{
+    const int64_t BIG = (int64_t)1 << 35; /* > every unary cost (<= 2^33 from pgxo_unary_q); n * BIG < 2^62 for n < 2^27 */
+    int opened = 0;
+    if (h_q <= 0) {
+        for (int64_t i = 0; i < n; ++i) {
+            int best = 0;
+            for (int l = 1; l < L; ++l) if (Dq[i * L + l] < Dq[i * L + best]) best = l;
+            labels[i] = best;
+        }
+        uint8_t *seen = (uint8_t *)calloc((size_t)L, 1);
+        for (int64_t i = 0; i < n; ++i) if (!seen[labels[i]]) { seen[labels[i]] = 1; ++opened; }
+        free(seen);
+    } else {
+        int64_t *e = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+        uint8_t *open = (uint8_t *)calloc((size_t)L, 1);
+        for (int64_t i = 0; i < n; ++i) { e[i] = BIG; labels[i] = 0; }
+        for (;;) {
+            int best = -1;
+            int64_t best_delta = 0;
+            for (int l = 0; l < L; ++l) {
+                if (open[l]) continue;
+                int64_t delta = h_q;
+                for (int64_t i = 0; i < n; ++i) {
+                    const int64_t d = Dq[i * L + l] - e[i];
+                    if (d < 0) delta += d;
+                }
+                if (delta < best_delta) { best_delta = delta; best = l; }
+            }
+            if (best < 0) break;
+            open[best] = 1;
+            ++opened;
+            for (int64_t i = 0; i < n; ++i)
+                if (Dq[i * L + best] < e[i]) { e[i] = Dq[i * L + best]; labels[i] = best; }
+        }
+        free(e); free(open);
+    }
+    if (energy_q) *energy_q = pgxo_energy(n, L, Dq, NULL, NULL, NULL, 0, h_q, labels);
+    return opened;
+}
+
+/* ------------------------------------------------------------------------------------------
  * GC-RANSAC's inlier/outlier labelling (gcransac::GCRANSAC::labeling; the graph-cut-ransac sources are
  * absent from the snapshot - call site /root/reference/src/pyprogressivex/include/progressive_x.h:294-299 - restated
  * from memory of upstream [U-12]).  The graph is built the way upstream builds it with Kolmogorov's Energy class:

@@ -83,6 +83,8 @@ int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, c
 int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
                    const int32_t *mult, int64_t lambda_q, int64_t h_q, int32_t *labels, int max_cycles,
                    int64_t *energy_q, int *cycles);
+/* U-8: GCO-v3's no-smooth-cost special cases (greedy facility location with per-label costs; argmin without) */
+int pgxo_greedy_labeling(int64_t n, int L, const int64_t *Dq, int64_t h_q, int32_t *labels, int64_t *energy_q);
 /* 8f rank 4: GC-RANSAC's inlier/outlier graph cut, graph built as upstream's Energy::add_term1/add_term2 would [U-12].
  * flags[n]: 1 = inlier; returns the inlier count.  off/idx: symmetric CSR (multiplicities are ignored: pairs count once). */
 int64_t pgxo_gc_labeling(int model_type, const double *pts, int64_t n, const double *model, double T2, double lambda,

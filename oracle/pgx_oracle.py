@@ -204,6 +204,17 @@ def expansion(Dq, graph, lambda_q, h_q, labels, max_cycles=1000):
     return labels, int(e.value), int(cyc.value)
 
 
+def greedy_labeling(Dq, h_q):
+    """U-8: GCO-v3's labelling of an energy without smooth costs (greedy facility location) -> (labels, energy_q, opened)"""
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64)
+    n, L = Dq.shape
+    labels = np.zeros(n, dtype=np.int32)
+    e = C.c_int64()
+    opened = lib().pgxo_greedy_labeling(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), C.c_int64(h_q), _p(labels, C.c_int32),
+                                        C.byref(e))
+    return labels, int(e.value), int(opened)
+
+
 def maxflow(nnodes, frm, to, cap, s, t):
     frm = _i32(frm); to = _i32(to); cap = np.ascontiguousarray(cap, dtype=np.int64)
     side = np.zeros(nnodes, dtype=np.uint8)

@@ -494,6 +494,7 @@ int pgx_pearl_unary(pgx_ctx* ctx, const double* models, int K, double threshold,
     PGX_TRY(unary_launch(ctx, K, threshold, lambda));
     ctx->L = L;
     ctx->dq_n = ctx->n;
+    ctx->dq_max = (int64_t)1 << 33;  // 2 (1 - lambda) <= 2 in 2^-32 fixed point (PEARL.h:123)
     if (Dq_out) {  // ABI layout is point-major N x L (as the reference's per-point functor); device is label-major
         std::vector<int64_t> tmp((size_t)L * (size_t)ctx->n);
         PGX_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->dq.p, tmp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -512,8 +513,15 @@ int pgx_set_unary_q(pgx_ctx* ctx, const int64_t* Dq, int64_t n, int L)
     if (!Dq || n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_unary_q: empty table");
     if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_unary_q: n must be < 2^31");
     std::vector<int64_t> tmp((size_t)L * (size_t)n);
+    int64_t mx = 0;
     for (int l = 0; l < L; ++l)
-        for (int64_t i = 0; i < n; ++i) tmp[(size_t)l * n + i] = Dq[i * L + l];
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t v = Dq[i * L + l];
+            tmp[(size_t)l * n + i] = v;
+            if (v < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_unary_q: negative cost at site %lld, label %d", (long long)i, l);
+            if (v > mx) mx = v;
+        }
+    ctx->dq_max = mx;
     PGX_TRY(ensure(ctx, ctx->dq, tmp.size() * sizeof(int64_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->dq.p, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -689,6 +697,19 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
     if (energy_q) *energy_q = new_e;
     if (energy) *energy = (double)new_e / 4294967296.0;
     if (cycles) *cycles = done;
+    return PGX_OK;
+}
+
+int pgx_greedy_labeling(pgx_ctx* ctx, double label_cost, int64_t* energy_q, double* energy, int* opened)
+{
+    CTX_GUARD(ctx);
+    int64_t lq, hq, e = 0;
+    PGX_TRY(flow_params(ctx, 0.0, label_cost, &lq, &hq));
+    int op = 0;
+    PGX_TRY(greedy_labeling_launch(ctx, hq, &e, &op));
+    if (energy_q) *energy_q = e;
+    if (energy) *energy = (double)e / 4294967296.0;
+    if (opened) *opened = op;
     return PGX_OK;
 }
 

@@ -74,6 +74,7 @@ struct pgx_ctx {
     int L = 0;          // labels of the resident unary table
     int64_t dq_n = 0;   // sites of the resident unary table
     pgx::DevBuf dq;     // label-major [L][n] int64
+    int64_t dq_max = 0; // upper bound of the table's entries (pgx_pearl_unary: 2^33; pgx_set_unary_q: the actual maximum)
     pgx::DevBuf kmodels;
     pgx::DevBuf labels; // int32 [n]
     int64_t labels_n = 0;
@@ -127,6 +128,7 @@ int unary_launch(pgx_ctx* ctx, int K, double threshold, double lambda);
 int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* sum);
 int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
 int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
+int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* opened);
 int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count);
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);

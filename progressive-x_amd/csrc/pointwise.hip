@@ -593,4 +593,127 @@ int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q
     return PGX_OK;
 }
 
+// ---- U-8: GCO-v3's labelling of an energy without smooth costs -------------------------------------------------------
+// PEARL sets no smooth cost and no neighbours when spatial_coherence_weight == 0 (PEARL.h:523-536) and then calls
+// expansion() (:550-551), whose first step in GCO-v3 is solveSpecialCases(): "data costs only" -> every site takes its
+// cheapest label; "data costs + per-label costs" -> solveGreedy(), the greedy uncapacitated-facility-location heuristic
+// (restated from the published algorithm [UPSTREAM-MEMORY]; the CPU restatement under oracle/ is the checker).  One round = one reduction over all sites for
+// every label not opened yet (integer sums: exact and order-free, so the host's choice is the oracle's) + one apply pass;
+// at most L rounds.  HBM-bound: a round reads (#closed labels + 1) * n * 8 B of the label-major table.
+constexpr long long kGreedyBig = 1ll << 35;  // "unassigned": above every unary cost (dq_max is checked), n * BIG < 2^62
+
+__global__ __launch_bounds__(kPwBlock) void greedy_init_kernel(long long* __restrict__ e, int* __restrict__ labels, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i < n) { e[i] = kGreedyBig; labels[i] = 0; }
+}
+
+__global__ __launch_bounds__(kPwBlock) void greedy_delta_kernel(const long long* __restrict__ dq, int64_t n, int L,
+                                                               const long long* __restrict__ e, unsigned long long open_mask,
+                                                               unsigned long long* __restrict__ delta /*[L]*/)
+{
+    __shared__ long long lds[kPwBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    const long long ei = i < n ? e[i] : 0;
+    for (int l = 0; l < L; ++l) {
+        if ((open_mask >> l) & 1ull) continue;  // uniform
+        long long d = 0;
+        if (i < n) { d = dq[(int64_t)l * n + i] - ei; if (d > 0) d = 0; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        __syncthreads();  // the previous label's partials have been read
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long s = 0;
+            for (int w = 0; w < kPwBlock / 64; ++w) s += lds[w];
+            if (s != 0) atomicAdd(&delta[l], (unsigned long long)s);  // two's complement: integer sums are exact
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPwBlock) void greedy_apply_kernel(const long long* __restrict__ dq, int64_t n, int alpha,
+                                                               long long* __restrict__ e, int* __restrict__ labels)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    const long long d = dq[(int64_t)alpha * n + i];
+    if (d < e[i]) { e[i] = d; labels[i] = alpha; }
+}
+
+__global__ __launch_bounds__(kPwBlock) void greedy_argmin_kernel(const long long* __restrict__ dq, int64_t n, int L,
+                                                                int* __restrict__ labels)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i >= n) return;
+    int best = 0;
+    long long bv = dq[i];
+    for (int l = 1; l < L; ++l) {
+        const long long v = dq[(int64_t)l * n + i];
+        if (v < bv) { bv = v; best = l; }  // first minimum
+    }
+    labels[i] = best;
+}
+
+int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* opened)
+{
+    const int64_t n = ctx->dq_n;
+    const int L = ctx->L;
+    if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_greedy_labeling: unary table not set");
+    if (L > 64) return fail(ctx, PGX_ERR_INVALID, "pgx_greedy_labeling: at most 64 labels (got %d)", L);
+    if (ctx->dq_max >= kGreedyBig || (double)n * (double)kGreedyBig >= 4.6e18)
+        return fail(ctx, PGX_ERR_RANGE, "pgx_greedy_labeling: fixed-point range exceeded (max unary %lld, n %lld)",
+                    (long long)ctx->dq_max, (long long)n);
+    PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
+    ctx->labels_n = n;
+    const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
+    const long long* dq = ctx->dq.as<long long>();
+    int* labels = ctx->labels.as<int>();
+    int count = 0;
+    if (h_q <= 0) {
+        hipLaunchKernelGGL(greedy_argmin_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, L, labels);
+        PGX_HIP(ctx, hipGetLastError());
+        count = -1;  // counted from the energy pass below
+    } else {
+        PGX_TRY(ensure(ctx, ctx->gc, (size_t)n * sizeof(long long) + 64 * sizeof(long long)));  // e[n] | delta[64]
+        long long* e = ctx->gc.as<long long>();
+        unsigned long long* d_delta = (unsigned long long*)(e + n);
+        hipLaunchKernelGGL(greedy_init_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, e, labels, n);
+        PGX_HIP(ctx, hipGetLastError());
+        unsigned long long open_mask = 0;
+        long long h_delta[64];
+        for (int round = 0; round < L; ++round) {
+            PGX_HIP(ctx, hipMemsetAsync(d_delta, 0, 64 * sizeof(long long), ctx->stream));
+            hipLaunchKernelGGL(greedy_delta_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, L, e, open_mask,
+                               d_delta);
+            PGX_HIP(ctx, hipGetLastError());
+            PGX_HIP(ctx, hipMemcpyAsync(h_delta, d_delta, (size_t)L * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+            PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            int best = -1;
+            long long best_delta = 0;
+            for (int l = 0; l < L; ++l) {
+                if ((open_mask >> l) & 1ull) continue;
+                const long long delta = h_delta[l] + (long long)h_q;
+                if (delta < best_delta) { best_delta = delta; best = l; }
+            }
+            if (best < 0) break;
+            open_mask |= 1ull << best;
+            ++count;
+            hipLaunchKernelGGL(greedy_apply_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, best, e, labels);
+            PGX_HIP(ctx, hipGetLastError());
+        }
+    }
+    int64_t eq = 0;
+    PGX_TRY(energy_launch(ctx, 0, h_q, &eq));
+    if (count < 0) {  // argmin path: labels in use = (energy's label-cost share is zero) count them on the host from a bucket pass
+        std::vector<int64_t> cnt((size_t)L, 0);
+        PGX_TRY(bucket_launch(ctx, L, cnt.data(), nullptr));
+        count = 0;
+        for (int l = 0; l < L; ++l) if (cnt[(size_t)l] > 0) ++count;
+    }
+    if (energy_q) *energy_q = eq;
+    if (opened) *opened = count;
+    return PGX_OK;
+}
+
 }  // namespace pgx

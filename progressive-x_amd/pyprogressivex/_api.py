@@ -11,6 +11,10 @@ Extensions that do not change the reference behaviour when left at their default
   neighborhood="flann_like"     U-7 switch: "flann_like" (<= 5 nearest neighbours inside the ball, what upstream's
                                 checks=6 approximate search can return at most), "radius" (all points in the ball),
                                 or "knn:<k>"
+  labeling_l0="greedy"          U-8 switch, only matters when spatial_coherence_weight == 0 (the default of four of the
+                                five entry points): PEARL then sets no smooth cost, and GCO-v3's expansion() labels such
+                                an energy by its special-case solver (greedy facility location over the label costs)
+                                instead of alpha-expansion; "expansion" = alpha-expansion moves (round 1's behaviour)
   local_optimization="auto"     U-12 switch: "auto" = GC-RANSAC's graph-cut local optimisation whenever the spatial
                                 coherence weight is in (0, 1) (the cut runs on the GPU, pgx_gc_labeling), iterated
                                 least-squares refits otherwise; "lsq" = refits only
@@ -68,7 +72,7 @@ def _unknown_sampler(sampler_id):
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
          do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-         local_optimization="auto"):
+         local_optimization="auto", labeling_l0="greedy"):
     n = pts.shape[0]
     if getattr(sampler_factory, "unknown", False):
         # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
@@ -97,7 +101,10 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         s.maximum_model_number = int(maximum_model_number)
     s.point_weights = weights
     s.max_outer_iterations = int(max_outer_iterations)
-    s.local_optimization = str(local_optimization)   # "auto": GC-RANSAC's graph-cut LO when 0 < lambda < 1; "lsq"
+    s.local_optimization = str(local_optimization)   # "auto": GC-RANSAC's graph-cut LO; "lsq": refits only
+    if labeling_l0 not in ("greedy", "expansion"):
+        raise ValueError("labeling_l0 should be 'greedy' or 'expansion'")
+    s.labeling_l0 = str(labeling_l0)
     px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
                               do_logging=do_logging, graph_resident=resident)
     models, stats = px.run()
@@ -113,15 +120,15 @@ def _stack(estimator, models, cols):
     return out
 
 
-def _sampler_factory(sampler_id, valid):
+def _sampler_factory(sampler_id, valid, pts=None, sizes=None, sample_size=None, prosac_sample_size=None):
     def make(n, rng, graph):
         kind = valid[sampler_id]
         if kind == "uniform":
             return _proposal.UniformSampler(n, rng)
         if kind == "prosac":
-            return _proposal.ProsacSampler(n, rng)
-        if kind == "pnapsac":
-            return _proposal.ProgressiveNapsacSampler(n, rng, graph)
+            return _proposal.ProsacSampler(n, rng, sample_size=prosac_sample_size)
+        if kind == "pnapsac":                # ProgressiveNapsacSampler<4>(&points, {16,8,4,2}, m, {w1,h1,w2,h2}, 0.5)
+            return _proposal.ProgressiveNapsacSampler(n, rng, pts, sizes, sample_size)
         return _proposal.NapsacSampler(n, rng, graph)
     make.unknown = sampler_id not in valid
     make.sampler_id = sampler_id
@@ -132,7 +139,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                      do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like",
-                     local_optimization="auto"):
+                     local_optimization="auto", labeling_l0="greedy"):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -145,12 +152,13 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
     est = (_estimators.SymmetricHomographyEstimator() if residual == "symmetric" else _estimators.HomographyEstimator())
     # NB: the driver never calls progressive_x.log(): do_logging only triggers the sampler notes (:219-226)
     models, labels, _ = _run(est, corrs, corrs, neighborhood_ball_radius,
-                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}),
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}, corrs,
+                                              (w1, h1, w2, h2), est.sample_size),
                              threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
     return _stack(est, models, 3), labels
 
 
@@ -158,7 +166,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto"):
+                     local_optimization="auto", labeling_l0="greedy"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -171,12 +179,13 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
     est = _estimators.FundamentalEstimator()
     # the driver ignores scoring_exponent (never calls setScoringExponent: :621-638) => ProgressiveX's default 2
     models, labels, _ = _run(est, corrs, corrs, neighborhood_ball_radius,
-                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}),
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}, corrs,
+                                              (w1, h1, w2, h2), est.sample_size),
                              threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
     return _stack(est, models, 3), labels
 
 
@@ -187,7 +196,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                         do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto"):
+                     local_optimization="auto", labeling_l0="greedy"):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -204,7 +213,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
                              weights=_weights(weights, n), seed=seed, max_outer_iterations=max_outer_iterations,
-                             neighborhood=neighborhood, local_optimization=local_optimization)
+                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
     return _stack(est, models, 3), labels
 
 
@@ -212,7 +221,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
               do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto"):
+                     local_optimization="auto", labeling_l0="greedy"):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -224,12 +233,13 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
         print("Note: PROSAC sampler requires the points to be order by quality, e.g., SNN ratio.")
     est = _estimators.LineEstimator()
     models, labels, _ = _run(est, points, points, neighborhood_ball_radius,
-                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "napsac"}),
+                             _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "napsac"},
+                                              prosac_sample_size=4),     # the HOMOGRAPHY sample size (quirk, :463)
                              threshold=threshold, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
     return _stack(est, models, 3), labels
 
 
@@ -237,7 +247,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
                 minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
                 neighborhood="flann_like",
-                     local_optimization="auto"):
+                     local_optimization="auto", labeling_l0="greedy"):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
     import time
     x1 = _as_f64(x1y1)
@@ -271,5 +281,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
     return _stack(est, models, 4), labels

@@ -34,7 +34,12 @@ class MultiModelSettings:
         # proposal_engine_settings (:66-71)
         self.max_iteration_number = 5000
         self.max_local_optimization_number = 50
-        self.max_graph_cut_number = 10        # gcransac::utils::Settings default [UPSTREAM-MEMORY]
+        self.max_graph_cut_number = 10        # gcransac::utils::Settings defaults [UPSTREAM-MEMORY]: graph cuts per proposal,
+        self.min_iteration_number = 20        # iterations the main loop always runs,
+        self.min_iteration_number_before_lo = 20   # iterations before the first local optimisation,
+        self.max_least_squares_iterations = 10     # refits of the final iterated least squares
+        self.labeling_l0 = "greedy"           # [U-8] lambda = 0: GCO-v3's special-case solver ("expansion": alpha-expansion)
+        self.lo_cadence = "every_best"        # "winner": round 1's stand-in (one local optimisation, on the batch winner)
         self.local_optimization = "auto"      # "auto": graph-cut LO when 0 < lambda < 1, else LSQ refits; "lsq": always LSQ
         # not in the reference: its outer loop is hard-capped at 10 proposals (progressive_x.h:272)
         self.max_outer_iterations = 10
@@ -80,7 +85,7 @@ def predicted_unseen_inliers(one_minus_confidence, sample_size, iteration_number
 # ---------------------------------------------------------------------------------------------------------------------
 class Pearl:
     def __init__(self, ctx, estimator, pts, threshold, spatial_coherence_weight, minimum_inlier_number, point_weights,
-                 maximum_iteration_number=100, do_logging=False):
+                 maximum_iteration_number=100, do_logging=False, labeling_l0="greedy"):
         self.ctx, self.est, self.pts = ctx, estimator, pts
         self.threshold = threshold
         self.lam = spatial_coherence_weight
@@ -90,6 +95,7 @@ class Pearl:
         self.maximum_iteration_number = maximum_iteration_number
         self.point_weights = point_weights
         self.do_logging = do_logging
+        self.labeling_l0 = labeling_l0   # U-8 switch, see labeling()
         self.n = pts.shape[0]
         self.has_engine = False      # alpha_expansion_engine != nullptr
         self.outliers_number = 0
@@ -110,7 +116,14 @@ class Pearl:
         self.ctx.pearl_unary(desc, self.threshold, self.lam)          # PEARL.h:512-519 data term
         lam = self.lam if self.lam > 0.0 else 0.0                     # :523-525, :532 smooth term only if > 0
         h = self.model_complexity_weight if self.model_complexity_weight > 0.0 else 0.0   # :528-529
-        eq, e, cycles = self.ctx.expansion(lam, h, 1000)              # :550-551
+        if lam == 0.0 and self.labeling_l0 == "greedy":
+            # [U-8] no setSmoothCost / setNeighbors call was made (:523-536), so GCO-v3's expansion() (:550-551) leaves
+            # through solveSpecialCases(): per-site argmin without label costs, greedy facility location with them -
+            # not alpha-expansion.  labeling_l0="expansion" runs the closed-form alpha-expansion moves instead.
+            eq, e, opened = self.ctx.greedy_labeling(h)
+            cycles = 1
+        else:
+            eq, e, cycles = self.ctx.expansion(lam, h, 1000)          # :550-551
         self.has_engine = True
         self.cycles += cycles
         return e
@@ -226,7 +239,8 @@ class ProgressiveX:
         if self.graph is not None and s.spatial_coherence_weight > 0.0 and not self.graph_resident:
             self.ctx.set_graph(*self.graph)
         self.pearl = Pearl(self.ctx, self.est, self.pts, s.inlier_outlier_threshold, s.spatial_coherence_weight,
-                           s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging)   # :527-534
+                           s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging,
+                           labeling_l0=getattr(s, "labeling_l0", "greedy"))                      # :527-534
         self.engine = _proposal.ProposalEngine(self.ctx, self.est, self.pts, self.sampler, s, self.exchange)
 
     # progressive_x.h:565-591

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
-    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_expansion_stats",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
@@ -297,6 +297,7 @@ class Context:
         self._ck(self._lib.pgx_pearl_unary(self._h, _ptr(m, C.c_double), C.c_int(K), C.c_double(threshold),
                                            C.c_double(lam), _ptr(out, C.c_int64)), "pgx_pearl_unary")
         self.L = K + 1
+        self._dq_n = self.n
         return out
 
     def set_unary_q(self, Dq):
@@ -304,6 +305,7 @@ class Context:
         self._ck(self._lib.pgx_set_unary_q(self._h, _ptr(Dq, C.c_int64), C.c_int64(Dq.shape[0]),
                                            C.c_int(Dq.shape[1])), "pgx_set_unary_q")
         self.L = Dq.shape[1]
+        self._dq_n = Dq.shape[0]
         if self.n == 0:
             self.n = Dq.shape[0]
 
@@ -447,6 +449,14 @@ class Context:
         self._ck(self._lib.pgx_expansion(self._h, C.c_double(lam), C.c_double(label_cost), C.c_int(int(max_cycles)),
                                          C.byref(eq), C.byref(e), C.byref(cyc)), "pgx_expansion")
         return eq.value, e.value, cyc.value
+
+    def greedy_labeling(self, label_cost):
+        """pgx_greedy_labeling [U-8]: GCO-v3's labelling of an energy without smooth costs -> (energy_q, energy, opened)"""
+        eq, e, op = C.c_int64(), C.c_double(), C.c_int()
+        self._ck(self._lib.pgx_greedy_labeling(self._h, C.c_double(label_cost), C.byref(eq), C.byref(e), C.byref(op)),
+                 "pgx_greedy_labeling")
+        self._nlabels = self._dq_n          # the labelling now covers the sites of the unary table
+        return eq.value, e.value, op.value
 
     def expansion_stats(self):
         st = np.zeros(8, dtype=np.int64)

@@ -11,10 +11,9 @@ absent from the snapshot (empty submodule), so the loop is restated [UPSTREAM-ME
     the early exit `count + 1 < best.inlier_number` (scoring_function_with_compound_model.h:105-106), "first strictly
     better score wins", and the adaptive iteration bound log(1-conf)/log(1-(inl/N)^m) — so for a given hypothesis list
     the CPU restatement and the GPU path select the same model;
-  * local optimisation of the winner: GC-RANSAC's graph-cut + inner-RANSAC procedure (`_graph_cut_lo`, the cut runs on
-    the GPU: pgx_gc_labeling) when the spatial coherence weight is in (0, 1); iterated least-squares refits on the
-    inliers otherwise (with lambda = 0 the cut is plain thresholding).  Both are capped by
-    max_local_optimization_number = 50 (progressive_x.h:68).
+  * the local optimisation - GC-RANSAC's graph-cut + inner-RANSAC procedure (`_graph_cut_lo`; the cut runs on the GPU,
+    pgx_gc_labeling, and is the scorer's inlier mask when lambda = 0) with max_local_optimization_number = 50 inner
+    trials (progressive_x.h:68) - runs inside that replay at every new so-far-best model, as the sequential loop does.
 """
 import numpy as np
 
@@ -66,15 +65,61 @@ class UniformSampler:
         return _distinct_rows(self.rng, np.full(count, self.n, dtype=np.int64), m)
 
 
-class ProsacSampler(UniformSampler):
-    """PROSAC-style progressive sampling: points are assumed ordered by quality; sample t draws from the top-n_t
-    prefix whose length grows linearly to n over `count` draws (simplified growth function) [UPSTREAM-MEMORY]."""
+def prosac_growth_function(n, m, t_n):
+    """Chum & Matas' PROSAC growth function T'_n as USAC / GC-RANSAC tabulate it [UPSTREAM-MEMORY]: g[i] = number of
+    samples after which the hypothesis-generation set grows beyond its i + 1 best points (g[i] = 1 for i < m)."""
+    g = np.ones(n, dtype=np.int64)
+    T_n = float(t_n)
+    for i in range(m):
+        T_n *= (m - i) / (n - i)
+    tp = 1
+    for i in range(n):
+        if i + 1 <= m:
+            g[i] = tp
+            continue
+        T_next = (i + 1) * T_n / (i + 1 - m)
+        tp = tp + int(np.ceil(T_next - T_n))
+        g[i] = tp
+        T_n = T_next
+    return g
 
-    def draw(self, count, m):
+
+class ProsacSampler(UniformSampler):
+    """gcransac::sampler::ProsacSampler (progressivex_python.cpp:222) [UPSTREAM-MEMORY: the USAC formulation].  Points
+    are assumed ordered by quality.  Sample number k (1-based, restarted by reset(), progressive_x.h:290) draws from the
+    best n_k points, n_k = the smallest n >= m with T'_n >= k: m - 1 of the first n_k - 1 at random plus point n_k - 1
+    itself; after `convergence_iterations` samples (GC-RANSAC's ransac_convergence_iterations, 100 000) it is uniform."""
+
+    def __init__(self, n, rng, sample_size=None, convergence_iterations=100000):
+        super().__init__(n, rng)
+        self.prosac_m = sample_size          # findLines builds it with the HOMOGRAPHY sample size (quirk, :463)
+        self.t_n = int(convergence_iterations)
+        self._growth = {}
+
+    def growth(self, m):
+        if m not in self._growth:
+            self._growth[m] = prosac_growth_function(self.n, m, self.t_n)
+        return self._growth[m]
+
+    def subset_sizes(self, first, count, m):
+        """n_k for the sample numbers first .. first + count - 1"""
+        k = np.arange(first, first + count, dtype=np.int64)
+        return np.minimum(self.n, np.maximum(m, np.searchsorted(self.growth(m), k, side="left") + 1))
+
+    def draw(self, count, m, first=1):
         if self.n < m:
             return np.zeros((0, m), dtype=np.int64)
-        tops = np.minimum(self.n, np.maximum(m, (m + (self.n - m) * (np.arange(count) + 1) / count).astype(np.int64)))
-        return _distinct_rows(self.rng, tops, m)
+        gm = max(m, min(self.n, self.prosac_m or m))
+        k = np.arange(first, first + count, dtype=np.int64)
+        nk = np.minimum(self.n, np.maximum(gm, np.searchsorted(self.growth(gm), k, side="left") + 1))
+        out = np.empty((count, m), dtype=np.int64)
+        if m > 1:
+            out[:, :m - 1] = _distinct_rows(self.rng, nk - 1, m - 1)
+        out[:, m - 1] = nk - 1
+        late = k > self.t_n
+        if late.any():
+            out[late] = _distinct_rows(self.rng, np.full(int(late.sum()), self.n, dtype=np.int64), m)
+        return out
 
 
 class NapsacSampler(UniformSampler):
@@ -97,18 +142,99 @@ class NapsacSampler(UniformSampler):
         return np.column_stack([centers, nbr])
 
 
-class ProgressiveNapsacSampler(NapsacSampler):
-    """P-NAPSAC stand-in: NAPSAC blended linearly into global uniform sampling over the first 0.5 * n draws
-    (the reference's blending length, progressivex_python.cpp:235) [UPSTREAM-MEMORY]."""
+class ProgressiveNapsacSampler(UniformSampler):
+    """gcransac::sampler::ProgressiveNapsacSampler<4>(&points, {16, 8, 4, 2}, m, {w1, h1, w2, h2}, 0.5)
+    (progressivex_python.cpp:229-238) after Barath et al., "MAGSAC++ / Progressive NAPSAC" [UPSTREAM-MEMORY].  Points are
+    assumed ordered by quality.
+
+      * the centre of sample k comes from a one-point PROSAC sampler (its growth function with m = 1, T_N = n is
+        T'_i = i + 1: sample k takes point k - 1, after n samples a uniformly random point);
+      * every point p keeps its own hit counter and neighbourhood size s_p (start: m); s_p grows while
+        hits_p > T''_{s_p}, T'' = the PROSAC growth function for m - 1 points and T_N = blend * n samples;
+      * the neighbourhood is the cell of p in the finest of the grid layers (16, 8, 4, 2 cells per image dimension, 4-D
+        cells over (x1, y1, x2, y2); members in index = quality order) that holds at least s_p points; the sample is p,
+        the s_p-th member of the cell and m - 2 random ones among the members before it (PROSAC inside the cell);
+        selected members get a hit;
+      * a point whose coarsest cell is too small, and every sample after blend * n, is drawn by the global PROSAC
+        sampler (sample number = the running count)."""
+
+    def __init__(self, n, rng, pts, sizes, sample_size, layers=(16, 8, 4, 2), blend=0.5):
+        super().__init__(n, rng)
+        self.m = int(sample_size)
+        self.max_local = int(blend * n)
+        self.prosac = ProsacSampler(n, rng)
+        pts = np.asarray(pts, dtype=np.float64)[:, :4]
+        sizes = np.asarray(sizes, dtype=np.float64).reshape(-1)[:pts.shape[1]]
+        self.cells = []          # per layer: (cell id per point, members per cell in index order)
+        for div in layers:
+            cell = np.clip(np.floor(pts / (sizes / div)), 0, div - 1).astype(np.int64)
+            cid = np.zeros(n, dtype=np.int64)
+            for d in range(cell.shape[1]):
+                cid = cid * div + cell[:, d]
+            order = np.argsort(cid, kind="stable")
+            bounds = np.nonzero(np.diff(cid[order]))[0] + 1
+            members = dict(zip(cid[order][np.concatenate([[0], bounds])].tolist(), np.split(order, bounds)))
+            self.cells.append((cid, members))
+        lm = max(self.m - 1, 1)
+        self.growth_local = prosac_growth_function(n, lm, max(self.max_local, 1)) if n > lm else np.ones(n, dtype=np.int64)
+        self.reset()
+
+    def reset(self):
+        self.hits = np.zeros(self.n, dtype=np.int64)
+        self.subset = np.full(self.n, self.m, dtype=np.int64)
+        self.layer = np.zeros(self.n, dtype=np.int64)
 
     def draw(self, count, m):
-        local = super().draw(count, m)
-        glob = UniformSampler.draw(self, count, m)
-        blend = max(1.0, 0.5 * self.n)
-        k = min(len(local), len(glob))
-        use_global = self.rng.random(k) < np.minimum(1.0, np.arange(k) / blend)
-        out = local[:k].copy()
-        out[use_global] = glob[:k][use_global]
+        if self.n < m:
+            return np.zeros((0, m), dtype=np.int64)
+        out = np.empty((count, m), dtype=np.int64)
+        n_local = min(count, self.max_local)
+        glob = np.zeros(count, dtype=bool)
+        glob[n_local:] = True
+        rng = self.rng
+        late_centres = rng.integers(0, self.n, max(0, n_local - self.n))
+        for k in range(n_local):
+            p = k if k < self.n else int(late_centres[k - self.n])
+            self.hits[p] += 1
+            sp = int(self.subset[p])
+            while sp < self.n and self.hits[p] > self.growth_local[sp - 1]:
+                sp += 1
+            self.subset[p] = sp
+            lay = int(self.layer[p])
+            nb = None
+            while lay < len(self.cells):
+                cid, members = self.cells[lay]
+                nb = members[int(cid[p])]
+                if len(nb) >= sp:
+                    break
+                lay += 1
+                nb = None
+            self.layer[p] = lay
+            if nb is None:
+                glob[k] = True
+                continue
+            others = nb[:sp]
+            others = others[others != p]                 # the centre is part of its own cell
+            if len(others) < m - 1:
+                glob[k] = True
+                continue
+            last = others[-1]                            # "the farthest one" in PROSAC order: always part of the sample
+            if m > 2:
+                pick = others[:-1][rng.permutation(len(others) - 1)[:m - 2]]
+                out[k, :m - 2] = pick
+                self.hits[pick] += 1
+            out[k, m - 2] = last
+            self.hits[last] += 1
+            out[k, m - 1] = p
+        gi = np.nonzero(glob)[0]
+        if len(gi):
+            # kth sample number of the global PROSAC sampler = the running sample count (setSampleNumber)
+            nk = self.prosac.subset_sizes(1, count, m)[gi]
+            g = np.empty((len(gi), m), dtype=np.int64)
+            if m > 1:
+                g[:, :m - 1] = _distinct_rows(rng, nk - 1, m - 1)
+            g[:, m - 1] = nk - 1
+            out[gi] = g
         return out
 
 
@@ -123,7 +249,8 @@ def ransac_iteration_bound(inlier_number, n, sample_size, confidence):
         return np.inf
     if qm >= 1.0:
         return 1.0
-    return np.log(1.0 - confidence) / np.log(1.0 - qm)
+    den = np.log1p(-qm)
+    return np.log(1.0 - confidence) / den if den < 0.0 else np.inf
 
 
 def replay_sequential(counts, scores, iteration_of, n, sample_size, confidence, max_iters, min_iters=0):
@@ -154,10 +281,23 @@ def replay_sequential(counts, scores, iteration_of, n, sample_size, confidence, 
 # the proposal engine
 # ---------------------------------------------------------------------------------------------------------------------
 class ProposalEngine:
+    """gcransac::GCRANSAC::run, restated [UPSTREAM-MEMORY, U-9] around ONE scoring launch per proposal:
+
+        draw all samples -> solve them (GPU) -> score every hypothesis (GPU) -> walk the table in generation order:
+          a hypothesis that beats the so-far-best score replaces it and tightens the iteration bound;
+          if that happens after `min_iteration_number_before_lo` iterations the LOCAL OPTIMISATION runs right there
+          (graph cut -> inner RANSAC of non-minimal refits -> one scoring launch, `_graph_cut_lo`) and its result, if
+          better, is what later hypotheses have to beat - the cadence of the sequential loop (progressive_x.h:294-299
+          with max_local_optimization_number = 50 inner trials, :68); the cuts of one proposal share the budget
+          max_graph_cut_number (10), as upstream's statistics.graph_cut_number does;
+        after the walk: one local optimisation if none ran, then the final iterated least squares (<= 10 refits)."""
+
     def __init__(self, ctx, estimator, pts, sampler, settings, exchange=None):
         self.ctx, self.est, self.pts, self.sampler, self.s = ctx, estimator, pts, sampler, settings
         self.exchange = exchange     # parallel.RcclExchange for multi-GPU sharding, None = single GPU
         self.n = pts.shape[0]
+        self.lo_runs = 0             # statistics of the last proposal
+        self.graph_cuts = 0
 
     def _score(self, models, T2, has_compound, exponent):
         if self.exchange is not None and self.exchange.world > 1:
@@ -168,7 +308,7 @@ class ProposalEngine:
     def run(self, T2, has_compound, exponent, weights=None):
         """One GC-RANSAC-style proposal.  Returns dict(model, inliers (ascending indices), iterations) or None."""
         est, s = self.est, self.s
-        self.sampler.reset()
+        self.sampler.reset()                                                   # progressive_x.h:290
         samples = self.sampler.draw(int(s.max_iteration_number), est.sample_size)
         if len(samples) == 0:
             return None
@@ -185,33 +325,70 @@ class ProposalEngine:
             if len(models) == 0:
                 return dict(model=None, inliers=np.zeros(0, np.int64), iterations=len(samples))
             table = self._score(models, T2, has_compound, exponent)
-        best, iters, history = replay_sequential(table["counts"], table["scores"], src, self.n, est.sample_size,
-                                                 s.confidence, s.max_iteration_number)
-        if best < 0:
-            return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iters)
-        model, score = models[best].copy(), float(table["scores"][best])
-        if self._use_graph_cut():
-            model, score = self._graph_cut_lo(model, score, T2, has_compound, exponent, weights)
-        else:
-            model, score = self._lsq_lo(model, score, T2, has_compound, exponent, weights)
+        counts = np.asarray(table["counts"], dtype=np.int64)
+        scores = np.where(counts > 0, np.asarray(table["scores"], dtype=np.float64), -np.inf)
+        scores = np.where(np.isnan(scores), -np.inf, scores)
+        max_iters = float(s.max_iteration_number)
+        min_iters = int(getattr(s, "min_iteration_number", 0))
+        lo_after = int(getattr(s, "min_iteration_number_before_lo", 0))
+        every_best = getattr(s, "lo_cadence", "every_best") == "every_best"
+        self.lo_runs, self.graph_cuts = 0, 0
+        model, best_score, best_count, it_best = None, -np.inf, 0, 0
+        bound = max_iters
+        h, H = 0, len(counts)
+        while h < H:
+            ahead = np.nonzero(scores[h:] > best_score)[0]                     # first strictly better score wins
+            if len(ahead) == 0:
+                break
+            h += int(ahead[0])
+            it = int(src[h]) + 1
+            if it > bound and it > min_iters:
+                break
+            c = int(counts[h])
+            if c + 1 < best_count:          # scoring_function_with_compound_model.h:105-106 -> Score(): not considered
+                h += 1
+                continue
+            model, best_score, best_count, it_best = models[h].copy(), float(scores[h]), c, it
+            if every_best and it > lo_after and c > est.sample_size:
+                model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
+                                                                          exponent, weights)
+            bound = min(max_iters, ransac_iteration_bound(best_count, self.n, est.sample_size, s.confidence))
+            h += 1
+        iterations = int(max(it_best, min(max_iters, np.ceil(bound)), min(min_iters, len(samples)), 1))
+        if model is None:
+            return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iterations)
+        if self.lo_runs == 0:               # "apply the local optimisation if it has not been applied yet"
+            model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
+                                                                      exponent, weights)
+        if self._use_graph_cut():           # final iterated least squares on the inliers
+            model, best_score = self._lsq_lo(model, best_score, T2, has_compound, exponent, weights,
+                                             budget=int(getattr(s, "max_least_squares_iterations", 10)))
         final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
-        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iters,
+        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iterations,
                     score=float(final["scores"][0]))
-
 
     # -- local optimisation ------------------------------------------------------------------------------------------
     def _use_graph_cut(self):
-        # "auto": the graph cut whenever it is not trivial (0 < lambda < 1); "lsq" forces the refit-only stand-in
-        lam = float(self.s.spatial_coherence_weight)
-        return getattr(self.s, "local_optimization", "auto") != "lsq" and 0.0 < lam < 1.0
+        # "auto": GC-RANSAC's graph-cut local optimisation (with lambda = 0 the cut is plain thresholding: the inlier
+        # mask); "lsq" forces the refit-only stand-in of round 1
+        return getattr(self.s, "local_optimization", "auto") != "lsq"
 
-    def _lsq_lo(self, model, score, T2, has_compound, exponent, weights):
-        """iterated least-squares refits on the inliers, scored with the same compound term (the stand-in used when the
-        spatial coherence weight is 0 and the graph cut degenerates to thresholding)"""
-        est, s = self.est, self.s
-        lo_budget = int(s.max_local_optimization_number)
-        while lo_budget > 0:
-            lo_budget -= 1
+    def _local_optimization(self, model, score, count, T2, has_compound, exponent, weights):
+        self.lo_runs += 1
+        if self._use_graph_cut():
+            return self._graph_cut_lo(model, score, count, T2, has_compound, exponent, weights)
+        m, sc = self._lsq_lo(model, score, T2, has_compound, exponent, weights, budget=int(self.s.max_local_optimization_number))
+        if sc > score:
+            one = self.ctx.score(m[None, :], T2, has_compound=has_compound, exponent=exponent)
+            return m, sc, int(one["counts"][0])
+        return model, score, count
+
+    def _lsq_lo(self, model, score, T2, has_compound, exponent, weights, budget):
+        """iterated least-squares refits on the inliers, scored with the same compound term: a refit is kept while the
+        score improves (gcransac's iteratedLeastSquaresFitting [UPSTREAM-MEMORY])"""
+        est = self.est
+        while budget > 0:
+            budget -= 1
             one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
             inl = mask_to_indices(one["masks"][0], self.n)
             if len(inl) < est.nonminimal_sample_size:
@@ -226,23 +403,32 @@ class ProposalEngine:
                 break
         return model, score
 
-    def _graph_cut_lo(self, model, score, T2, has_compound, exponent, weights):
+    def _cut_inliers(self, model, T2, has_compound, exponent):
+        """GCRANSAC::labeling: the inlier/outlier graph cut of `model`.  One exact min-cut on the GPU (pgx_gc_labeling)
+        when 0 < lambda < 1; without a pairwise term the cut decouples into r^2 < T^2, i.e. the scorer's inlier mask."""
+        lam = float(self.s.spatial_coherence_weight)
+        if 0.0 < lam < 1.0:
+            return np.nonzero(self.ctx.gc_labeling(model, T2, lam))[0].astype(np.int64)
+        one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+        return mask_to_indices(one["masks"][0], self.n)
+
+    def _graph_cut_lo(self, model, score, count, T2, has_compound, exponent, weights):
         """gcransac::GCRANSAC::graphCutLocalOptimization, restated [UPSTREAM-MEMORY, U-12] and batched:
 
-          repeat (at most max_graph_cut_number = 10 times):
-            inliers <- the inlier/outlier graph cut of the best model (one exact min-cut on the GPU, pgx_gc_labeling);
+          repeat (while the proposal's graph-cut budget max_graph_cut_number = 10 lasts):
+            inliers <- the inlier/outlier graph cut of the best model (`_cut_inliers`);
             inner RANSAC: max_local_optimization_number samples of min(7 * sample size, |inliers|) inliers, each refitted
             by the non-minimal solver (batched Gram pass on the GPU: pgx_gram_batch, all samples per launch); all candidates are scored in ONE launch and then walked in
             order - a strictly better score replaces the best model, exactly what the sequential loop would keep;
             stop when a round brought no improvement."""
         est, s = self.est, self.s
-        lam = float(s.spatial_coherence_weight)
         rng = self.sampler.rng
         limit = 7 * est.sample_size
         trials = int(s.max_local_optimization_number)
-        for _ in range(int(getattr(s, "max_graph_cut_number", 10))):
-            flags = self.ctx.gc_labeling(model, T2, lam)
-            inl = np.nonzero(flags)[0].astype(np.int64)
+        max_cuts = int(getattr(s, "max_graph_cut_number", 10))
+        while self.graph_cuts < max_cuts:
+            self.graph_cuts += 1
+            inl = self._cut_inliers(model, T2, has_compound, exponent)
             size = min(limit, len(inl))
             cands = []
             if size < len(inl) and size >= est.nonminimal_sample_size:
@@ -254,14 +440,15 @@ class ProposalEngine:
             if not cands:
                 break
             cands = np.asarray(cands, dtype=np.float64)
-            table = self.ctx.score(cands, T2, has_compound=has_compound, exponent=exponent)
+            table = self._score(cands, T2, has_compound, exponent) if len(cands) > 1 else \
+                self.ctx.score(cands, T2, has_compound=has_compound, exponent=exponent)
             updated = False
             for h in range(len(cands)):
                 if int(table["counts"][h]) > 0 and float(table["scores"][h]) > score:
-                    model, score, updated = cands[h].copy(), float(table["scores"][h]), True
+                    model, score, count, updated = cands[h].copy(), float(table["scores"][h]), int(table["counts"][h]), True
             if not updated:
                 break
-        return model, score
+        return model, score, count
 
 
 def mask_to_indices(mask_row, n):

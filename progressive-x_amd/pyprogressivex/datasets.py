@@ -216,5 +216,61 @@ def misclassification(segmentation, ref_segmentation):
     return 1.0 - conf[r, c].sum() / len(seg)
 
 
+def misclassification_labeling(labeling, annotation, K, K_annot):
+    """progx_utils.h:201-274, the (labeling, annotation) overload of getMisclassificationError, restated literally:
+    predicted label l means cluster l + 1 (labels with l + 1 > K are left unassigned, -1 = outlier stays 0), every
+    ground-truth cluster 1..K_annot greedily takes the unused predicted cluster with the largest overlap (first maximum
+    wins; the first candidate is always taken because the reference compares an int -1 with a size_t), matched points
+    take the annotation's id, the error is the PERCENTAGE of points whose ids still differ."""
+    lab = np.asarray(labeling).astype(np.int64)
+    ann = np.asarray(annotation).astype(np.int64)
+    all1 = np.full(lab.shape[0], -1, dtype=np.int64)
+    ok = lab + 1 <= K
+    all1[ok] = lab[ok] + 1
+    used = np.zeros(K + 1, dtype=bool)
+    pair = {0: 0}
+    for i in range(1, K_annot + 1):
+        best, best_size = -1, -1
+        for j in range(1, K + 1):
+            if used[j]:
+                continue
+            size = int(np.count_nonzero((all1 == j) & (ann == i)))
+            if best == -1 or best_size < size:
+                best, best_size = j, size
+        if best == -1:
+            continue
+        used[best] = True
+        pair[i] = best
+    gt_pair = np.array([pair.get(int(a), 0) for a in ann], dtype=np.int64)
+    hit = (lab != -1) & (all1 == gt_pair)
+    all1 = np.where(hit, ann, all1)
+    return 100.0 * float(np.count_nonzero(all1 != ann)) / lab.shape[0]
+
+
+def misclassification_models(preferences, annotation, K_annot):
+    """progx_utils.h:98-199, the (models, annotation) overload: a point is claimed by the FIRST model whose preference
+    exceeds FLT_EPSILON; over all permutations of the model ids the smallest number of points whose claimed id differs
+    from the annotation (unclaimed points are right iff the annotation is 0), as a PERCENTAGE.  The permutation loop is an
+    assignment problem and is solved as one; -1 for more than 9 models, as in the reference."""
+    from scipy.optimize import linear_sum_assignment
+    pref = np.asarray(preferences, dtype=np.float64)
+    ann = np.asarray(annotation).astype(np.int64)
+    K = pref.shape[0]
+    if K > 9:
+        return -1.0
+    claimed = pref > np.finfo(np.float32).eps
+    owner = np.where(claimed.any(axis=0), np.argmax(claimed, axis=0), -1)      # first model with preference 1
+    mk = max(K, K_annot)
+    gain = np.zeros((mk, mk), dtype=np.int64)                                   # gain[m, id-1] = points of m annotated id
+    for m in range(K):
+        ids, cnt = np.unique(ann[owner == m], return_counts=True)
+        for a, c in zip(ids, cnt):
+            if 1 <= a <= mk:
+                gain[m, a - 1] += c
+    r, c = linear_sum_assignment(-gain)
+    right = int(gain[r, c].sum()) + int(np.count_nonzero((owner == -1) & (ann == 0)))
+    return 100.0 * float(ann.shape[0] - right) / ann.shape[0]
+
+
 MODEL_TYPES = dict(line=_lib.LINE2D, homography=_lib.HOMOGRAPHY, fundamental=_lib.FUNDAMENTAL, pnp=_lib.PNP,
                    vanishing_point=_lib.VANISHING_POINT)

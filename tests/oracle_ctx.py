@@ -138,6 +138,10 @@ class OracleContext:
                                           self.labels, max_cycles)
         return e, e / 2.0 ** 32, cyc
 
+    def greedy_labeling(self, label_cost):
+        self.labels, e, opened = O.greedy_labeling(self.Dq, O.quantize(label_cost))
+        return e, e / 2.0 ** 32, opened
+
     def expansion_stats(self):
         return dict(self._stats)
 

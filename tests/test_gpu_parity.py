@@ -948,3 +948,42 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     Ga, ca, _ = gpu_ctx.gram(_lib.GRAM_PNP_GN, ("label", 3), params=poses[3])
     Gb, cb, _ = gpu_ctx.gram(_lib.GRAM_PNP_GN, ("index", sel), params=poses[3])
     assert ca == cb == len(sel) and np.abs(Ga - Gb).max() <= REL * np.abs(Ga).max()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# U-8: the lambda = 0 labelling GCO-v3 takes (greedy facility location over the label costs / per-site argmin)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,L", [(1, 2), (64, 3), (255, 2), (4097, 5), (20011, 11), (100003, 9)])
+@pytest.mark.parametrize("h", [0.0, 3.0, 40.0])
+def test_greedy_labeling_matches_oracle(gpu_ctx, oracle, n, L, h):
+    rng = np.random.default_rng(n + L)
+    D = rng.integers(0, 2 << 32, (n, L)).astype(np.int64)
+    cheap = rng.integers(0, L, n)
+    D[np.arange(n), cheap] >>= 6                                   # clusters
+    D[:, L - 1] = 1 << 32                                           # the outlier label's constant cost
+    if n > 64:
+        D[:64] = (D[:64] >> 30) << 30                               # ties
+    gpu_ctx.set_unary_q(D)
+    gpu_ctx.set_labels(np.full(n, L - 1, np.int32))                 # ignored by the heuristic
+    eq, e, opened = gpu_ctx.greedy_labeling(h)
+    ref_labels, ref_e, ref_opened = oracle.greedy_labeling(D, oracle.quantize(h))
+    assert np.array_equal(gpu_ctx.get_labels(), ref_labels) and eq == ref_e
+    assert opened == (ref_opened if h > 0 else len(set(ref_labels.tolist())))
+    assert gpu_ctx.energy(0.0, h)[0] == eq
+
+
+def test_greedy_labeling_on_a_real_unary_table_and_error_paths(gpu_ctx, oracle):
+    mt, pts, models, thr = make_case("homography", 20011, 3, seed=3)
+    gpu_ctx.set_points(mt, pts)
+    Dq = gpu_ctx.pearl_unary(models, thr, 0.0, want_table=True)
+    eq, e, opened = gpu_ctx.greedy_labeling(10.0)
+    ref_labels, ref_e, ref_opened = oracle.greedy_labeling(Dq, oracle.quantize(10.0))
+    assert np.array_equal(gpu_ctx.get_labels(), ref_labels) and eq == ref_e and opened == ref_opened == 4
+    gpu_ctx.set_labels(np.zeros(len(pts), np.int32))
+    eq2, _, _ = gpu_ctx.expansion(0.0, 10.0)
+    print(f"lambda = 0 labelling energies: greedy {eq / 2 ** 32:.3f}, alpha-expansion from zeros {eq2 / 2 ** 32:.3f}")
+    with pytest.raises(_lib.PgxError, match="fixed-point range"):
+        gpu_ctx.set_unary_q(np.full((10, 2), 1 << 40, np.int64))
+        gpu_ctx.greedy_labeling(1.0)
+    with pytest.raises(_lib.PgxError, match="negative cost"):
+        gpu_ctx.set_unary_q(np.full((10, 2), -1, np.int64))

@@ -199,3 +199,60 @@ def test_preference_slots_are_recycled(oracle_backend):
     # the first model is accepted (Tanimoto 0/0 -> NaN -> valid), every later proposal overlaps it a little and is rejected
     # (until 10 rejections end the run): all of them reuse slot 1
     assert len(L) == 1 and len(seen) >= 5 and seen[0] == 0 and set(seen[1:]) == {1}
+
+
+def test_bundled_scenes_reach_the_recorded_numbers_on_the_cpu_port(oracle_backend):
+    """One seed of three bundled scenes with the recording notebook's exact arguments (scripts/eval_scenes.py) through the
+    CPU-backed context: the host logic alone (samplers, replay with local optimisation, PEARL, Tanimoto gate) reaches
+    the reference's recorded misclassification errors; the GPU suite repeats this on libpgx with three seeds."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_scenes", os.path.join(root, "scripts", "eval_scenes.py"))
+    E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E)
+    assert E.homography_scene("unionhouse", 0)[0] <= 3 * E.RECORDED_H["unionhouse"]
+    assert E.homography_scene("oldclassicswing", 0)[0] <= 3 * E.RECORDED_H["oldclassicswing"]
+    assert E.two_view_scene("book", 0)[0] <= 3 * E.RECORDED_F["book"]
+
+
+def test_misclassification_overloads_of_progx_utils():
+    """progx_utils.h:98-274: both getMisclassificationError overloads, against brute force over permutations."""
+    import itertools
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n, K, Ka = 60, int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        ann = rng.integers(0, Ka + 1, n)
+        lab = rng.integers(-1, K + 1, n)
+        # (labeling, annotation): literal greedy pairing, checked against a direct transcription
+        got = datasets.misclassification_labeling(lab, ann, K, Ka)
+        all1 = np.where(lab + 1 <= K, lab + 1, -1)
+        used, pair = set(), {0: 0}
+        for i in range(1, Ka + 1):
+            best, size = -1, -1
+            for j in range(1, K + 1):
+                if j in used:
+                    continue
+                sz = int(((all1 == j) & (ann == i)).sum())
+                if best == -1 or size < sz:
+                    best, size = j, sz
+            if best != -1:
+                used.add(best)
+                pair[i] = best
+        out = all1.copy()
+        for j in range(n):
+            if lab[j] != -1 and all1[j] == pair.get(int(ann[j]), 0):
+                out[j] = ann[j]
+        assert got == 100.0 * (out != ann).sum() / n
+        # (models, annotation): permutations of the model ids by brute force
+        pref = (rng.random((K, n)) < 0.3).astype(float)
+        got = datasets.misclassification_models(pref, ann, Ka)
+        owner = np.where(pref.any(axis=0), np.argmax(pref > 0, axis=0), -1)
+        mk = max(K, Ka)
+        best = n
+        for perm in itertools.permutations(range(mk)):
+            ids = np.where(owner >= 0, np.array(perm)[np.maximum(owner, 0)] + 1, 0)
+            err = int(((owner >= 0) & (ids != ann)).sum() + ((owner < 0) & (ann != 0)).sum())
+            best = min(best, err)
+        assert abs(got - 100.0 * best / n) < 1e-12
+    assert datasets.misclassification_models(np.zeros((10, 5)), np.zeros(5, int), 2) == -1.0

@@ -422,3 +422,61 @@ def test_gc_labeling_minimises_the_restated_energy(oracle):
         assert energy(tuple(int(f) for f in flags)) == best
         assert np.array_equal(flags, inter)
     assert hit_tie > 5
+
+
+def test_greedy_labeling_u8_against_a_python_transcription_and_brute_force(oracle):
+    """U-8: GCO-v3's labelling of an energy without smooth costs.  The C restatement is checked against a direct Python
+    transcription of the greedy facility-location rule on random instances, against brute force over all L^n labellings
+    (<= 12 sites: greedy is a heuristic - never better than the optimum, optimal on instances with well separated
+    clusters), and the h = 0 case (per-site argmin) IS the optimum."""
+    import itertools
+    rng = np.random.default_rng(5)
+
+    def transcription(D, h):
+        n, L = D.shape
+        if h <= 0:
+            return np.argmin(D, axis=1).astype(np.int32)
+        e = np.full(n, 1 << 35, dtype=np.int64)
+        lab = np.zeros(n, dtype=np.int32)
+        closed = list(range(L))
+        while closed:
+            deltas = [h + int(np.minimum(D[:, l] - e, 0).sum()) for l in closed]
+            k = int(np.argmin(deltas))                         # first minimum = lowest label index
+            if deltas[k] >= 0:
+                break
+            l = closed.pop(k)
+            take = D[:, l] < e
+            e[take] = D[take, l]
+            lab[take] = l
+        return lab
+
+    def energy(D, h, lab):
+        return int(D[np.arange(len(lab)), lab].sum()) + h * len(set(lab.tolist()))
+
+    optimal = 0
+    for trial in range(300):
+        n, L = int(rng.integers(1, 13)), int(rng.integers(2, 5))
+        D = rng.integers(0, 2 << 32, (n, L)).astype(np.int64)
+        if trial % 3 == 0:                                      # ties everywhere
+            D = (D >> 31) << 31
+        if trial % 5 == 0:                                      # separated clusters: one cheap label per site
+            D[np.arange(n), rng.integers(0, L, n)] >>= 8
+        h = int(rng.integers(0, 3)) * int(rng.integers(0, 4 << 32))
+        lab, e, opened = oracle.greedy_labeling(D, h)
+        ref = transcription(D, h)
+        assert np.array_equal(lab, ref), (trial, lab, ref)
+        assert e == energy(D, h, lab) and opened >= len(set(lab.tolist()))
+        if L ** n <= 30000:
+            best = min(energy(D, h, np.array(c, dtype=np.int32)) for c in itertools.product(range(L), repeat=n))
+            assert e >= best
+            optimal += e == best
+            if h == 0:
+                assert e == best
+    assert optimal > 100          # the heuristic finds the optimum on most of these small instances
+    # golden case readable by hand: two sites, label 1 is cheaper for both but costs a second opening
+    D = np.array([[10, 4], [10, 4]], dtype=np.int64) << 32
+    lab, e, opened = oracle.greedy_labeling(D, 3 << 32)
+    assert lab.tolist() == [1, 1] and opened == 1 and e == (8 + 3) << 32
+    D = np.array([[1, 9], [9, 1]], dtype=np.int64) << 32
+    assert oracle.greedy_labeling(D, 20 << 32)[0].tolist() == [0, 0]      # a second label is not worth 20
+    assert oracle.greedy_labeling(D, 2 << 32)[0].tolist() == [0, 1]
