@@ -8,6 +8,16 @@ One step = one pass of the proposal hot path over one batch: score every hypothe
 vector, hypotheses) are resident in HBM before the timed region starts.  Weak scaling: every rank scores its own 2048
 hypotheses against all points, value = (points x hypotheses of all ranks) / time.
 
+The JSON line carries, next to the headline:
+  roofline       HBM roofline of the dominant kernel: ALGORITHMIC bytes of SURVEY 8(d) (N d 8 + M p 8 + M 16 + N 8 for the
+                 compound vector; no derived copies) / that kernel's HIP-event time measured live; PMC traffic from the
+                 committed rocprofv3 passes; executed work from device counters (pgx_score_stats)
+  cpu_baseline   the oracle (single-threaded C port of the reference path) on this box's host cores, bounded sample
+  legs           secondary measurements on 1 GPU (never the headline): the same batch uploaded and sorted inside the step,
+                 a RANSAC-like batch generated inside the step by the device P3P solver (samples -> solve -> score -> fetch
+                 -> select: end-to-end models/s), the dense unfiltered kernel with its true FP64 fraction, Sampson scoring at
+                 C3 size, vanishing-point scoring at C5 size, one pgx_set_points
+
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 via
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
 (RANK / LOCAL_RANK / WORLD_SIZE from the env; torch itself is not imported: the data plane is RCCL inside libpgx).
@@ -23,17 +33,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "progressive-x_amd"))
 
-# HBM bytes per launch of the default workload from the committed PMC passes (profiles/round1_bench_v12_final.txt),
-# summed over the three kernels of one launch (cull, group-major score, finish): FETCH_SIZE 267746.8 + 3439.0 + 36.5 KiB,
-# x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM), + WRITE_SIZE 27527.2 + 4276.5 + 158.8 KiB
-# (writes: survivor bit masks of the cull pass, accumulator atomics; fetch: the 8 waves that share a 64-point group run
-# on the 8 XCDs -- wave p of every group on XCD p, which keeps each XCD's hypotheses, their constants and their accumulator
-# atomics in its own L2 -- so every XCD's L2 fetches all rows once: 8 x 80 MB.  Co-locating a group's waves cuts the fetch
-# 8x but every XCD then updates every accumulator: measured 0.31 instead of 0.28 ms)
-PMC_TRAFFIC_DEFAULT = int((2 * (267746.8 + 3439.0 + 36.5) + 27527.2 + 4276.5 + 158.8) * 1024)
+# HBM bytes per launch of the default workload from the committed PMC passes, summed over the kernels of one launch:
+# FETCH_SIZE x 2 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, in KiB.
+PMC = {"source": "profiles/round1_bench_v12_final.txt",
+       "fetch_kib": 267746.8 + 3439.0 + 36.5, "write_kib": 27527.2 + 4276.5 + 158.8,
+       "valu_busy_frac": 0.56}       # SQ pass of the same file: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")   # refreshed by scripts/profile_bench.sh when re-profiled
+if os.path.exists(PMC_FILE):
+    with open(PMC_FILE) as _f:
+        PMC = json.load(_f)
+PMC_TRAFFIC_DEFAULT = int((2 * PMC["fetch_kib"] + PMC["write_kib"]) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
-FLOPS_PER_PAIR_PNP = 25        # 9 mul + 9 add (3x4 projection) + 2 div + 2 sub + 2 mul + 1 add
+FLOPS_PER_PAIR = {"pnp": 25, "fundamental": 33, "vanishing_point": 24}   # exact residual + score update, DESIGN.md 5.1
 
 
 def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
@@ -80,7 +92,138 @@ def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
     return out
 
 
+def timed_steps(ctx, step, steps, warmup):
+    """(seconds per step by the wall clock, mean HIP-event ms of the three scoring kernels) of `step` on one context"""
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    kt = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        kt.append(ctx.score_kernel_times())
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps, np.mean(np.array(kt), axis=0)
+
+
+def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warmup):
+    """Bounded extra measurements on one GPU; every entry says what the step contained."""
+    legs = {}
+    n, M = pts.shape[0], hyps.shape[0]
+    steps = max(5, min(steps, 20))
+    buf = ctx.score_buffers()
+
+    # (1) the headline batch, but uploaded (and locality-sorted) inside every step: what a proposal with host-made hypotheses pays
+    def step_upload():
+        ctx.score_upload(hyps)
+        ctx.score_launch(T2, has_compound=True)
+        res = ctx.score_fetch(exponent=2, out=buf)
+        return parallel.select_best(res["scores"], res["counts"])
+    s, kt = timed_steps(ctx, step_upload, steps, warmup)
+    legs["upload_inclusive"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s, "kernel_ms": [float(x) for x in kt],
+                                "step": "pgx_score_upload (196 KB of models + locality sort) + launch + fetch + select"}
+
+    # (2) RANSAC-like batch generated INSIDE the step: random minimal samples -> device P3P (4 slots per sample) -> cull ->
+    #     score -> fetch -> sequential selection.  The number SURVEY 8(f)1 calls end-to-end models/s.
+    rng = np.random.default_rng(7)
+    S = M // 4
+    inl = [np.nonzero(gt == 1 + k)[0] for k in range(16)]
+
+    def draw():
+        # half of the samples all-inlier (as a converging RANSAC sees them), half uniformly random
+        smp = rng.integers(0, n, (S, 3))
+        for r in range(0, S, 2):
+            smp[r] = rng.choice(inl[(r // 2) % 16], 3, replace=False)
+        return smp.astype(np.int32)
+
+    def step_ransac():
+        ctx.solve_minimal(draw(), fetch=False)
+        ctx.score_launch(T2, has_compound=True)
+        res = ctx.score_fetch(exponent=2, out=buf)
+        return parallel.select_best(res["scores"], res["counts"])
+    s, kt = timed_steps(ctx, step_ransac, steps, warmup)
+    st = ctx.score_stats(T2, has_compound=True)
+    legs["ransac_like_end_to_end"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s, "residual_evals_per_sec": n * M / s,
+                                      "kernel_ms": [float(x) for x in kt], "work": st,
+                                      "step": f"{S} minimal samples drawn on the host (half all-inlier, half random) -> "
+                                              "pgx_solve_minimal (device P3P, 4 slots each) -> launch -> fetch -> select"}
+    ctx.score_upload(hyps)    # leave the metric batch resident
+
+    # (3) one pgx_set_points (the once-per-problem preprocessing of the group-major path)
+    t0 = time.perf_counter()
+    ctx.set_points(_lib.PNP, pts)
+    legs["set_points"] = {"ms": 1e3 * (time.perf_counter() - t0), "what": "upload of 40 MB + Morton sort + group bounds, once per problem"}
+
+    # (4) dense mode: no group test, no rejection filter - every pair through the exact FP64 path (true FP64 fraction)
+    saved = {k: os.environ.get(k) for k in ("PGX_NO_GROUP", "PGX_NO_FILTER")}
+    os.environ["PGX_NO_GROUP"], os.environ["PGX_NO_FILTER"] = "1", "1"
+    try:
+        dense = _lib.Context(ctx.device_id)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        dense.score_profile(True)
+        dense.set_points(_lib.PNP, pts)
+        dense.preference(gt_pose0, T2, slot=0)
+        dense.compound_update([0])
+        dense.score_upload(hyps)
+        dbuf = dense.score_buffers()
+
+        def step_dense():
+            dense.score_launch(T2, has_compound=True)
+            return dense.score_fetch(exponent=2, out=dbuf)
+        s, kt = timed_steps(dense, step_dense, min(steps, 10), 2)
+        tf = n * M * FLOPS_PER_PAIR["pnp"] / (kt[0] * 1e-3) / 1e12
+        legs["dense_unfiltered"] = {"ms_per_step": 1e3 * s, "kernel_ms": float(kt[0]), "residual_evals_per_sec": n * M / s,
+                                    "fp64_tflops": tf, "fp64_frac_of_no_fma_peak": tf / (FP64_VALU_PEAK_TFLOPS / 2),
+                                    "step": "PGX_NO_GROUP=1 PGX_NO_FILTER=1: score_kernel<PnP, FILT=0>, all 2.05e9 pairs exact"}
+    finally:
+        dense.close()
+
+    # (5) Sampson scoring at C3 size and vanishing-point scoring at C5 size: 2048 hypotheses from the device solvers
+    for name, mt, make, m, slots, thr in (("c3_sampson", _lib.FUNDAMENTAL, datasets.make_two_view_motions, 7, 3, 0.75),
+                                          ("c5_vanishing_point", _lib.VANISHING_POINT, datasets.make_vanishing_points, 2, 1, 1.5)):
+        p2, g2, models = make(seed=0)
+        c2 = _lib.Context(ctx.device_id)
+        try:
+            c2.score_profile(True)
+            c2.set_points(mt, p2)
+            T2b = 2.25 * thr * thr
+            c2.preference(np.asarray(models[0]).reshape(-1), T2b, slot=0)
+            c2.compound_update([0])
+            S2 = (M + slots - 1) // slots
+            K2 = int(g2.max())
+            smp = np.array([rng.choice(np.nonzero(g2 == 1 + r % K2)[0], m, replace=False) if r % 2 == 0 else
+                            rng.choice(len(g2), m, replace=False) for r in range(S2)], dtype=np.int32)
+            c2.solve_minimal(smp, fetch=False)
+            b2 = c2.score_buffers()
+
+            def step2():
+                c2.score_launch(T2b, has_compound=True)
+                return c2.score_fetch(exponent=2, out=b2)
+            s, kt = timed_steps(c2, step2, min(steps, 10), 2)
+            Mb = c2.M
+            key = "fundamental" if mt == _lib.FUNDAMENTAL else "vanishing_point"
+            tf = len(p2) * Mb * FLOPS_PER_PAIR[key] / (float(kt[0] + kt[1]) * 1e-3) / 1e12
+            legs[name] = {"points": int(len(p2)), "hypotheses": int(Mb), "ms_per_step": 1e3 * s,
+                          "kernel_ms": [float(x) for x in kt], "residual_evals_per_sec": len(p2) * Mb / s,
+                          "models_per_sec": Mb / s, "work": c2.score_stats(T2b, has_compound=True),
+                          "effective_fp64_tflops": tf,
+                          "step": "resident batch from pgx_solve_minimal (half all-inlier, half random samples): launch + fetch"}
+        finally:
+            c2.close()
+    return legs
+
+
+gt_pose0 = None
+
+
 def main():
+    global gt_pose0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -88,6 +231,7 @@ def main():
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--hyps", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
     from pyprogressivex import _lib, datasets, parallel
@@ -99,15 +243,17 @@ def main():
     # ---- synthetic workload (identical points on every rank; per-rank hypothesis batches)
     n_obj = 16
     per_obj = args.points // 20
-    x1, x2, K, _, gt = datasets.make_poses(n_per_object=per_obj, n_objects=n_obj,
-                                           n_outliers=args.points - n_obj * per_obj, seed=0)
+    x1, x2, K, gt_labels, gt = datasets.make_poses(n_per_object=per_obj, n_objects=n_obj,
+                                                   n_outliers=args.points - n_obj * per_obj, seed=0)
     pts, f = datasets.normalize_pnp(x1, x2, K)
     thr = 4.0 / f                       # find6DPoses default threshold 4 px (bindings.cpp:467), normalised (:96-98)
     T2 = 9.0 / 4.0 * thr * thr          # progressive_x.h:523
     hyps = datasets.make_pose_hypotheses(gt, M=args.hyps, seed=1 + rank)
+    gt_pose0 = gt[0]
 
     ctx = _lib.Context(local)
     info = ctx.device_info()
+    ctx.score_profile(True)             # HIP events around each scoring kernel, on the stream the kernels run on
     ctx.set_points(_lib.PNP, pts)
     # a non-empty compound instance: the preference vector of the first accepted model (GT pose 0)
     ctx.preference(gt[0], T2, slot=0)
@@ -121,17 +267,15 @@ def main():
     fetch_buf = None if use_comm else ctx.score_buffers()   # reused every step (results are consumed before the next one)
 
     def step():
-        ctx.timer_start()
         ctx.score_launch(T2, has_compound=True)
-        ctx.timer_mark()                 # HIP events on the stream the kernels run on; no host wait here
         if use_comm:
             ctx.score_allgather()
             res = ctx.score_fetch_all(exponent=2)
         else:
             res = ctx.score_fetch(exponent=2, out=fetch_buf)
-        kernel_ms = ctx.timer_elapsed()  # the fetch synchronised the stream: the events are complete
+        kt = ctx.score_kernel_times()    # the fetch synchronised the stream: the events are complete
         best = parallel.select_best(res["scores"], res["counts"])
-        return kernel_ms, best, res
+        return kt, best, res
 
     for _ in range(args.warmup):
         step()
@@ -155,8 +299,12 @@ def main():
         pairs_per_step = n * M * world
         ms_per_step = 1e3 * elapsed / args.steps
         alg_bytes, pairs = ctx.score_algorithmic_bytes()
-        k_ms = float(np.mean(kernel_ms))
+        kt = np.mean(np.array(kernel_ms), axis=0)
+        k_ms = float(kt[1]) if kt[1] > 0 else float(kt[0])      # the dominant kernel: group-major scoring
+        launch_ms = float(kt.sum())
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        work = ctx.score_stats(T2, has_compound=True)
+        default_workload = n == 1000000 and M == 2048
         out = {
             "metric": "residual_evals_per_sec",
             "value": pairs_per_step / (elapsed / args.steps),
@@ -174,18 +322,29 @@ def main():
             "winner": {"index": best, "inliers": int(res["counts"][best]) if best >= 0 else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": PMC_TRAFFIC_DEFAULT if (n == 1000000 and M == 2048) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/round1_bench_v12_final.txt",
-                         "kernel": "pgx::score_group_kernel<PnP> (+ score_cull_kernel, score_finish_kernel)", "kernel_ms": k_ms,
+                         "traffic": PMC_TRAFFIC_DEFAULT if default_workload else None,
+                         "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes, {PMC['source']}",
+                         "kernel": "pgx::score_group_kernel<PnP>", "kernel_ms": k_ms,
+                         "launch_kernels_ms": {"cull": float(kt[0]), "group_major": float(kt[1]), "finish": float(kt[2]),
+                                               "sum": launch_ms},
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "arithmetic bound by construction (~0.04 algorithmic B/pair); 93 % of the (hypothesis, 64-point group) pairs are culled by a bound test, see valu_fp64"},
-            "valu_fp64": {"effective_tflops": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12,
-                          "peak_tflops_fma": FP64_VALU_PEAK_TFLOPS, "peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
-                          "effective_over_no_fma_peak": pairs * FLOPS_PER_PAIR_PNP / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS / 2),
-                          "flops_per_pair": FLOPS_PER_PAIR_PNP, "pairs_per_launch": pairs,
-                          "note": "effective = what evaluating every pair exactly would cost; the kernels evaluate ~7 % of the "
-                                  "pairs with the f32 pre-filter and ~0.3 % exactly (DESIGN.md 5.2c), so the ratio may exceed 1"},
+                         "algorithmic_bytes_formula": "N d 8 + M p 8 + M 16 + N 8 (compound), SURVEY 8(d); no derived copies",
+                         "note": "arithmetic/latency bound by construction (~0.02 algorithmic B/pair): the fraction is small "
+                                 "whatever the kernel does; see `executed` for the work actually done"},
+            "executed": {"pairs": work["pairs"], "group_pairs": work["group_pairs"],
+                         "surviving_group_steps": work["surviving_group_steps"],
+                         "f32_filter_evaluations": work["surviving_group_steps"] * 64,
+                         "exact_fp64_evaluations": work["exact_evaluations"], "inlier_pairs": work["inlier_pairs"],
+                         "exact_fp64_tflops": work["exact_evaluations"] * FLOPS_PER_PAIR["pnp"] / (k_ms * 1e-3) / 1e12,
+                         "valu_busy_frac": PMC.get("valu_busy_frac") if default_workload else None,
+                         "valu_busy_source": f"SQ_ACTIVE_INST_VALU pass, {PMC['source']}",
+                         "source": "device counters of an untimed launch of the same kernels (pgx_score_stats)",
+                         "effective_fp64_tflops_if_every_pair_were_exact": pairs * FLOPS_PER_PAIR["pnp"] / (k_ms * 1e-3) / 1e12,
+                         "note": "'effective' is NOT a utilisation: a bound test culls (hypothesis, 64-point group) pairs, an f32 "
+                                 "filter the rest; only exact_fp64_evaluations run the reference's FP64 residual"},
         }
+        if world == 1 and not args.no_legs and default_workload:
+            out["legs"] = secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt_labels, T2, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pts, hyps, T2, comp)
             out["cpu_baseline"] = cb

@@ -93,6 +93,17 @@ int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values,
                     double *scores, uint64_t *masks);
 /* what one pgx_score_launch reads+writes at minimum (points + models + compound + results), for rooflines */
 int pgx_score_algorithmic_bytes(pgx_ctx *ctx, int want_masks, int64_t *bytes, int64_t *pairs);
+/* Work counters of one scoring launch of the resident batch (a separate, untimed launch of the same kernels with counting
+ * switched on): [0] (point, hypothesis) pairs, [1] (hypothesis, 64-point group) pairs, [2] group steps that survived the
+ * bound test (64 f32 filter evaluations each), [3] exact FP64 residual evaluations (-1: not counted on this path),
+ * [4] inlier pairs, [6] path (1 = every pair visited, 2 = cull + group-major), [7] filter (0 none, 1 f64, 2 f32). */
+int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8]);
+/* Per-kernel HIP-event timing of the scoring launches on the context's stream (bench.py's roofline block): with profiling
+ * on, every pgx_score_launch records events around its kernels; pgx_score_kernel_times returns the durations of the last
+ * launch in ms: [0] cull (or the chunked kernel), [1] group-major scoring (the dominant kernel; 0 on the chunked path),
+ * [2] finish / reduce. */
+int pgx_score_profile(pgx_ctx *ctx, int on);
+int pgx_score_kernel_times(pgx_ctx *ctx, float ms[3]);
 
 /* ---- a2/a3: Model::setPreferenceVector (progx_model.h:70-87) + the three reductions of isPutativeModelValid
  * (progressive_x.h:583-585).  The preference vector is kept on the device in `slot` (>=0) for a4; pref_out optional. */

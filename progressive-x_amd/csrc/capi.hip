@@ -123,10 +123,11 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
-                      &ctx->weights};
+                      &ctx->weights, &ctx->stats_buf};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    for (int k = 0; k < 4; ++k) if (ctx->kev[k]) (void)hipEventDestroy(ctx->kev[k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -419,13 +420,61 @@ int pgx_score(pgx_ctx* ctx, const double* models, int M, double T2, int has_comp
 int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, int64_t* pairs)
 {
     if (!ctx || ctx->n <= 0 || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_algorithmic_bytes: nothing to score");
-    // points once + compound once + models once + (count,value,shared) per hypothesis (+ optional bit masks)
-    int64_t b = ctx->n * ctx->D * 8 + ctx->n * 8 + (int64_t)ctx->M * ctx->P * 8 + (int64_t)ctx->M * 24;
-    if (ctx->last_score_filtered == 1) b += ctx->n * 8;   // per-point scale of the FP64 rejection filter
-    if (ctx->last_score_filtered == 2) b += ctx->n * 32;  // f32 rows of the FP32 pre-filter
+    // the inputs once and the outputs once - N d 8 (points) + M p 8 (hypotheses) + M 16 (count, score), plus
+    // the compound preference vector (N 8) when the compound term is on.  Derived copies this library keeps (f32 shadow rows,
+    // sorted copies, group bounds) are NOT algorithmic bytes.
+    int64_t b = ctx->n * ctx->D * 8 + (int64_t)ctx->M * ctx->P * 8 + (int64_t)ctx->M * 16;
+    if (ctx->score_has_compound) b += ctx->n * 8;
     if (want_masks) b += (int64_t)ctx->M * ((ctx->n + 63) / 64) * 8;
     if (bytes) *bytes = b;
     if (pairs) *pairs = ctx->n * (int64_t)ctx->M;
+    return PGX_OK;
+}
+
+int pgx_score_profile(pgx_ctx* ctx, int on)
+{
+    CTX_GUARD(ctx);
+    if (on && !ctx->kev[0])
+        for (int k = 0; k < 4; ++k) PGX_HIP(ctx, hipEventCreate(&ctx->kev[k]));
+    ctx->score_profile = on ? 1 : 0;
+    return PGX_OK;
+}
+
+int pgx_score_kernel_times(pgx_ctx* ctx, float ms[3])
+{
+    CTX_GUARD(ctx);
+    if (!ms || !ctx->kev[0] || ctx->last_score_path == 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_kernel_times: no profiled launch");
+    PGX_HIP(ctx, hipEventSynchronize(ctx->kev[3]));
+    for (int k = 0; k < 3; ++k) PGX_HIP(ctx, hipEventElapsedTime(&ms[k], ctx->kev[k], ctx->kev[k + 1]));
+    return PGX_OK;
+}
+
+int pgx_score_stats(pgx_ctx* ctx, double T2, int has_compound, int64_t stats[8])
+{
+    CTX_GUARD(ctx);
+    if (!stats) return fail(ctx, PGX_ERR_INVALID, "pgx_score_stats: stats is NULL");
+    for (int k = 0; k < 8; ++k) stats[k] = 0;
+    ctx->score_stats = 1;
+    ctx->score_has_compound = has_compound != 0;
+    const int rc = score_launch(ctx, T2, has_compound, 0);
+    ctx->score_stats = 0;
+    if (rc != PGX_OK) return rc;
+    const int64_t groups = (ctx->n + 63) / 64;
+    stats[0] = ctx->n * (int64_t)ctx->M;   // (point, hypothesis) pairs of the batch
+    stats[6] = ctx->last_score_path;
+    stats[7] = ctx->last_score_filtered;
+    if (ctx->last_score_path == 2) {
+        unsigned long long h[8];
+        PGX_HIP(ctx, hipMemcpyAsync(h, ctx->stats_buf.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        stats[1] = groups * (int64_t)ctx->M;  // (hypothesis, group) bound tests an un-hierarchical cull would run
+        stats[2] = (int64_t)h[0];             // surviving (hypothesis, group) steps: 64 f32 filter evaluations each
+        stats[3] = (int64_t)h[1];             // exact FP64 residual evaluations
+        stats[4] = (int64_t)h[2];             // inlier pairs
+    } else {
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        stats[3] = ctx->last_score_filtered ? -1 : stats[0];  // unfiltered chunked kernel: every pair is evaluated exactly
+    }
     return PGX_OK;
 }
 

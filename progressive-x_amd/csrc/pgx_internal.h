@@ -28,6 +28,8 @@ struct pgx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};  // pgx_score_profile: around the kernels of one scoring launch
+    int score_profile = 0;
     std::string err;
     int cu_count = 0;
 
@@ -41,6 +43,9 @@ struct pgx_ctx {
     double fscale = 0.0;     // max(1, max |coordinate|) over all points: isotropic pre-scaling of the minimal solvers
     int filter_enabled = 1;  // PGX_NO_FILTER: 1 = no rejection filter, 2 = FP64 filter only (A/B, debugging)
     int last_score_filtered = 0;
+    int last_score_path = 0;       // 1 = chunked kernel (every pair visited), 2 = cull + group-major
+    int score_stats = 0;           // set by pgx_score_stats for one launch: work counters in stats_buf
+    pgx::DevBuf stats_buf;
     int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)
     // spatially sorted copies for the score kernel (group-level rejection); aliases of the originals
     // when point_sort is off

@@ -451,12 +451,13 @@ __device__ __forceinline__ long long to_fixed(double x)
 
 constexpr int kGroupWaves = 1;  // waves per workgroup of the group-major kernel
 
-template <int MT, bool MASK>
+template <int MT, bool MASK, bool STATS = false>
 __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
     const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
     const float* __restrict__ hyp32, double qscale, unsigned long long* __restrict__ acc /* [3][Mpad]: count, value, shared */,
-    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t)
+    int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t,
+    unsigned long long* __restrict__ stats = nullptr /* STATS: [0] surviving (hypothesis, group) steps, [1] exact evaluations, [2] inlier pairs */)
 {
     // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     __shared__ float s_h32[kGroupWaves][64][kHypRow];
     __shared__ unsigned s_queue[kGroupWaves][128];
     int qn = 0;  // queued candidate pairs of this wave (wave-uniform)
+    unsigned long long st_steps = 0, st_exact = 0, st_inl = 0;  // STATS only (wave-uniform / per-lane partials)
     // Exact evaluation of up to 64 queued (hypothesis, point) pairs, one per lane.  A pair's point lives in the registers
     // of lane `src` of this wave (shuffles), its model is gathered from global memory.  Every contribution is converted to
     // 2^-q fixed point BEFORE any summation, so the accumulated integers do not depend on how pairs were batched:
@@ -524,9 +526,11 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
 #pragma unroll
             for (int k = 0; k < R::P; ++k) mdl[k] = models_t[(int64_t)k * Mpad + m];  // neighbours in m share cache lines
             const double sq = R::squared(q_pt, mdl);
+            if (STATS) ++st_exact;
             if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
                 const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
                 cnt = 1;
+                if (STATS) ++st_inl;
                 val = to_fixed(sc * qscale);
                 if (has_comp) shq = to_fixed(cv_min(q_cmp, sc) * qscale);           // :115-117
             }
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     for (int w = part; w < W; w += split) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
         if (todo == 0) continue;
+        if (STATS) st_steps += (unsigned long long)__popcll(todo);
         __builtin_amdgcn_wave_barrier();  // the previous word's reads are done (LDS ops of a wave execute in order)
         if ((todo >> lane) & 1ull) {
             const int64_t ml = (int64_t)w * 64 + lane;
@@ -588,6 +593,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
                 for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
                 const double sq = R::squared(pt, mdl);
                 inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
+                if (STATS) { ++st_exact; if (inl) ++st_inl; }
                 if (inl) {
                     sc = cv_max(0.0, 1.0 - sq / T2);      // :94
                     if (has_comp) shv = cv_min(cmp, sc);  // :115-117
@@ -613,6 +619,18 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     if (!MASK && qn > 0) {
         __builtin_amdgcn_wave_barrier();
         drain(qn);
+    }
+    if (STATS) {  // one set of atomics per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            st_exact += __shfl_down(st_exact, off, 64);
+            st_inl += __shfl_down(st_inl, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&stats[0], st_steps);
+            atomicAdd(&stats[1], st_exact);
+            atomicAdd(&stats[2], st_inl);
+        }
     }
 }
 
@@ -832,10 +850,12 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
             PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
+            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
                                ctx->cull_lists.as<unsigned long long>(), hyp32, models_t);
             PGX_HIP(ctx, hipGetLastError());
+            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream));
             const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
             const int xcd_local = ctx->score_group_xcd;
             const unsigned gblocks = xcd_local ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
@@ -845,20 +865,34 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t);
+            } else if (ctx->score_stats) {  // pgx_score_stats: the same launch with work counters (never timed)
+                PGX_TRY(ensure(ctx, ctx->stats_buf, 8 * sizeof(unsigned long long)));
+                PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+                hipLaunchKernelGGL((score_group_kernel<MT, false, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
+                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
+                                   ctx->stats_buf.as<unsigned long long>());
             } else {
                 hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t);
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
+                                   (unsigned long long*)nullptr);
             }
             PGX_HIP(ctx, hipGetLastError());
+            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream));
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
                                ctx->Mpad, qscale, ctx->perm.as<int>(), ctx->counts.as<long long>(), ctx->values.as<double>(),
                                ctx->shared.as<double>());
             PGX_HIP(ctx, hipGetLastError());
+            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
+            ctx->last_score_path = 2;
             return PGX_OK;
         }
     }
+    ctx->last_score_path = 1;
+    if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
     if constexpr (Filter<MT>::enabled) {
         if (want_masks) {
             if (deferred) score_launch_deferred<MT, true>(ctx, T2, has_compound, guard);
@@ -876,11 +910,13 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
     }
     PGX_HIP(ctx, hipGetLastError());
+    if (ctx->score_profile) { PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream)); }
     hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
                        ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
                        ctx->chunks, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
                        ctx->values.as<double>(), ctx->shared.as<double>());
     PGX_HIP(ctx, hipGetLastError());
+    if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
     return PGX_OK;
 }
 

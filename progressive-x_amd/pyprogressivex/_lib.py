@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "pgx_version", "pgx_device_count", "pgx_global_error", "pgx_create", "pgx_destroy", "pgx_last_error",
     "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_timer_mark", "pgx_timer_elapsed", "pgx_device_info",
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
-    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes",
+    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats",
@@ -265,6 +265,24 @@ class Context:
         self._ck(self._lib.pgx_score_algorithmic_bytes(self._h, C.c_int(1 if want_masks else 0), C.byref(b),
                                                        C.byref(p)), "pgx_score_algorithmic_bytes")
         return b.value, p.value
+
+    def score_profile(self, on=True):
+        self._ck(self._lib.pgx_score_profile(self._h, C.c_int(1 if on else 0)), "pgx_score_profile")
+
+    def score_kernel_times(self):
+        """ms of (cull or chunked kernel, group-major kernel, finish/reduce) of the last profiled scoring launch"""
+        ms = (C.c_float * 3)()
+        self._ck(self._lib.pgx_score_kernel_times(self._h, ms), "pgx_score_kernel_times")
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def score_stats(self, T2, has_compound=False):
+        """pgx_score_stats: work counters of one (untimed) scoring launch of the resident batch."""
+        st = np.zeros(8, dtype=np.int64)
+        self._ck(self._lib.pgx_score_stats(self._h, C.c_double(T2), C.c_int(1 if has_compound else 0), _ptr(st, C.c_int64)),
+                 "pgx_score_stats")
+        return dict(pairs=int(st[0]), group_pairs=int(st[1]), surviving_group_steps=int(st[2]), exact_evaluations=int(st[3]),
+                    inlier_pairs=int(st[4]), path={1: "every pair", 2: "cull + group-major"}.get(int(st[6]), "?"),
+                    filter={0: "none", 1: "f64", 2: "f32"}.get(int(st[7]), "?"))
 
     # -- preference / compound -------------------------------------------------------------------------------------
     def preference(self, model, T2, slot, want_pref=False):
