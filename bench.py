@@ -208,7 +208,7 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
             s, kt = timed_steps(c2, step2, min(steps, 10), 2)
             Mb = c2.M
             key = "fundamental" if mt == _lib.FUNDAMENTAL else "vanishing_point"
-            tf = len(p2) * Mb * FLOPS_PER_PAIR[key] / (float(kt[0] + kt[1]) * 1e-3) / 1e12
+            tf = len(p2) * Mb * FLOPS_PER_PAIR[key] / (float(kt[0] + kt[1] + kt[3]) * 1e-3) / 1e12
             legs[name] = {"points": int(len(p2)), "hypotheses": int(Mb), "ms_per_step": 1e3 * s,
                           "kernel_ms": [float(x) for x in kt], "residual_evals_per_sec": len(p2) * Mb / s,
                           "models_per_sec": Mb / s, "work": c2.score_stats(T2b, has_compound=True),
@@ -326,7 +326,8 @@ def main():
                          "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes, {PMC['source']}",
                          "kernel": "pgx::score_group_kernel<PnP>", "kernel_ms": k_ms,
                          "launch_kernels_ms": {"cull": float(kt[0]), "group_major": float(kt[1]), "finish": float(kt[2]),
-                                               "sum": launch_ms},
+                                               "exact_queue": float(kt[3]), "sum": launch_ms,
+                                               "note": "HIP events on the kernels' stream; an event pair costs ~5 us itself"},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_formula": "N d 8 + M p 8 + M 16 + N 8 (compound), SURVEY 8(d); no derived copies",
                          "note": "arithmetic/latency bound by construction (~0.02 algorithmic B/pair): the fraction is small "

@@ -101,9 +101,9 @@ int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8])
 /* Per-kernel HIP-event timing of the scoring launches on the context's stream (bench.py's roofline block): with profiling
  * on, every pgx_score_launch records events around its kernels; pgx_score_kernel_times returns the durations of the last
  * launch in ms: [0] cull (or the chunked kernel), [1] group-major scoring (the dominant kernel; 0 on the chunked path),
- * [2] finish / reduce. */
+ * [2] finish / reduce, [3] exact evaluation of the queued candidates (0 when it runs inside the group-major kernel). */
 int pgx_score_profile(pgx_ctx *ctx, int on);
-int pgx_score_kernel_times(pgx_ctx *ctx, float ms[3]);
+int pgx_score_kernel_times(pgx_ctx *ctx, float ms[4]);
 
 /* ---- a2/a3: Model::setPreferenceVector (progx_model.h:70-87) + the three reductions of isPutativeModelValid
  * (progressive_x.h:583-585).  The preference vector is kept on the device in `slot` (>=0) for a4; pref_out optional. */

@@ -102,6 +102,13 @@ int pgx_create(int device_id, pgx_ctx** out)
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_EXW")) { int v = std::atoi(b); if (v >= 1 && v <= 16) ctx->score_exact_waves = v; }
+    if (const char* b = std::getenv("PGX_SCORE_CULL_SEGS")) { int v = std::atoi(b); if (v >= 1 && v <= 65535) ctx->score_cull_segs = v; }
+    if (const char* b = std::getenv("PGX_SCORE_NREP")) { int v = std::atoi(b); if (v >= 0 && v <= 1024) ctx->score_nrep = v; }
+    if (const char* b = std::getenv("PGX_SCORE_QUEUE")) ctx->score_queue = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SCORE_ABLATE")) { int v = std::atoi(b); if (v >= 0 && v <= 9) ctx->score_ablate = v; }
+    if (const char* b = std::getenv("PGX_SCORE_PIPE")) { int v = std::atoi(b); if (v >= 0 && v <= 2) ctx->score_pipe = v; }
+    if (const char* b = std::getenv("PGX_SCORE_SOA")) ctx->score_soa = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_SPLIT")) { int v = std::atoi(b); if (v >= 1 && v <= 1024) ctx->score_split = v; }
     if (const char* b = std::getenv("PGX_SCORE_NO_CULL")) ctx->score_cull = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
@@ -123,11 +130,11 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
-                      &ctx->weights, &ctx->stats_buf};
+                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->cand};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
-    for (int k = 0; k < 4; ++k) if (ctx->kev[k]) (void)hipEventDestroy(ctx->kev[k]);
+    for (int k = 0; k < 5; ++k) if (ctx->kev[k]) (void)hipEventDestroy(ctx->kev[k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -435,17 +442,20 @@ int pgx_score_profile(pgx_ctx* ctx, int on)
 {
     CTX_GUARD(ctx);
     if (on && !ctx->kev[0])
-        for (int k = 0; k < 4; ++k) PGX_HIP(ctx, hipEventCreate(&ctx->kev[k]));
+        for (int k = 0; k < 5; ++k) PGX_HIP(ctx, hipEventCreate(&ctx->kev[k]));
     ctx->score_profile = on ? 1 : 0;
     return PGX_OK;
 }
 
-int pgx_score_kernel_times(pgx_ctx* ctx, float ms[3])
+int pgx_score_kernel_times(pgx_ctx* ctx, float ms[4])
 {
     CTX_GUARD(ctx);
     if (!ms || !ctx->kev[0] || ctx->last_score_path == 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_kernel_times: no profiled launch");
     PGX_HIP(ctx, hipEventSynchronize(ctx->kev[3]));
-    for (int k = 0; k < 3; ++k) PGX_HIP(ctx, hipEventElapsedTime(&ms[k], ctx->kev[k], ctx->kev[k + 1]));
+    PGX_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->kev[0], ctx->kev[1]));
+    PGX_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->kev[1], ctx->kev[2]));
+    PGX_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->kev[4], ctx->kev[3]));
+    PGX_HIP(ctx, hipEventElapsedTime(&ms[3], ctx->kev[2], ctx->kev[4]));
     return PGX_OK;
 }
 

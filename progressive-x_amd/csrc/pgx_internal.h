@@ -28,7 +28,7 @@ struct pgx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};  // pgx_score_profile: around the kernels of one scoring launch
+    hipEvent_t kev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pgx_score_profile: [0] start, [1] after cull, [2] after group-major, [4] after exact, [3] after finish
     int score_profile = 0;
     std::string err;
     int cu_count = 0;
@@ -53,6 +53,15 @@ struct pgx_ctx {
     int group_filter = 1;        // PGX_NO_GROUP=1 disables the sorted copies and the group test (A/B)
     int comp_dirty = 0;          // comp changed since comp_s was gathered
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
+    pgx::DevBuf pts_g, p32_g;    // group-blocked SoA copies of the sorted rows: [group][coordinate][64] (group-major kernel)
+    int score_exact_waves = 1;   // waves per segment of the candidate queue in score_exact_kernel (PGX_SCORE_EXW)
+    int score_cull_segs = 256;   // segments of groups per hypothesis word in the cull kernel (PGX_SCORE_CULL_SEGS; 8192 waves at M = 2048)
+    int score_nrep = 0;         // replicas of the integer accumulators (PGX_SCORE_NREP, multiple of 8); 0 = automatic: 8 when a group's waves share an XCD, else 1
+    int score_queue = 0;         // PGX_SCORE_QUEUE=1: candidates go to a global queue and are evaluated by score_exact_kernel (measured slower; A/B)
+    pgx::DevBuf cand;            // global candidate queue [kCandSegs][qcap] of (hypothesis, sorted point index)
+    int score_ablate = 0;        // PGX_SCORE_ABLATE (measurement only, wrong results): 1 skips the exact evaluation, 2 the filter loop too
+    int score_pipe = 0;          // PGX_SCORE_PIPE: 0 plain survivor loop, 1 prefetch of the next hypothesis' constants, 2 two per step
+    int score_soa = 1;           // PGX_SCORE_SOA=0: the group-major kernel reads the AoS copies (A/B)
     int score_cull = 1;          // cull + survivor kernels instead of in-kernel group skipping (PGX_SCORE_NO_CULL=1: A/B)
     int score_group_xcd = 0;     // PGX_SCORE_GROUP_XCD=1: a group's workgroups on one XCD (less HBM fetch, slower: A/B)
     int score_split = 8;         // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT)

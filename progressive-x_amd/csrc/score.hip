@@ -15,6 +15,7 @@
 // The kernel is FP64-VALU bound (≈0.02 algorithmic bytes per pair); MFMA is deliberately unused: there is no
 // dense contraction, every pair is a projective map + divide + compare.
 #include <cmath>
+#include <cstdlib>
 
 #include "pgx_internal.h"
 
@@ -360,7 +361,6 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
 //                       bit-reproducible although the accumulation order is not fixed.  q = 62 - ceil(log2 n): the
 //                       quantisation error of a sum is < (#groups with inliers) * 2^-(q+1), ~1e-13 relative.
 //   score_finish_kernel accumulators -> counts / values / shared in the caller's hypothesis order.
-constexpr int kCullSegs = 256;  // segments of groups per hypothesis wave in the cull kernel (8192 waves at M = 2048)
 constexpr int kHypRow = 20;    // floats per hypothesis: Filter32<MT>::Lane, padded
 
 template <class LaneT>
@@ -450,14 +450,20 @@ __device__ __forceinline__ long long to_fixed(double x)
 }
 
 constexpr int kGroupWaves = 1;  // waves per workgroup of the group-major kernel
+constexpr int kCandSegs = 16384;   // segments of the global candidate queue (power of two; one reservation counter each)
+constexpr int kCandStride = 8;     // counters 32 B apart
 
-template <int MT, bool MASK, bool STATS = false>
+template <int MT, bool MASK, bool STATS = false, int PIPE = 0>
 __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
     const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
     const float* __restrict__ hyp32, double qscale, unsigned long long* __restrict__ acc /* [3][Mpad]: count, value, shared */,
     int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t,
-    unsigned long long* __restrict__ stats = nullptr /* STATS: [0] surviving (hypothesis, group) steps, [1] exact evaluations, [2] inlier pairs */)
+    unsigned long long* __restrict__ stats /* STATS: [0] surviving (hypothesis, group) steps, [1] exact evaluations, [2] inlier pairs */,
+    const double* __restrict__ pts_g /* [groups][D][64]: group-blocked SoA copy of the rows (nullptr: AoS) */,
+    const float* __restrict__ p32_g /* [groups][6][64] */,
+    unsigned long long* __restrict__ cand /* [kCandSegs][qcap] global candidate queue (nullptr: exact evaluation in place) */,
+    unsigned* __restrict__ cand_cnt /* [kCandSegs * kCandStride] */, int qcap, int nrep)
 {
     // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
@@ -470,6 +476,8 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // group's workgroups on one XCD (FETCH_SIZE 165 -> 45 MiB but 0.51 ms); one wave per workgroup with 8 parts per
     // group: 0.28 ms (16 parts: 250 k workgroups, the dispatcher limits at ~1.3 ns per workgroup).
     const int wv = 0;
+    const int ablate = xcd_local >> 4;  // measurement only (PGX_SCORE_ABLATE): 1 = no exact evaluation, 2 = no filter loop either
+    xcd_local &= 1;
     int g, part;
     if (xcd_local) {  // workgroup ids go round-robin over the 8 XCDs: all parts of a group on one XCD (its L2 fetches the rows once)
         const int slot = (int)(blockIdx.x >> 3);
@@ -492,11 +500,25 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const int64_t jj = valid ? j : n - 1;
     double pt[R::D];
     float p32[8];
+    if (pts_g != nullptr) {
+        // group-blocked SoA copies: every load instruction of the wave reads one contiguous 512 B (256 B) run instead of 64
+        // rows 40 B (32 B) apart - 13 loads touch 17 cache lines instead of ~100 (the tail group is padded with its last row)
 #pragma unroll
-    for (int q = 0; q < R::D; ++q) pt[q] = pts[jj * R::D + q];
+        for (int q = 0; q < R::D; ++q) pt[q] = pts_g[((int64_t)g * R::D + q) * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) p32[q] = pts32[jj * 8 + q];
+        for (int q = 0; q < 6; ++q) p32[q] = p32_g[((int64_t)g * 6 + q) * 64 + lane];
+        p32[6] = p32[7] = 0.0f;
+    } else {
+#pragma unroll
+        for (int q = 0; q < R::D; ++q) pt[q] = pts[jj * R::D + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p32[q] = pts32[jj * 8 + q];
+    }
     const double cmp = has_comp ? comp[jj] : 0.0;
+    // nrep replicas of the integer accumulators, chosen by workgroup id: workgroup ids go round-robin over the XCDs, so with
+    // nrep a multiple of 8 a replica is only ever updated from one XCD (its atomics stay in that L2), and the hot
+    // hypotheses (thousands of updates) do not serialise on three addresses.  score_finish_kernel adds the replicas (exact).
+    acc += (size_t)(blockIdx.x % (unsigned)nrep) * 3 * (size_t)Mpad;
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
     // The f32 constants of a word's surviving hypotheses are staged in LDS by the lanes that own them (one vector-load
     // round trip per 64 hypotheses) and read back as broadcasts: one scalar-memory round trip per hypothesis (~1 us
@@ -506,12 +528,14 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     __shared__ unsigned s_queue[kGroupWaves][128];
     int qn = 0;  // queued candidate pairs of this wave (wave-uniform)
     unsigned long long st_steps = 0, st_exact = 0, st_inl = 0;  // STATS only (wave-uniform / per-lane partials)
+    int nflush = 0;  // batches this wave has handed to the global candidate queue
     // Exact evaluation of up to 64 queued (hypothesis, point) pairs, one per lane.  A pair's point lives in the registers
     // of lane `src` of this wave (shuffles), its model is gathered from global memory.  Every contribution is converted to
     // 2^-q fixed point BEFORE any summation, so the accumulated integers do not depend on how pairs were batched:
     // results are bit-reproducible and independent of the launch geometry.  Equal hypotheses are adjacent in the queue
     // (pairs are appended hypothesis by hypothesis): a segmented shuffle reduction leaves one atomic set per run.
     auto drain = [&](int c) {
+        if (ablate >= 1) return;
         const bool act = lane < c;
         const unsigned e = act ? s_queue[wv][lane] : 0u;
         const int m = act ? (int)(e >> 6) : -1 - lane;
@@ -549,6 +573,28 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
         }
     };
+    // Hand-over of `c` queued candidates to the global queue (one segment per workgroup id, one reservation per flush): the
+    // exact FP64 evaluation then runs in score_exact_kernel with all 64 lanes busy, instead of here where a wave's last
+    // batch is on average 40 % full and every batch ends the wave's work with a dependent gather + atomics.  A full
+    // segment makes the wave evaluate in place (the reserved slots are marked empty).
+    auto flush = [&](int c) {
+        if (MASK || STATS || cand == nullptr) { drain(c); return; }
+        if (ablate >= 1) return;
+        // a wave's successive batches go to different segments (a dense group would otherwise fill one): segments end up
+        // equally loaded, which is what the consumer's one-wave-per-segment schedule needs
+        const unsigned seg = ((unsigned)blockIdx.x + (unsigned)(nflush++) * 7919u) & (unsigned)(kCandSegs - 1);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&cand_cnt[seg * kCandStride], (unsigned)c);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const bool fits = base + (unsigned)c <= (unsigned)qcap;
+        if (lane < c && base + (unsigned)lane < (unsigned)qcap) {
+            const unsigned e = s_queue[wv][lane];
+            const unsigned long long entry = fits ? (((unsigned long long)(e >> 6) << 32) | (unsigned long long)((unsigned)g * 64u + (e & 63u)))
+                                                  : ~0ull;
+            cand[(size_t)seg * (size_t)qcap + base + lane] = entry;
+        }
+        if (!fits) drain(c);
+    };
     for (int w = part; w < W; w += split) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
         if (todo == 0) continue;
@@ -560,6 +606,60 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             for (int k = 0; k < kHypRow; ++k) s_h32[wv][lane][k] = hyp32[ml * kHypRow + k];
         }
         __builtin_amdgcn_wave_barrier();
+        if (ablate >= 2) continue;
+        if constexpr (!MASK && PIPE > 0) {
+            // Software-pipelined walk over the survivors: the constants of the NEXT hypothesis (PIPE == 2: of the next two)
+            // are requested from LDS before the current one is evaluated, so the ~100-cycle LDS round trip overlaps the
+            // filter arithmetic instead of heading every step's dependency chain (ISA of the plain loop: s_ff1 -> ds_read
+            // x4 -> s_waitcnt -> 18 VALU -> ballot -> branch, strictly serial; VALU 56 % busy).
+            auto append = [&](int h, bool cand) {
+                const unsigned long long cm = __ballot(cand);
+                if (cm == 0) return;
+                const int m = w * 64 + h;
+                if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
+                    ((unsigned)m << 6) | (unsigned)lane;
+                qn += __popcll(cm);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    flush(64);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned mv = s_queue[wv][64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    s_queue[wv][lane] = mv;
+                    qn -= 64;
+                }
+            };
+            if constexpr (PIPE == 1) {
+                int hA = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                LaneT lnA = lane_load<LaneT>(&s_h32[wv][hA][0]);
+                for (;;) {
+                    const bool more = todo != 0;
+                    const int hB = more ? __builtin_ctzll(todo) : hA;
+                    todo &= todo - 1;  // 0 stays 0
+                    const LaneT lnB = lane_load<LaneT>(&s_h32[wv][hB][0]);  // in flight while A is evaluated
+                    append(hA, valid && !F32::reject(p32, lnA, T2d32));
+                    if (!more) break;
+                    hA = hB;
+                    lnA = lnB;
+                }
+            } else {
+                while (todo != 0) {  // two hypotheses per step: two independent FMA chains, one loop overhead
+                    const int hA = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const bool two = todo != 0;
+                    const int hB = two ? __builtin_ctzll(todo) : hA;
+                    todo &= todo - 1;
+                    const LaneT lnA = lane_load<LaneT>(&s_h32[wv][hA][0]);
+                    const LaneT lnB = lane_load<LaneT>(&s_h32[wv][hB][0]);
+                    const bool cA = valid && !F32::reject(p32, lnA, T2d32);
+                    const bool cB = two && valid && !F32::reject(p32, lnB, T2d32);
+                    append(hA, cA);
+                    append(hB, cB);
+                }
+            }
+            continue;
+        }
         while (todo != 0) {
             const int h = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -576,7 +676,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
                 qn += __popcll(cm);
                 if (qn >= 64) {
                     __builtin_amdgcn_wave_barrier();
-                    drain(64);
+                    flush(64);
                     __builtin_amdgcn_wave_barrier();
                     const unsigned mv = s_queue[wv][64 + lane];
                     __builtin_amdgcn_wave_barrier();
@@ -618,7 +718,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     }
     if (!MASK && qn > 0) {
         __builtin_amdgcn_wave_barrier();
-        drain(qn);
+        flush(qn);
     }
     if (STATS) {  // one set of atomics per wave
 #pragma unroll
@@ -634,16 +734,102 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     }
 }
 
+// Exact FP64 evaluation of the queued candidate pairs, 64 per wave step with every lane busy: the point row and the model
+// are gathered from memory (the rows of a producer's batch are neighbours in the sorted copy, its hypotheses form runs),
+// the residual is the oracle's operation order, every contribution becomes 2^-q fixed point BEFORE any summation and goes
+// to the hypothesis' integer accumulators - the same integers the in-place path adds, so the results do not depend on
+// which path a pair took.
+constexpr int kExactUnroll = 4;  // batches of 64 pairs a wave has in flight
+
+template <int MT>
+__global__ __launch_bounds__(64) void score_exact_kernel(
+    const double* __restrict__ pts_s, const double* __restrict__ comp, const double* __restrict__ models_t, int Mpad, double T2,
+    int has_comp, double qscale, const unsigned long long* __restrict__ cand, const unsigned* __restrict__ cand_cnt, int qcap,
+    unsigned long long* __restrict__ acc, int nrep, int kExactWaves, int ablate)
+{
+    using R = Residual<MT>;
+    const int lane = (int)threadIdx.x;
+    // kExactWaves waves share a segment; a wave takes kExactUnroll consecutive batches per step and issues the entry loads,
+    // then the row / model gathers of ALL of them before any arithmetic: the chain count -> entries -> rows/models ->
+    // arithmetic is three dependent memory round trips (the rows were written by another XCD: L2 misses), and with one
+    // batch in flight per wave the kernel was nothing but that latency.
+    const unsigned seg = (unsigned)blockIdx.x / (unsigned)kExactWaves, k = (unsigned)blockIdx.x % (unsigned)kExactWaves;
+    unsigned cnt = cand_cnt[seg * kCandStride];
+    if (cnt > (unsigned)qcap) cnt = (unsigned)qcap;
+    acc += (size_t)(blockIdx.x % (unsigned)nrep) * 3 * (size_t)Mpad;
+    const unsigned long long* q = cand + (size_t)seg * (size_t)qcap;
+    for (unsigned base = k * 64u * kExactUnroll; base < cnt; base += 64u * kExactUnroll * (unsigned)kExactWaves) {
+        unsigned long long e[kExactUnroll];
+#pragma unroll
+        for (int u = 0; u < kExactUnroll; ++u) e[u] = base + 64u * u + lane < cnt ? q[base + 64u * u + lane] : ~0ull;
+        double pt[kExactUnroll][R::D], mdl[kExactUnroll][R::P], cj[kExactUnroll];
+#pragma unroll
+        for (int u = 0; u < kExactUnroll; ++u) {
+            const bool act = e[u] != ~0ull;
+            const unsigned j = act ? (unsigned)e[u] : 0u, m = act ? (unsigned)(e[u] >> 32) : 0u;
+            const double* __restrict__ row = pts_s + (size_t)j * R::D;
+#pragma unroll
+            for (int qq = 0; qq < R::D; ++qq) pt[u][qq] = row[qq];
+#pragma unroll
+            for (int qq = 0; qq < R::P; ++qq) mdl[u][qq] = models_t[(size_t)qq * (unsigned)Mpad + m];
+            cj[u] = has_comp ? comp[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kExactUnroll; ++u) {
+            if (base + 64u * u >= cnt) break;  // uniform
+            const bool act = e[u] != ~0ull;
+            const int m = act ? (int)(e[u] >> 32) : -1 - lane;
+            long long c1 = 0, val = 0, shq = 0;
+            if (act) {
+                const double sq = R::squared(pt[u], mdl[u]);
+                if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
+                    const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
+                    c1 = 1;
+                    val = to_fixed(sc * qscale);
+                    if (has_comp) shq = to_fixed(cv_min(cj[u], sc) * qscale);           // :115-117
+                }
+            }
+            // segmented sums over RUNS of equal hypotheses.  A segment concatenates the batches of several producer waves, so
+            // the same hypothesis may come back after other ones: runs are identified by their first lane (from the ballot
+            // of the run heads), not by the hypothesis index, so that only contiguous entries are combined.
+            const int mp = __shfl_up(m, 1, 64);
+            const bool head = lane == 0 || mp != m;
+            const unsigned long long heads = __ballot(head);
+            const int rs = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));  // first lane of this lane's run
+            for (int off = 1; off < 64; off <<= 1) {
+                const int ro = __shfl_down(rs, off, 64);
+                const bool same = lane + off < 64 && ro == rs;
+                if (__ballot(same) == 0) break;
+                const long long c2 = __shfl_down(c1, off, 64), v2 = __shfl_down(val, off, 64), s2 = __shfl_down(shq, off, 64);
+                if (same) { c1 += c2; val += v2; shq += s2; }
+            }
+            if (act && head && c1 > 0 && ablate != 4) {
+                atomicAdd(&acc[m], (unsigned long long)c1);
+                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long long* __restrict__ acc, int M, int Mpad, double qscale,
                                                            const int* __restrict__ perm, long long* __restrict__ counts,
-                                                           double* __restrict__ values, double* __restrict__ shared)
+                                                           double* __restrict__ values, double* __restrict__ shared, int nrep)
 {
     const int m = (int)(blockIdx.x * 256 + threadIdx.x);
     if (m >= M) return;
     const int o = perm[m];  // hypotheses were scored in locality order: results go back to the caller's order
-    counts[o] = (long long)acc[m];
-    values[o] = (double)(long long)acc[(int64_t)Mpad + m] / qscale;
-    shared[o] = (double)(long long)acc[2 * (int64_t)Mpad + m] / qscale;
+    // nrep per-XCD replicas of the integer accumulators (co-located groups): integer sums, exact in any order
+    unsigned long long c = 0, v = 0, sh = 0;
+    for (int r = 0; r < nrep; ++r) {
+        const unsigned long long* a = acc + (size_t)r * 3 * (size_t)Mpad;
+        c += a[m];
+        v += a[(int64_t)Mpad + m];
+        sh += a[2 * (int64_t)Mpad + m];
+    }
+    counts[o] = (long long)c;
+    values[o] = (double)(long long)v / qscale;
+    shared[o] = (double)(long long)sh / qscale;
 }
 
 // ---- filtered variant with deferred exact evaluation ------------------------------------------------
@@ -839,17 +1025,31 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         if (filt32 && !deferred && ctx->point_sort && ctx->score_cull) {
             // ---- cull, then score group-major
             const int groups = (int)((ctx->n + 63) / 64);
+            const int kCullSegs = ctx->score_cull_segs;
             const int gps = ((groups + kCullSegs - 1) / kCullSegs + kSuper - 1) / kSuper * kSuper;  // whole super-groups per segment
             const int W = ctx->Mpad / 64;
             PGX_TRY(ensure(ctx, ctx->cull_lists, (size_t)groups * W * sizeof(unsigned long long)));             // keep[g][w]
-            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + 3 * sizeof(long long) + Residual<MT>::P * sizeof(double))));  // hyp32 | acc | models_t
+            const int nrep = ctx->score_nrep > 0 ? ctx->score_nrep : (ctx->score_group_xcd ? 8 : 1);
+            const int xcd_local = (ctx->score_group_xcd ? 1 : 0) | ((ctx->score_ablate < 4 ? ctx->score_ablate : 0) << 4);  // per-XCD replicas of the accumulators when a group's waves share an XCD
+            // global candidate queue (exact evaluation in its own dense kernel): kCandSegs segments, capacity from the batch size
+            const bool use_queue = ctx->score_queue && !want_masks && !ctx->score_stats;
+            int qcap = 256;
+            while ((int64_t)qcap * kCandSegs * 64 < ctx->n * (int64_t)ctx->M && qcap < 8192) qcap *= 2;  // ~1/64 of the pairs
+            if (const char* b = std::getenv("PGX_SCORE_QCAP")) { const int v = std::atoi(b); if (v >= 64 && v <= 65536) qcap = v; }
+            const size_t cnt_bytes = use_queue ? (size_t)kCandSegs * kCandStride * sizeof(unsigned) : 0;
+            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + (size_t)nrep * 3 * sizeof(long long) + Residual<MT>::P * sizeof(double)) + cnt_bytes));  // hyp32 | acc[nrep] | cand_cnt | models_t
+            if (use_queue) PGX_TRY(ensure(ctx, ctx->cand, (size_t)kCandSegs * (size_t)qcap * sizeof(unsigned long long)));
             float* hyp32 = ctx->cull_counts.as<float>();
             unsigned long long* acc = (unsigned long long*)(ctx->cull_counts.as<char>() + (size_t)ctx->Mpad * kHypRow * sizeof(float));
-            double* models_t = (double*)(acc + 3 * (size_t)ctx->Mpad);
+            unsigned* cand_cnt = (unsigned*)(acc + (size_t)nrep * 3 * (size_t)ctx->Mpad);  // zeroed by the same memset as acc
+            double* models_t = (double*)((char*)cand_cnt + cnt_bytes);
+            unsigned long long* cand = use_queue ? ctx->cand.as<unsigned long long>() : (unsigned long long*)nullptr;
+            const double* pts_g = ctx->score_soa && ctx->pts_g.p ? ctx->pts_g.as<double>() : (const double*)nullptr;
+            const float* p32_g = ctx->score_soa && ctx->pts_g.p ? ctx->p32_g.as<float>() : (const float*)nullptr;
             int lg = 0;
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
-            PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)ctx->Mpad * 3 * sizeof(long long), ctx->stream));
+            PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)nrep * ctx->Mpad * 3 * sizeof(long long) + cnt_bytes, ctx->stream));
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
@@ -857,14 +1057,14 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream));
             const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
-            const int xcd_local = ctx->score_group_xcd;
-            const unsigned gblocks = xcd_local ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
+            const unsigned gblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
             if (want_masks) {
                 PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
                 hipLaunchKernelGGL((score_group_kernel<MT, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t);
+                                   qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
+                                   (unsigned long long*)nullptr, pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep);
             } else if (ctx->score_stats) {  // pgx_score_stats: the same launch with work counters (never timed)
                 PGX_TRY(ensure(ctx, ctx->stats_buf, 8 * sizeof(unsigned long long)));
                 PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
@@ -872,19 +1072,31 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   ctx->stats_buf.as<unsigned long long>());
+                                   ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep);
             } else {
-                hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
-                                   ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
-                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   (unsigned long long*)nullptr);
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
+                                       ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
+                                       ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                       qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
+                                       (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep);
+                };
+                if (ctx->score_pipe == 2) launch(score_group_kernel<MT, false, false, 2>);
+                else if (ctx->score_pipe == 1) launch(score_group_kernel<MT, false, false, 1>);
+                else launch(score_group_kernel<MT, false, false, 0>);
             }
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream));
+            if (use_queue) {
+                hipLaunchKernelGGL((score_exact_kernel<MT>), dim3((unsigned)(kCandSegs * ctx->score_exact_waves)), dim3(64), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->comp_s.as<double>(), models_t, ctx->Mpad, T2, has_compound, qscale, cand,
+                                   cand_cnt, qcap, acc, nrep, ctx->score_exact_waves, ctx->score_ablate);
+                PGX_HIP(ctx, hipGetLastError());
+            }
+            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream));
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
                                ctx->Mpad, qscale, ctx->perm.as<int>(), ctx->counts.as<long long>(), ctx->values.as<double>(),
-                               ctx->shared.as<double>());
+                               ctx->shared.as<double>(), nrep);
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
             ctx->last_score_path = 2;
@@ -910,7 +1122,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
     }
     PGX_HIP(ctx, hipGetLastError());
-    if (ctx->score_profile) { PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream)); }
+    if (ctx->score_profile) { PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream)); }
     hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
                        ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
                        ctx->chunks, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
@@ -1041,6 +1253,21 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
     // super-groups of kSuper consecutive groups (512 points): the cull kernel tests them first; rows behind the group rows
     for (int64_t sg = 0; sg < supers; ++sg)
         bounds(sg * kSuper * 64, (sg + 1) * kSuper * 64 < n ? (sg + 1) * kSuper * 64 : n, gb.data() + (size_t)(groups + sg) * kGroupRow);
+    {   // group-blocked SoA copies for the group-major kernel: [group][coordinate][64]; the tail group repeats its last row
+        std::vector<double> pg((size_t)groups * d * 64);
+        std::vector<float> p32g((size_t)groups * 6 * 64);
+        for (int64_t g = 0; g < groups; ++g)
+            for (int l = 0; l < 64; ++l) {
+                const int64_t j = g * 64 + l < n ? g * 64 + l : n - 1;
+                for (int k = 0; k < d; ++k) pg[((size_t)g * d + k) * 64 + l] = sp[(size_t)j * d + k];
+                for (int k = 0; k < 6; ++k) p32g[((size_t)g * 6 + k) * 64 + l] = sp32[(size_t)j * 8 + k];
+            }
+        PGX_TRY(ensure(ctx, ctx->pts_g, pg.size() * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->p32_g, p32g.size() * sizeof(float)));
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->pts_g.p, pg.data(), pg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        PGX_HIP(ctx, hipMemcpyAsync(ctx->p32_g.p, p32g.data(), p32g.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors die at the end of this block
+    }
     PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
     PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));

@@ -270,10 +270,11 @@ class Context:
         self._ck(self._lib.pgx_score_profile(self._h, C.c_int(1 if on else 0)), "pgx_score_profile")
 
     def score_kernel_times(self):
-        """ms of (cull or chunked kernel, group-major kernel, finish/reduce) of the last profiled scoring launch"""
-        ms = (C.c_float * 3)()
+        """ms of (cull or chunked kernel, group-major kernel, finish/reduce, exact evaluation of the queued candidates) of
+        the last profiled scoring launch"""
+        ms = (C.c_float * 4)()
         self._ck(self._lib.pgx_score_kernel_times(self._h, ms), "pgx_score_kernel_times")
-        return float(ms[0]), float(ms[1]), float(ms[2])
+        return float(ms[0]), float(ms[1]), float(ms[2]), float(ms[3])
 
     def score_stats(self, T2, has_compound=False):
         """pgx_score_stats: work counters of one (untimed) scoring launch of the resident batch."""

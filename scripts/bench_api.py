@@ -42,6 +42,7 @@ def timed(name, fn, gt, rows, *args, **kw):
         _lib.Context.expansion = expansion
         stats["maxflow"] = acc
     kw.setdefault("local_optimization", os.environ.get("BENCH_LO", "auto"))   # "lsq": refit-only local optimisation
+    kw.setdefault("labeling_l0", os.environ.get("BENCH_L0", "greedy"))        # U-8 switch (lambda = 0 only)
     t0 = time.perf_counter()
     models, labels = fn(*args, **kw)
     dt = time.perf_counter() - t0

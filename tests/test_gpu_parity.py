@@ -202,15 +202,26 @@ def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["pnp", "homography"])
-def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch):
+def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch, oracle):
     # per-pair fixed point + integer accumulation: the results of the group-major path do not depend on how many waves share
-    # a group, on queue boundaries or on the order in which groups finish — bitwise equal across PGX_SCORE_SPLIT values
+    # a group, on queue boundaries, on the order in which groups finish, on where a pair is evaluated (in the producing wave
+    # or, through the global candidate queue, in score_exact_kernel - including segments that overflow), on how many
+    # accumulator replicas there are, on the row layout or on the survivor-loop variant: bitwise equal across every switch
     mt, pts, models, thr = make_case(name, 50000, 700, seed=21)
     T2 = 2.25 * thr * thr
     comp = np.random.default_rng(3).random(len(pts))
+    configs = [{"PGX_SCORE_SPLIT": s} for s in ("1", "3", "8", "16")] + [
+        {"PGX_SCORE_GROUP_XCD": "1"}, {"PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_SPLIT": "2"}, {"PGX_SCORE_NREP": "64"},
+        {"PGX_SCORE_SOA": "0"}, {"PGX_SCORE_PIPE": "1"}, {"PGX_SCORE_PIPE": "2"},
+        {"PGX_SCORE_QUEUE": "1"}, {"PGX_SCORE_QUEUE": "1", "PGX_SCORE_QCAP": "64", "PGX_SCORE_EXW": "3"},
+        {"PGX_SCORE_QUEUE": "1", "PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_CULL_SEGS": "31"}]
+    keys = sorted({k for c in configs for k in c})
     outs = []
-    for split in ("1", "3", "8", "16"):
-        monkeypatch.setenv("PGX_SCORE_SPLIT", split)
+    for cfg in configs:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in cfg.items():
+            monkeypatch.setenv(k, v)
         ctx = _lib.Context(0)
         try:
             ctx.set_points(mt, pts)
@@ -219,9 +230,13 @@ def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch):
             outs.append(ctx.score(models, T2, has_compound=True, exponent=2))
         finally:
             ctx.close()
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
     for o in outs[1:]:
         for key in ("counts", "values", "shared", "scores"):
             assert np.array_equal(o[key], outs[0][key]), key
+    ref = oracle.score(mt, pts, models, T2, compound=comp, has_compound=True, exponent=2)
+    assert np.array_equal(outs[0]["counts"], ref["counts"]) and _rel(outs[0]["values"], ref["values"]) <= REL
 
 
 def test_score_early_exit_predicate_is_order_free(oracle):
