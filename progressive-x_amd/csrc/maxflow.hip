@@ -23,6 +23,7 @@ struct MaxflowState {
     DevBuf cap, tot, ex, rt, d, f, g, small, front;
     int* h_flags = nullptr;  // pinned host mirror for flag read-backs
     DevBuf lists;            // act[2][n] | mark[n]
+    DevBuf bar;              // grid barrier of the persistent kernels: arrivals | generation (zeroed once)
     int next_stamp = 1;
     int64_t mark_n = 0;
 };
@@ -57,14 +58,16 @@ struct Stage {
     int base;
 };
 
-__device__ __forceinline__ void stage_flush(const MfView& v, Stage& st, int k)
+__device__ __forceinline__ void stage_flush(const MfView& v, Stage& st, int k, int level_base = -1)
 {
     __syncthreads();
     const int n = st.count;
     if (n > 0) {
-        if (threadIdx.x == 0) st.base = mf_level_base(v, k) + atomicAdd(&v.fcount[k % 3], n);
+        if (threadIdx.x == 0) st.base = (level_base >= 0 ? level_base : mf_level_base(v, k)) + atomicAdd(&v.fcount[k % 3], n);
         __syncthreads();
-        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) v.order[st.base + i] = st.list[i];
+        // device-scope (write-through) stores: the persistent BFS reads the entries in the same kernel from other XCDs
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x)
+            __hip_atomic_store(&v.order[st.base + i], st.list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (threadIdx.x == 0) st.count = 0;
     }
@@ -310,17 +313,13 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_init(MfView v, int, int)
     if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One BFS level for the calling workgroup (all of its threads): the frontier part (F sites of level k-1 at `fin`), then the
+// hub part when a hub received distance k-1 (`ev`).  level_base = where level k starts in `order`.  Returns "labelled".
 // stage_margin: the most one pass can append (256 threads x arcs per thread); 0 = append straight to `order`
-__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int stage_margin)
+__device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, const int* __restrict__ fin, int level_base, int ev,
+                                               int stage_margin, int* s_min, Stage& s_stage)
 {
-    __shared__ int s_min[kMfMaxLabels];
-    __shared__ Stage s_stage;
-    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
-    if (threadIdx.x == 0) s_stage.count = 0;
-    __syncthreads();
     bool r = false;
-    const int F = v.fcount[(k - 1) % 3];
-    const int* __restrict__ fin = v.order + v.lvl[k - 1];
     const int sub = (int)(threadIdx.x & 7);
     const int64_t nthreads = (int64_t)gridDim.x * kMfBlock;
     const int64_t gtid = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
@@ -331,28 +330,39 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
     for (int64_t q0 = 0; v.off != nullptr && q0 < F; q0 += nthreads >> 3) {
         const int64_t q = q0 + (gtid >> 3);
         if (q < F) {
-            const int w = fin[q];
+            const int w = __hip_atomic_load(&fin[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
                 const int uu = v.idx[a];
                 // residual of the reverse arc uu -> w without the gather through rev[a]; label test folded into d (kMfDead)
                 const bool want = v.tot[a] - __hip_atomic_load(&v.cap[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
                                   __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
-                r |= mf_bfs_label(v, uu, k, s_min, want, -1, scnt, slist);
+                r |= mf_bfs_label(v, uu, k, s_min, want, level_base, scnt, slist);
             }
         }
-        if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k);
+        if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k, level_base);
     }
-    const int ev = mf_bfs_hub_events(v, k);
     if (ev != 0) {
         const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;  // whole workgroups iterate together
         for (int64_t u0 = (int64_t)blockIdx.x * kMfBlock; u0 < rounded; u0 += nthreads) {
             const int64_t u = u0 + threadIdx.x;
             r |= u < v.n ? mf_body_bfs_hubpass(v, u, k, (ev & 1) != 0, s_min, scnt, slist)
-                         : mf_bfs_label(v, 0, k, s_min, false, -1, scnt, slist);
-            if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k);
+                         : mf_bfs_label(v, 0, k, s_min, false, level_base, scnt, slist);
+            if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k, level_base);
         }
     }
-    stage_flush(v, s_stage, k);
+    stage_flush(v, s_stage, k, level_base);
+    return r;
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int stage_margin)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    __shared__ Stage s_stage;
+    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    if (threadIdx.x == 0) s_stage.count = 0;
+    __syncthreads();
+    const bool r = bfs_level_body(v, k, v.fcount[(k - 1) % 3], v.order + v.lvl[k - 1], mf_level_base(v, k), mf_bfs_hub_events(v, k),
+                                  stage_margin, s_min, s_stage);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         v.lvl[k] = mf_level_base(v, k);
         v.fcount[(k + 1) % 3] = 0;  // slot of the level after this one
@@ -360,6 +370,87 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
     const int count = __syncthreads_count(r ? 1 : 0);
     if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
     if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- persistent kernels: all BFS levels / all wave levels of one global relabel in ONE launch ---------------------------
+// The level loop used to be driven by the host: one launch per level (median 11 us for frontiers of a few thousand sites, 55
+// levels per relabel in the moves that hand a new instance its points) plus a flag read-back every 8-64 levels.  Here the
+// workgroups of a co-resident grid (cooperative launch, one workgroup per CU) run the levels back to back and meet at a
+// grid barrier: arrival counter + generation word, relaxed device-scope atomics.  NO cache-wide fence: a release / acquire
+// pair at device scope writes back and invalidates the whole L2 of every XCD on gfx950 (measured: ~60 us per level, 3x
+// slower than the launches it replaced).  Instead everything one level hands to the next across workgroups is written
+// with device-scope (write-through) stores or atomics and read with device-scope loads - the frontier entries, the level
+// counters, the hub distances, d[], cap[], ex[] - and a workgroup arrives only after all of its memory operations have
+// been acknowledged (s_waitcnt 0 before the workgroup barrier).
+__device__ __forceinline__ void mf_grid_barrier(unsigned* bar, unsigned nblocks)
+{
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores and atomics have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+// levels 2 .. until two consecutive levels label nothing (what the host loop tested through flags[0]).  flags[5] = the last
+// level run, flags[0] = the last level that labelled a site; the one-thread epilogue (mf_body_bfs_finish) follows in its own
+// launch (it reads the hub distances with plain loads).
+__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_persist(MfView v, int stage_margin, int slot, unsigned* bar)
+{
+    __shared__ int s_min[kMfMaxLabels];
+    __shared__ Stage s_stage;
+    __shared__ int s_ctl[4];  // frontier size, hub events, stop
+    int base_prev = 0;        // lvl[k - 1]: level 1 starts at 0
+    int k = 1;
+    for (;;) {
+        ++k;
+        if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+        if (threadIdx.x == 0) {
+            s_stage.count = 0;
+            s_ctl[0] = __hip_atomic_load(&v.fcount[(k - 1) % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int ev = 0;  // mf_bfs_hub_events with device-scope loads (the distances were written earlier in THIS kernel)
+            if (v.has_alpha_hub[0] && __hip_atomic_load(&v.bfs_hubA_d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 1;
+            for (int l = 0; l < v.L; ++l)
+                if (v.hub_exists[l] && __hip_atomic_load(&v.bfs_hub_d[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 2;
+            s_ctl[1] = ev;
+        }
+        __syncthreads();
+        const int F = s_ctl[0], ev = s_ctl[1];
+        const int level_base = base_prev + F;  // level k starts behind level k-1
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            v.lvl[k] = level_base;
+            __hip_atomic_store(&v.fcount[(k + 1) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // free since level k-1 ended
+        }
+        const bool r = bfs_level_body(v, k, F, v.order + base_prev, level_base, ev, stage_margin, s_min, s_stage);
+        const int count = __syncthreads_count(r ? 1 : 0);
+        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mf_grid_barrier(bar, gridDim.x);
+        if (threadIdx.x == 0)
+            s_ctl[2] = __hip_atomic_load(&v.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= k - 2 || k >= v.hmax;
+        __syncthreads();
+        base_prev = level_base;
+        if (s_ctl[2]) break;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.flags[5] = k;
+}
+
+// wave pass: levels kstart .. 1, farthest first, a grid barrier between levels (level k pushes into level k-1)
+__global__ __launch_bounds__(kMfBlock) void mf_k_wave_persist(MfView v, int kstart, unsigned* bar)
+{
+    for (int k = kstart; k >= 1; --k) {
+        const int lo = v.lvl[k], hi = v.lvl[k + 1];
+        for (int i = lo + (int)(blockIdx.x * kMfBlock + threadIdx.x); i < hi; i += (int)(gridDim.x * kMfBlock))
+            mf_body_wave(v, v.order[i], k);
+        if (k > 1) mf_grid_barrier(bar, gridDim.x);
+    }
 }
 
 // stranded excess of the sites (maxflow_body.cuh mf_body_stuck_excess): per-workgroup sum, one atomic per workgroup
@@ -395,6 +486,7 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
     case 3: mf_body_sweep_epilogue(v, a0, a1, a2); break;
+    case 4: mf_body_bfs_finish(v, a0, v.flags[5]); break;  // after mf_k_bfs_persist: the level count is on the device
     }
 }
 
@@ -444,7 +536,37 @@ struct HipBackend {
     unsigned blocks;
     bool v_has_graph;
     unsigned list_blocks;
+    bool persist = false;        // level loops inside persistent cooperative kernels (PGX_MF_PERSIST=0: one launch per level)
+    unsigned coop_blocks = 0;    // co-resident grid of the persistent kernels: one workgroup per CU
     hipError_t err = hipSuccess;
+
+    bool persistent() const { return persist; }
+    int stage_margin() const
+    {
+        // staging needs room for everything one pass can append: 256 threads x ceil(max degree / 8) arcs each
+        const int per_pass = kMfBlock * ((ctx->max_degree + 7) / 8);
+        return per_pass <= kStageCap / 2 ? (per_pass > 0 ? per_pass : kMfBlock) : 0;
+    }
+    void bfs_all(const MfView& v, int slot)
+    {
+        MfView vv = v;
+        int margin = stage_margin();
+        unsigned* bar = st->bar.as<unsigned>();
+        void* args[] = {&vv, &margin, &slot, &bar};
+        hipError_t e = hipLaunchCooperativeKernel((const void*)mf_k_bfs_persist, dim3(coop_blocks), dim3(kMfBlock), args, 0, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        check();
+        single(v, 4, slot);
+    }
+    void wave_all(const MfView& v, int kstart)
+    {
+        MfView vv = v;
+        unsigned* bar = st->bar.as<unsigned>();
+        void* args[] = {&vv, &kstart, &bar};
+        hipError_t e = hipLaunchCooperativeKernel((const void*)mf_k_wave_persist, dim3(coop_blocks), dim3(kMfBlock), args, 0, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        check();
+    }
 
     void check() { if (err == hipSuccess) err = hipGetLastError(); }
     template <class K> void site(K k, const MfView& v, int a0 = 0, int a1 = 0)
@@ -483,10 +605,7 @@ struct HipBackend {
     void bfs_level(const MfView& v, int k)
     {
         const unsigned g = blocks < (unsigned)kBfsLevelBlocks ? blocks : (unsigned)kBfsLevelBlocks;
-        // staging needs room for everything one pass can append: 256 threads x ceil(max degree / 8) arcs each
-        const int per_pass = kMfBlock * ((ctx->max_degree + 7) / 8);
-        const int margin = per_pass <= kStageCap / 2 ? (per_pass > 0 ? per_pass : kMfBlock) : 0;
-        hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k, margin);
+        hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k, stage_margin());
         check();
     }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
@@ -587,7 +706,7 @@ void maxflow_free(pgx_ctx* ctx)
     if (!ctx->mf) return;
     MaxflowState* st = ctx->mf;
     release(st->cap); release(st->tot); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
-    release(st->small); release(st->front); release(st->lists);
+    release(st->small); release(st->front); release(st->lists); release(st->bar);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
     delete st;
     ctx->mf = nullptr;
@@ -763,6 +882,18 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.gate = std::getenv("PGX_MF_NO_GATE") ? 0 : 1;
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
+    if (!st->bar.p) {
+        PGX_TRY(ensure(ctx, st->bar, 64));
+        PGX_HIP(ctx, hipMemsetAsync(st->bar.p, 0, 64, ctx->stream));
+    }
+    {
+        const char* e = std::getenv("PGX_MF_PERSIST");
+        // opt-in: measured equal-to-slower than one launch per level (a grid barrier over 256 workgroups on 8 XCDs costs what
+        // a launch costs); unstaged appends use plain stores, so staging is a precondition
+        be.persist = e && e[0] == '1' && be.stage_margin() > 0;
+        const unsigned cus = ctx->cu_count > 0 ? (unsigned)ctx->cu_count : 64u;
+        be.coop_blocks = be.blocks < cus ? be.blocks : cus;
+    }
     MfTuning tune;
     if (const char* e = std::getenv("PGX_MF_WAVE")) tune.wave = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_LIST_DIV")) tune.list_div = std::atoi(e);

@@ -37,29 +37,41 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // ---- global relabel
         be.bfs_reset(v);
         be.bfs_init(v);
-        // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
-        // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
         int level = 1, last = 1;
-        for (int round = 0;; ++round) {
-            const int batch = round == 0 ? tune.bfs_batch : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
-            for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
-            last = be.read_flag(v, 0);
-            if (last <= level - 2 || level >= v.hmax) break;
+        const int slot = (sweep_id + 2) % 3;
+        int fl[8];
+        if (be.persistent()) {
+            // all levels + the one-thread epilogue in ONE cooperative launch (grid barrier between levels); the level
+            // counters come back with the flags: [5] = last level run, [0] = last level that labelled a site
+            be.bfs_all(v, slot);
+            be.count_active(v);
+            be.read_flags(v, fl);
+            level = fl[5];
+            last = fl[0];
+        } else {
+            // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
+            // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
+            for (int round = 0;; ++round) {
+                const int batch = round == 0 ? tune.bfs_batch : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
+                for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
+                last = be.read_flag(v, 0);
+                if (last <= level - 2 || level >= v.hmax) break;
+            }
+            be.bfs_finish(v, slot, level);
+            be.count_active(v);
+            be.read_flags(v, fl);
         }
         stats[2] += 1;
         stats[3] += level;
-        const int slot = (sweep_id + 2) % 3;
-        be.bfs_finish(v, slot, level);
-        be.count_active(v);
-        int fl[8];
-        be.read_flags(v, fl);
         if (fl[1] == 0) { converged = true; break; }
         if (tune.debug)
             std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d\n", v.alpha, it, level, fl[3], fl[7]);
         if (tune.debug > 1) be.debug_dump(v, tune.debug == 4 ? level : fl[3]);
         // ---- wave pass over the BFS levels, farthest first
         if (tune.wave && v.off != nullptr) {
-            for (int k = (last + 1 < level ? last + 1 : level); k >= 1; --k) be.wave(v, k);  // levels beyond `last` are empty
+            const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
+            if (be.persistent()) be.wave_all(v, kstart);
+            else for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
         }
         // ---- push-relabel sweeps: over all sites, or over a work list while few sites are active and no beta hub can

@@ -39,6 +39,9 @@ struct EmuBackend {
         mf_body_hub_setup(v);
     }
     int read_count(const MfView& v, int l) { return v.cnt[l]; }
+    bool persistent() const { return false; }      // the emulation runs the host-driven level loops
+    void bfs_all(const MfView&, int) {}
+    void wave_all(const MfView&, int) {}
     void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
     void bfs_reset(const MfView& v) { mf_body_bfs_reset(v); }
     void bfs_init(const MfView& v) { each([&](int64_t u) { if (mf_body_bfs_init(v, u, v.bfs_hub_d)) v.flags[0] = 1; }); }

@@ -307,7 +307,7 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave"])
+@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent"])
 def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
     # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
     if forced == "list_sweeps":
@@ -315,6 +315,8 @@ def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
     if forced == "no_wave":
         monkeypatch.setenv("PGX_MF_WAVE", "0")
         monkeypatch.setenv("PGX_MF_LIST_DIV", "0")
+    if forced == "persistent":   # BFS / wave level loops inside cooperative kernels with a grid barrier
+        monkeypatch.setenv("PGX_MF_PERSIST", "1")
     rng = np.random.default_rng(2024)
     for trial in range(60):
         n = int(rng.integers(2, 300))
@@ -940,8 +942,8 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     assert arcs > 4 * n
     gpu_ctx.pearl_unary(poses[:9], 4.0 / f, lam)
     results = []
-    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}):
-        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE"):
+    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}):
+        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
