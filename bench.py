@@ -152,7 +152,9 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
     # (3) one pgx_set_points (the once-per-problem preprocessing of the group-major path)
     t0 = time.perf_counter()
     ctx.set_points(_lib.PNP, pts)
-    legs["set_points"] = {"ms": 1e3 * (time.perf_counter() - t0), "what": "upload of 40 MB + Morton sort + group bounds, once per problem"}
+    legs["set_points"] = {"ms": 1e3 * (time.perf_counter() - t0),
+                          "what": "pgx_set_points, once per problem: upload of 40 MB + filter scales, f32 rows, Morton keys, "
+                                  "radix sort, sorted / group-blocked copies and group bounds on the device (setpoints.hip)"}
 
     # (4) dense mode: no group test, no rejection filter - every pair through the exact FP64 path (true FP64 fraction)
     saved = {k: os.environ.get(k) for k in ("PGX_NO_GROUP", "PGX_NO_FILTER")}

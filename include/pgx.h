@@ -103,6 +103,10 @@ int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8])
  * launch in ms: [0] cull (or the chunked kernel), [1] group-major scoring (the dominant kernel; 0 on the chunked path),
  * [2] finish / reduce, [3] exact evaluation of the queued candidates (0 when it runs inside the group-major kernel). */
 int pgx_score_profile(pgx_ctx *ctx, int on);
+/* Diagnostic read-back of what pgx_set_points derived for the score path (tests compare the device preprocessing with the
+ * host version bit for bit): what = 0 sorted order (n int32), 1 group + super-group rows ((groups + supers) x 12 f32),
+ * 2 / 3 the group-blocked f64 / f32 row copies, 4 the sorted f32 rows.  bytes must match exactly. */
+int pgx_score_debug_fetch(pgx_ctx *ctx, int what, void *out, int64_t bytes);
 int pgx_score_kernel_times(pgx_ctx *ctx, float ms[4]);
 
 /* ---- a2/a3: Model::setPreferenceVector (progx_model.h:70-87) + the three reductions of isPutativeModelValid

@@ -102,6 +102,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SETPOINTS_HOST")) ctx->setpoints_host = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_EXW")) { int v = std::atoi(b); if (v >= 1 && v <= 16) ctx->score_exact_waves = v; }
     if (const char* b = std::getenv("PGX_SCORE_CULL_SEGS")) { int v = std::atoi(b); if (v >= 1 && v <= 65535) ctx->score_cull_segs = v; }
     if (const char* b = std::getenv("PGX_SCORE_NREP")) { int v = std::atoi(b); if (v >= 0 && v <= 1024) ctx->score_nrep = v; }
@@ -206,13 +207,10 @@ int pgx_device_info(pgx_ctx* ctx, char* name, int name_len, int* cu_count, int64
 }
 
 /* ---- resident data ---------------------------------------------------------------------------------------- */
-int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
+// The host version of the preprocessing (round 1; PGX_SETPOINTS_HOST=1 keeps it for A/B and as the cross-check of
+// setpoints.hip: both produce the same sorted order and the same group rows).
+static int set_points_host(pgx_ctx* ctx, int model_type, const double* points, int64_t n, int d)
 {
-    CTX_GUARD(ctx);
-    int d = 0, p = 0;
-    if (model_dims(model_type, &d, &p) != 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: bad model type %d", model_type);
-    if (!points || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: empty input");
-    if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: n must be < 2^31");
     PGX_TRY(ensure(ctx, ctx->pts, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->comp, (size_t)n * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pmax, (size_t)n * sizeof(double)));
@@ -249,13 +247,29 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     PGX_HIP(ctx, hipMemcpyAsync(ctx->pmax.p, pmax.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)n * sizeof(double), ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
-    ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
     ctx->point_sort = 0;
     ctx->comp_dirty = 1;
-    ctx->weights_n = 0;  // weights belong to a point set
     if (obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(umax))
         PGX_TRY(score_sort_points(ctx, points, p32.data(), pmax.data()));
+    return PGX_OK;
+}
+
+int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
+{
+    CTX_GUARD(ctx);
+    int d = 0, p = 0;
+    if (model_dims(model_type, &d, &p) != 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: bad model type %d", model_type);
+    if (!points || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: empty input");
+    if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: n must be < 2^31");
+    ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
+    ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
+    ctx->weights_n = 0;  // weights belong to a point set
+    if (!ctx->setpoints_host) {
+        // upload + every derived copy on the device (setpoints.hip): filter scales, f32 rows, Morton order, group bounds
+        PGX_TRY(set_points_device(ctx, model_type, points, n));
+    } else {
+        PGX_TRY(set_points_host(ctx, model_type, points, n, d));
+    }
     for (DevBuf& b : ctx->slots) release(b);
     ctx->slots.clear();
     return PGX_OK;
@@ -435,6 +449,28 @@ int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, in
     if (want_masks) b += (int64_t)ctx->M * ((ctx->n + 63) / 64) * 8;
     if (bytes) *bytes = b;
     if (pairs) *pairs = ctx->n * (int64_t)ctx->M;
+    return PGX_OK;
+}
+
+int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)
+{
+    CTX_GUARD(ctx);
+    if (!out || bytes <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: empty destination");
+    if (!ctx->point_sort) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: no sorted copies for the resident points");
+    const int64_t groups = (ctx->n + 63) / 64, supers = (groups + kSuper - 1) / kSuper;
+    const DevBuf* b = nullptr;
+    int64_t have = 0;
+    switch (what) {
+    case 0: b = &ctx->pperm; have = ctx->n * 4; break;
+    case 1: b = &ctx->gbounds; have = (groups + supers) * kGroupRow * 4; break;
+    case 2: b = &ctx->pts_g; have = groups * 64 * ctx->D * 8; break;
+    case 3: b = &ctx->p32_g; have = groups * 64 * 6 * 4; break;
+    case 4: b = &ctx->pts32_s; have = ctx->n * 8 * 4; break;
+    default: return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: unknown buffer %d", what);
+    }
+    if (bytes != have) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: buffer %d holds %lld bytes, asked for %lld", what, (long long)have, (long long)bytes);
+    PGX_HIP(ctx, hipMemcpyAsync(out, b->p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PGX_OK;
 }
 

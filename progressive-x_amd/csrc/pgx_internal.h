@@ -54,6 +54,7 @@ struct pgx_ctx {
     int comp_dirty = 0;          // comp changed since comp_s was gathered
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     pgx::DevBuf pts_g, p32_g;    // group-blocked SoA copies of the sorted rows: [group][coordinate][64] (group-major kernel)
+    int setpoints_host = 0;      // PGX_SETPOINTS_HOST=1: round 1's host preprocessing in pgx_set_points (A/B, cross-check)
     int score_exact_waves = 1;   // waves per segment of the candidate queue in score_exact_kernel (PGX_SCORE_EXW)
     int score_cull_segs = 256;   // segments of groups per hypothesis word in the cull kernel (PGX_SCORE_CULL_SEGS; 8192 waves at M = 2048)
     int score_nrep = 0;         // replicas of the integer accumulators (PGX_SCORE_NREP, multiple of 8); 0 = automatic: 8 when a group's waves share an XCD, else 1
@@ -133,7 +134,13 @@ inline int64_t quantize(double x) { return (int64_t)__builtin_nearbyint(x * 4294
 // weight of one directed neighbour entry, forced even so that w/2 is exact in the expansion graph
 inline int64_t quantize_lambda(double lambda) { return 2 * (int64_t)__builtin_nearbyint(lambda * 2147483648.0); }
 
+// group bounds of the score path (score.hip consumes them, setpoints.hip / score_sort_points build them)
+constexpr double kGroupInflate = 1.00001;
+constexpr int kGroupRow = 12;  // floats per group: c[3], rho, ub, vb, ru, rv, scale, pad[3]
+constexpr int kSuper = 8;      // groups per super-group (512 points): first level of the cull kernel
+
 // launchers implemented in the .hip translation units
+int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n);  // setpoints.hip: upload + all preprocessing
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
 int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, const double* pmax);  // builds the sorted copies
 int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pref, double out3[3]);

@@ -121,9 +121,7 @@ template <int MT> struct Filter32 {
 // test (centre errors <= a few tau T |z_c|), radii and norms stored rounded up by 1e-5, T inflated by 2^-6.  A wave
 // skips the 64 points when all of its 64 hypotheses reject the group (the batch is in locality order, so a wave's
 // hypotheses look at the same image region): 74 % of the (wave, group) pairs of the metric batch.
-constexpr double kGroupInflate = 1.00001;
-constexpr int kGroupRow = 12;  // floats per group: c[3], rho, ub, vb, ru, rv, scale, pad[3]
-constexpr int kSuper = 8;      // groups per super-group (512 points): first level of the cull kernel
+// kGroupInflate, kGroupRow, kSuper: pgx_internal.h (shared with setpoints.hip, which builds the rows on the device)
 
 template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;

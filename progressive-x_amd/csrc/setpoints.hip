@@ -1,0 +1,299 @@
+// setpoints.hip — pgx_set_points on the device: everything the score path derives from the points once per problem.
+//
+// Replaces the host loops of round 1 (58-89 ms at N = 1e6: filter scales, f32 rows, Morton keys, a 4-pass radix sort,
+// sorted copies, per-group bounds) by kernels on the context's stream; the caller's buffer is read exactly once (the
+// upload).  What is computed is unchanged - same keys, a stable sort, the same f64 arithmetic for the bounds - so the
+// sorted order, the group rows and therefore every culling decision are those of the host version (PGX_SETPOINTS_HOST=1
+// keeps it for A/B; a GPU test compares the two bit for bit).
+//
+// Serves: the resident data of MSACScoringFunctionWithCompoundModel::getScore
+// (/root/reference/src/pyprogressivex/include/scoring_function_with_compound_model.h:61-125), which upstream re-reads from a
+// cv::Mat per hypothesis; the reference has no preprocessing step of its own.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+namespace {
+
+constexpr int kSpBlock = 256;
+
+// order-preserving map double -> u64 (for atomicMin / atomicMax on doubles)
+__device__ __forceinline__ unsigned long long f64_key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+inline double key_f64(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double x;
+    std::memcpy(&x, &b, 8);
+    return x;
+}
+
+// stats: [0..4] min key per dim, [5..9] max key per dim, [10] max |observed| key, [11] max |coord| key (NaN ignored),
+//        [12] flags: bit 0 = a non-finite coordinate, bit 1 = a NaN among the observed coordinates
+__global__ __launch_bounds__(kSpBlock) void sp_prep_kernel(const double* __restrict__ pts, int64_t n, int d, int obs0, int in0, int in1,
+                                                           double* __restrict__ pmax, float* __restrict__ p32,
+                                                           unsigned long long* __restrict__ stats)
+{
+    __shared__ unsigned long long s_min[5], s_max[5], s_um, s_fs;
+    __shared__ unsigned s_flag;
+    if (threadIdx.x < 5) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; }
+    if (threadIdx.x == 0) { s_um = 0ull; s_fs = 0ull; s_flag = 0u; }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (i < n) {
+        double r[5];
+        unsigned flag = 0;
+        for (int k = 0; k < d; ++k) {
+            r[k] = pts[i * d + k];
+            if (!(fabs(r[k]) <= 1.7976931348623157e308)) flag |= 1u;  // NaN or Inf
+            atomicMin(&s_min[k], f64_key(r[k]));   // NaN keys sort above +Inf / below -Inf: harmless, the flag decides
+            atomicMax(&s_max[k], f64_key(r[k]));
+            const double a = fabs(r[k]);
+            if (a == a) atomicMax(&s_fs, f64_key(a));
+        }
+        double pm = 1.0;
+        if (obs0 >= 0) {
+            const double a = fabs(r[obs0]), b = fabs(r[obs0 + 1]);
+            if (!(a == a) || !(b == b)) flag |= 2u;
+            else { atomicMax(&s_um, f64_key(a)); atomicMax(&s_um, f64_key(b)); }
+            for (int k = in0; k <= in1; ++k) { const double v = fabs(r[k]); if (!(v <= pm)) pm = v; }
+            float* q = p32 + i * 8;   // f32 row of the pre-filter: coordinates, then the scale rounded up
+            for (int k = 0; k < 8; ++k) q[k] = 0.0f;
+            for (int k = 0; k < d; ++k) q[k] = (float)r[k];
+            q[5] = (float)(pm * 1.000001);
+        } else {
+            float* q = p32 + i * 8;
+            for (int k = 0; k < 8; ++k) q[k] = 0.0f;
+        }
+        pmax[i] = pm;
+        if (flag) atomicOr(&s_flag, flag);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d) {
+        atomicMin(&stats[threadIdx.x], s_min[threadIdx.x]);
+        atomicMax(&stats[5 + threadIdx.x], s_max[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(&stats[10], s_um);
+        atomicMax(&stats[11], s_fs);
+        if (s_flag) atomicOr(&stats[12], (unsigned long long)s_flag);
+    }
+}
+
+struct MortonArg {
+    double lo[5], inv[5];
+    int d, bits;
+};
+
+__global__ __launch_bounds__(kSpBlock) void sp_keys_kernel(const double* __restrict__ pts, int64_t n, MortonArg m,
+                                                           unsigned* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned qmax = (1u << m.bits) - 1u;
+    unsigned key = 0;
+    for (int k = 0; k < m.d; ++k) {
+        const double t = (pts[i * m.d + k] - m.lo[k]) * m.inv[k];
+        unsigned v = t > 0.0 ? (unsigned)t : 0u;
+        if (v > qmax) v = qmax;
+        for (int b = 0; b < m.bits; ++b) key |= ((v >> b) & 1u) << (b * m.d + m.d - 1 - k);  // bit b of coordinate k
+    }
+    keys[i] = key;
+    vals[i] = (unsigned)i;
+}
+
+// sorted copies: AoS rows (chunked kernel, exact kernel), f32 rows, scales, and the group-blocked SoA copies
+__global__ __launch_bounds__(kSpBlock) void sp_gather_kernel(const double* __restrict__ pts, const float* __restrict__ p32,
+                                                             const double* __restrict__ pmax, const unsigned* __restrict__ order,
+                                                             int64_t n, int d, int64_t padded, int* __restrict__ pperm,
+                                                             double* __restrict__ pts_s, float* __restrict__ p32_s,
+                                                             double* __restrict__ pmax_s, double* __restrict__ pts_g,
+                                                             float* __restrict__ p32_g)
+{
+    const int64_t j = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (j >= padded) return;
+    const int64_t jj = j < n ? j : n - 1;   // the tail group repeats its last row
+    const int64_t i = (int64_t)order[jj];
+    const int64_t g = j >> 6;
+    const int l = (int)(j & 63);
+    for (int k = 0; k < d; ++k) {
+        const double v = pts[i * d + k];
+        if (j < n) pts_s[j * d + k] = v;
+        pts_g[(g * d + k) * 64 + l] = v;
+    }
+    for (int k = 0; k < 8; ++k) {
+        const float v = p32[i * 8 + k];
+        if (j < n) p32_s[j * 8 + k] = v;
+        if (k < 6) p32_g[(g * 6 + k) * 64 + l] = v;
+    }
+    if (j < n) { pperm[j] = (int)i; pmax_s[j] = pmax[i]; }
+}
+
+// bounds of `span` consecutive sorted points per workgroup (64 = a group, 512 = a super-group); the arithmetic of the
+// host version (score_sort_points): box centres in f64 -> f32, radius about the STORED f32 centre, inflated extents
+template <int SPAN>
+__global__ __launch_bounds__(SPAN) void sp_bounds_kernel(const double* __restrict__ sp, int64_t n, int d, int in0, int in1, int ob0,
+                                                         float* __restrict__ rows /* first row of this level */)
+{
+    __shared__ double s_lo[5], s_hi[5];
+    __shared__ unsigned long long s_red[3];
+    __shared__ float s_c[3], s_ob[2];
+    const int64_t a = (int64_t)blockIdx.x * SPAN, j = a + threadIdx.x;
+    const bool valid = j < n;
+    if (threadIdx.x < 5) { s_lo[threadIdx.x] = 0.0; s_hi[threadIdx.x] = 0.0; }
+    if (threadIdx.x < 3) s_red[threadIdx.x] = 0ull;
+    __syncthreads();
+    double r[5] = {0, 0, 0, 0, 0};
+    if (valid)
+        for (int k = 0; k < d; ++k) r[k] = sp[j * d + k];
+    // min / max of every coordinate over the valid points (wave shuffles, then LDS across the waves)
+    __shared__ double s_wlo[SPAN / 64][5], s_whi[SPAN / 64][5];
+    for (int k = 0; k < d; ++k) {
+        double lo = valid ? r[k] : 1.7976931348623157e308, hi = valid ? r[k] : -1.7976931348623157e308;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            if (l2 < lo) lo = l2;
+            if (h2 > hi) hi = h2;
+        }
+        if ((threadIdx.x & 63) == 0) { s_wlo[threadIdx.x >> 6][k] = lo; s_whi[threadIdx.x >> 6][k] = hi; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d) {
+        double lo = s_wlo[0][threadIdx.x], hi = s_whi[0][threadIdx.x];
+        for (int w = 1; w < SPAN / 64; ++w) {
+            if (s_wlo[w][threadIdx.x] < lo) lo = s_wlo[w][threadIdx.x];
+            if (s_whi[w][threadIdx.x] > hi) hi = s_whi[w][threadIdx.x];
+        }
+        s_lo[threadIdx.x] = lo;
+        s_hi[threadIdx.x] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k <= in1 - in0; ++k) s_c[k] = (float)(0.5 * (s_lo[in0 + k] + s_hi[in0 + k]));
+        for (int k = in1 - in0 + 1; k < 3; ++k) s_c[k] = 0.0f;
+        s_ob[0] = (float)(0.5 * (s_lo[ob0] + s_hi[ob0]));
+        s_ob[1] = (float)(0.5 * (s_lo[ob0 + 1] + s_hi[ob0 + 1]));
+    }
+    __syncthreads();
+    double s2 = 0.0, du = 0.0, dv = 0.0;
+    if (valid) {
+        for (int k = in0; k <= in1; ++k) { const double df = r[k] - (double)s_c[k - in0]; s2 += df * df; }
+        du = fabs(r[ob0] - (double)s_ob[0]);
+        dv = fabs(r[ob0 + 1] - (double)s_ob[1]);
+    }
+    // maxima of non-negative doubles: their bit patterns order like unsigned integers
+    atomicMax(&s_red[0], (unsigned long long)__double_as_longlong(s2));
+    atomicMax(&s_red[1], (unsigned long long)__double_as_longlong(du));
+    atomicMax(&s_red[2], (unsigned long long)__double_as_longlong(dv));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* row = rows + (int64_t)blockIdx.x * kGroupRow;
+        const double rho2 = __longlong_as_double((long long)s_red[0]), ru = __longlong_as_double((long long)s_red[1]),
+                     rv = __longlong_as_double((long long)s_red[2]);
+        double scale = 1.0;
+        for (int k = 0; k <= in1 - in0; ++k) if (fabs((double)s_c[k]) > scale) scale = fabs((double)s_c[k]);
+        row[0] = s_c[0]; row[1] = s_c[1]; row[2] = s_c[2];
+        row[3] = (float)(sqrt(rho2) * kGroupInflate + 1e-30);
+        row[4] = s_ob[0]; row[5] = s_ob[1];
+        row[6] = (float)(ru * kGroupInflate + 1e-30);
+        row[7] = (float)(rv * kGroupInflate + 1e-30);
+        row[8] = (float)(scale * 1.000001);
+        row[9] = row[10] = row[11] = 0.0f;
+    }
+}
+
+}  // namespace
+
+int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
+{
+    const int d = ctx->D;
+    int obs0 = -1, in0 = 0, in1 = -1;
+    if (model_type == kPnP) { obs0 = 0; in0 = 2; in1 = 4; }
+    else if (model_type == kHomography) { obs0 = 2; in0 = 0; in1 = 1; }
+    PGX_TRY(ensure(ctx, ctx->pts, (size_t)n * d * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->comp, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pmax, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pts32, (size_t)n * 8 * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->scratch, 16 * sizeof(unsigned long long)));
+    unsigned long long init[16];
+    for (int k = 0; k < 16; ++k) init[k] = 0ull;
+    for (int k = 0; k < 5; ++k) init[k] = ~0ull;
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->pts.p, points, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipMemsetAsync(ctx->comp.p, 0, (size_t)n * sizeof(double), ctx->stream));
+    const unsigned blocks = (unsigned)((n + kSpBlock - 1) / kSpBlock);
+    hipLaunchKernelGGL(sp_prep_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, d, obs0, in0, in1,
+                       ctx->pmax.as<double>(), ctx->pts32.as<float>(), ctx->scratch.as<unsigned long long>());
+    PGX_HIP(ctx, hipGetLastError());
+    unsigned long long st[16];
+    PGX_HIP(ctx, hipMemcpyAsync(st, ctx->scratch.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also: the caller's buffer has been consumed
+    const unsigned flags = (unsigned)st[12];
+    ctx->umax = obs0 >= 0 ? ((flags & 2u) ? std::nan("") : (st[10] ? key_f64(st[10]) : 0.0)) : 0.0;
+    const double fs = st[11] ? key_f64(st[11]) : 0.0;
+    ctx->fscale = fs > 1.0 ? fs : 1.0;   // NaN coordinates leave it at what the finite ones give; the solvers then produce NaN models
+    ctx->point_sort = 0;
+    ctx->comp_dirty = 1;
+    if (!(obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(ctx->umax)) || (flags & 1u)) return PGX_OK;
+
+    // ---- Morton order of all coordinates (stable: ties keep index order), sorted copies, group bounds
+    MortonArg m;
+    m.d = d;
+    m.bits = 30 / d;
+    for (int k = 0; k < 5; ++k) { m.lo[k] = 0.0; m.inv[k] = 0.0; }
+    for (int k = 0; k < d; ++k) {
+        const double a = key_f64(st[k]), b = key_f64(st[5 + k]);
+        m.lo[k] = a;
+        m.inv[k] = b > a ? (double)(1u << m.bits) / (b - a) : 0.0;
+    }
+    const int64_t groups = (n + 63) / 64, supers = (groups + kSuper - 1) / kSuper, padded = groups * 64;
+    size_t tmp_bytes = 0;
+    unsigned* nullu = nullptr;
+    PGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, nullu, nullu, nullu, nullu, (size_t)n, 0, (unsigned)(m.bits * d), ctx->stream));
+    const size_t arr = ((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, 4 * arr + tmp_bytes + 256));
+    unsigned* k_in = (unsigned*)ctx->fit_scratch.p;
+    unsigned* k_out = (unsigned*)((char*)ctx->fit_scratch.p + arr);
+    unsigned* v_in = (unsigned*)((char*)ctx->fit_scratch.p + 2 * arr);
+    unsigned* v_out = (unsigned*)((char*)ctx->fit_scratch.p + 3 * arr);
+    void* tmp = (char*)ctx->fit_scratch.p + 4 * arr;
+    hipLaunchKernelGGL(sp_keys_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, m, k_in, v_in);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)(m.bits * d), ctx->stream));
+    PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->comp_s, (size_t)n * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->pperm, (size_t)n * sizeof(int)));
+    PGX_TRY(ensure(ctx, ctx->pts_g, (size_t)padded * d * sizeof(double)));
+    PGX_TRY(ensure(ctx, ctx->p32_g, (size_t)padded * 6 * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)(groups + supers) * kGroupRow * sizeof(float)));
+    hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((padded + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, ctx->stream,
+                       ctx->pts.as<double>(), ctx->pts32.as<float>(), ctx->pmax.as<double>(), v_out, n, d, padded, ctx->pperm.as<int>(),
+                       ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->pmax_s.as<double>(), ctx->pts_g.as<double>(),
+                       ctx->p32_g.as<float>());
+    PGX_HIP(ctx, hipGetLastError());
+    const int ib0 = model_type == kPnP ? 2 : 0, ib1 = model_type == kPnP ? 4 : 1, ob0 = model_type == kPnP ? 0 : 2;
+    hipLaunchKernelGGL((sp_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n, d, ib0, ib1, ob0,
+                       ctx->gbounds.as<float>());
+    hipLaunchKernelGGL((sp_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream, ctx->pts_s.as<double>(), n, d,
+                       ib0, ib1, ob0, ctx->gbounds.as<float>() + groups * kGroupRow);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemsetAsync(ctx->comp_s.p, 0, (size_t)n * sizeof(double), ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->point_sort = 1;
+    ctx->comp_dirty = 1;
+    return PGX_OK;
+}
+
+}  // namespace pgx

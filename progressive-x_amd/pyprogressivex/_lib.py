@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "pgx_version", "pgx_device_count", "pgx_global_error", "pgx_create", "pgx_destroy", "pgx_last_error",
     "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_timer_mark", "pgx_timer_elapsed", "pgx_device_info",
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
-    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times",
+    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats",
@@ -265,6 +265,19 @@ class Context:
         self._ck(self._lib.pgx_score_algorithmic_bytes(self._h, C.c_int(1 if want_masks else 0), C.byref(b),
                                                        C.byref(p)), "pgx_score_algorithmic_bytes")
         return b.value, p.value
+
+    def score_debug_fetch(self, what):
+        """pgx_score_debug_fetch: 'order' | 'bounds' | 'rows64' | 'rows32' | 'rows32_sorted' of the resident point set"""
+        d = POINT_DIM[self.model_type]
+        groups = (self.n + 63) // 64
+        supers = (groups + 7) // 8
+        spec = {"order": (0, np.int32, (self.n,)), "bounds": (1, np.float32, (groups + supers, 12)),
+                "rows64": (2, np.float64, (groups, d, 64)), "rows32": (3, np.float32, (groups, 6, 64)),
+                "rows32_sorted": (4, np.float32, (self.n, 8))}[what]
+        out = np.empty(spec[2], dtype=spec[1])
+        self._ck(self._lib.pgx_score_debug_fetch(self._h, C.c_int(spec[0]), out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)),
+                 "pgx_score_debug_fetch")
+        return out
 
     def score_profile(self, on=True):
         self._ck(self._lib.pgx_score_profile(self._h, C.c_int(1 if on else 0)), "pgx_score_profile")

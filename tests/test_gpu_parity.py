@@ -1004,3 +1004,51 @@ def test_greedy_labeling_on_a_real_unary_table_and_error_paths(gpu_ctx, oracle):
         gpu_ctx.greedy_labeling(1.0)
     with pytest.raises(_lib.PgxError, match="negative cost"):
         gpu_ctx.set_unary_q(np.full((10, 2), -1, np.int64))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# pgx_set_points on the device (setpoints.hip) == the host preprocessing of round 1, bit for bit
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,n", [("pnp", 1), ("pnp", 63), ("pnp", 64), ("pnp", 5000), ("pnp", 100003), ("homography", 513),
+                                    ("homography", 20011)])
+def test_set_points_device_equals_host_preprocessing(name, n, monkeypatch, oracle):
+    mt, pts, models, thr = make_case(name, n, 70, seed=n)
+    if n > 1000:
+        pts[7] = pts[3]                       # exact duplicates: the stable sort must keep them in index order
+        pts[11, 0] = pts[:, 0].max() * 3.0    # a far point: the quantisation range
+    T2 = 2.25 * thr * thr
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PGX_SETPOINTS_HOST", mode)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(mt, pts)
+            got[mode] = {k: ctx.score_debug_fetch(k) for k in ("order", "bounds", "rows64", "rows32", "rows32_sorted")}
+            got[mode]["score"] = ctx.score(models, T2, want_masks=True)
+        finally:
+            ctx.close()
+    monkeypatch.delenv("PGX_SETPOINTS_HOST")
+    for k in ("order", "bounds", "rows64", "rows32", "rows32_sorted"):
+        assert np.array_equal(got["0"][k], got["1"][k]), k
+    for k in ("counts", "values", "masks"):
+        assert np.array_equal(got["0"]["score"][k], got["1"]["score"][k]), k
+    ref = oracle.score(mt, pts, models, T2, want_masks=True)
+    assert np.array_equal(got["0"]["score"]["counts"], ref["counts"]) and np.array_equal(got["0"]["score"]["masks"], ref["masks"])
+
+
+def test_set_points_device_non_finite_points_disable_the_sorted_path(oracle):
+    mt, pts, models, thr = make_case("pnp", 3000, 40, seed=9)
+    T2 = 2.25 * thr * thr
+    for bad in (np.nan, np.inf):
+        q = pts.copy()
+        q[17, 3] = bad
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(mt, q)
+            with pytest.raises(_lib.PgxError, match="no sorted copies"):
+                ctx.score_debug_fetch("order")
+            got = ctx.score(models, T2)
+        finally:
+            ctx.close()
+        ref = oracle.score(mt, q, models, T2)
+        assert np.array_equal(got["counts"], ref["counts"])
