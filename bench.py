@@ -186,6 +186,31 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
     finally:
         dense.close()
 
+    # (6) RCCL on the timed path with a single rank (the N > 1 runs are the driver's): launch + all-gather + fetch of the table
+    try:
+        cc = _lib.Context(ctx.device_id)
+        try:
+            cc.score_profile(True)
+            cc.set_points(_lib.PNP, pts)
+            cc.preference(gt_pose0, T2, slot=0)
+            cc.compound_update([0])
+            cc.score_upload(hyps)
+            parallel.init_rccl(cc, 0, 1)
+
+            def step_comm():
+                cc.score_launch(T2, has_compound=True)
+                cc.score_allgather()
+                res = cc.score_fetch_all(exponent=2)
+                return parallel.select_best(res["scores"], res["counts"])
+            s, kt = timed_steps(cc, step_comm, steps, warmup)
+            legs["rccl_single_rank"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s, "kernel_ms": [float(x) for x in kt],
+                                        "step": "launch + ncclAllGather of (count, value, shared) over a 1-rank communicator + fetch + select"}
+            cc.comm_destroy()
+        finally:
+            cc.close()
+    except Exception as e:       # never fail the bench over a secondary leg
+        legs["rccl_single_rank"] = {"error": str(e)}
+
     # (5) Sampson scoring at C3 size and vanishing-point scoring at C5 size: 2048 hypotheses from the device solvers
     for name, mt, make, m, slots, thr in (("c3_sampson", _lib.FUNDAMENTAL, datasets.make_two_view_motions, 7, 3, 0.75),
                                           ("c5_vanishing_point", _lib.VANISHING_POINT, datasets.make_vanishing_points, 2, 1, 1.5)):

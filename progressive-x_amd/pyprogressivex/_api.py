@@ -79,6 +79,13 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         _unknown_sampler(sampler_factory.sampler_id)
         return [], np.zeros(n, dtype=np.int32), None
     ctx = _context()
+    # multi-GPU (one process per GPU, WORLD_SIZE > 1): the proposal batches are sharded over the ranks and the score triples
+    # all-gathered over RCCL (parallel.py); everything else runs replicated, so every rank returns the same result.  All
+    # ranks must draw the same samples: an unset seed is replaced by one the launch agrees on.
+    from . import parallel
+    exchange = parallel.default_exchange(ctx)
+    if exchange is not None and seed is None:
+        seed = parallel.shared_seed()
     rng = np.random.default_rng(seed)
     # FlannNeighborhoodGraph(&points, radius) [U-7]: built on the GPU (pgx_graph_build) and left resident there; the
     # CSR comes back for the neighbourhood samplers.
@@ -106,7 +113,7 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         raise ValueError("labeling_l0 should be 'greedy' or 'expansion'")
     s.labeling_l0 = str(labeling_l0)
     px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
-                              do_logging=do_logging, graph_resident=resident)
+                              do_logging=do_logging, graph_resident=resident, exchange=exchange)
     models, stats = px.run()
     labeling = np.asarray(stats.labeling, dtype=np.int64).astype(np.int32)     # bindings.cpp:152-156
     return models, labeling, stats

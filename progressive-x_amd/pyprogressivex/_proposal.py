@@ -312,14 +312,33 @@ class ProposalEngine:
         samples = self.sampler.draw(int(s.max_iteration_number), est.sample_size)
         if len(samples) == 0:
             return None
-        on_device = est.device_minimal and (self.exchange is None or self.exchange.world == 1)
-        if on_device:
+        sharded = self.exchange is not None and (self.exchange.world > 1 or getattr(self.ctx, "force_comm", False))
+        model_of = None
+        if est.device_minimal and not sharded:
             # hypotheses generated on the GPU from the resident points and scored where they are (no model upload);
             # a degenerate sample is a NaN model: never an inlier, never the winner
             models = self.ctx.solve_minimal(samples)
             src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)
             self.ctx.score_launch(T2, has_compound=has_compound)
             table = self.ctx.score_fetch(exponent)
+        elif est.device_minimal:
+            # multi-GPU: every rank solves and scores ITS slice of the (identical) sample list on its own GPU; one
+            # all-gather of the (count, value, shared) triples gives every rank the whole table, and every rank walks it
+            # the same way.  Models are not exchanged: the few the walk needs are re-solved from their samples (the device
+            # solvers are deterministic, so every rank gets the bits the owning rank scored).
+            from . import parallel
+            ex = self.exchange
+            shard, per, bounds = parallel.shard_samples(np.asarray(samples), ex.world, ex.rank)
+            self.ctx.solve_minimal(shard, fetch=False)
+            self.ctx.score_launch(T2, has_compound=has_compound)
+            table = parallel.merge_sample_tables(ex.gather_scores(self.ctx, exponent), len(samples), ex.world, est.device_slots)
+            src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)
+            models = None
+            smp = np.asarray(samples)
+
+            def model_of(h):
+                s_idx, slot = divmod(int(h), est.device_slots)
+                return np.asarray(self.ctx.solve_minimal(smp[s_idx:s_idx + 1])[slot], dtype=np.float64).copy()
         else:
             models, src = est.minimal(self.pts, samples)
             if len(models) == 0:
@@ -348,7 +367,8 @@ class ProposalEngine:
             if c + 1 < best_count:          # scoring_function_with_compound_model.h:105-106 -> Score(): not considered
                 h += 1
                 continue
-            model, best_score, best_count, it_best = models[h].copy(), float(scores[h]), c, it
+            model = model_of(h) if model_of is not None else models[h].copy()
+            best_score, best_count, it_best = float(scores[h]), c, it
             if every_best and it > lo_after and c > est.sample_size:
                 model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
                                                                           exponent, weights)
@@ -440,8 +460,8 @@ class ProposalEngine:
             if not cands:
                 break
             cands = np.asarray(cands, dtype=np.float64)
-            table = self._score(cands, T2, has_compound, exponent) if len(cands) > 1 else \
-                self.ctx.score(cands, T2, has_compound=has_compound, exponent=exponent)
+            # (multi-GPU: every rank scores the few refits itself - replicas, no exchange)
+            table = self.ctx.score(cands, T2, has_compound=has_compound, exponent=exponent)
             updated = False
             for h in range(len(cands)):
                 if int(table["counts"][h]) > 0 and float(table["scores"][h]) > score:

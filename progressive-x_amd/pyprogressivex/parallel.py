@@ -8,7 +8,7 @@ The reference has no counterpart (single-threaded CPU: progressive_x.h:251-489, 
 
 Data plane: RCCL all-gather inside libpgx.so (pgx_score_allgather), bootstrapped here with a file rendezvous for the
 ncclUniqueId (single node, which is what the launch contract covers).  For CPU tests of this host logic the exchange
-runs over torch.distributed/gloo with an injected scorer.
+runs over torch.distributed/gloo (tests/gloo_exchange.py, a test double outside this package).
 """
 import os
 import time
@@ -178,34 +178,65 @@ class RcclExchange:
         self.ctx = ctx
         self.world, self.rank = ctx.nranks, ctx.rank
 
+    def gather_scores(self, ctx, exponent):
+        """After ctx.score_launch on every rank's shard: the rank-major table of all shards, on every rank."""
+        if self.world == 1 and not getattr(ctx, "force_comm", False):
+            return ctx.score_fetch(exponent)
+        ctx.score_allgather()
+        return ctx.score_fetch_all(exponent)
+
     def score_shard(self, shard, T2, has_compound, exponent):
         self.ctx.score_upload(shard)
         self.ctx.score_launch(T2, has_compound=has_compound)
-        if self.world == 1:
-            return self.ctx.score_fetch(exponent)
-        self.ctx.score_allgather()
-        return self.ctx.score_fetch_all(exponent)
+        return self.gather_scores(self.ctx, exponent)
 
 
-class GlooExchange:
-    """CPU stand-in for tests of the host logic: `scorer(shard) -> dict` is injected, exchange over torch.distributed."""
+_process_exchange = None
 
-    def __init__(self, scorer, world, rank):
-        self.scorer, self.world, self.rank = scorer, world, rank
 
-    def score_shard(self, shard, T2, has_compound, exponent):
-        import torch
-        import torch.distributed as dist
-        local = self.scorer(shard, T2, has_compound, exponent)
-        if self.world == 1:
-            return local
-        out = {}
-        for key in ("counts", "values", "shared", "scores"):
-            t = torch.from_numpy(np.ascontiguousarray(local[key]))
-            parts = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(parts, t)
-            out[key] = torch.cat(parts).numpy()
-        return out
+def default_exchange(ctx):
+    """The exchange the drop-in API uses: None on one GPU; with WORLD_SIZE > 1 (one process per GPU, launched by
+    torch.distributed.run or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE) the node-wide RCCL communicator, created
+    once per process.  PGX_FORCE_COMM=1 puts RCCL on the path with a single rank (tests, bench leg)."""
+    global _process_exchange
+    rank, world, _ = rank_env()
+    force = os.environ.get("PGX_FORCE_COMM") == "1"
+    if world == 1 and not force:
+        return None
+    if _process_exchange is None or _process_exchange.ctx is not ctx:
+        if getattr(ctx, "nranks", 1) != world or not getattr(ctx, "_comm_ready", False):
+            init_rccl(ctx, rank, world)
+            ctx._comm_ready = True
+        ctx.force_comm = force
+        _process_exchange = RcclExchange(ctx)
+    return _process_exchange
+
+
+def shared_seed():
+    """A seed every rank of one launch agrees on without communicating (the API's seed=None in a multi-rank launch)."""
+    import hashlib
+    return int.from_bytes(hashlib.sha256(_launcher_key().encode()).digest()[:8], "little")
+
+
+def shard_samples(samples, world, rank):
+    """Contiguous shard of the sample list for this rank, padded to the common length by repeating the first sample (the
+    padding's hypotheses are cut away when the gathered tables are merged)."""
+    S = samples.shape[0]
+    per, bounds = shard_bounds(S, world)
+    lo, hi = bounds[rank]
+    shard = np.repeat(samples[:1], per, axis=0)
+    shard[: hi - lo] = samples[lo:hi]
+    return np.ascontiguousarray(shard), per, bounds
+
+
+def merge_sample_tables(gathered, S, world, slots):
+    """rank-major tables of per * slots hypotheses per rank -> the S * slots hypotheses in global sample order."""
+    per, bounds = shard_bounds(S, world)
+    out = {}
+    for key in ("counts", "values", "shared", "scores"):
+        arr = np.asarray(gathered[key]).reshape(world, per * slots)
+        out[key] = np.concatenate([arr[r, : (hi - lo) * slots] for r, (lo, hi) in enumerate(bounds)])
+    return out
 
 
 def score_sharded(exchange, models, T2, has_compound=False, exponent=2):

@@ -127,6 +127,24 @@ def test_bundled_tless_poses():
         assert np.median([r[g][1] for r in runs]) <= 3 * rec_mm, runs
 
 
+def test_api_with_rccl_on_the_path_equals_the_plain_api(monkeypatch):
+    """PGX_FORCE_COMM=1: the drop-in API with the multi-GPU data plane switched on for a single rank - every proposal's
+    samples go through shard -> device solve -> score -> RCCL all-gather -> merge, winners re-solved from their samples -
+    returns exactly what the plain single-GPU call returns (the N > 1 merge logic is covered by the world-2 gloo test)."""
+    pts, gt, _ = datasets.make_homographies(n_per_plane=300, n_planes=3, n_outliers=400, seed=5)
+    kw = dict(threshold=3.0, conf=0.99, sampler_id=0, seed=2, minimum_point_number=40)
+    monkeypatch.delenv("PGX_FORCE_COMM", raising=False)
+    H0, lab0 = px.findHomographies(pts, 1000, 1000, 1000, 1000, **kw)
+    monkeypatch.setenv("PGX_FORCE_COMM", "1")
+    H1, lab1 = px.findHomographies(pts, 1000, 1000, 1000, 1000, **kw)
+    x1, x2, K, gtp, poses = datasets.make_poses(n_per_object=500, n_objects=2, n_outliers=300, seed=1)
+    P1, labp1 = px.find6DPoses(x1, x2, K, seed=3, minimum_point_number=30)
+    monkeypatch.delenv("PGX_FORCE_COMM")
+    P0, labp0 = px.find6DPoses(x1, x2, K, seed=3, minimum_point_number=30)
+    assert H0.shape[0] >= 6 and np.array_equal(H0, H1) and np.array_equal(lab0, lab1)
+    assert P0.shape[0] >= 3 and np.array_equal(P0, P1) and np.array_equal(labp0, labp1)
+
+
 def test_switches_ball_graph_and_refit_only_local_optimisation(monkeypatch):
     # neighborhood="radius" -> the exhaustive ball graph (PGX_GRAPH_BALL); local_optimization="lsq" -> no graph cut
     pts, gt, _ = datasets.make_lines(n_per_line=300, n_lines=3, n_outliers=300, seed=4)

@@ -699,6 +699,7 @@ def test_gram_error_paths_and_empty_selection(gpu_ctx):
     out = np.zeros(15)
     cnt, bad = C.c_int64(), C.c_int64()
     idx = np.array([1], np.int32)
+    gpu_ctx.set_weights(None)      # (the wpow = 3 call above had uploaded its weights before failing)
     rc = gpu_ctx._lib.pgx_gram(gpu_ctx._h, C.c_int(_lib.GRAM_AFFINE), None, C.c_int(0), C.c_int(0),
                                idx.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(1), C.c_int(0), C.c_int(1), C.c_int(2),
                                out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(bad))

@@ -19,6 +19,7 @@ import torch.distributed as dist
 import pgx_oracle as O
 from pyprogressivex import parallel
 from helpers import make_case
+from gloo_exchange import GlooExchange
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 mt, pts, models, thr = make_case("pnp", 3000, 37, seed=4)      # 37 hypotheses: ragged shards (19 + 18)
@@ -26,7 +27,7 @@ T2 = 2.25 * thr * thr
 comp = np.linspace(0, 1, 3000)
 def scorer(shard, T2, has_compound, exponent):
     return O.score(mt, pts, shard, T2, compound=comp, has_compound=has_compound, exponent=exponent)
-ex = parallel.GlooExchange(scorer, world, rank)
+ex = GlooExchange(world, rank, scorer)
 table = parallel.score_sharded(ex, models, T2, has_compound=True, exponent=2)
 full = O.score(mt, pts, models, T2, compound=comp, has_compound=True, exponent=2)
 for k in ("counts", "values", "shared", "scores"):
@@ -56,6 +57,68 @@ def test_sharded_scoring_world2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok best" in o for o in outs)
+
+
+WORKER_E2E = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(r"{root}", "progressive-x_amd"), os.path.join(r"{root}", "oracle"), r"{here}"]
+import torch.distributed as dist
+from pyprogressivex import _engine, _estimators, _proposal, datasets
+from oracle_ctx import OracleContext
+from gloo_exchange import GlooExchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+def run(kind, exchange):
+    if kind == "homography":
+        pts, gt, _ = datasets.make_homographies(n_per_plane=200, n_planes=3, n_outliers=300, seed=2)
+        est, thr, lam = _estimators.HomographyEstimator(), 3.0, 0.0
+    else:
+        x1, x2, K, gt, poses = datasets.make_poses(n_per_object=300, n_objects=2, n_outliers=200, seed=3)
+        pts, f = datasets.normalize_pnp(x1, x2, K)
+        est, thr, lam = _estimators.PnPEstimator(), 4.0 / f, 0.0
+    s = _engine.MultiModelSettings()
+    s.minimum_number_of_inliers = 30
+    s.inlier_outlier_threshold = thr
+    s.set_confidence(0.99)
+    s.spatial_coherence_weight = lam
+    s.max_iteration_number = 301                      # odd: ragged sample shards (151 + 150)
+    ctx = OracleContext()
+    rng = np.random.default_rng(5)                    # the same seed on every rank
+    px = _engine.ProgressiveX(ctx, est, pts, None, _proposal.UniformSampler(len(pts), rng), s, exchange=exchange)
+    models, st = px.run()
+    return np.array([m.descriptor for m in models]), np.asarray(st.labeling)
+
+for kind in ("homography", "pnp"):
+    m1, l1 = run(kind, None)                                  # world 1: the whole batch on this "GPU"
+    m2, l2 = run(kind, GlooExchange(world, rank))             # world 2: half of the samples per rank + all-gather
+    assert len(m1) >= 2 and m1.shape == m2.shape and np.array_equal(m1, m2), kind
+    assert np.array_equal(l1, l2), kind
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok e2e")
+'''
+
+
+def test_progressive_x_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """ProposalEngine.run / ProgressiveX.run end to end with the proposal batches sharded over world_size = 2 (every rank
+    solves and scores its slice of the samples, gloo all-gather of the score triples): models and labelling are BITWISE
+    those of the unsharded run, on both ranks."""
+    script = tmp_path / "worker_e2e.py"
+    script.write_text(WORKER_E2E.format(root=ROOT, here=HERE))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok e2e" in o for o in outs)
 
 
 def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
