@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""profile_<tag>.txt (scripts/rocpd_summary.py) -> the PMC constants bench.py quotes (profiles/pmc_current.json):
+FETCH_SIZE / WRITE_SIZE in KiB summed over the kernels of one scoring launch, the VALU-busy fraction of the dominant
+kernel from the SQ pass (SQ_ACTIVE_INST_VALU counts quad-cycles: x4 SIMD-cycles; 1024 SIMDs x kernel cycles at 2.4 GHz)."""
+import json
+import sys
+
+src, committed_as = sys.argv[1], sys.argv[2]
+vals = {}
+for line in open(src):
+    name, parts = line[:50].strip(), line[50:].split()      # fixed-width columns: kernel names contain blanks
+    if len(parts) >= 8 and name.startswith("pgx::score_") and parts[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU"):
+        if ", true, " in name and "group_kernel" in name:
+            continue                                          # the counting variant of pgx_score_stats (never timed)
+        vals[(name.split("<")[0], parts[0])] = (float(parts[1]), float(parts[-1]))
+fetch = sum(v[0] for (k, c), v in vals.items() if c == "FETCH_SIZE")
+write = sum(v[0] for (k, c), v in vals.items() if c == "WRITE_SIZE")
+busy = None
+key = ("pgx::score_group_kernel", "SQ_ACTIVE_INST_VALU")
+if key in vals:
+    quad_cycles, avg_ns = vals[key]
+    busy = quad_cycles * 4.0 / (1024 * avg_ns * 2.4)
+print(json.dumps({"source": committed_as, "fetch_kib": fetch, "write_kib": write, "valu_busy_frac": busy}))
