@@ -464,7 +464,7 @@ int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)
     case 0: b = &ctx->pperm; have = ctx->n * 4; break;
     case 1: b = &ctx->gbounds; have = (groups + supers) * kGroupRow * 4; break;
     case 2: b = &ctx->pts_g; have = groups * 64 * ctx->D * 8; break;
-    case 3: b = &ctx->p32_g; have = groups * 64 * 6 * 4; break;
+    case 3: b = &ctx->p32_g; have = groups * 64 * 8 * 4; break;
     case 4: b = &ctx->pts32_s; have = ctx->n * 8 * 4; break;
     default: return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: unknown buffer %d", what);
     }

@@ -105,8 +105,10 @@ __device__ __forceinline__ float f32_up(double x) { return (float)(x * kInflate)
 
 template <int MT> struct Filter32 {
     static constexpr bool enabled = false;
+    static constexpr int kRowVals = 6;    // floats of a point's f32 row the filter reads
+    static constexpr int kGroupVals = 9;  // floats of a group row the bound test reads
     struct Lane {};
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD&, double) { return {}; }
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD&, double, double) { return {}; }
     static __device__ __forceinline__ bool reject(const float*, const Lane&, float) { return false; }
     static __device__ __forceinline__ bool group_reject(const float*, const Lane&, float) { return false; }
 };
@@ -125,11 +127,14 @@ template <int MT> struct Filter32 {
 
 template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;
-    struct Lane { float m[12]; float c1, c0; float n0, n1, n2; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard32) {
+    static constexpr int kRowVals = 6, kGroupVals = 9;
+    struct Lane { float m[12]; float c1, c0; float n0, n1, n2; float nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard32, double) {
         Lane ln;
+        bool nan = false;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) ln.m[k] = (float)m[k];
+        for (int k = 0; k < 12; ++k) { ln.m[k] = (float)m[k]; nan |= !(m[k] == m[k]); }
+        ln.nanh = nan ? 1.0f : 0.0f;  // a NaN entry makes every residual NaN (all 12 enter it): never an inlier
         ln.n0 = (float)(sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * kGroupInflate);
         ln.n1 = (float)(sqrt(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) * kGroupInflate);
         ln.n2 = (float)(sqrt(m[8] * m[8] + m[9] * m[9] + m[10] * m[10]) * kGroupInflate);
@@ -159,7 +164,10 @@ template <> struct Filter32<kPnP> {
         const float cx = __builtin_fmaf(m[0], g[0], __builtin_fmaf(m[1], g[1], __builtin_fmaf(m[2], g[2], m[3])));
         const float cy = __builtin_fmaf(m[4], g[0], __builtin_fmaf(m[5], g[1], __builtin_fmaf(m[6], g[2], m[7])));
         const float cz = __builtin_fmaf(m[8], g[0], __builtin_fmaf(m[9], g[1], __builtin_fmaf(m[10], g[2], m[11])));
-        if (!(cz == cz)) return true;  // NaN hypothesis: its residuals are NaN, never an inlier
+        // NaN hypothesis: its residuals are NaN, never an inlier.  (Tested on the hypothesis itself: an entry that merely
+        // overflows f32 gives inf - inf = NaN HERE although its f64 residuals may be perfectly good - such a group is kept,
+        // every comparison below being false on NaN.)
+        if (ln.nanh != 0.0f) return true;
         const bool trust = __builtin_fmaf(ln.c1, g[8], ln.c0) <= fabsf(cz);
         const float dz = ln.n2 * g[3], dx = ln.n0 * g[3], dy = ln.n1 * g[3];
         const float zs = fabsf(cz) + dz;
@@ -173,11 +181,14 @@ template <> struct Filter32<kPnP> {
 
 template <> struct Filter32<kHomography> {
     static constexpr bool enabled = true;
-    struct Lane { float m[9]; float c1, c0; float n0, n1, n2; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32) {
+    static constexpr int kRowVals = 6, kGroupVals = 9;
+    struct Lane { float m[9]; float c1, c0; float n0, n1, n2; float nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32, double) {
         Lane ln;
+        bool nan = false;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) ln.m[k] = (float)h[k];
+        for (int k = 0; k < 9; ++k) { ln.m[k] = (float)h[k]; nan |= !(h[k] == h[k]); }
+        ln.nanh = nan ? 1.0f : 0.0f;
         ln.n0 = (float)(sqrt(h[0] * h[0] + h[1] * h[1]) * kGroupInflate);
         ln.n1 = (float)(sqrt(h[3] * h[3] + h[4] * h[4]) * kGroupInflate);
         ln.n2 = (float)(sqrt(h[6] * h[6] + h[7] * h[7]) * kGroupInflate);
@@ -206,7 +217,7 @@ template <> struct Filter32<kHomography> {
         const float cx = __builtin_fmaf(h[0], g[0], __builtin_fmaf(h[1], g[1], h[2]));
         const float cy = __builtin_fmaf(h[3], g[0], __builtin_fmaf(h[4], g[1], h[5]));
         const float cz = __builtin_fmaf(h[6], g[0], __builtin_fmaf(h[7], g[1], h[8]));
-        if (!(cz == cz)) return true;
+        if (ln.nanh != 0.0f) return true;  // NaN entry: every residual is NaN
         const bool trust = __builtin_fmaf(ln.c1, g[8], ln.c0) <= fabsf(cz);
         const float dz = ln.n2 * g[3], dx = ln.n0 * g[3], dy = ln.n1 * g[3];
         const float zs = fabsf(cz) + dz;
@@ -215,6 +226,74 @@ template <> struct Filter32<kHomography> {
         const float my = __builtin_fmaf(g[7], zs, __builtin_fmaf(fabsf(g[5]), dz, dy));
         const float tol = Tup * zs;
         return trust && ((ex - mx > tol) || (ey - my > tol));
+    }
+};
+
+// ---- vanishing points (vanishing_point_estimator.h:166-189) ---------------------------------------------------------------
+// r = |N| / D with N = lx xs + ly ys + lz and D = ||(lx, ly)||, l = m x v (m = the segment's midpoint).  Expanding l gives
+//   N = v0 a + v1 b + v2 c,   a = (ys - ye) / 2,  b = (xe - xs) / 2,  c = (xs ye - xe ys) / 2      (exact identity)
+//   lx = my v2 - v1,  ly = v0 - mx v2
+// so a segment's f32 row holds (a, b, c, mx, my, P, P^2), P = max(|coordinates|, 1) rounded up, and the filter is 17 f32
+// operations without a division or a root.  Error budget (u = 2^-24, eps = 2^-53, tau = 2^-10):
+//   |N~ - N*| <= E_N = 8 u (|v0||a| + |v1||b| + |v2||c|) + 2^-50 |v2| P^2      (inputs rounded to f32, three FMAs; c itself is
+//                                                                              a difference of two f64 products)
+//   ||(lx~, ly~) - (lx*, ly*)|| <= 6 u (P |v2| + |v0| + |v1|) =: E_D
+//   the exact path's own f64 evaluation: |N_c - N*| <= 8 eps (2 P^2 |v2| + 3 P (|v0| + |v1|)) =: E64
+// trust test  D~ >= t(P) = e2 P^2 + e1 P + e0  (constants below) makes E_D <= tau D and E64 <= tau T D; then
+//   reject  <=>  trust  and  m := |N~| - E_N > 0  and  m^2 > T2 (1 + 2^-6) D~^2
+// implies r* = |N*| / D* > T (1 + tau)^3 and the computed r_c >= r* (1 - tau) / (1 + tau) > T: the exact path would not
+// have accepted.  NaN / Inf anywhere make a comparison false: not rejected.
+// Group test: the same quantities on the group's box of ORIENTED, LENGTH-NORMALISED features (a, b, c) / h, h = half the
+// segment length (the residual is h |sin angle(segment, direction to the vanishing point)|): with centre (A, B, C, MX, MY),
+// radii (rA, rB, rC), rM = radius of the midpoints, hmin = the shortest half length,
+//   |N^_i| >= |N^(centre)| - (|v0| rA + |v1| rB + |v2| rC),   D_i <= D(centre) + |v2| rM,
+// and no member is an inlier when hmin (|N^c| - R_N) > T'' (Dc + R_D), under the trust test at Dc - R_D with the group's
+// largest P.  Groups are built from the Morton order of (mx, my, orientation) - setpoints.hip.
+template <> struct Filter32<kVanishingPoint> {
+    static constexpr bool enabled = true;
+    static constexpr int kRowVals = 7, kGroupVals = 12;
+    struct Lane { float v[3]; float e2, e1, e0, e50, t2pp, invT, nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& v, double, double T2) {
+        Lane ln;
+        ln.v[0] = (float)v[0]; ln.v[1] = (float)v[1]; ln.v[2] = (float)v[2];
+        ln.nanh = (v[0] == v[0] && v[1] == v[1] && v[2] == v[2]) ? 0.0f : 1.0f;
+        const double V1 = fabs(v[0]) + fabs(v[1]), V2 = fabs(v[2]), T = sqrt(T2);
+        const double k38 = 3.637978807091713e-12 /* 2^-38 */, k11 = 4.8828125e-4 /* 2^-11 */;
+        ln.e2 = f32_up(k38 * V2 / T * 1.001);
+        ln.e1 = f32_up((k11 * V2 + k38 * V1 / T) * 1.001);
+        ln.e0 = fmaxf(f32_up(k11 * V1 * 1.001), 1e-37f);
+        ln.e50 = f32_up(8.881784197001252e-16 /* 2^-50 */ * V2 * 1.001);
+        ln.t2pp = f32_up(T2 * (1.0 + 1.0 / 64.0));
+        ln.invT = (float)(1.0 / (T * (1.0 + 1.0 / 64.0)) * 0.99999);  // rounded DOWN: 1 / T''
+        return ln;
+    }
+    // p = (a, b, c, mx, my, P, P^2, -) in f32
+    static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float) {
+        const float* v = ln.v;
+        const float N = __builtin_fmaf(v[0], p[0], __builtin_fmaf(v[1], p[1], v[2] * p[2]));
+        const float S = __builtin_fmaf(fabsf(v[0]), fabsf(p[0]), __builtin_fmaf(fabsf(v[1]), fabsf(p[1]), fabsf(v[2]) * fabsf(p[2])));
+        const float lx = __builtin_fmaf(p[4], v[2], -v[1]);
+        const float ly = __builtin_fmaf(-p[3], v[2], v[0]);
+        const float D2 = __builtin_fmaf(lx, lx, ly * ly);
+        const float tt = __builtin_fmaf(ln.e2, p[6], __builtin_fmaf(ln.e1, p[5], ln.e0));
+        const float m = fabsf(N) - __builtin_fmaf(4.76837158203125e-7f /* 8 u */, S, ln.e50 * p[6]);
+        return (D2 >= tt * tt) && (m > 0.0f) && (m * m > ln.t2pp * D2);  // every comparison is false on NaN
+    }
+    // g = (A, B, C, MX, MY, rA, rB, rC, rM, hmin, Pmax, P2max)
+    static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float) {
+        const float* v = ln.v;
+        if (ln.nanh != 0.0f) return true;  // NaN entry in the hypothesis: every residual is NaN, never an inlier
+        const float N = __builtin_fmaf(v[0], g[0], __builtin_fmaf(v[1], g[1], v[2] * g[2]));
+        const float S = __builtin_fmaf(fabsf(v[0]), fabsf(g[0]), __builtin_fmaf(fabsf(v[1]), fabsf(g[1]), fabsf(v[2]) * fabsf(g[2])));
+        const float RN = __builtin_fmaf(fabsf(v[0]), g[5], __builtin_fmaf(fabsf(v[1]), g[6], fabsf(v[2]) * g[7]));
+        const float lx = __builtin_fmaf(g[4], v[2], -v[1]);
+        const float ly = __builtin_fmaf(-g[3], v[2], v[0]);
+        const float D2 = __builtin_fmaf(lx, lx, ly * ly);
+        const float RD = fabsf(v[2]) * g[8] * 1.001f;
+        const float tt = __builtin_fmaf(ln.e2, g[11], __builtin_fmaf(ln.e1, g[10], ln.e0)) + RD;  // trust at Dc - R_D
+        const float L = fabsf(N) - RN * 1.001f - 1.9073486328125e-6f /* 32 u */ * S;
+        const float G = L * g[9] * ln.invT - RD;
+        return (D2 >= tt * tt * 1.001f) && (G > 0.0f) && (G * G > D2 * 1.004f);
     }
 };
 
@@ -254,7 +333,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(
     using F = Filter<MT>;
     using F32 = Filter32<MT>;
     const typename F::Lane flane = F::prep(mdl, guard);
-    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    const typename F32::Lane flane32 = F32::prep(mdl, guard32, T2);
     const double T2d = T2 * (1.0 + kFilterDelta);
     const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
     const float Tup32 = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));  // group test
@@ -401,7 +480,7 @@ __global__ __launch_bounds__(64 * kCullWaves) void score_cull_kernel(
     double mdl[R::P];
 #pragma unroll
     for (int k = 0; k < R::P; ++k) mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
-    const typename F32::Lane flane32 = F32::prep(mdl, guard32);
+    const typename F32::Lane flane32 = F32::prep(mdl, guard32, T2);
     if (seg == 0 && w < W) {
         lane_store(flane32, hyp32 + (int64_t)m * kHypRow);
 #pragma unroll
@@ -421,17 +500,17 @@ __global__ __launch_bounds__(64 * kCullWaves) void score_cull_kernel(
         if (w >= W) continue;
         for (int sgi = 0; sgi < scnt; ++sgi) {
             const int i0 = sgi * kSuper, i1 = i0 + kSuper < cnt ? i0 + kSuper : cnt;
-            float sr[9];
+            float sr[kGroupRow];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) sr[k] = s_gb[kCullTile + sgi][k];  // same address in every lane: LDS broadcast
+            for (int k = 0; k < F32::kGroupVals; ++k) sr[k] = s_gb[kCullTile + sgi][k];  // same address in every lane: LDS broadcast
             if (__ballot(live && !F32::group_reject(sr, flane32, Tup32)) == 0) {  // no hypothesis of the word reaches these 512 points
                 if (lane < i1 - i0) keep[(int64_t)(t0 + i0 + lane) * W + w] = 0;
                 continue;
             }
             for (int i = i0; i < i1; ++i) {
-                float gr[9];
+                float gr[kGroupRow];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) gr[k] = s_gb[i][k];
+                for (int k = 0; k < F32::kGroupVals; ++k) gr[k] = s_gb[i][k];
                 const unsigned long long bm = __ballot(live && !F32::group_reject(gr, flane32, Tup32));
                 if (lane == 0) keep[(int64_t)(t0 + i) * W + w] = bm;
             }
@@ -459,7 +538,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t,
     unsigned long long* __restrict__ stats /* STATS: [0] surviving (hypothesis, group) steps, [1] exact evaluations, [2] inlier pairs */,
     const double* __restrict__ pts_g /* [groups][D][64]: group-blocked SoA copy of the rows (nullptr: AoS) */,
-    const float* __restrict__ p32_g /* [groups][6][64] */,
+    const float* __restrict__ p32_g /* [groups][8][64] */,
     unsigned long long* __restrict__ cand /* [kCandSegs][qcap] global candidate queue (nullptr: exact evaluation in place) */,
     unsigned* __restrict__ cand_cnt /* [kCandSegs * kCandStride] */, int qcap, int nrep)
 {
@@ -504,8 +583,9 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
 #pragma unroll
         for (int q = 0; q < R::D; ++q) pt[q] = pts_g[((int64_t)g * R::D + q) * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) p32[q] = p32_g[((int64_t)g * 6 + q) * 64 + lane];
-        p32[6] = p32[7] = 0.0f;
+        for (int q = 0; q < 8; ++q) p32[q] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < F32::kRowVals; ++q) p32[q] = p32_g[((int64_t)g * 8 + q) * 64 + lane];
     } else {
 #pragma unroll
         for (int q = 0; q < R::D; ++q) pt[q] = pts[jj * R::D + q];
@@ -1015,6 +1095,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         guard32 = 5.5 * 5.9604644775390625e-8 * (1.0 + ctx->umax + T) * 1024.0 / T;
         filt32 = std::isfinite(guard32) && guard32 < 1e30;
     }
+    if constexpr (MT == kVanishingPoint)   // its own trust test per pair, no global guard (Filter32<kVanishingPoint>)
+        filt32 = ctx->filter_enabled == 1 && T > 0.0 && std::isfinite(T) && T2 < 1e30;
     ctx->last_score_filtered = filt32 ? 2 : (filt ? 1 : 0);
     // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
     // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).
@@ -1253,12 +1335,12 @@ int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, cons
         bounds(sg * kSuper * 64, (sg + 1) * kSuper * 64 < n ? (sg + 1) * kSuper * 64 : n, gb.data() + (size_t)(groups + sg) * kGroupRow);
     {   // group-blocked SoA copies for the group-major kernel: [group][coordinate][64]; the tail group repeats its last row
         std::vector<double> pg((size_t)groups * d * 64);
-        std::vector<float> p32g((size_t)groups * 6 * 64);
+        std::vector<float> p32g((size_t)groups * 8 * 64, 0.0f);
         for (int64_t g = 0; g < groups; ++g)
             for (int l = 0; l < 64; ++l) {
                 const int64_t j = g * 64 + l < n ? g * 64 + l : n - 1;
                 for (int k = 0; k < d; ++k) pg[((size_t)g * d + k) * 64 + l] = sp[(size_t)j * d + k];
-                for (int k = 0; k < 6; ++k) p32g[((size_t)g * 6 + k) * 64 + l] = sp32[(size_t)j * 8 + k];
+                for (int k = 0; k < 8; ++k) p32g[((size_t)g * 8 + k) * 64 + l] = sp32[(size_t)j * 8 + k];
             }
         PGX_TRY(ensure(ctx, ctx->pts_g, pg.size() * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->p32_g, p32g.size() * sizeof(float)));

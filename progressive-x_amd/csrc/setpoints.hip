@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kSpBlock) void sp_gather_kernel(const double* __res
     for (int k = 0; k < 8; ++k) {
         const float v = p32[i * 8 + k];
         if (j < n) p32_s[j * 8 + k] = v;
-        if (k < 6) p32_g[(g * 6 + k) * 64 + l] = v;
+        p32_g[(g * 8 + k) * 64 + l] = v;
     }
     if (j < n) { pperm[j] = (int)i; pmax_s[j] = pmax[i]; }
 }
@@ -212,6 +212,121 @@ __global__ __launch_bounds__(SPAN) void sp_bounds_kernel(const double* __restric
     }
 }
 
+// ---- vanishing points: oriented, length-normalised segment features (score.hip Filter32<kVanishingPoint>) ---------------
+struct VpFeat {
+    double a, b, c, mx, my, h, P;
+};
+
+__device__ __forceinline__ VpFeat vp_features(const double* __restrict__ r)
+{
+    VpFeat f;
+    const double dx = r[2] - r[0], dy = r[3] - r[1];
+    const bool flip = dx < 0.0 || (dx == 0.0 && dy < 0.0);   // canonical orientation: N only enters through |N|
+    f.a = (r[1] - r[3]) / 2.0;
+    f.b = (r[2] - r[0]) / 2.0;
+    f.c = (r[0] * r[3] - r[2] * r[1]) / 2.0;
+    if (flip) { f.a = -f.a; f.b = -f.b; f.c = -f.c; }
+    f.mx = (r[0] + r[2]) / 2.0;
+    f.my = (r[1] + r[3]) / 2.0;
+    f.h = 0.5 * sqrt(dx * dx + dy * dy);
+    double P = 1.0;
+    for (int k = 0; k < 4; ++k) { const double v = fabs(r[k]); if (!(v <= P)) P = v; }
+    f.P = P;
+    return f;
+}
+
+// f32 row (a, b, c, mx, my, P, P^2, 0) and the sort key: Morton code of (mx, my, orientation), 10 bits each
+__global__ __launch_bounds__(kSpBlock) void sp_vp_rows_kernel(const double* __restrict__ pts, int64_t n, double x0, double xinv, double y0,
+                                                              double yinv, float* __restrict__ p32, unsigned* __restrict__ keys,
+                                                              unsigned* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (i >= n) return;
+    const VpFeat f = vp_features(pts + i * 4);
+    float* q = p32 + i * 8;
+    q[0] = (float)f.a; q[1] = (float)f.b; q[2] = (float)f.c; q[3] = (float)f.mx; q[4] = (float)f.my;
+    q[5] = (float)(f.P * 1.000001);
+    q[6] = (float)(f.P * f.P * 1.000001);
+    q[7] = 0.0f;
+    // orientation of the canonical direction (b, -a) = (dx, dy) / 2 with dx >= 0: angle in (-pi/2, pi/2]
+    const double th = atan2(-f.a, f.b);
+    const double t[3] = {(f.mx - x0) * xinv, (f.my - y0) * yinv, (th + 1.5707963267948966) * (1024.0 / 3.141592653589793)};
+    unsigned key = 0;
+    for (int k = 0; k < 3; ++k) {
+        unsigned v = t[k] > 0.0 ? (unsigned)t[k] : 0u;
+        if (v > 1023u) v = 1023u;
+        for (int b = 0; b < 10; ++b) key |= ((v >> b) & 1u) << (b * 3 + 2 - k);
+    }
+    keys[i] = key;
+    vals[i] = (unsigned)i;
+}
+
+// group rows (A, B, C, MX, MY, rA, rB, rC, rM, hmin, Pmax, P2max) over SPAN consecutive sorted segments
+template <int SPAN>
+__global__ __launch_bounds__(SPAN) void sp_vp_bounds_kernel(const double* __restrict__ sp, int64_t n, float* __restrict__ rows)
+{
+    __shared__ double s_wlo[SPAN / 64][5], s_whi[SPAN / 64][5];
+    __shared__ float s_c[5];
+    __shared__ unsigned long long s_red[6];   // radii of the 3 features, of the midpoints (squared), max P, max 1/h (as min h)
+    const int64_t j = (int64_t)blockIdx.x * SPAN + threadIdx.x;
+    const bool valid = j < n;
+    if (threadIdx.x < 6) s_red[threadIdx.x] = 0ull;
+    VpFeat f = {0, 0, 0, 0, 0, 1, 1};
+    double feat[5] = {0, 0, 0, 0, 0};
+    if (valid) {
+        f = vp_features(sp + j * 4);
+        feat[0] = f.a / f.h; feat[1] = f.b / f.h; feat[2] = f.c / f.h; feat[3] = f.mx; feat[4] = f.my;   // h = 0: NaN row, never culled
+    }
+    for (int k = 0; k < 5; ++k) {
+        // NaN features must poison the row: min / max by comparisons would skip them, so they are mapped to +-inf first
+        const bool bad = valid && !(feat[k] == feat[k]);
+        double lo = valid ? (bad ? -1.0 / 0.0 : feat[k]) : 1.7976931348623157e308;
+        double hi = valid ? (bad ? 1.0 / 0.0 : feat[k]) : -1.7976931348623157e308;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            if (l2 < lo) lo = l2;
+            if (h2 > hi) hi = h2;
+        }
+        if ((threadIdx.x & 63) == 0) { s_wlo[threadIdx.x >> 6][k] = lo; s_whi[threadIdx.x >> 6][k] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double lo = s_wlo[0][threadIdx.x], hi = s_whi[0][threadIdx.x];
+        for (int w = 1; w < SPAN / 64; ++w) {
+            if (s_wlo[w][threadIdx.x] < lo) lo = s_wlo[w][threadIdx.x];
+            if (s_whi[w][threadIdx.x] > hi) hi = s_whi[w][threadIdx.x];
+        }
+        s_c[threadIdx.x] = (float)(0.5 * (lo + hi));   // -inf + inf = NaN: a degenerate member poisons the centre
+    }
+    __syncthreads();
+    if (valid) {
+        double rm2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double dfk = fabs(feat[k] - (double)s_c[k]);
+            atomicMax(&s_red[k], (unsigned long long)__double_as_longlong(dfk == dfk ? dfk : 1.0 / 0.0));
+        }
+        const double ddx = f.mx - (double)s_c[3], ddy = f.my - (double)s_c[4];
+        rm2 = ddx * ddx + ddy * ddy;
+        atomicMax(&s_red[3], (unsigned long long)__double_as_longlong(rm2 == rm2 ? rm2 : 1.0 / 0.0));
+        atomicMax(&s_red[4], (unsigned long long)__double_as_longlong(f.P == f.P ? f.P : 1.0 / 0.0));
+        const double ih = 1.0 / f.h;   // max of 1 / h = 1 / min h (h = 0 -> inf -> hmin = 0: the test can never fire)
+        atomicMax(&s_red[5], (unsigned long long)__double_as_longlong(ih == ih ? ih : 1.0 / 0.0));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* row = rows + (int64_t)blockIdx.x * kGroupRow;
+        for (int k = 0; k < 5; ++k) row[k] = s_c[k];
+        for (int k = 0; k < 3; ++k) row[5 + k] = (float)(__longlong_as_double((long long)s_red[k]) * kGroupInflate + 1e-30);
+        row[8] = (float)(sqrt(__longlong_as_double((long long)s_red[3])) * kGroupInflate + 1e-30);
+        const double ihmax = __longlong_as_double((long long)s_red[5]);
+        row[9] = ihmax > 0.0 ? (float)(1.0 / ihmax * 0.99999) : 0.0f;   // hmin rounded DOWN
+        const double P = __longlong_as_double((long long)s_red[4]);
+        row[10] = (float)(P * 1.000001);
+        row[11] = (float)(P * P * 1.000001);
+    }
+}
+
 }  // namespace
 
 int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
@@ -244,6 +359,47 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     ctx->fscale = fs > 1.0 ? fs : 1.0;   // NaN coordinates leave it at what the finite ones give; the solvers then produce NaN models
     ctx->point_sort = 0;
     ctx->comp_dirty = 1;
+    if (model_type == kVanishingPoint && ctx->group_filter && ctx->filter_enabled == 1 && !(flags & 1u) && n >= 1) {
+        // ---- segments: f32 feature rows, Morton order of (midpoint, orientation), group rows of the normalised features
+        const double xa = std::fmin(key_f64(st[0]), key_f64(st[2])), xb = std::fmax(key_f64(st[5]), key_f64(st[7]));
+        const double ya = std::fmin(key_f64(st[1]), key_f64(st[3])), yb = std::fmax(key_f64(st[6]), key_f64(st[8]));
+        const int64_t groups = (n + 63) / 64, supers = (groups + kSuper - 1) / kSuper, padded = groups * 64;
+        size_t tmp_bytes = 0;
+        unsigned* nullu = nullptr;
+        PGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, nullu, nullu, nullu, nullu, (size_t)n, 0, 30u, ctx->stream));
+        const size_t arr = ((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255;
+        PGX_TRY(ensure(ctx, ctx->fit_scratch, 4 * arr + tmp_bytes + 256));
+        unsigned* k_in = (unsigned*)ctx->fit_scratch.p;
+        unsigned* k_out = (unsigned*)((char*)ctx->fit_scratch.p + arr);
+        unsigned* v_in = (unsigned*)((char*)ctx->fit_scratch.p + 2 * arr);
+        unsigned* v_out = (unsigned*)((char*)ctx->fit_scratch.p + 3 * arr);
+        void* tmp = (char*)ctx->fit_scratch.p + 4 * arr;
+        hipLaunchKernelGGL(sp_vp_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, xa,
+                           xb > xa ? 1024.0 / (xb - xa) : 0.0, ya, yb > ya ? 1024.0 / (yb - ya) : 0.0, ctx->pts32.as<float>(), k_in, v_in);
+        PGX_HIP(ctx, hipGetLastError());
+        PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, 30u, ctx->stream));
+        PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
+        PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->comp_s, (size_t)n * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->pperm, (size_t)n * sizeof(int)));
+        PGX_TRY(ensure(ctx, ctx->pts_g, (size_t)padded * d * sizeof(double)));
+        PGX_TRY(ensure(ctx, ctx->p32_g, (size_t)padded * 8 * sizeof(float)));
+        PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)(groups + supers) * kGroupRow * sizeof(float)));
+        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((padded + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, ctx->stream,
+                           ctx->pts.as<double>(), ctx->pts32.as<float>(), ctx->pmax.as<double>(), v_out, n, d, padded, ctx->pperm.as<int>(),
+                           ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->pmax_s.as<double>(), ctx->pts_g.as<double>(),
+                           ctx->p32_g.as<float>());
+        hipLaunchKernelGGL((sp_vp_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n,
+                           ctx->gbounds.as<float>());
+        hipLaunchKernelGGL((sp_vp_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream,
+                           ctx->pts_s.as<double>(), n, ctx->gbounds.as<float>() + groups * kGroupRow);
+        PGX_HIP(ctx, hipGetLastError());
+        PGX_HIP(ctx, hipMemsetAsync(ctx->comp_s.p, 0, (size_t)n * sizeof(double), ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->point_sort = 1;
+        return PGX_OK;
+    }
     if (!(obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(ctx->umax)) || (flags & 1u)) return PGX_OK;
 
     // ---- Morton order of all coordinates (stable: ties keep index order), sorted copies, group bounds
@@ -276,7 +432,7 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     PGX_TRY(ensure(ctx, ctx->comp_s, (size_t)n * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pperm, (size_t)n * sizeof(int)));
     PGX_TRY(ensure(ctx, ctx->pts_g, (size_t)padded * d * sizeof(double)));
-    PGX_TRY(ensure(ctx, ctx->p32_g, (size_t)padded * 6 * sizeof(float)));
+    PGX_TRY(ensure(ctx, ctx->p32_g, (size_t)padded * 8 * sizeof(float)));
     PGX_TRY(ensure(ctx, ctx->gbounds, (size_t)(groups + supers) * kGroupRow * sizeof(float)));
     hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((padded + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, ctx->stream,
                        ctx->pts.as<double>(), ctx->pts32.as<float>(), ctx->pmax.as<double>(), v_out, n, d, padded, ctx->pperm.as<int>(),

@@ -272,7 +272,7 @@ class Context:
         groups = (self.n + 63) // 64
         supers = (groups + 7) // 8
         spec = {"order": (0, np.int32, (self.n,)), "bounds": (1, np.float32, (groups + supers, 12)),
-                "rows64": (2, np.float64, (groups, d, 64)), "rows32": (3, np.float32, (groups, 6, 64)),
+                "rows64": (2, np.float64, (groups, d, 64)), "rows32": (3, np.float32, (groups, 8, 64)),
                 "rows32_sorted": (4, np.float32, (self.n, 8))}[what]
         out = np.empty(spec[2], dtype=spec[1])
         self._ck(self._lib.pgx_score_debug_fetch(self._h, C.c_int(spec[0]), out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)),

@@ -138,6 +138,9 @@ def test_score_filter_adversarial(gpu_ctx, oracle, name):
     models[42, 0] = np.inf
     models[43] = gt * 1e150
     models[44] = gt * 1e-150
+    models[45] = gt * 1e150          # entries that overflow f32 with mixed signs: inf - inf inside the f32 bound tests
+    models[45, ::2] *= -1.0
+    models[46] = -gt * 1e150
     gpu_ctx.set_points(mt, pts)
     gpu_ctx.set_compound(None)
     sq0 = oracle.squared_residuals(mt, pts, gt)
@@ -157,6 +160,79 @@ def test_score_filter_adversarial(gpu_ctx, oracle, name):
     got = gpu_ctx.score(models, 2.25 * thr * thr, want_masks=True)
     ref = oracle.score(mt, big, models, 2.25 * thr * thr, want_masks=True)
     assert np.array_equal(got["counts"], ref["counts"]) and np.array_equal(got["masks"], ref["masks"])
+
+
+def test_vanishing_point_filter_and_cull_adversarial(oracle, monkeypatch):
+    """Filter32<kVanishingPoint> + the group test on oriented, length-normalised segment features must never change a
+    result.  Stress: thresholds exactly ON residuals, vanishing points a hair from ground truth, AT a segment's midpoint
+    (D = 0) and at infinity (v2 = 0), zero-length / reversed / duplicated / huge / tiny segments, NaN and Inf, garbage
+    hypotheses, thresholds from 1e-30 to 1e30 - all against the oracle bit for bit, with and without masks, and against
+    the dense kernel (PGX_NO_GROUP=1)."""
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("PGX_NO_GROUP", "1")
+    plain = _lib.Context(0)
+    monkeypatch.delenv("PGX_NO_GROUP")
+    culled = _lib.Context(0)
+    try:
+        for trial in range(10):
+            n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 30011]))
+            mt, pts, models, thr = make_case("vanishing_point", n, 64, seed=500 + trial)
+            pts, models = pts.copy(), models.copy()
+            gt = models[0].copy()
+            for k in range(8, 30):                    # a hair away from ground truth
+                models[k] = gt * (1.0 + rng.normal(0, 10.0 ** rng.uniform(-12, -3), 3))
+            if n >= 1000:
+                pts[5, 2:] = pts[5, :2]               # zero-length segment
+                pts[6] = pts[7][[2, 3, 0, 1]]         # the reverse of its neighbour
+                pts[8:40] = pts[8]                    # duplicates
+                pts[40:50] *= 1e6                     # huge coordinates
+                pts[50:60] *= 1e-6                    # tiny segments near the origin
+                m = 0.5 * (pts[60, :2] + pts[60, 2:])
+                models[30] = np.array([m[0], m[1], 1.0])              # the vanishing point AT a midpoint: D = 0 there
+                models[31] = np.array([m[0], m[1], 1.0]) * (1 + 1e-15)
+            models[32] = np.array([1.0, 0.0, 0.0])    # at infinity
+            models[33] = np.array([0.0, 1.0, 0.0])
+            models[34] = np.array([3.0, -2.0, 1e-300])
+            models[35] = np.nan
+            models[36] = 0.0
+            models[37] = np.array([np.inf, 1.0, 1.0])
+            models[38] = gt * 1e150
+            models[39] = gt * 1e-150
+            models[40:] = rng.normal(0, 1, (models.shape[0] - 40, 3)) * rng.choice([1e-3, 1.0, 1e3], (models.shape[0] - 40, 1))
+            sq0 = oracle.squared_residuals(mt, pts, gt)
+            finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
+            T2s = [2.25 * thr * thr, 1e-30, 1e30]
+            if len(finite):
+                mid = finite[len(finite) // 3]
+                T2s += [mid, np.nextafter(mid, np.inf), np.nextafter(mid, 0), finite[0], finite[-1] * 4]
+            for ctx in (plain, culled):
+                ctx.set_points(mt, pts)
+            if n >= 64:
+                assert culled.score_debug_fetch("order").shape == (n,)     # the sorted path is active
+            for T2 in T2s:
+                ref = oracle.score(mt, pts, models, float(T2), want_masks=True)
+                b = culled.score(models, float(T2), want_masks=True)
+                assert np.array_equal(b["counts"], ref["counts"]), (trial, T2)
+                assert np.array_equal(b["masks"], ref["masks"]), (trial, T2)
+                # sums are 2^-q fixed point (q = 50 for small n): absolute 1e-13, relative 1e-9 on sums of order >= 1
+                assert np.all(np.abs(b["values"] - ref["values"]) <= REL * np.maximum(np.abs(ref["values"]), 1e-4))
+                c = culled.score(models, float(T2))
+                assert np.array_equal(c["counts"], ref["counts"]), (trial, T2, "queued path")
+                assert np.array_equal(c["values"], b["values"])
+                a = plain.score(models, float(T2))
+                assert np.array_equal(a["counts"], ref["counts"])
+        # non-finite data: no sorted copies, the dense kernel answers
+        mt, pts, models, thr = make_case("vanishing_point", 3000, 16, seed=3)
+        pts = pts.copy()
+        pts[17, 1] = np.nan
+        culled.set_points(mt, pts)
+        with pytest.raises(_lib.PgxError, match="no sorted copies"):
+            culled.score_debug_fetch("order")
+        got = culled.score(models, 2.25 * thr * thr)
+        assert np.array_equal(got["counts"], oracle.score(mt, pts, models, 2.25 * thr * thr)["counts"])
+    finally:
+        plain.close()
+        culled.close()
 
 
 @pytest.mark.parametrize("name", ["pnp", "homography"])
