@@ -98,9 +98,10 @@ int pgx_score_algorithmic_bytes(pgx_ctx *ctx, int want_masks, int64_t *bytes, in
  * bound test (64 f32 filter evaluations each), [3] exact FP64 residual evaluations (-1: not counted on this path),
  * [4] inlier pairs, [6] path (1 = every pair visited, 2 = cull + group-major), [7] filter (0 none, 1 f64, 2 f32). */
 int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8]);
-/* Per-kernel HIP-event timing of the scoring launches on the context's stream (bench.py's roofline block): with profiling
- * on, every pgx_score_launch records events around its kernels; pgx_score_kernel_times returns the durations of the last
- * launch in ms: [0] cull (or the chunked kernel), [1] group-major scoring (the dominant kernel; 0 on the chunked path),
+/* Per-kernel HIP-event timing of the scoring launches on the context's stream (bench.py's roofline block).  on = 1: every
+ * pgx_score_launch records two events around its DOMINANT kernel (group-major scoring, or the chunked kernel); on = 2:
+ * events around every kernel of the launch (an event costs ~5 us on the stream, so the breakdown is taken outside timed
+ * regions).  pgx_score_kernel_times returns the durations of the last launch in ms (0 where not recorded): [0] cull (or the chunked kernel), [1] group-major scoring (the dominant kernel; 0 on the chunked path),
  * [2] finish / reduce, [3] exact evaluation of the queued candidates (0 when it runs inside the group-major kernel). */
 int pgx_score_profile(pgx_ctx *ctx, int on);
 /* Diagnostic read-back of what pgx_set_points derived for the score path (tests compare the device preprocessing with the

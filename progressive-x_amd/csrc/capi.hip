@@ -479,7 +479,7 @@ int pgx_score_profile(pgx_ctx* ctx, int on)
     CTX_GUARD(ctx);
     if (on && !ctx->kev[0])
         for (int k = 0; k < 5; ++k) PGX_HIP(ctx, hipEventCreate(&ctx->kev[k]));
-    ctx->score_profile = on ? 1 : 0;
+    ctx->score_profile = on < 0 ? 0 : (on > 2 ? 2 : on);
     return PGX_OK;
 }
 
@@ -487,11 +487,21 @@ int pgx_score_kernel_times(pgx_ctx* ctx, float ms[4])
 {
     CTX_GUARD(ctx);
     if (!ms || !ctx->kev[0] || ctx->last_score_path == 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_kernel_times: no profiled launch");
-    PGX_HIP(ctx, hipEventSynchronize(ctx->kev[3]));
-    PGX_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->kev[0], ctx->kev[1]));
-    PGX_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->kev[1], ctx->kev[2]));
-    PGX_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->kev[4], ctx->kev[3]));
-    PGX_HIP(ctx, hipEventElapsedTime(&ms[3], ctx->kev[2], ctx->kev[4]));
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+    if (ctx->score_profile == 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_kernel_times: profiling is off");
+    if (ctx->last_score_path == 2) {   // cull + group-major
+        PGX_HIP(ctx, hipEventSynchronize(ctx->score_profile >= 2 ? ctx->kev[3] : ctx->kev[2]));
+        PGX_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->kev[1], ctx->kev[2]));
+        if (ctx->score_profile >= 2) {
+            PGX_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->kev[0], ctx->kev[1]));
+            PGX_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->kev[4], ctx->kev[3]));
+            PGX_HIP(ctx, hipEventElapsedTime(&ms[3], ctx->kev[2], ctx->kev[4]));
+        }
+    } else {                           // chunked kernel + reduce
+        PGX_HIP(ctx, hipEventSynchronize(ctx->score_profile >= 2 ? ctx->kev[3] : ctx->kev[1]));
+        PGX_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->kev[0], ctx->kev[1]));
+        if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->kev[4], ctx->kev[3]));
+    }
     return PGX_OK;
 }
 

@@ -1130,7 +1130,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
             PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)nrep * ctx->Mpad * 3 * sizeof(long long) + cnt_bytes, ctx->stream));
-            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
+            if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
                                ctx->cull_lists.as<unsigned long long>(), hyp32, models_t);
@@ -1173,12 +1173,12 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    cand_cnt, qcap, acc, nrep, ctx->score_exact_waves, ctx->score_ablate);
                 PGX_HIP(ctx, hipGetLastError());
             }
-            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream));
+            if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream));
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
                                ctx->Mpad, qscale, ctx->perm.as<int>(), ctx->counts.as<long long>(), ctx->values.as<double>(),
                                ctx->shared.as<double>(), nrep);
             PGX_HIP(ctx, hipGetLastError());
-            if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
+            if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
             ctx->last_score_path = 2;
             return PGX_OK;
         }
@@ -1202,13 +1202,14 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
     }
     PGX_HIP(ctx, hipGetLastError());
-    if (ctx->score_profile) { PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream)); }
+    if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream));
+    if (ctx->score_profile >= 2) { PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream)); PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream)); }
     hipLaunchKernelGGL(score_reduce_kernel, dim3((unsigned)((ctx->M + 63) / 64)), dim3(64 * kReduceWaves), 0,
                        ctx->stream, ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
                        ctx->chunks, ctx->Mpad, ctx->M, ctx->perm.as<int>(), ctx->counts.as<long long>(),
                        ctx->values.as<double>(), ctx->shared.as<double>());
     PGX_HIP(ctx, hipGetLastError());
-    if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
+    if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
     return PGX_OK;
 }
 

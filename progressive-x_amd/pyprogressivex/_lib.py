@@ -279,8 +279,10 @@ class Context:
                  "pgx_score_debug_fetch")
         return out
 
-    def score_profile(self, on=True):
-        self._ck(self._lib.pgx_score_profile(self._h, C.c_int(1 if on else 0)), "pgx_score_profile")
+    def score_profile(self, on=1):
+        """0 off; 1 = HIP events around the dominant scoring kernel only; 2 (or True) = around every kernel of a launch"""
+        level = 2 if on is True else int(on)
+        self._ck(self._lib.pgx_score_profile(self._h, C.c_int(level)), "pgx_score_profile")
 
     def score_kernel_times(self):
         """ms of (cull or chunked kernel, group-major kernel, finish/reduce, exact evaluation of the queued candidates) of
