@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts_g /* [groups][D][64]: group-blocked SoA copy of the rows (nullptr: AoS) */,
     const float* __restrict__ p32_g /* [groups][8][64] */,
     unsigned long long* __restrict__ cand /* [kCandSegs][qcap] global candidate queue (nullptr: exact evaluation in place) */,
-    unsigned* __restrict__ cand_cnt /* [kCandSegs * kCandStride] */, int qcap, int nrep)
+    unsigned* __restrict__ cand_cnt /* [kCandSegs * kCandStride] */, int qcap, int nrep, int dense_min)
 {
     // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
@@ -651,6 +651,42 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
         }
     };
+    // Exact evaluation IN PLACE for one hypothesis: the candidates of this group are the active lanes (point in registers,
+    // the f64 model at a wave-uniform address), per-lane fixed point, one integer shuffle tree, one set of atomics.  Used by
+    // the mask-producing variant for every step and by the queued variant for DENSE steps (>= dense_min candidates of 64):
+    // through the queue such a step would pay the shuffles, the model gather and the segmented reduction per pair for
+    // nothing - its 64 pairs already sit in 64 lanes.  The same per-pair integers as the queued path: bitwise equal sums.
+    auto direct = [&](int m, bool cand) {
+        double sc = 0.0, shv = 0.0;
+        bool inl = false;
+        if (cand) {  // exact path: oracle operation order, no contraction
+            double mdl[R::P];
+#pragma unroll
+            for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
+            const double sq = R::squared(pt, mdl);
+            inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
+            if (STATS) { ++st_exact; if (inl) ++st_inl; }
+            if (inl) {
+                sc = cv_max(0.0, 1.0 - sq / T2);      // :94
+                if (has_comp) shv = cv_min(cmp, sc);  // :115-117
+            }
+        }
+        const unsigned long long bm = __ballot(inl);
+        if (bm == 0) return;
+        // per-lane fixed point first (the same integers the queued path adds up), then an exact integer tree
+        long long val = inl ? to_fixed(sc * qscale) : 0, shq = (inl && has_comp) ? to_fixed(shv * qscale) : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            val += __shfl_down(val, off, 64);
+            shq += __shfl_down(shq, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
+            atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+            if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+            if (MASK) masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
+        }
+    };
     // Hand-over of `c` queued candidates to the global queue (one segment per workgroup id, one reservation per flush): the
     // exact FP64 evaluation then runs in score_exact_kernel with all 64 lanes busy, instead of here where a wave's last
     // batch is on average 40 % full and every batch ends the wave's work with a dependent gather + atomics.  A full
@@ -694,6 +730,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
                 const unsigned long long cm = __ballot(cand);
                 if (cm == 0) return;
                 const int m = w * 64 + h;
+                if (__popcll(cm) >= dense_min) { direct(m, cand); return; }
                 if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
                     ((unsigned)m << 6) | (unsigned)lane;
                 qn += __popcll(cm);
@@ -746,7 +783,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             const bool cand = valid && !F32::reject(p32, ln, T2d32);
             const unsigned long long cm = __ballot(cand);
             if (cm == 0) continue;
-            if (!MASK) {
+            if (!MASK && __popcll(cm) < dense_min) {
                 // the exact path with ~3 of 64 lanes busy per (hypothesis, group) was most of this kernel: candidates
                 // are queued instead and evaluated 64 at a time
                 if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
@@ -763,35 +800,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
                 }
                 continue;
             }
-            double sc = 0.0, shv = 0.0;
-            bool inl = false;
-            if (cand) {  // exact path: oracle operation order, no contraction
-                double mdl[R::P];
-#pragma unroll
-                for (int k = 0; k < R::P; ++k) mdl[k] = models[(int64_t)m * R::P + k];
-                const double sq = R::squared(pt, mdl);
-                inl = sq < T2;  // strict, scoring_function_with_compound_model.h:85
-                if (STATS) { ++st_exact; if (inl) ++st_inl; }
-                if (inl) {
-                    sc = cv_max(0.0, 1.0 - sq / T2);      // :94
-                    if (has_comp) shv = cv_min(cmp, sc);  // :115-117
-                }
-            }
-            const unsigned long long bm = __ballot(inl);
-            if (bm == 0) continue;
-            // per-lane fixed point first (the same integers the queued path adds up), then an exact integer tree
-            long long val = inl ? to_fixed(sc * qscale) : 0, shq = (inl && has_comp) ? to_fixed(shv * qscale) : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                val += __shfl_down(val, off, 64);
-                shq += __shfl_down(shq, off, 64);
-            }
-            if (lane == 0) {
-                atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
-                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
-                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
-                masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
-            }
+            direct(m, cand);
         }
     }
     if (!MASK && qn > 0) {
@@ -1144,7 +1153,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   (unsigned long long*)nullptr, pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep);
+                                   (unsigned long long*)nullptr, pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep, 65);
             } else if (ctx->score_stats) {  // pgx_score_stats: the same launch with work counters (never timed)
                 PGX_TRY(ensure(ctx, ctx->stats_buf, 8 * sizeof(unsigned long long)));
                 PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
@@ -1152,14 +1161,14 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep);
+                                   ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep, ctx->score_dense_min);
             } else {
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                        ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                        ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                        qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                       (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep);
+                                       (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep, ctx->score_dense_min);
                 };
                 if (ctx->score_pipe == 2) launch(score_group_kernel<MT, false, false, 2>);
                 else if (ctx->score_pipe == 1) launch(score_group_kernel<MT, false, false, 1>);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgx.so")
+LIB_PATH = os.environ.get("PGX_LIBPGX") or os.path.join(_HERE, "libpgx.so")   # PGX_LIBPGX: A/B of kernel builds
 
 LINE2D, HOMOGRAPHY, FUNDAMENTAL, PNP, VANISHING_POINT, HOMOGRAPHY_SYM = range(6)
 POINT_DIM = {0: 2, 1: 4, 2: 4, 3: 5, 4: 4, 5: 4}
