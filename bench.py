@@ -127,13 +127,16 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
     #     score -> fetch -> sequential selection.  The number SURVEY 8(f)1 calls end-to-end models/s.
     rng = np.random.default_rng(7)
     S = M // 4
-    inl = [np.nonzero(gt == 1 + k)[0] for k in range(16)]
+    per_obj_min = int(min(np.count_nonzero(gt == 1 + k) for k in range(16)))
+    inl = np.stack([np.nonzero(gt == 1 + k)[0][:per_obj_min] for k in range(16)]) if per_obj_min > 0 else None
 
     def draw():
-        # half of the samples all-inlier (as a converging RANSAC sees them), half uniformly random
+        # half of the samples all-inlier (as a converging RANSAC sees them), half uniformly random; vectorised: the host's
+        # share of a proposal is one RNG call per half
         smp = rng.integers(0, n, (S, 3))
-        for r in range(0, S, 2):
-            smp[r] = rng.choice(inl[(r // 2) % 16], 3, replace=False)
+        if inl is not None:
+            rows = np.arange(0, S, 2)
+            smp[rows] = inl[((rows // 2) % 16)[:, None], rng.integers(0, per_obj_min, (len(rows), 3))]
         return smp.astype(np.int32)
 
     def step_ransac():

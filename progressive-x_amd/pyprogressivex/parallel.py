@@ -81,12 +81,25 @@ def _rendezvous_dir():
     Refuses a directory owned by somebody else or writable by group/others (another local user could pre-create the id
     file and hang the bootstrap or join the ranks to a foreign communicator)."""
     import stat
-    base = os.environ.get("PGX_RDV_DIR") or os.environ.get("XDG_RUNTIME_DIR")
-    if not base:
-        base = os.path.join("/tmp", f"pgx_rdv_{os.getuid()}")
-        os.makedirs(base, mode=0o700, exist_ok=True)
-    st = os.stat(base)
-    if st.st_uid != os.getuid() or (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH)):
+
+    def usable(path):
+        try:
+            st = os.stat(path)
+        except OSError:
+            return False
+        return stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH))
+
+    explicit = os.environ.get("PGX_RDV_DIR")
+    if explicit:
+        if not usable(explicit):
+            raise PermissionError(f"PGX_RDV_DIR={explicit} must exist, be owned by uid {os.getuid()} and not be group/world writable")
+        return explicit
+    xdg = os.environ.get("XDG_RUNTIME_DIR")
+    if xdg and usable(xdg):          # often set but absent inside containers: then fall through
+        return xdg
+    base = os.path.join("/tmp", f"pgx_rdv_{os.getuid()}")
+    os.makedirs(base, mode=0o700, exist_ok=True)
+    if not usable(base):
         raise PermissionError(f"rendezvous directory {base} must be owned by uid {os.getuid()} and not group/world writable")
     return base
 
