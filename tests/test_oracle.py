@@ -480,3 +480,28 @@ def test_greedy_labeling_u8_against_a_python_transcription_and_brute_force(oracl
     D = np.array([[1, 9], [9, 1]], dtype=np.int64) << 32
     assert oracle.greedy_labeling(D, 20 << 32)[0].tolist() == [0, 0]      # a second label is not worth 20
     assert oracle.greedy_labeling(D, 2 << 32)[0].tolist() == [0, 1]
+
+
+def test_round2_golden_vectors(oracle):
+    """tests/golden/kat_r2.npz (make_golden_r2.py): greedy labelling, PROSAC growth function, sampler draws for fixed seeds.
+    Regression fixtures of the build - the reference holds none."""
+    import os
+    from pyprogressivex import _proposal
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_r2.npz"))
+    for k in range(3):
+        lab, e, opened = oracle.greedy_labeling(g[f"greedy{k}_D"], oracle.quantize(float(g[f"greedy{k}_h"][0])))
+        assert np.array_equal(lab, g[f"greedy{k}_labels"]) and e == int(g[f"greedy{k}_energy"][0]) and opened == int(g[f"greedy{k}_opened"][0])
+    gf = _proposal.prosac_growth_function(249, 7, 100000)
+    assert np.array_equal(gf, g["prosac_growth_249_7"])
+    # properties of T'_n: 1 for n <= m, strictly increasing afterwards, T'_N close to T_N (the last subset is drawn T_N times)
+    assert np.all(gf[:7] == 1) and np.all(np.diff(gf[6:]) >= 1) and 0.9e5 < gf[-1] < 1.1e5
+    assert np.array_equal(_proposal.prosac_growth_function(2000, 4, 100000)[::50], g["prosac_growth_2000_4"])
+    assert np.array_equal(_proposal.ProsacSampler(300, np.random.default_rng(1)).draw(400, 4), g["prosac_draw"])
+    pn = _proposal.ProgressiveNapsacSampler(300, np.random.default_rng(2), g["pnapsac_pts"], (640, 480, 640, 480), 4)
+    draw = pn.draw(400, 4)
+    assert np.array_equal(draw, g["pnapsac_draw"])
+    # the first blend * n samples are local: centre k - 1 in the last column, companions from the centre's grid cells
+    assert np.array_equal(draw[:150, 3][:100], np.arange(100))
+    cid, members = pn.cells[-1]                     # coarsest layer (2 cells per dimension)
+    local = sum(set(r[:3]).issubset(set(members[int(cid[r[3]])].tolist())) for r in draw[:150])
+    assert local >= 100                             # the rest fell through to the global PROSAC sampler
