@@ -55,6 +55,7 @@ struct pgx_ctx {
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     pgx::DevBuf pts_g, p32_g;    // group-blocked SoA copies of the sorted rows: [group][coordinate][64] (group-major kernel)
     int setpoints_host = 0;      // PGX_SETPOINTS_HOST=1: round 1's host preprocessing in pgx_set_points (A/B, cross-check)
+    int score_wg = 0;            // PGX_SCORE_WG=1: workgroup variant of the group-major kernel (constants staged once per chunk of groups)
     int score_dense_min = 32;    // steps with at least this many candidates of 64 are evaluated in place, not queued (PGX_SCORE_DENSE; 65 = never)
     int score_exact_waves = 1;   // waves per segment of the candidate queue in score_exact_kernel (PGX_SCORE_EXW)
     int score_cull_segs = 256;   // segments of groups per hypothesis word in the cull kernel (PGX_SCORE_CULL_SEGS; 8192 waves at M = 2048)

@@ -826,6 +826,176 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
 // the residual is the oracle's operation order, every contribution becomes 2^-q fixed point BEFORE any summation and goes
 // to the hypothesis' integer accumulators - the same integers the in-place path adds, so the results do not depend on
 // which path a pair took.
+// ---- workgroup variant of the group-major kernel (PGX_SCORE_WG=1) --------------------------------------------------------
+// What the ablation of score_group_kernel says: a third of its time is per-wave start-up plus the four
+// dependent global -> LDS round trips that stage the constants of a word's survivors, and the exact batches at the end of
+// 125 k short-lived waves are 40 % full.  Here a 4-wave workgroup owns (a chunk of kWgChunk consecutive groups, part p):
+// the f32 constants of ALL of the part's hypotheses are staged in LDS ONCE per workgroup, the waves take groups from an LDS
+// counter, and a wave's candidate queue lives across its groups - a queued pair names (hypothesis, group, lane) and the
+// exact evaluation gathers its point row from the group-blocked copy instead of shuffling registers - so batches are full
+// except the wave's last.  Same per-pair fixed point, same integer atomics: bitwise the results of the other kernels.
+constexpr int kWgChunk = 16;   // groups per workgroup
+constexpr int kWgWaves = 4;
+constexpr int kWgRow = 20;     // floats per hypothesis in LDS (= kHypRow: the rows of hyp32 as they are, 80 bytes)
+
+template <int MT>
+__global__ __launch_bounds__(64 * kWgWaves) void score_group_kernel_wg(
+    const double* __restrict__ comp, int64_t n, int groups, const double* __restrict__ models, int W, int wpp /* words per part */,
+    double T2, int has_comp, const unsigned long long* __restrict__ keep, const float* __restrict__ hyp32, double qscale,
+    unsigned long long* __restrict__ acc, int Mpad, const double* __restrict__ models_t, const double* __restrict__ pts_g,
+    const float* __restrict__ p32_g, int nrep, int dense_min, int parts)
+{
+    using R = Residual<MT>;
+    using F32 = Filter32<MT>;
+    using LaneT = typename F32::Lane;
+    static_assert(sizeof(LaneT) / 4 <= kWgRow, "Filter32 lane constants must fit an LDS row");
+    extern __shared__ float s_dyn[];                       // [wpp * 64][kWgRow] constants of the part's hypotheses
+    __shared__ unsigned s_queue[kWgWaves][128];
+    __shared__ int s_next;
+    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+    const int part = (int)(blockIdx.x % (unsigned)parts), chunk = (int)(blockIdx.x / (unsigned)parts);
+    // this part's words of 64 hypotheses: part, part + parts, ... (INTERLEAVED: the batch is in locality order, a contiguous
+    // range of words would give one part all hypotheses of an object and the other parts nothing to do for its groups)
+    const int nw = part < W ? (W - part + parts - 1) / parts : 0;
+    acc += (size_t)(blockIdx.x % (unsigned)nrep) * 3 * (size_t)Mpad;
+    // stage the constants once (all threads; 64-byte rows)
+    for (int e = (int)threadIdx.x; e < nw * 64 * (kWgRow / 4); e += 64 * kWgWaves) {
+        const int hyp = e / (kWgRow / 4), q4 = e % (kWgRow / 4);
+        const int64_t mg = (int64_t)(part + (hyp >> 6) * parts) * 64 + (hyp & 63);   // global hypothesis of local slot `hyp`
+        const float4 v = *reinterpret_cast<const float4*>(hyp32 + mg * kHypRow + q4 * 4);
+        *reinterpret_cast<float4*>(s_dyn + (size_t)hyp * kWgRow + q4 * 4) = v;
+    }
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
+    const int g0 = chunk * kWgChunk;
+    int qn = 0;
+    // exact evaluation of c queued pairs, one per lane: rows gathered from the group-blocked copies (just read by this wave)
+    auto drain = [&](int c) {
+        const bool act = lane < c;
+        const unsigned e = act ? s_queue[wv][lane] : 0u;
+        const int m = act ? (int)(e >> 10) : -1 - lane;
+        long long cnt = 0, val = 0, shq = 0;
+        if (act) {
+            const int64_t g = g0 + (int)((e >> 6) & 15u);
+            const int sl = (int)(e & 63u);
+            double pt[R::D], mdl[R::P];
+#pragma unroll
+            for (int k = 0; k < R::D; ++k) pt[k] = pts_g[(g * R::D + k) * 64 + sl];
+#pragma unroll
+            for (int k = 0; k < R::P; ++k) mdl[k] = models_t[(int64_t)k * Mpad + m];
+            const double sq = R::squared(pt, mdl);
+            if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
+                const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
+                cnt = 1;
+                val = to_fixed(sc * qscale);
+                if (has_comp) {
+                    const int64_t j = g * 64 + sl < n ? g * 64 + sl : n - 1;
+                    shq = to_fixed(cv_min(comp[j], sc) * qscale);                   // :115-117
+                }
+            }
+        }
+        const int mp = __shfl_up(m, 1, 64);
+        const bool head = lane == 0 || mp != m;
+        const unsigned long long heads = __ballot(head);
+        const int rs = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));  // first lane of this lane's run
+        for (int off = 1; off < 64; off <<= 1) {
+            const int ro = __shfl_down(rs, off, 64);
+            const bool same = lane + off < 64 && ro == rs;
+            if (__ballot(same) == 0) break;
+            const long long c2 = __shfl_down(cnt, off, 64), v2 = __shfl_down(val, off, 64), s2 = __shfl_down(shq, off, 64);
+            if (same) { cnt += c2; val += v2; shq += s2; }
+        }
+        if (act && head && cnt > 0) {
+            atomicAdd(&acc[m], (unsigned long long)cnt);
+            atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+            if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+        }
+    };
+    for (;;) {
+        int gi = 0;
+        if (lane == 0) gi = atomicAdd(&s_next, 1);
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        const int g = g0 + gi;
+        if (gi >= kWgChunk || g >= groups) break;
+        unsigned long long todo[8];   // wpp <= 8 words per part
+        unsigned long long any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { todo[k] = k < nw ? keep[(int64_t)g * W + part + k * parts] : 0ull; any |= todo[k]; }
+        if (any == 0) continue;
+        const int64_t j = (int64_t)g * 64 + lane;
+        const bool valid = j < n;
+        double pt[R::D];
+        float p32[8];
+#pragma unroll
+        for (int q = 0; q < R::D; ++q) pt[q] = pts_g[((int64_t)g * R::D + q) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p32[q] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < F32::kRowVals; ++q) p32[q] = p32_g[((int64_t)g * 8 + q) * 64 + lane];
+        const double cmp = has_comp ? comp[valid ? j : n - 1] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long td = todo[k];
+            while (td != 0) {
+                const int h = __builtin_ctzll(td);
+                td &= td - 1;
+                const int hl = k * 64 + h;              // hypothesis index inside the part
+                const int m = (part + k * parts) * 64 + h;
+                const LaneT ln = lane_load<LaneT>(s_dyn + (size_t)hl * kWgRow);   // LDS broadcast
+                const bool cand = valid && !F32::reject(p32, ln, T2d32);
+                const unsigned long long cm = __ballot(cand);
+                if (cm == 0) continue;
+                if (__popcll(cm) >= dense_min) {        // dense step: in place (same integers as the queued path)
+                    double sc = 0.0, shv = 0.0;
+                    bool inl = false;
+                    if (cand) {
+                        double mdl[R::P];
+#pragma unroll
+                        for (int q = 0; q < R::P; ++q) mdl[q] = models[(int64_t)m * R::P + q];
+                        const double sq = R::squared(pt, mdl);
+                        inl = sq < T2;
+                        if (inl) {
+                            sc = cv_max(0.0, 1.0 - sq / T2);
+                            if (has_comp) shv = cv_min(cmp, sc);
+                        }
+                    }
+                    const unsigned long long bm = __ballot(inl);
+                    if (bm == 0) continue;
+                    long long val = inl ? to_fixed(sc * qscale) : 0, shq = (inl && has_comp) ? to_fixed(shv * qscale) : 0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        val += __shfl_down(val, off, 64);
+                        shq += __shfl_down(shq, off, 64);
+                    }
+                    if (lane == 0) {
+                        atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
+                        atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
+                        if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
+                    }
+                    continue;
+                }
+                if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
+                    ((unsigned)m << 10) | ((unsigned)gi << 6) | (unsigned)lane;
+                qn += __popcll(cm);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    drain(64);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned mv = s_queue[wv][64 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    s_queue[wv][lane] = mv;
+                    qn -= 64;
+                }
+            }
+        }
+    }
+    if (qn > 0) {
+        __builtin_amdgcn_wave_barrier();
+        drain(qn);
+    }
+}
+
 constexpr int kExactUnroll = 4;  // batches of 64 pairs a wave has in flight
 
 template <int MT>
@@ -1170,7 +1340,17 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                        qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
                                        (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep, ctx->score_dense_min);
                 };
-                if (ctx->score_pipe == 2) launch(score_group_kernel<MT, false, false, 2>);
+                const int parts = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
+                const int wpp = (W + parts - 1) / parts;
+                if (ctx->score_wg && !use_queue && pts_g != nullptr && wpp <= 8 && ctx->Mpad < (1 << 22)) {
+                    // workgroup variant: grid = chunks x parts, workgroup id % parts = part (= XCD when parts == 8)
+                    const unsigned chunks = (unsigned)((groups + kWgChunk - 1) / kWgChunk);
+                    hipLaunchKernelGGL((score_group_kernel_wg<MT>), dim3(chunks * (unsigned)parts), dim3(64 * kWgWaves),
+                                       (size_t)wpp * 64 * kWgRow * sizeof(float), ctx->stream, ctx->comp_s.as<double>(), ctx->n, groups,
+                                       ctx->models.as<double>(), W, wpp, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                       qscale, acc, ctx->Mpad, models_t, pts_g, p32_g, nrep, ctx->score_dense_min, parts);
+                }
+                else if (ctx->score_pipe == 2) launch(score_group_kernel<MT, false, false, 2>);
                 else if (ctx->score_pipe == 1) launch(score_group_kernel<MT, false, false, 1>);
                 else launch(score_group_kernel<MT, false, false, 0>);
             }
