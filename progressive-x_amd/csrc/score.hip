@@ -297,6 +297,83 @@ template <> struct Filter32<kVanishingPoint> {
     }
 };
 
+// ---- fundamental matrices: Sampson distance [U-2] (residuals.cuh Residual<kFundamental>) -----------------------------------
+// n(p) = x_b^T F x_a (x_a = (p0, p1, 1), x_b = (p2, p3, 1)) is BILINEAR in the four image coordinates and the Sampson
+// denominator is the squared norm of its gradient: (rxc, ryc, rx, ry) = (dn/dp0, dn/dp1, dn/dp2, dn/dp3).  So the squared
+// residual is n^2 / |grad n|^2 and the filter needs neither the division nor a root: 21 f32 operations per pair.
+// With A4 = |f0| + |f1| + |f3| + |f4|, B4 = |f2| + |f5| + |f6| + |f7|, P = max(|coordinates|, 1) rounded up, u = 2^-24,
+// eta = 2^-126 (an operation that underflows may be flushed), tau = 2^-10:
+//   |n~ - n*| and |n_c - n*| (the exact path's own f64 evaluation) together  <= E_n = 8.5 u (A4 P^2 + B4 P + |f8|) + 16 eta P^2
+//                                   (inputs rounded to f32, at most seven roundings on any of the nine terms)
+//   ||grad~ - grad*|| + ||grad_c - grad*||  <= E_D = 4.1 u (2 A4 P + B4) + 8 eta P      (four components, two FMAs each)
+// trust test  D~ >= t(P) = E_D / tau  gives D_c <= D~ (1 + 1.01 tau)^2 (D~ = ||grad~||), and then
+//   reject  <=>  trust  and  m := |n~| - E_n > 0  and  m^2 > T2 (1 + 2^-6) D~^2
+// implies the computed r_c^2 = fl(fl(n_c^2) / D_c) >= m^2 / (D~^2 (1 + 1.01 tau)^2) (1 - 3 eps) > T2: the exact path would not have
+// accepted.  NaN / Inf make a comparison false: not rejected; a hypothesis with |f_k| Pmax^2 > 1e36 for some entry (a term of
+// n~ could overflow f32 and not the one that cancels it) gets t(P) = inf and is never rejected; one with a NaN entry has NaN
+// residuals everywhere (all nine entries enter n) and is culled outright.
+// Group test: for a member c + d of the group (d1, d2 = the offsets in the two images, |d1| <= r1, |d2| <= r2, |d| <= R),
+//   n(c + d) = n(c) + grad n(c) . d + d2^T A d1,   A = (f0 f1; f3 f4),        grad n(c + d) = grad n(c) + (A^T d2, A d1),
+// so |n| >= |n(c)| - ||grad n(c)|| R - ||A|| r1 r2 and ||grad n|| <= ||grad n(c)|| + ||A|| R: no member is an inlier when
+//   |n~(c)| - E_n - (G + E_D) R - ||A||_F r1 r2  >  T'' (G + E_D + ||A||_F R),   G = ||grad~(c)||,
+// the error terms taken at the group's largest P (the centre lies inside the box), every subtracted term inflated.
+// Groups are 64 consecutive points of the Morton order of all four coordinates (setpoints.hip): 51 % of the (hypothesis,
+// group) pairs of the C3 set are culled (scripts/analysis_sampson_bound.py; per-coordinate extents would give 53 %).
+template <> struct Filter32<kFundamental> {
+    static constexpr bool enabled = true;
+    static constexpr int kRowVals = 7, kGroupVals = 9;
+    struct Lane { float f[9]; float e1, e0, n2, n1, n0, t2pp, nA, nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& f, double pscale2 /* max(|coordinate|, 1)^2 over the point set */, double T2) {
+        Lane ln;
+        bool nan = false, big = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { ln.f[k] = (float)f[k]; nan |= !(f[k] == f[k]); big |= !(fabs(f[k]) * pscale2 <= 1e36); }
+        ln.nanh = nan ? 1.0f : 0.0f;
+        const double A4 = fabs(f[0]) + fabs(f[1]) + fabs(f[3]) + fabs(f[4]), B4 = fabs(f[2]) + fabs(f[5]) + fabs(f[6]) + fabs(f[7]);
+        const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38, itau = 1024.0;
+        ln.e1 = f32_up((4.1 * u * 2.0 * A4 + 8.0 * eta) * itau);
+        ln.e0 = big ? __builtin_inff() : fmaxf(f32_up(4.1 * u * B4 * itau), 1e-12f);
+        ln.n2 = f32_up(8.5 * u * A4 + 16.0 * eta);
+        ln.n1 = f32_up(8.5 * u * B4);
+        ln.n0 = f32_up(8.5 * u * fabs(f[8]));
+        ln.t2pp = f32_up(T2 * (1.0 + 1.0 / 64.0));
+        ln.nA = f32_up(sqrt(f[0] * f[0] + f[1] * f[1] + f[3] * f[3] + f[4] * f[4]) * 1.001);
+        return ln;
+    }
+    // p = (x_a, y_a, x_b, y_b, -, P, P^2, -) in f32
+    static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float) {
+        const float* f = ln.f;
+        const float rxc = __builtin_fmaf(f[0], p[2], __builtin_fmaf(f[3], p[3], f[6]));
+        const float ryc = __builtin_fmaf(f[1], p[2], __builtin_fmaf(f[4], p[3], f[7]));
+        const float rwc = __builtin_fmaf(f[2], p[2], __builtin_fmaf(f[5], p[3], f[8]));
+        const float n = __builtin_fmaf(p[0], rxc, __builtin_fmaf(p[1], ryc, rwc));
+        const float rx = __builtin_fmaf(f[0], p[0], __builtin_fmaf(f[1], p[1], f[2]));
+        const float ry = __builtin_fmaf(f[3], p[0], __builtin_fmaf(f[4], p[1], f[5]));
+        const float D2 = __builtin_fmaf(rxc, rxc, __builtin_fmaf(ryc, ryc, __builtin_fmaf(rx, rx, ry * ry)));
+        const float tt = __builtin_fmaf(ln.e1, p[5], ln.e0);
+        const float m = fabsf(n) - __builtin_fmaf(ln.n2, p[6], __builtin_fmaf(ln.n1, p[5], ln.n0));
+        return (D2 >= tt * tt) && (m > 0.0f) && (m * m > ln.t2pp * D2);  // every comparison is false on NaN
+    }
+    // g = (ca_x, ca_y, cb_x, cb_y, r1, r2, R, Pmax, P2max, -, -, -)
+    static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float Tup) {
+        const float* f = ln.f;
+        if (ln.nanh != 0.0f) return true;  // NaN entry in the hypothesis: every residual is NaN, never an inlier
+        const float rxc = __builtin_fmaf(f[0], g[2], __builtin_fmaf(f[3], g[3], f[6]));
+        const float ryc = __builtin_fmaf(f[1], g[2], __builtin_fmaf(f[4], g[3], f[7]));
+        const float rwc = __builtin_fmaf(f[2], g[2], __builtin_fmaf(f[5], g[3], f[8]));
+        const float n = __builtin_fmaf(g[0], rxc, __builtin_fmaf(g[1], ryc, rwc));
+        const float rx = __builtin_fmaf(f[0], g[0], __builtin_fmaf(f[1], g[1], f[2]));
+        const float ry = __builtin_fmaf(f[3], g[0], __builtin_fmaf(f[4], g[1], f[5]));
+        const float D2 = __builtin_fmaf(rxc, rxc, __builtin_fmaf(ryc, ryc, __builtin_fmaf(rx, rx, ry * ry)));
+        const float ED = __builtin_fmaf(ln.e1, g[7], ln.e0) * 9.765625e-4f /* tau */;   // inf for a hypothesis beyond f32: never culled
+        const float G = __builtin_sqrtf(D2) * 1.001f + ED;
+        const float En = __builtin_fmaf(ln.n2, g[8], __builtin_fmaf(ln.n1, g[7], ln.n0));
+        const float L = fabsf(n) - En - (G * g[6] + ln.nA * g[4] * g[5]) * 1.001f;
+        const float U = __builtin_fmaf(ln.nA, g[6], G) * 1.001f;
+        return L > Tup * U;  // false on NaN / Inf arithmetic
+    }
+};
+
 // FILT: 0 = no filter, 1 = FP64 filter, 2 = FP32 pre-filter
 template <int MT, bool MASK, int FILT>
 __global__ __launch_bounds__(kScoreBlock) void score_kernel(
@@ -1276,6 +1353,10 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     }
     if constexpr (MT == kVanishingPoint)   // its own trust test per pair, no global guard (Filter32<kVanishingPoint>)
         filt32 = ctx->filter_enabled == 1 && T > 0.0 && std::isfinite(T) && T2 < 1e30;
+    if constexpr (MT == kFundamental) {    // likewise; the bounds on T keep T2 * D~^2 (D~ >= 1e-12) inside the f32 normal range
+        filt32 = ctx->filter_enabled == 1 && T2 > 1e-12 && T2 < 1e12 && std::isfinite(ctx->fscale);
+        guard32 = ctx->fscale * ctx->fscale;   // Filter32<kFundamental>::prep: overflow guard of the f32 terms (fscale >= 1)
+    }
     ctx->last_score_filtered = filt32 ? 2 : (filt ? 1 : 0);
     // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
     // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).

@@ -327,6 +327,86 @@ __global__ __launch_bounds__(SPAN) void sp_vp_bounds_kernel(const double* __rest
     }
 }
 
+// ---- fundamental matrices: f32 rows (x_a, y_a, x_b, y_b, 0, P, P^2, 0) and group rows of the 4-D boxes ---------------------
+// (score.hip Filter32<kFundamental>: P = max(|coordinates|, 1) rounded up)
+__global__ __launch_bounds__(kSpBlock) void sp_fund_rows_kernel(const double* __restrict__ pts, int64_t n, float* __restrict__ p32,
+                                                                double* __restrict__ pmax)
+{
+    const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (i >= n) return;
+    double P = 1.0;
+    float* q = p32 + i * 8;
+    for (int k = 0; k < 4; ++k) {
+        const double v = pts[i * 4 + k];
+        q[k] = (float)v;
+        if (!(fabs(v) <= P)) P = fabs(v);
+    }
+    q[4] = 0.0f;
+    q[5] = (float)(P * 1.000001);
+    q[6] = (float)(P * P * 1.000001);
+    q[7] = 0.0f;
+    pmax[i] = P;
+}
+
+// group rows (ca_x, ca_y, cb_x, cb_y, r1, r2, R, Pmax, P2max, 0, 0, 0) over SPAN consecutive sorted correspondences: box centre
+// in f64 -> f32, radii about the STORED f32 centre (r1 / r2: the two images, R: all four coordinates), inflated
+template <int SPAN>
+__global__ __launch_bounds__(SPAN) void sp_fund_bounds_kernel(const double* __restrict__ sp, int64_t n, float* __restrict__ rows)
+{
+    __shared__ double s_wlo[SPAN / 64][4], s_whi[SPAN / 64][4];
+    __shared__ float s_c[4];
+    __shared__ unsigned long long s_red[4];   // r1^2, r2^2, R^2, P
+    const int64_t j = (int64_t)blockIdx.x * SPAN + threadIdx.x;
+    const bool valid = j < n;
+    if (threadIdx.x < 4) s_red[threadIdx.x] = 0ull;
+    double r[4] = {0, 0, 0, 0};
+    if (valid)
+        for (int k = 0; k < 4; ++k) r[k] = sp[j * 4 + k];
+    for (int k = 0; k < 4; ++k) {
+        double lo = valid ? r[k] : 1.7976931348623157e308, hi = valid ? r[k] : -1.7976931348623157e308;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            if (l2 < lo) lo = l2;
+            if (h2 > hi) hi = h2;
+        }
+        if ((threadIdx.x & 63) == 0) { s_wlo[threadIdx.x >> 6][k] = lo; s_whi[threadIdx.x >> 6][k] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double lo = s_wlo[0][threadIdx.x], hi = s_whi[0][threadIdx.x];
+        for (int w = 1; w < SPAN / 64; ++w) {
+            if (s_wlo[w][threadIdx.x] < lo) lo = s_wlo[w][threadIdx.x];
+            if (s_whi[w][threadIdx.x] > hi) hi = s_whi[w][threadIdx.x];
+        }
+        s_c[threadIdx.x] = (float)(0.5 * (lo + hi));
+    }
+    __syncthreads();
+    if (valid) {
+        double d2[4], P = 1.0;
+        for (int k = 0; k < 4; ++k) {
+            const double df = r[k] - (double)s_c[k];
+            d2[k] = df * df;
+            if (fabs(r[k]) > P) P = fabs(r[k]);
+        }
+        const double a = d2[0] + d2[1], b = d2[2] + d2[3];
+        atomicMax(&s_red[0], (unsigned long long)__double_as_longlong(a));
+        atomicMax(&s_red[1], (unsigned long long)__double_as_longlong(b));
+        atomicMax(&s_red[2], (unsigned long long)__double_as_longlong(a + b));
+        atomicMax(&s_red[3], (unsigned long long)__double_as_longlong(P));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* row = rows + (int64_t)blockIdx.x * kGroupRow;
+        for (int k = 0; k < 4; ++k) row[k] = s_c[k];
+        for (int k = 0; k < 3; ++k) row[4 + k] = (float)(sqrt(__longlong_as_double((long long)s_red[k])) * kGroupInflate + 1e-30);
+        const double P = __longlong_as_double((long long)s_red[3]);
+        row[7] = (float)(P * 1.000002);    // >= |stored centre| too: the centre lies in the box up to its f32 rounding
+        row[8] = (float)(P * P * 1.000004);
+        row[9] = row[10] = row[11] = 0.0f;
+    }
+}
+
 }  // namespace
 
 int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
@@ -400,7 +480,13 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
         ctx->point_sort = 1;
         return PGX_OK;
     }
-    if (!(obs0 >= 0 && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(ctx->umax)) || (flags & 1u)) return PGX_OK;
+    const bool fund = model_type == kFundamental;
+    if (!((obs0 >= 0 || fund) && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(ctx->umax)) || (flags & 1u)) return PGX_OK;
+    if (fund) {   // f32 rows of the Sampson filter (the prep kernel left them zero) + the scales
+        hipLaunchKernelGGL(sp_fund_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, ctx->pts32.as<float>(),
+                           ctx->pmax.as<double>());
+        PGX_HIP(ctx, hipGetLastError());
+    }
 
     // ---- Morton order of all coordinates (stable: ties keep index order), sorted copies, group bounds
     MortonArg m;
@@ -440,10 +526,17 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
                        ctx->p32_g.as<float>());
     PGX_HIP(ctx, hipGetLastError());
     const int ib0 = model_type == kPnP ? 2 : 0, ib1 = model_type == kPnP ? 4 : 1, ob0 = model_type == kPnP ? 0 : 2;
-    hipLaunchKernelGGL((sp_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n, d, ib0, ib1, ob0,
-                       ctx->gbounds.as<float>());
-    hipLaunchKernelGGL((sp_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream, ctx->pts_s.as<double>(), n, d,
-                       ib0, ib1, ob0, ctx->gbounds.as<float>() + groups * kGroupRow);
+    if (fund) {
+        hipLaunchKernelGGL((sp_fund_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n,
+                           ctx->gbounds.as<float>());
+        hipLaunchKernelGGL((sp_fund_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream,
+                           ctx->pts_s.as<double>(), n, ctx->gbounds.as<float>() + groups * kGroupRow);
+    } else {
+        hipLaunchKernelGGL((sp_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n, d, ib0, ib1, ob0,
+                           ctx->gbounds.as<float>());
+        hipLaunchKernelGGL((sp_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream, ctx->pts_s.as<double>(), n, d,
+                           ib0, ib1, ob0, ctx->gbounds.as<float>() + groups * kGroupRow);
+    }
     PGX_HIP(ctx, hipGetLastError());
     PGX_HIP(ctx, hipMemsetAsync(ctx->comp_s.p, 0, (size_t)n * sizeof(double), ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));

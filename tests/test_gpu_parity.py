@@ -235,7 +235,100 @@ def test_vanishing_point_filter_and_cull_adversarial(oracle, monkeypatch):
         culled.close()
 
 
-@pytest.mark.parametrize("name", ["pnp", "homography"])
+def test_fundamental_filter_and_cull_adversarial(oracle, monkeypatch):
+    """Filter32<kFundamental> (division-free f32 Sampson test) + the bilinear group bound on the 4-D boxes must never change
+    a result.  Stress: thresholds exactly ON residuals, matrices a hair from ground truth, correspondences AT the two
+    epipoles (zero gradient: 0 / 0), matrices whose gradient vanishes everywhere (only f8) or that are rank 1 / zero /
+    NaN / Inf / 1e+-150 / f32-overflowing with mixed signs, duplicated / huge / tiny coordinates, thresholds from 1e-30 to
+    1e30 (outside [1e-12, 1e12] the library must fall back to the dense kernel) - all against the oracle bit for bit, with
+    and without masks, and against the dense kernel (PGX_NO_GROUP=1)."""
+    rng = np.random.default_rng(13)
+    monkeypatch.setenv("PGX_NO_GROUP", "1")
+    plain = _lib.Context(0)
+    monkeypatch.delenv("PGX_NO_GROUP")
+    culled = _lib.Context(0)
+    try:
+        for trial in range(10):
+            n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 30011]))
+            mt, pts, models, thr = make_case("fundamental", n, 64, seed=700 + trial)
+            pts, models = pts.copy(), models.copy()
+            gt = models[0].copy()
+            for k in range(8, 28):                    # a hair away from ground truth
+                models[k] = gt * (1.0 + rng.normal(0, 10.0 ** rng.uniform(-12, -3), 9))
+            F = gt.reshape(3, 3)
+            ea = np.linalg.svd(F)[2][-1]              # F ea = 0: (rx, ry) vanish at ea in the first image
+            eb = np.linalg.svd(F.T)[2][-1]            # F^T eb = 0: (rxc, ryc, rwc) vanish at eb in the second image
+            if n >= 1000:
+                if abs(ea[2]) > 1e-12 and abs(eb[2]) > 1e-12:
+                    pts[5] = np.concatenate([ea[:2] / ea[2], eb[:2] / eb[2]])     # zero gradient: r^2 = 0 / 0
+                    pts[6, :2] = ea[:2] / ea[2]
+                    pts[7, 2:] = eb[:2] / eb[2]
+                pts[8:40] = pts[8]                    # duplicates
+                pts[40:50] *= 1e6                     # huge coordinates
+                pts[50:60] *= 1e-6
+                pts[60:64, 0] *= 1e10                 # products that overflow f32 once squared
+                if trial % 2:
+                    pts[64:70] *= 1e13                # ... and P^2 Pmax^2 scales that must switch the filter off per hypothesis
+            models[28] = 0.0
+            models[28, 8] = 1.0                       # n = 1 everywhere, zero gradient: r^2 = inf
+            models[29] = np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]).reshape(-1)   # rank 1
+            models[30] = 0.0
+            models[31] = np.nan
+            models[32] = gt
+            models[32, 4] = np.nan
+            models[33] = gt
+            models[33, 2] = np.inf
+            models[34] = gt * 1e150
+            models[35] = gt * 1e-150
+            models[36] = gt * 1e150
+            models[36, ::2] *= -1.0                   # entries that overflow f32 with mixed signs
+            models[37] = gt * 1e33                    # beyond the per-hypothesis overflow guard, finite in f32
+            models[38] = gt * 1e-33
+            models[39] = gt * 1e-43                   # denormal in f32
+            models[40:] = rng.normal(0, 1, (models.shape[0] - 40, 9)) * rng.choice([1e-6, 1e-3, 1.0], (models.shape[0] - 40, 9))
+            sq0 = oracle.squared_residuals(mt, pts, gt)
+            finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
+            T2s = [2.25 * thr * thr, 1e-30, 1e30, 1e-11, 1e11]
+            if len(finite):
+                mid = finite[len(finite) // 3]
+                T2s += [mid, np.nextafter(mid, np.inf), np.nextafter(mid, 0), finite[0], finite[-1] * 4]
+            for ctx in (plain, culled):
+                ctx.set_points(mt, pts)
+            if n >= 64:
+                assert culled.score_debug_fetch("order").shape == (n,)     # the sorted path is active
+            for T2 in T2s:
+                ref = oracle.score(mt, pts, models, float(T2), want_masks=True)
+                b = culled.score(models, float(T2), want_masks=True)
+                assert np.array_equal(b["counts"], ref["counts"]), (trial, T2)
+                assert np.array_equal(b["masks"], ref["masks"]), (trial, T2)
+                assert np.all(np.abs(b["values"] - ref["values"]) <= REL * np.maximum(np.abs(ref["values"]), 1e-4))
+                c = culled.score(models, float(T2))
+                assert np.array_equal(c["counts"], ref["counts"]), (trial, T2, "queued path")
+                if 1e-12 < T2 < 1e12:
+                    assert np.array_equal(c["values"], b["values"])
+                a = plain.score(models, float(T2))
+                assert np.array_equal(a["counts"], ref["counts"])
+        # the filter is in use at ordinary thresholds and not outside its range
+        mt, pts, models, thr = make_case("fundamental", 5000, 16, seed=3)
+        culled.set_points(mt, pts)
+        culled.score_upload(models)
+        st = culled.score_stats(2.25 * thr * thr)
+        assert st["path"] == "cull + group-major" and st["filter"] == "f32" and st["exact_evaluations"] < st["pairs"] // 4
+        assert culled.score_stats(1e-20)["path"] == "every pair"
+        # non-finite data: no sorted copies, the dense kernel answers
+        pts = pts.copy()
+        pts[17, 1] = np.nan
+        culled.set_points(mt, pts)
+        with pytest.raises(_lib.PgxError, match="no sorted copies"):
+            culled.score_debug_fetch("order")
+        got = culled.score(models, 2.25 * thr * thr)
+        assert np.array_equal(got["counts"], oracle.score(mt, pts, models, 2.25 * thr * thr)["counts"])
+    finally:
+        plain.close()
+        culled.close()
+
+
+@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental"])
 def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
     # The group-major path (Morton-sorted points, bound test per 64-point group, fixed-point accumulation) against the
     # plain chunked kernel on data built to stress the bound: wide magnitude ranges, duplicated points, groups of one,
@@ -277,7 +370,7 @@ def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
         culled.close()
 
 
-@pytest.mark.parametrize("name", ["pnp", "homography"])
+@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental"])
 def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch, oracle):
     # per-pair fixed point + integer accumulation: the results of the group-major path do not depend on how many waves share
     # a group, on queue boundaries, on the order in which groups finish, on where a pair is evaluated (in the producing wave
