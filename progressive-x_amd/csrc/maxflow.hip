@@ -26,6 +26,7 @@ struct MaxflowState {
     DevBuf bar;              // grid barrier of the persistent kernels: arrivals | generation (zeroed once)
     int next_stamp = 1;
     int64_t mark_n = 0;
+    int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
 };
 
 constexpr int kMfMaxLabels = 64;
@@ -171,6 +172,7 @@ __device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool li
 // sweep over all sites
 __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
 {
+    if (mf_sweep_idle(v)) return;
     __shared__ SweepLds s;
     sweep_lds_init(s);
     const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_build_list(MfView v, int stamp,
 
 __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp)
 {
+    if (mf_sweep_idle(v)) return;
     __shared__ SweepLds s;
     sweep_lds_init(s);
     const int cnt = v.acnt[parity];
@@ -206,6 +209,61 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, 
         mf_list_append(v, 1 - parity, pushed, fresh);
     }
     mf_sweep_flush(v, cur, true, s, any);
+}
+
+// ---- list-mode sweeps of a SHORT work list: up to `budget` sweeps in one launch of one workgroup --------------------------
+// A list-mode sweep over a few hundred sites is two launches (sweep + one-thread epilogue, ~23 us) for ~3 us of dependent
+// gathers, and a round issues up to 96 of them: at C4 33 400 of the 43 700 sweeps of a find6DPoses call, median list 700
+// sites.  Here ONE workgroup of 1024 threads runs the sweeps back to back - sweep, epilogue by thread 0, next sweep - with
+// workgroup barriers in between: its waves share the CU's vector L1 (write-through, coherent within the workgroup), so
+// plain stores of one sweep are visible to the plain loads of the next after a barrier, and everything contended is an
+// atomic at L2 as before.  No grid barrier, no device-scope fence (the two things that sank the persistent kernels,
+// DESIGN.md 5.4).  The kernel stops when the round is finished (no work left), when a site pushed back into a beta hub
+// (flags[6]: every member must take part again - the host switches to full sweeps), when the list outgrows `cap`, or when
+// the budget is spent; flags[5] = sweeps done.  Same bodies, same rotation of slots / lists / stamps as the host loop: a
+// pure scheduling change (labels are those of the unique minimal sink side either way).  MEASURED: no gain - opt-in only.
+constexpr int kTailBlock = 1024;
+
+__global__ __launch_bounds__(kTailBlock) void mf_k_sweep_tail(MfView v, int sweep_id, int parity, int stamp, int budget, int cap)
+{
+    __shared__ SweepLds s;
+    __shared__ int s_ctl[4];  // list size, stop
+    int done = 0;
+    if (v.has_alpha_hub[0] == 0) {   // (the alpha hub's words are read as uniform gates by the bodies: not in this kernel)
+        for (; done < budget; ++done) {
+            if (threadIdx.x == 0) s_ctl[0] = __hip_atomic_load(&v.acnt[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < kMfMaxLabels) s.min[threadIdx.x] = kMfInf;
+            if (threadIdx.x <= kMfMaxLabels) { s.want[threadIdx.x] = 0; s.got[threadIdx.x] = 0; }
+            if (threadIdx.x == 0) s.pushA = 0;
+            __syncthreads();
+            const int cnt = s_ctl[0];
+            if (cnt > cap) break;
+            const int cur = (sweep_id + done) % 3, prev = (sweep_id + done + 2) % 3, next = (sweep_id + done + 1) % 3;
+            const int st = stamp + 1 + done;
+            const int* __restrict__ in = v.act[parity];
+            bool any = false;
+            const int rounded = (cnt + kTailBlock - 1) / kTailBlock * kTailBlock;
+            for (int i = (int)threadIdx.x; i < rounded; i += kTailBlock) {
+                const int u = i < cnt ? in[i] : -1;
+                int pushed = -1;
+                any |= mf_sweep_step(v, u, prev, cur, true, s, &pushed);
+                const bool again = u >= 0 && mf_listed(v, u) && mf_list_claim(v, u, st);
+                mf_list_append(v, 1 - parity, u, again);
+                const bool fresh = pushed >= 0 && mf_list_claim(v, pushed, st);
+                mf_list_append(v, 1 - parity, pushed, fresh);
+            }
+            const int work = __syncthreads_count(any ? 1 : 0);   // also: every append of this sweep has been issued
+            if (threadIdx.x == 0) {
+                v.flags[1] = work > 0 ? 1 : 0;
+                mf_body_sweep_epilogue(v, cur, next, parity);    // latches flags[4], clears flags[1] and the consumed list
+                s_ctl[1] = (v.flags[4] == 0 || __hip_atomic_load(&v.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+            }
+            parity ^= 1;
+            __syncthreads();
+            if (s_ctl[1]) { ++done; break; }
+        }
+    }
+    if (threadIdx.x == 0) v.flags[5] = done;
 }
 
 // ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
@@ -485,7 +543,7 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
-    case 3: mf_body_sweep_epilogue(v, a0, a1, a2); break;
+    case 3: if (!mf_sweep_idle(v)) mf_body_sweep_epilogue(v, a0, a1, a2); break;
     case 4: mf_body_bfs_finish(v, a0, v.flags[5]); break;  // after mf_k_bfs_persist: the level count is on the device
     }
 }
@@ -678,6 +736,15 @@ struct HipBackend {
         return s;
     }
     void build_list(const MfView& v, int stamp) { site(mf_k_build_list, v, stamp); }
+    int tail_cap = 0;            // longest work list the one-workgroup sweep kernel takes (PGX_MF_TAIL=<sites>; 0 = off, the default:
+                                 // measured equal within noise at 256-512 sites, 3-15 % slower at 1024-2048 - a sweep is a chain of ~10
+                                 // dependent L2 round trips either way)
+    int sweep_tail_cap() const { return tail_cap; }
+    void sweep_tail(const MfView& v, int sweep_id, int parity, int stamp, int budget)
+    {
+        hipLaunchKernelGGL(mf_k_sweep_tail, dim3(1), dim3(kTailBlock), 0, ctx->stream, v, sweep_id, parity, stamp, budget, tail_cap);
+        check();
+    }
     void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
     {
         hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
@@ -902,7 +969,9 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (const char* e = std::getenv("PGX_MF_DEBUG")) tune.debug = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
-    if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) tune.bfs_batch = x; }
+    tune.bfs_hint = st->bfs_hint;
+    if (const char* e = std::getenv("PGX_MF_TAIL")) { const int x = std::atoi(e); if (x >= 0) be.tail_cap = x; }
+    if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) { tune.bfs_batch = x; tune.bfs_hint = nullptr; } }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);
     if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
     if (r != 0)

@@ -281,10 +281,17 @@ PGX_HD void mf_body_bfs_reset(const MfView& v)
     v.flags[0] = 0;
     v.flags[1] = 0;
     v.flags[3] = 0;
+    v.flags[4] = 1;  // "work left": the sweeps of this round run until an epilogue clears it (mf_sweep_idle)
     v.flags[6] = 0;
     v.flags[7] = 0;
     v.acnt[0] = v.acnt[1] = 0;
 }
+
+// The sweeps of a round are enqueued in batches between two flag read-backs.  Once an epilogue has latched "no work left"
+// (no site holds excess that reaches t, no hub can deliver) every later sweep of the round would change nothing: sweep
+// kernels and epilogues leave at once (a plain read: flags[4] was written by an earlier kernel).  Most rounds of the
+// steady-state moves finish within 2-3 sweeps of the 8 a batch issues.
+PGX_HD bool mf_sweep_idle(const MfView& v) { return v.flags[4] == 0; }
 
 // level 1: sites with residual capacity to t.  Returns true iff the site was labelled.
 PGX_HD bool mf_body_bfs_init(const MfView& v, int64_t u, int* hub_acc, int* stage_cnt = nullptr, int* stage_list = nullptr)

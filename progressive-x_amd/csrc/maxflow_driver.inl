@@ -19,6 +19,7 @@ struct MfTuning {
     int wave = 1;             // run the level-ordered wave pass after each global relabel
     int list_div = 8;         // sweeps visit a work list instead of all sites when <= n / list_div sites are active (0 = never)
     int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
+    int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
 // returns 0 on success, 1 if the cap on global relabels was hit
@@ -51,12 +52,20 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         } else {
             // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
             // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
+            // The first batch is sized by the depth of the previous search of the same kind - the first search of a move (from
+            // the initial preflow: deep) or a later one (after the sweeps: a few levels) - which in a steady-state cycle are
+            // about equally deep from move to move; a fixed batch of eight launched most of its levels on empty frontiers
+            // at C5.  A search whose last labelled level is `last` needs the levels 2 .. last + 2.
+            int first = tune.bfs_batch;
+            int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
+            if (hint && *hint > 0) first = *hint + 2 < 64 ? *hint + 2 : 64;
             for (int round = 0;; ++round) {
-                const int batch = round == 0 ? tune.bfs_batch : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
+                const int batch = round == 0 ? first : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
                 for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
                 last = be.read_flag(v, 0);
                 if (last <= level - 2 || level >= v.hmax) break;
             }
+            if (hint) *hint = last > 1 ? last : 1;
             be.bfs_finish(v, slot, level);
             be.count_active(v);
             be.read_flags(v, fl);
@@ -80,8 +89,23 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         const int budget = list_mode ? tune.sweeps_list : tune.sweeps_per_relabel;
         const int stamp = be.take_stamps(v, budget + 2);
         if (list_mode) be.build_list(v, stamp);
-        int parity = 0;
-        for (int s = 0; s < budget; ++s) {
+        int parity = 0, s = 0;
+        bool round_done = false;
+        if (list_mode && be.sweep_tail_cap() > 0 && fl[3] <= be.sweep_tail_cap()) {
+            // short work list: the sweeps run back to back inside one workgroup (maxflow.hip mf_k_sweep_tail) until the
+            // round is finished, the list outgrows the workgroup, a hub comes back into play, or the budget is spent
+            be.sweep_tail(v, sweep_id, parity, stamp, budget);
+            be.read_flags(v, fl);
+            const int done = fl[5];
+            s = done;
+            sweep_id += done;
+            parity ^= done & 1;
+            stats[1] += done;
+            stats[6] += done;
+            if (fl[4] == 0) round_done = true;
+            else if (fl[6] != 0) list_mode = false;
+        }
+        for (; s < budget && !round_done; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
             if (list_mode) {
                 be.sweep_list(v, prev, cur, parity, stamp + 1 + s);

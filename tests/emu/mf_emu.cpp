@@ -42,6 +42,8 @@ struct EmuBackend {
     bool persistent() const { return false; }      // the emulation runs the host-driven level loops
     void bfs_all(const MfView&, int) {}
     void wave_all(const MfView&, int) {}
+    int sweep_tail_cap() const { return 0; }       // device-only scheduling variants
+    void sweep_tail(const MfView&, int, int, int, int) {}
     void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
     void bfs_reset(const MfView& v) { mf_body_bfs_reset(v); }
     void bfs_init(const MfView& v) { each([&](int64_t u) { if (mf_body_bfs_init(v, u, v.bfs_hub_d)) v.flags[0] = 1; }); }
@@ -91,6 +93,7 @@ struct EmuBackend {
     }
     void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
     {
+        if (mf_sweep_idle(v)) return;
         std::vector<int> lst(v.act[parity], v.act[parity] + v.acnt[parity]);
         if (shuffle) std::shuffle(lst.begin(), lst.end(), rng);
         int* out = v.act[1 - parity];
@@ -104,6 +107,7 @@ struct EmuBackend {
     }
     void sweep(const MfView& v, int prev, int cur)
     {
+        if (mf_sweep_idle(v)) return;
         each([&](int64_t u) { if (step(v, u, prev, cur, false, nullptr)) v.flags[1] = 1; });
     }
     void dump(const MfView& v, const char* tag)
@@ -118,7 +122,12 @@ struct EmuBackend {
             std::fprintf(stderr, "  u=%lld l=%d d=%d ex=%lld rt=%lld f=%lld g=%lld\n", (long long)u, v.labels[u], v.d[u], (long long)v.ex[u],
                          (long long)v.rt[u], (long long)v.f[u], (long long)v.g[u]);
     }
-    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { mf_body_sweep_epilogue(v, cur, next, consumed); dump(v, "after sweep"); }
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed)
+    {
+        if (mf_sweep_idle(v)) return;
+        mf_body_sweep_epilogue(v, cur, next, consumed);
+        dump(v, "after sweep");
+    }
     long long stuck_excess(const MfView& v)
     {
         long long s = 0;
