@@ -478,11 +478,14 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent"])
+@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail"])
 def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
     # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
     if forced == "list_sweeps":
         monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
+    if forced == "tail":         # list-mode sweeps back to back inside one workgroup (mf_k_sweep_tail)
+        monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
+        monkeypatch.setenv("PGX_MF_TAIL", "2048")
     if forced == "no_wave":
         monkeypatch.setenv("PGX_MF_WAVE", "0")
         monkeypatch.setenv("PGX_MF_LIST_DIV", "0")
@@ -515,9 +518,12 @@ def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
             labels = ref
 
 
-@pytest.mark.parametrize("list_div", ["8", "1"])
+@pytest.mark.parametrize("list_div", ["8", "1", "tail"])
 @pytest.mark.parametrize("n,lam,h", [(3000, 0.3, 10.0), (3000, 0.0, 10.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0)])
 def test_full_expansion_matches_oracle(gpu_ctx, oracle, n, lam, h, list_div, monkeypatch):
+    if list_div == "tail":       # short work lists swept inside one workgroup; a cap of 300 sites also exercises the hand-back
+        monkeypatch.setenv("PGX_MF_TAIL", "300")
+        list_div = "1"
     monkeypatch.setenv("PGX_MF_LIST_DIV", list_div)
     Dq, graph = realistic_labeling_problem(n, L=6, lam=lam, seed=n)
     lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
@@ -1114,8 +1120,8 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     assert arcs > 4 * n
     gpu_ctx.pearl_unary(poses[:9], 4.0 / f, lam)
     results = []
-    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}):
-        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST"):
+    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}, {"PGX_MF_TAIL": "1024"}):
+        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST", "PGX_MF_TAIL"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
