@@ -82,6 +82,8 @@ class Estimator:
         lockstep, each step is ONE pgx_gram_batch launch.  Returns a list of B model lists."""
         index = np.asarray(index)
         B, m = index.shape
+        if hasattr(self, "_fit_batch"):          # an estimator whose refit is vectorised over the batch (PnP)
+            return self._fit_batch(ctx, index, weights, init)
         gens = [self._fit(init) for _ in range(B)]
         results, pending = [None] * B, {}
         for b, g in enumerate(gens):
@@ -483,6 +485,52 @@ class PnPEstimator(Estimator):
                 break
         out = np.column_stack([R, t])
         return [out.reshape(-1)] if np.isfinite(out).all() else []
+
+
+    def _fit_batch(self, ctx, index, weights, init):
+        """`_fit` for B selections at once (nonminimal_batch): the same Gauss-Newton iteration with the 6x6 solves, the
+        rotation updates and the convergence tests done on [B, ...] arrays - 50 refits x 10 iterations per graph-cut round
+        were 13 us of lstsq + 15 us of small-array numpy each, a third of C4's proposal time.  The solve is the
+        pseudo-inverse with lstsq's cut-off (singular values below eps * 6 * s_max dropped), so a selection's iterates are
+        those of `_fit` up to rounding."""
+        B, m = index.shape
+        if init is None or B == 0:
+            return [[] for _ in range(B)]
+        P0 = np.asarray(init, dtype=np.float64).reshape(3, 4)
+        R = np.broadcast_to(P0[:, :3], (B, 3, 3)).copy()
+        t = np.broadcast_to(P0[:, 3], (B, 3)).copy()
+        running = np.ones(B, dtype=bool)        # still iterating
+        failed = np.zeros(B, dtype=bool)
+        eye = np.eye(3)
+        for _ in range(10):
+            act = np.nonzero(running)[0]
+            if act.size == 0:
+                break
+            prm = np.concatenate([R[act], t[act][:, :, None]], axis=2).reshape(act.size, 12)
+            G, bad = ctx.gram_batch(_lib.GRAM_PNP_GN, index[act], params=prm, weights=weights, wpow=2)
+            A, b = G[:, :6, :6], -G[:, :6, 6]
+            ok = (bad == 0) & np.isfinite(A).all(axis=(1, 2)) & np.isfinite(b).all(axis=1) & (m >= 4)
+            failed[act[~ok]] = True
+            running[act[~ok]] = False
+            if not ok.any():
+                break
+            act, A, b = act[ok], A[ok], b[ok]
+            delta = np.einsum("bij,bj->bi", np.linalg.pinv(A, rcond=6 * np.finfo(np.float64).eps), b)
+            om = delta[:, :3]
+            ang = np.linalg.norm(om, axis=1)
+            k = om / np.where(ang > 0, ang, 1.0)[:, None]
+            Kx = np.zeros((act.size, 3, 3))
+            Kx[:, 0, 1], Kx[:, 0, 2] = -k[:, 2], k[:, 1]
+            Kx[:, 1, 0], Kx[:, 1, 2] = k[:, 2], -k[:, 0]
+            Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 1], k[:, 0]
+            rot = eye + np.sin(ang)[:, None, None] * Kx + (1 - np.cos(ang))[:, None, None] * (Kx @ Kx)
+            rot[ang == 0] = eye                   # R <- exp([omega]_x) R ; t <- t + dt
+            R[act] = rot @ R[act]
+            t[act] = t[act] + delta[:, 3:]
+            running[act[np.linalg.norm(delta, axis=1) < 1e-12]] = False
+        out = np.concatenate([R, t[:, :, None]], axis=2).reshape(B, 12)
+        good = ~failed & np.isfinite(out).all(axis=1)
+        return [[out[b]] if good[b] else [] for b in range(B)]
 
 
 ESTIMATORS = {
