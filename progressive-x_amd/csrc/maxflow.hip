@@ -33,12 +33,13 @@ constexpr int kMfMaxLabels = 64;
 
 __global__ __launch_bounds__(kMfBlock) void mf_k_count(MfView v, int, int)
 {
-    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
-    // per-block LDS histogram, one global atomic per (block, label present)
+    // per-block LDS histogram, one global atomic per (block, label present); grid-stride: same-address atomics cost ~20 ns
+    // each, serialised, so the number of workgroups is capped by the launcher (kAggBlocks)
     __shared__ int hist[kMfMaxLabels];
     if (threadIdx.x < kMfMaxLabels) hist[threadIdx.x] = 0;
     __syncthreads();
-    if (u < v.n) atomicAdd(&hist[v.labels[u]], 1);
+    for (int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x; u < v.n; u += (int64_t)gridDim.x * kMfBlock)
+        atomicAdd(&hist[v.labels[u]], 1);
     __syncthreads();
     if ((int)threadIdx.x < v.L && hist[threadIdx.x] > 0) atomicAdd(&v.cnt[threadIdx.x], hist[threadIdx.x]);
 }
@@ -85,13 +86,17 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     __shared__ int s_min[kMfMaxLabels];
     if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
     __syncthreads();
-    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
-    bool r = false;
-    if (u < v.n) {
-        if (WHAT == kCountActive) r = mf_body_count_active(v, u);
-        else if (WHAT == kApply) r = mf_body_apply(v, u);
+    int mine = 0;   // grid-stride (kAggBlocks workgroups): one set of global atomics per workgroup, not per 256 sites
+    for (int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x; u < v.n; u += (int64_t)gridDim.x * kMfBlock) {
+        if (WHAT == kCountActive) mine += mf_body_count_active(v, u) ? 1 : 0;
+        else if (WHAT == kApply) mine += mf_body_apply(v, u) ? 1 : 0;
     }
-    const int count = __syncthreads_count(r ? 1 : 0);
+    __shared__ int s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    if (mine > 0) atomicAdd(&s_count, mine);
+    __syncthreads();
+    const int count = s_count;
     if (WHAT == kCountActive) {
         if (threadIdx.x == 0 && count > 0) {
             __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -175,8 +180,15 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
     if (mf_sweep_idle(v)) return;
     __shared__ SweepLds s;
     sweep_lds_init(s);
-    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
-    const bool r = mf_sweep_step(v, u < v.n ? u : -1, prev, cur, false, s, nullptr);
+    // grid-stride over 256-site chunks: a workgroup ends with up to L atomicMin on the hub heights (~20 ns each, serialised
+    // per address) - with one workgroup per chunk that was 3 906 of them per label at N = 1e6, most of the 70 us a sweep
+    // over all sites took there (12 k such sweeps per find6DPoses call)
+    bool r = false;
+    const int64_t chunks = (v.n + kMfBlock - 1) / kMfBlock;
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const int64_t u = c * kMfBlock + threadIdx.x;
+        r |= mf_sweep_step(v, u < v.n ? u : -1, prev, cur, false, s, nullptr);
+    }
     mf_sweep_flush(v, cur, false, s, r);
 }
 
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_persist(MfView v, int stage
             int ev = 0;  // mf_bfs_hub_events with device-scope loads (the distances were written earlier in THIS kernel)
             if (v.has_alpha_hub[0] && __hip_atomic_load(&v.bfs_hubA_d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 1;
             for (int l = 0; l < v.L; ++l)
-                if (v.hub_exists[l] && __hip_atomic_load(&v.bfs_hub_d[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 2;
+                if (v.hub_exists[l] == 2 && __hip_atomic_load(&v.bfs_hub_d[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 2;
             s_ctl[1] = ev;
         }
         __syncthreads();
@@ -536,14 +548,49 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
         mf_body_wave(v, v.order[i], k);
 }
 
+// The sweep epilogue (maxflow_body.cuh mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
+// labels through a chain of dependent loads (~5.3 us; at C5 a call ran 80 k of them, 19 % of its GPU time).  Same result.
+__device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed)
+{
+    const int l = (int)threadIdx.x;   // one wave, L <= 64
+    const int prev = (cur + 2) % 3;
+    bool hub_act = false;
+    if (l < v.L) {
+        const int exists = v.hub_exists[l];
+        const long long he = v.hub_e[l];
+        int mc = v.hub_min[cur * v.L + l];
+        if (exists && (consumed >= 0 || he <= 0) && mc == kMfInf) {   // no scan was requested: keep the last known height
+            mc = v.hub_min[prev * v.L + l];
+            v.hub_min[cur * v.L + l] = mc;
+        }
+        v.hub_min[next * v.L + l] = kMfInf;
+        hub_act = exists && he > 0 && mc != kMfInf;
+    }
+    const bool any = __ballot(hub_act) != 0;
+    if (l == 0) {
+        int act = v.flags[1];
+        if (any) act = 1;
+        if (v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.hubA_min[cur] != ~0ull) act = 1;
+        v.hubA_min[next] = ~0ull;
+        v.hubA_want[next] = 0;
+        v.flags[4] = act;
+        v.flags[1] = 0;
+        if (consumed >= 0) v.acnt[consumed] = 0;
+    }
+}
+
 __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    if (what == 3) {   // all 64 lanes
+        if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave(v, a0, a1, a2);
+        return;
+    }
+    if (threadIdx.x != 0) return;
     switch (what) {
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
-    case 3: if (!mf_sweep_idle(v)) mf_body_sweep_epilogue(v, a0, a1, a2); break;
     case 4: mf_body_bfs_finish(v, a0, v.flags[5]); break;  // after mf_k_bfs_persist: the level count is on the device
     }
 }
@@ -644,11 +691,17 @@ struct HipBackend {
         if (e != hipSuccess && err == hipSuccess) err = e;
         return st->h_flags[0];
     }
+    static constexpr unsigned kAggBlocks = 512;   // kernels that end with per-workgroup atomics on a few addresses
+    template <class K> void agg(K k, const MfView& v)
+    {
+        hipLaunchKernelGGL(k, dim3(blocks < kAggBlocks ? blocks : kAggBlocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+        check();
+    }
     void count_and_setup(const MfView& v)
     {
         hipError_t e = hipMemsetAsync(v.cnt, 0, sizeof(int) * (size_t)v.L, ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
-        site(mf_k_count, v);
+        agg(mf_k_count, v);
         single(v, 0);
     }
     int read_count(const MfView& v, int l) { return read_int(v.cnt + l); }
@@ -656,7 +709,7 @@ struct HipBackend {
     void bfs_reset(const MfView& v) { single(v, 1); }
     void bfs_init(const MfView& v)
     {
-        const unsigned g = blocks < 1024u ? blocks : 1024u;
+        const unsigned g = blocks < bfs_init_blocks ? blocks : bfs_init_blocks;
         hipLaunchKernelGGL(mf_k_bfs_init, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
         check();
     }
@@ -721,8 +774,13 @@ struct HipBackend {
                      n_stuck, s_stuck / 4294967296.0, n_exit, s_rt / 4294967296.0, n_relay);
     }
     void bfs_finish(const MfView& v, int slot, int last_level) { single(v, 2, slot, last_level); }
-    void count_active(const MfView& v) { site(mf_k_agg<kCountActive>, v); }
-    void sweep(const MfView& v, int prev, int cur) { site(mf_k_sweep, v, prev, cur); }
+    void count_active(const MfView& v) { agg(mf_k_agg<kCountActive>, v); }
+    unsigned sweep_blocks = 512;     // workgroups of a sweep over all sites (PGX_MF_SWEEP_BLOCKS)
+    void sweep(const MfView& v, int prev, int cur)
+    {
+        hipLaunchKernelGGL(mf_k_sweep, dim3(blocks < sweep_blocks ? blocks : sweep_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur);
+        check();
+    }
     void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { single(v, 3, cur, next, consumed); }
     int take_stamps(const MfView& v, int count)
     {
@@ -736,6 +794,8 @@ struct HipBackend {
         return s;
     }
     void build_list(const MfView& v, int stamp) { site(mf_k_build_list, v, stamp); }
+    unsigned bfs_init_blocks = 256;  // every workgroup ends with one atomic on the level counter and up to L on the hub distances:
+                                     // ~20 ns each, serialised per address (PGX_MF_INIT_BLOCKS)
     int tail_cap = 0;            // longest work list the one-workgroup sweep kernel takes (PGX_MF_TAIL=<sites>; 0 = off, the default:
                                  // measured equal within noise at 256-512 sites, 3-15 % slower at 1024-2048 - a sweep is a chain of ~10
                                  // dependent L2 round trips either way)
@@ -763,7 +823,7 @@ struct HipBackend {
             if (peek(v.hub_exists + l)) { const long long he = peek(v.hub_e + l); if (he > 0) total += he; }
         return total;
     }
-    void apply(const MfView& v) { site(mf_k_agg<kApply>, v); }
+    void apply(const MfView& v) { agg(mf_k_agg<kApply>, v); }
 };
 
 }  // namespace
@@ -800,7 +860,7 @@ static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* change
     const unsigned blocks = (unsigned)((n + kMfBlock - 1) / kMfBlock);
     MfView v{};
     v.n = n; v.L = L; v.alpha = alpha; v.labels = ctx->labels.as<int>(); v.cnt = d_cnt;
-    hipLaunchKernelGGL(mf_k_count, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+    hipLaunchKernelGGL(mf_k_count, dim3(blocks < 512u ? blocks : 512u), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
     hipLaunchKernelGGL(mf_k_l0_reduce, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
                        ctx->labels.as<int>(), n, L, alpha, d_sums);
     PGX_HIP(ctx, hipGetLastError());
@@ -855,7 +915,7 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
         PGX_HIP(ctx, hipMemsetAsync(st->small.p, 0, move_bytes, ctx->stream));
         MfView v{};
         v.n = n; v.L = L; v.alpha = alpha; v.labels = ctx->labels.as<int>(); v.cnt = d_cnt;
-        hipLaunchKernelGGL(mf_k_count, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+        hipLaunchKernelGGL(mf_k_count, dim3(blocks < 512u ? blocks : 512u), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
         hipLaunchKernelGGL(mf_k_l0_reduce, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
                            ctx->labels.as<int>(), n, L, alpha, d_sums);
         hipLaunchKernelGGL(mf_k_l0_apply_dev, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, ctx->dq.as<long long>(),
@@ -970,6 +1030,8 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
     tune.bfs_hint = st->bfs_hint;
+    if (const char* e = std::getenv("PGX_MF_INIT_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_init_blocks = (unsigned)x; }
+    if (const char* e = std::getenv("PGX_MF_SWEEP_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.sweep_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_TAIL")) { const int x = std::atoi(e); if (x >= 0) be.tail_cap = x; }
     if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) { tune.bfs_batch = x; tune.bfs_hint = nullptr; } }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);

@@ -65,7 +65,7 @@ struct MfView {
     long long* g;         // [n] flow sent into the alpha hub (residual of y_alpha -> p)
     // hubs
     int* cnt;                      // [L] label histogram
-    int* hub_exists;               // [L] beta hub present
+    int* hub_exists;               // [L] beta hub present: 1, or 2 once a member pulled from it (only then can a member hold f > 0)
     long long* hub_e;              // [L] beta hub excess
     int* has_alpha_hub;            // [1]
     long long* hubA_rt;            // [1] residual y_alpha -> t
@@ -334,7 +334,7 @@ PGX_HD int mf_bfs_hub_events(const MfView& v, int k)
     int ev = 0;
     if (v.has_alpha_hub[0] && v.bfs_hubA_d[0] == k - 1) ev |= 1;
     for (int l = 0; l < v.L; ++l)
-        if (v.hub_exists[l] && v.bfs_hub_d[l] == k - 1) ev |= 2;
+        if (v.hub_exists[l] == 2 && v.bfs_hub_d[l] == k - 1) ev |= 2;  // == 2: some member holds f > 0 (else the pass over all sites labels nobody)
     return ev;
 }
 
@@ -357,7 +357,10 @@ PGX_HD void mf_body_bfs_finish(const MfView& v, int slot, int last_level)
 // After a global relabel: does site u hold excess that can reach t?
 PGX_HD bool mf_body_count_active(const MfView& v, int64_t u)
 {
-    return v.labels[u] != v.alpha && mf_load64(&v.ex[u]) > 0 && v.d[u] != kMfInf;
+    // plain loads, issued together: everything read here was written by earlier kernels
+    const int lu = v.labels[u], du = v.d[u];
+    const long long e = v.ex[u];
+    return lu != v.alpha && e > 0 && du != kMfInf;
 }
 
 // ---- work lists ---------------------------------------------------------------------------------------------------
@@ -524,7 +527,10 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
     // forward by the epilogue (heights only grow, so a stale value is a valid lower bound: a member may still push back
     // into the hub, which then holds excess and is rescanned).  Sites without excess and without hub business are done.
     if (io->granted > 0) {  // hub -> u (mf_body_pull_want)
-        if (io->which == 1) v.f[u] += io->granted;
+        if (io->which == 1) {
+            v.f[u] += io->granted;
+            if (v.hub_exists[lu] != 2) mf_store32(&v.hub_exists[lu], 2);  // the BFS runs this hub's member pass from now on
+        }
         else mf_add64(&v.g[u], -io->granted);
         mf_add64(&v.ex[u], io->granted);
         work = true;
