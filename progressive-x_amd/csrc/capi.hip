@@ -223,7 +223,7 @@ static int set_points_host(pgx_ctx* ctx, int model_type, const double* points, i
     double umax = 0.0;
     int obs0 = -1, obs1 = -1, in0 = 0, in1 = -1;
     if (model_type == kPnP) { obs0 = 0; obs1 = 1; in0 = 2; in1 = 4; }
-    else if (model_type == kHomography) { obs0 = 2; obs1 = 3; in0 = 0; in1 = 1; }
+    else if (model_type == kHomography || model_type == kHomographySym) { obs0 = 2; obs1 = 3; in0 = 0; in1 = 3; }
     if (obs0 >= 0)
         for (int64_t i = 0; i < n; ++i) {
             const double* r = points + i * d;

@@ -90,6 +90,12 @@ template <> struct Filter<kHomography> {
     }
 };
 
+// Symmetric transfer error, model [H | H^-1]: r^2 = fl(forward + backward) >= the forward term, which is computed in exactly
+// the operation order of Residual<kHomography> (residuals.cuh) - rounding is monotone and the backward term is >= 0 or NaN -
+// so every pair the forward filters prove "not an inlier" is not an inlier of the symmetric residual either: the
+// homography filters are reused on the first nine entries.  (The backward term is not filtered.)
+template <> struct Filter<kHomographySym> : Filter<kHomography> {};
+
 // ---- FP32 pre-filter -------------------------------------------------------------------------------
 // Same inequality evaluated in single precision on f32 copies of the point (one 32-byte row: coords, scale) and of the
 // hypothesis: 18 VALU ops at the f32 rate instead of 17 at the f64 rate.  Error budget: inputs rounded to f32 and three
@@ -179,11 +185,22 @@ template <> struct Filter32<kPnP> {
     }
 };
 
+// Homographies are scored in PIXEL coordinates (|coordinates| ~ 1e3): there the trust test of the PnP filter above (errors
+// <= tau T |t3| with tau = 2^-10) fails for almost every pair - E32 (1 + U) ~ 0.5 px against tau T ~ 0.004 px - and the
+// filter would pass everything on.  So this filter carries its error terms explicitly instead (like the vanishing-point and
+// Sampson filters below): with E_t = 5.5 u (L2 P + t) + 4 eta bounding the f32 error of t1, t2, t3 AND the exact path's own
+// f64 rounding (L2 = largest |h_a| + |h_b| of a row, t = largest |h_c|, P = max(|coordinates|, 1) rounded up),
+//   |a~ - a*| <= E_a = E_t (1 + P) + 1.01 u (P |t3~| + |a~|)        (a = x2 t3 - t1: the product, the rounded x2, the FMA)
+//   reject  <=>  max(|a~| - E_a, 0)^2 + max(|b~| - E_b, 0)^2  >  T2 (1 + 2^-6) (|t3~| + E_t)^2
+// which implies (a*^2 + b*^2) / t3*^2 > T2 (1 + 2^-6)(1 - 8 u) and the computed r_c^2 >= that (1 - 10 eps) > T2.  Overflow of
+// an f32 product makes E_a infinite (it contains P |t3~| and |a~|): inf - inf = NaN, not rejected.  No global guard.
+// Group test: as for PnP with the same explicit terms at the group's scales - |u_i z_i - x_i| >= ex - mx - E_g and
+// |z_i| <= |cz| + dz + E_t, E_g = E_t (1 + |ub|) + 1.01 u (|ub| |cz| + ex).
 template <> struct Filter32<kHomography> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 6, kGroupVals = 9;
-    struct Lane { float m[9]; float c1, c0; float n0, n1, n2; float nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32, double) {
+    struct Lane { float m[9]; float e1, e0; float n0, n1, n2; float nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double, double) {
         Lane ln;
         bool nan = false;
 #pragma unroll
@@ -194,22 +211,26 @@ template <> struct Filter32<kHomography> {
         ln.n2 = (float)(sqrt(h[6] * h[6] + h[7] * h[7]) * kGroupInflate);
         const double l2 = fmax(fabs(h[0]) + fabs(h[1]), fmax(fabs(h[3]) + fabs(h[4]), fabs(h[6]) + fabs(h[7])));
         const double t = fmax(fabs(h[2]), fmax(fabs(h[5]), fabs(h[8])));
-        ln.c1 = f32_up(guard32 * l2);
-        ln.c0 = fmaxf(f32_up(guard32 * t), 1e-30f);
+        const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38;
+        ln.e1 = f32_up(5.5 * u * l2 + 4.0 * eta);
+        ln.e0 = f32_up(5.5 * u * t + eta);
         return ln;
     }
-    // p = (x1, y1, x2, y2, -, scale, -, -) in f32
+    // p = (x1, y1, x2, y2, -, P, -, -) in f32, P = max(|all four coordinates|, 1) rounded up
     static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float T2d) {
         const float* h = ln.m;
         const float t1 = __builtin_fmaf(h[0], p[0], __builtin_fmaf(h[1], p[1], h[2]));
         const float t2 = __builtin_fmaf(h[3], p[0], __builtin_fmaf(h[4], p[1], h[5]));
         const float t3 = __builtin_fmaf(h[6], p[0], __builtin_fmaf(h[7], p[1], h[8]));
-        const float a = __builtin_fmaf(p[2], t3, -t1);
-        const float b = __builtin_fmaf(p[3], t3, -t2);
-        const float lhs = __builtin_fmaf(b, b, a * a);
-        const float rhs = (t3 * t3) * T2d;
-        const bool trust = __builtin_fmaf(ln.c1, p[5], ln.c0) <= fabsf(t3);
-        return trust && (lhs > rhs);
+        const float a = fabsf(__builtin_fmaf(p[2], t3, -t1));
+        const float b = fabsf(__builtin_fmaf(p[3], t3, -t2));
+        const float Et = __builtin_fmaf(ln.e1, p[5], ln.e0);
+        const float at3 = fabsf(t3);
+        const float base = __builtin_fmaf(6.0202e-8f /* 1.01 u */ * p[5], at3, __builtin_fmaf(Et, p[5], Et));
+        const float ma = fmaxf(a - __builtin_fmaf(6.0202e-8f, a, base), 0.0f);   // fmaxf(NaN, 0) = 0: never rejects on its own
+        const float mb = fmaxf(b - __builtin_fmaf(6.0202e-8f, b, base), 0.0f);
+        const float den = at3 + Et;
+        return __builtin_fmaf(mb, mb, ma * ma) > (den * den) * T2d && (base == base);   // NaN / inf error terms: not rejected
     }
     // g = (c1x, c1y, 0, rho, x2b, y2b, r2x, r2y, scale, -, -, -)
     static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float Tup) {
@@ -218,14 +239,18 @@ template <> struct Filter32<kHomography> {
         const float cy = __builtin_fmaf(h[3], g[0], __builtin_fmaf(h[4], g[1], h[5]));
         const float cz = __builtin_fmaf(h[6], g[0], __builtin_fmaf(h[7], g[1], h[8]));
         if (ln.nanh != 0.0f) return true;  // NaN entry: every residual is NaN
-        const bool trust = __builtin_fmaf(ln.c1, g[8], ln.c0) <= fabsf(cz);
+        const float Et = __builtin_fmaf(ln.e1, g[8], ln.e0);
         const float dz = ln.n2 * g[3], dx = ln.n0 * g[3], dy = ln.n1 * g[3];
-        const float zs = fabsf(cz) + dz;
+        const float acz = fabsf(cz);
+        const float zs = acz + dz + Et;
         const float ex = fabsf(__builtin_fmaf(g[4], cz, -cx)), ey = fabsf(__builtin_fmaf(g[5], cz, -cy));
-        const float mx = __builtin_fmaf(g[6], zs, __builtin_fmaf(fabsf(g[4]), dz, dx));
-        const float my = __builtin_fmaf(g[7], zs, __builtin_fmaf(fabsf(g[5]), dz, dy));
+        const float aub = fabsf(g[4]), avb = fabsf(g[5]);
+        const float Egx = __builtin_fmaf(Et, aub, Et) + 6.0202e-8f * __builtin_fmaf(aub, acz, ex);
+        const float Egy = __builtin_fmaf(Et, avb, Et) + 6.0202e-8f * __builtin_fmaf(avb, acz, ey);
+        const float mx = __builtin_fmaf(g[6], zs, __builtin_fmaf(aub, dz, dx)) + Egx;
+        const float my = __builtin_fmaf(g[7], zs, __builtin_fmaf(avb, dz, dy)) + Egy;
         const float tol = Tup * zs;
-        return trust && ((ex - mx > tol) || (ey - my > tol));
+        return (ex - mx * 1.0001f > tol) || (ey - my * 1.0001f > tol);  // false on NaN / inf arithmetic
     }
 };
 
@@ -371,6 +396,57 @@ template <> struct Filter32<kFundamental> {
         const float L = fabsf(n) - En - (G * g[6] + ln.nA * g[4] * g[5]) * 1.001f;
         const float U = __builtin_fmaf(ln.nA, g[6], G) * 1.001f;
         return L > Tup * U;  // false on NaN / Inf arithmetic
+    }
+};
+
+// ---- symmetric transfer error: the homography filter and group bound on the forward part (see Filter<kHomographySym>) --------
+template <> struct Filter32<kHomographySym> : Filter32<kHomography> {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double guard32, double T2) {
+        Lane ln = Filter32<kHomography>::prep(h, guard32, T2);
+        bool nan = false;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) nan |= !(h[k] == h[k]);   // a NaN anywhere (also in the inverse) makes every residual NaN
+        ln.nanh = nan ? 1.0f : 0.0f;
+        return ln;
+    }
+};
+
+// ---- 2-D lines [U-4]: r = |a x + b y + c| (Residual<kLine2D>), inlier iff r^2 < T2 ------------------------------------------------
+// Three f32 FMAs; with P = max(|x|, |y|, 1) rounded up, u = 2^-24, eta = 2^-126:
+//   |n~ - n*| + |n_c - n*| (the exact path's own rounding)  <= E = 4.1 u ((|a| + |b|) P + |c|) + 4 eta P
+//   reject  <=>  m := |n~| - E > T'' = T (1 + 2^-6):  then |n_c| > T (1 + 2^-6) and the computed r_c^2 = fl(n_c^2) > T2.
+// A hypothesis with an entry times the largest P of the set beyond 1e36 gets E = inf (never rejected), one with a NaN entry
+// is culled outright (all three entries enter every residual).  Group test on the 2-D box of 64 Morton-consecutive points
+// (centre, radius R): |n(x)| >= |n(centre)| - ||(a, b)|| R, the error term at the group's largest P.  The dense kernel costs
+// ~10 instructions per pair, so the filter itself buys nothing - the cull does: a line's inliers are a strip of width 2T.
+template <> struct Filter32<kLine2D> {
+    static constexpr bool enabled = true;
+    static constexpr int kRowVals = 6, kGroupVals = 4;
+    struct Lane { float a, b, c, e1, e0, nrm, tpp, nanh; };
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double pscale /* max(|coordinate|, 1) over the set */, double T2) {
+        Lane ln;
+        ln.a = (float)m[0]; ln.b = (float)m[1]; ln.c = (float)m[2];
+        ln.nanh = (m[0] == m[0] && m[1] == m[1] && m[2] == m[2]) ? 0.0f : 1.0f;
+        const bool big = !(fabs(m[0]) * pscale <= 1e36) || !(fabs(m[1]) * pscale <= 1e36) || !(fabs(m[2]) <= 1e36);
+        const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38;
+        ln.e1 = f32_up(4.1 * u * (fabs(m[0]) + fabs(m[1])) + 4.0 * eta);
+        ln.e0 = big ? __builtin_inff() : f32_up(4.1 * u * fabs(m[2]) + eta);
+        ln.nrm = f32_up(sqrt(m[0] * m[0] + m[1] * m[1]) * 1.001);
+        ln.tpp = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
+        return ln;
+    }
+    // p = (x, y, -, -, -, P, -, -) in f32
+    static __device__ __forceinline__ bool reject(const float* p, const Lane& ln, float) {
+        const float n = __builtin_fmaf(ln.a, p[0], __builtin_fmaf(ln.b, p[1], ln.c));
+        const float m = fabsf(n) - __builtin_fmaf(ln.e1, p[5], ln.e0);
+        return m > ln.tpp;  // false on NaN / inf - inf
+    }
+    // g = (cx, cy, R, Pmax)
+    static __device__ __forceinline__ bool group_reject(const float* g, const Lane& ln, float) {
+        if (ln.nanh != 0.0f) return true;  // NaN entry in the hypothesis: every residual is NaN, never an inlier
+        const float n = __builtin_fmaf(ln.a, g[0], __builtin_fmaf(ln.b, g[1], ln.c));
+        const float m = fabsf(n) - __builtin_fmaf(ln.e1, g[3], ln.e0) - ln.nrm * g[2] * 1.001f;
+        return m > ln.tpp * 1.001f;
     }
 };
 
@@ -1353,6 +1429,12 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     }
     if constexpr (MT == kVanishingPoint)   // its own trust test per pair, no global guard (Filter32<kVanishingPoint>)
         filt32 = ctx->filter_enabled == 1 && T > 0.0 && std::isfinite(T) && T2 < 1e30;
+    if constexpr (MT == kHomography || MT == kHomographySym)   // explicit per-pair error terms, no global guard (Filter32<kHomography>)
+        filt32 = ctx->filter_enabled == 1 && T2 > 1e-24 && T2 < 1e24;
+    if constexpr (MT == kLine2D) {         // per-pair error term, no global guard; T'' must be an ordinary f32
+        filt32 = ctx->filter_enabled == 1 && T2 > 1e-24 && T2 < 1e24 && std::isfinite(ctx->fscale);
+        guard32 = ctx->fscale;             // Filter32<kLine2D>::prep: overflow guard (fscale >= 1)
+    }
     if constexpr (MT == kFundamental) {    // likewise; the bounds on T keep T2 * D~^2 (D~ >= 1e-12) inside the f32 normal range
         filt32 = ctx->filter_enabled == 1 && T2 > 1e-12 && T2 < 1e12 && std::isfinite(ctx->fscale);
         guard32 = ctx->fscale * ctx->fscale;   // Filter32<kFundamental>::prep: overflow guard of the f32 terms (fscale >= 1)

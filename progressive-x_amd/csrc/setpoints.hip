@@ -329,15 +329,16 @@ __global__ __launch_bounds__(SPAN) void sp_vp_bounds_kernel(const double* __rest
 
 // ---- fundamental matrices: f32 rows (x_a, y_a, x_b, y_b, 0, P, P^2, 0) and group rows of the 4-D boxes ---------------------
 // (score.hip Filter32<kFundamental>: P = max(|coordinates|, 1) rounded up)
-__global__ __launch_bounds__(kSpBlock) void sp_fund_rows_kernel(const double* __restrict__ pts, int64_t n, float* __restrict__ p32,
-                                                                double* __restrict__ pmax)
+__global__ __launch_bounds__(kSpBlock) void sp_fund_rows_kernel(const double* __restrict__ pts, int64_t n, int d /* 4, or 2 for lines */,
+                                                                float* __restrict__ p32, double* __restrict__ pmax)
 {
     const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
     if (i >= n) return;
     double P = 1.0;
     float* q = p32 + i * 8;
-    for (int k = 0; k < 4; ++k) {
-        const double v = pts[i * 4 + k];
+    for (int k = 0; k < 4; ++k) q[k] = 0.0f;
+    for (int k = 0; k < d; ++k) {
+        const double v = pts[i * d + k];
         q[k] = (float)v;
         if (!(fabs(v) <= P)) P = fabs(v);
     }
@@ -407,6 +408,56 @@ __global__ __launch_bounds__(SPAN) void sp_fund_bounds_kernel(const double* __re
     }
 }
 
+// 2-D lines: group rows (cx, cy, R, Pmax, 0 ...) - score.hip Filter32<kLine2D>
+template <int SPAN>
+__global__ __launch_bounds__(SPAN) void sp_line_bounds_kernel(const double* __restrict__ sp, int64_t n, float* __restrict__ rows)
+{
+    __shared__ double s_wlo[SPAN / 64][2], s_whi[SPAN / 64][2];
+    __shared__ float s_c[2];
+    __shared__ unsigned long long s_red[2];   // R^2, P
+    const int64_t j = (int64_t)blockIdx.x * SPAN + threadIdx.x;
+    const bool valid = j < n;
+    if (threadIdx.x < 2) s_red[threadIdx.x] = 0ull;
+    double r[2] = {0, 0};
+    if (valid) { r[0] = sp[j * 2]; r[1] = sp[j * 2 + 1]; }
+    for (int k = 0; k < 2; ++k) {
+        double lo = valid ? r[k] : 1.7976931348623157e308, hi = valid ? r[k] : -1.7976931348623157e308;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            if (l2 < lo) lo = l2;
+            if (h2 > hi) hi = h2;
+        }
+        if ((threadIdx.x & 63) == 0) { s_wlo[threadIdx.x >> 6][k] = lo; s_whi[threadIdx.x >> 6][k] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double lo = s_wlo[0][threadIdx.x], hi = s_whi[0][threadIdx.x];
+        for (int w = 1; w < SPAN / 64; ++w) {
+            if (s_wlo[w][threadIdx.x] < lo) lo = s_wlo[w][threadIdx.x];
+            if (s_whi[w][threadIdx.x] > hi) hi = s_whi[w][threadIdx.x];
+        }
+        s_c[threadIdx.x] = (float)(0.5 * (lo + hi));
+    }
+    __syncthreads();
+    if (valid) {
+        const double dx = r[0] - (double)s_c[0], dy = r[1] - (double)s_c[1];
+        double P = 1.0;
+        if (fabs(r[0]) > P) P = fabs(r[0]);
+        if (fabs(r[1]) > P) P = fabs(r[1]);
+        atomicMax(&s_red[0], (unsigned long long)__double_as_longlong(dx * dx + dy * dy));
+        atomicMax(&s_red[1], (unsigned long long)__double_as_longlong(P));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* row = rows + (int64_t)blockIdx.x * kGroupRow;
+        row[0] = s_c[0]; row[1] = s_c[1];
+        row[2] = (float)(sqrt(__longlong_as_double((long long)s_red[0])) * kGroupInflate + 1e-30);
+        row[3] = (float)(__longlong_as_double((long long)s_red[1]) * 1.000002);   // >= |stored centre| too
+        for (int k = 4; k < kGroupRow; ++k) row[k] = 0.0f;
+    }
+}
+
 }  // namespace
 
 int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n)
@@ -414,7 +465,7 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     const int d = ctx->D;
     int obs0 = -1, in0 = 0, in1 = -1;
     if (model_type == kPnP) { obs0 = 0; in0 = 2; in1 = 4; }
-    else if (model_type == kHomography) { obs0 = 2; in0 = 0; in1 = 1; }
+    else if (model_type == kHomography || model_type == kHomographySym) { obs0 = 2; in0 = 0; in1 = 3; }  // scale over all four coordinates (Filter32<kHomography>); Sym: the forward part
     PGX_TRY(ensure(ctx, ctx->pts, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->comp, (size_t)n * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pmax, (size_t)n * sizeof(double)));
@@ -480,10 +531,11 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
         ctx->point_sort = 1;
         return PGX_OK;
     }
-    const bool fund = model_type == kFundamental;
+    const bool line = model_type == kLine2D;
+    const bool fund = model_type == kFundamental || line;   // model types whose f32 rows / boxes are built from ALL coordinates
     if (!((obs0 >= 0 || fund) && ctx->group_filter && ctx->filter_enabled == 1 && std::isfinite(ctx->umax)) || (flags & 1u)) return PGX_OK;
-    if (fund) {   // f32 rows of the Sampson filter (the prep kernel left them zero) + the scales
-        hipLaunchKernelGGL(sp_fund_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, ctx->pts32.as<float>(),
+    if (fund) {   // f32 rows of the Sampson / line filter (the prep kernel left them zero) + the scales
+        hipLaunchKernelGGL(sp_fund_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, d, ctx->pts32.as<float>(),
                            ctx->pmax.as<double>());
         PGX_HIP(ctx, hipGetLastError());
     }
@@ -526,7 +578,12 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
                        ctx->p32_g.as<float>());
     PGX_HIP(ctx, hipGetLastError());
     const int ib0 = model_type == kPnP ? 2 : 0, ib1 = model_type == kPnP ? 4 : 1, ob0 = model_type == kPnP ? 0 : 2;
-    if (fund) {
+    if (line) {
+        hipLaunchKernelGGL((sp_line_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n,
+                           ctx->gbounds.as<float>());
+        hipLaunchKernelGGL((sp_line_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream,
+                           ctx->pts_s.as<double>(), n, ctx->gbounds.as<float>() + groups * kGroupRow);
+    } else if (fund) {
         hipLaunchKernelGGL((sp_fund_bounds_kernel<64>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->pts_s.as<double>(), n,
                            ctx->gbounds.as<float>());
         hipLaunchKernelGGL((sp_fund_bounds_kernel<64 * kSuper>), dim3((unsigned)supers), dim3(64 * kSuper), 0, ctx->stream,

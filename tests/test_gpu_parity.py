@@ -235,6 +235,82 @@ def test_vanishing_point_filter_and_cull_adversarial(oracle, monkeypatch):
         culled.close()
 
 
+@pytest.mark.parametrize("name", ["line", "homography_sym"])
+def test_line_and_symmetric_filters_adversarial(oracle, name, monkeypatch):
+    """Filter32<kLine2D> (three f32 FMAs + the group bound on 2-D boxes) and the symmetric transfer error on the forward
+    homography filters: thresholds exactly ON residuals, hypotheses a hair from ground truth, zero / NaN / Inf / 1e+-150 /
+    f32-overflowing hypotheses, huge / tiny / duplicated points, vanishing denominators of BOTH directions (symmetric),
+    thresholds 1e-30 .. 1e30 - against the oracle bit for bit, with and without masks, and against the dense kernel."""
+    rng = np.random.default_rng(17)
+    monkeypatch.setenv("PGX_NO_GROUP", "1")
+    plain = _lib.Context(0)
+    monkeypatch.delenv("PGX_NO_GROUP")
+    culled = _lib.Context(0)
+    try:
+        for trial in range(8):
+            n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 30011]))
+            mt, pts, models, thr = make_case(name, n, 64, seed=900 + trial)
+            pts, models = pts.copy(), models.copy()
+            gt = models[0].copy()
+            P = gt.shape[0]
+            for k in range(8, 28):
+                models[k] = gt * (1.0 + rng.normal(0, 10.0 ** rng.uniform(-12, -3), P))
+            if n >= 1000:
+                pts[8:40] = pts[8]
+                pts[40:50] *= 1e6
+                pts[50:60] *= 1e-6
+                pts[60:64, 0] *= 1e10
+                if trial % 2:
+                    pts[64:70] *= 1e30
+                if name == "homography_sym":      # t3 = 0 for the forward map, s3 = 0 for the inverse
+                    H, Hi = gt[:9].reshape(3, 3), gt[9:].reshape(3, 3)
+                    for i in range(100, 140):
+                        if H[2, 1] != 0:
+                            pts[i, 1] = -(H[2, 0] * pts[i, 0] + H[2, 2]) / H[2, 1] * (1.0 + (i % 5) * 1e-16)
+                    for i in range(140, 180):
+                        if Hi[2, 1] != 0:
+                            pts[i, 3] = -(Hi[2, 0] * pts[i, 2] + Hi[2, 2]) / Hi[2, 1] * (1.0 + (i % 5) * 1e-16)
+            models[30] = 0.0
+            models[31] = np.nan
+            models[32] = gt
+            models[32, P - 1] = np.nan            # NaN in the last entry only (the inverse part of a symmetric model)
+            models[33] = gt
+            models[33, 2] = np.inf
+            models[34] = gt * 1e150
+            models[35] = gt * 1e-150
+            models[36] = gt * 1e150
+            models[36, ::2] *= -1.0
+            models[37] = gt * 1e33
+            models[38] = gt * 1e-43
+            models[40:] = rng.normal(0, 1, (models.shape[0] - 40, P)) * rng.choice([1e-3, 1.0, 1e3], (models.shape[0] - 40, 1))
+            sq0 = oracle.squared_residuals(mt, pts, gt)
+            finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
+            T2s = [2.25 * thr * thr, 1e-30, 1e30, 1e-23, 1e23]
+            if len(finite):
+                mid = finite[len(finite) // 3]
+                T2s += [mid, np.nextafter(mid, np.inf), np.nextafter(mid, 0), finite[0], finite[-1] * 4]
+            for ctx in (plain, culled):
+                ctx.set_points(mt, pts)
+            for T2 in T2s:
+                ref = oracle.score(mt, pts, models, float(T2), want_masks=True)
+                b = culled.score(models, float(T2), want_masks=True)
+                assert np.array_equal(b["counts"], ref["counts"]), (trial, T2)
+                assert np.array_equal(b["masks"], ref["masks"]), (trial, T2)
+                assert np.all(np.abs(b["values"] - ref["values"]) <= REL * np.maximum(np.abs(ref["values"]), 1e-4))
+                c = culled.score(models, float(T2))
+                assert np.array_equal(c["counts"], ref["counts"]), (trial, T2, "queued path")
+                a = plain.score(models, float(T2))
+                assert np.array_equal(a["counts"], ref["counts"])
+        mt, pts, models, thr = make_case(name, 5000, 16, seed=3)
+        culled.set_points(mt, pts)
+        culled.score_upload(models)
+        st = culled.score_stats(2.25 * thr * thr)
+        assert st["path"] == "cull + group-major" and st["filter"] == "f32" and st["exact_evaluations"] < st["pairs"] // 2
+    finally:
+        plain.close()
+        culled.close()
+
+
 def test_fundamental_filter_and_cull_adversarial(oracle, monkeypatch):
     """Filter32<kFundamental> (division-free f32 Sampson test) + the bilinear group bound on the 4-D boxes must never change
     a result.  Stress: thresholds exactly ON residuals, matrices a hair from ground truth, correspondences AT the two
@@ -328,7 +404,7 @@ def test_fundamental_filter_and_cull_adversarial(oracle, monkeypatch):
         culled.close()
 
 
-@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental"])
+@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental", "homography_sym", "line"])
 def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
     # The group-major path (Morton-sorted points, bound test per 64-point group, fixed-point accumulation) against the
     # plain chunked kernel on data built to stress the bound: wide magnitude ranges, duplicated points, groups of one,
@@ -370,7 +446,7 @@ def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
         culled.close()
 
 
-@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental"])
+@pytest.mark.parametrize("name", ["pnp", "homography", "fundamental", "homography_sym", "line"])
 def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch, oracle):
     # per-pair fixed point + integer accumulation: the results of the group-major path do not depend on how many waves share
     # a group, on queue boundaries, on the order in which groups finish, on where a pair is evaluated (in the producing wave
