@@ -94,6 +94,24 @@ def test_bundled_two_view_scenes(scene):
     assert np.median(mes) <= 3 * rec, f"{scene}: misclassification {mes} vs recorded {rec}"
 
 
+def test_example_notebook_two_view_call_finds_the_recorded_number_of_motions():
+    """examples/example_multi_two_view_motion.ipynb (cells 4-5) runs findTwoViewMotions on the bundled breadcube
+    correspondences (images 640 x 480) with threshold 0.5, conf 0.5, spatial coherence 0.5, ball radius 20, Tanimoto 0.4,
+    10 000 iterations, 7 points, at most 4 models, the uniform sampler, exponent 3 - and records "Models found = 2.0".
+    The scene has two motions (ground truth in build/data/breadcube): the same call here, over three seeds."""
+    corrs, gt = datasets.load_points_with_labels(os.path.join(SCENES, "breadcube.txt"))
+    counts, mes = [], []
+    for seed in range(3):
+        F, lab = px.findTwoViewMotions(np.ascontiguousarray(corrs), 640, 480, 640, 480, threshold=0.5, conf=0.5,
+                                       spatial_coherence_weight=0.5, neighborhood_ball_radius=20, maximum_tanimoto_similarity=0.4,
+                                       max_iters=10000, minimum_point_number=7, maximum_model_number=4, sampler_id=0,
+                                       scoring_exponent=3.0, do_logging=False, seed=seed)
+        counts.append(F.shape[0] // 3)
+        mes.append(round(float(datasets.misclassification(lab, gt)), 4))
+    print(f"example two-view call: models {counts} (recorded 2), misclassification {mes}")
+    assert int(np.median(counts)) == 2, counts   # (no error is recorded for this call; at threshold 0.5 ours is 0.14-0.26)
+
+
 def test_bundled_cubetoy_explained_miss():
     """cubetoy (recorded 0.012) is the one bundled scene where the recorded number is NOT reached reliably (0.09-0.6 over
     seeds and samplers, profiles/round2_scenes.txt).  Why, pinned here: the two motions share most of their epipolar
