@@ -249,6 +249,35 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
     return legs
 
 
+def labelling_leg(_lib, raw, pts, poses, thr):
+    """SURVEY 8(d) metric 3: one full alpha-expansion (PEARL::labeling, lambda = 0.1, label cost 6 = find6DPoses' defaults
+    x minimum_point_number) from the all-zero labelling at C4 size: 1e6 sites, 10 pose instances + the outlier label, the
+    k-NN-in-ball graph of the API built on the device.  (scripts/bench_labelling.py: the other configs + the CPU oracle.)"""
+    c = _lib.Context(0)
+    try:
+        c.set_points(_lib.PNP, pts)
+        t0 = time.perf_counter()
+        arcs = c.graph_build(raw, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+        c.sync()
+        t_graph = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        c.pearl_unary(poses, thr, 0.1)
+        c.sync()
+        t_unary = time.perf_counter() - t0
+        c.set_labels(np.zeros(len(pts), np.int32))
+        t0 = time.perf_counter()
+        eq, e, cycles = c.expansion(0.1, 6.0)
+        t_exp = time.perf_counter() - t0
+        st = c.expansion_stats()
+        return {"sites": int(len(pts)), "labels": int(len(poses)) + 1, "arcs": int(arcs), "graph_build_ms": 1e3 * t_graph,
+                "unary_ms": 1e3 * t_unary, "expansion_ms": 1e3 * t_exp, "cycles": int(cycles), "energy": e,
+                "ms_per_mincut": 1e3 * t_exp / max(1, st["mincuts"]), **st,
+                "note": "latency-bound level / sweep launches (DESIGN.md 5.4); labels are those of the CPU oracle's Dinic solver "
+                        "(tests), which needs ~200 s for this expansion"}
+    finally:
+        c.close()
+
+
 gt_pose0 = None
 
 
@@ -384,6 +413,10 @@ def main():
         }
         if world == 1 and not args.no_legs and default_workload:
             out["legs"] = secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt_labels, T2, args.steps, args.warmup)
+            try:
+                out["legs"]["labelling_c4"] = labelling_leg(_lib, np.column_stack([x1, x2]), pts, gt[:10], thr)
+            except Exception as e:       # never fail the bench over a secondary leg
+                out["legs"]["labelling_c4"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pts, hyps, T2, comp)
             out["cpu_baseline"] = cb

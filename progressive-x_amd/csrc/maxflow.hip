@@ -391,6 +391,10 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
 {
     bool r = false;
     const int sub = (int)(threadIdx.x & 7);
+    // no hub at all in this move (label cost 0: the inlier / outlier cut of the local optimisation; or every label but alpha
+    // unused): labelling a site then needs neither its label nor the hub table - one dependent gather less per pass
+    bool hubs = v.has_alpha_hub[0] != 0;
+    for (int l = 0; l < v.L; ++l) hubs |= v.hub_exists[l] != 0;
     const int64_t nthreads = (int64_t)gridDim.x * kMfBlock;
     const int64_t gtid = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
     int* const scnt = stage_margin > 0 ? &s_stage.count : nullptr;
@@ -403,10 +407,11 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
             const int w = __hip_atomic_load(&fin[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
                 const int uu = v.idx[a];
-                // residual of the reverse arc uu -> w without the gather through rev[a]; label test folded into d (kMfDead)
-                const bool want = v.tot[a] - __hip_atomic_load(&v.cap[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
-                                  __hip_atomic_load(&v.d[uu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kMfInf;
-                r |= mf_bfs_label(v, uu, k, s_min, want, level_base, scnt, slist);
+                // residual of the reverse arc uu -> w without the gather through rev[a]; label test folded into d (kMfDead).
+                // The compare-and-swap itself tests "still unlabelled" (no load of d first: one round trip less per pass;
+                // a failed CAS on an already labelled neighbour costs what the load did)
+                const bool want = v.tot[a] - __hip_atomic_load(&v.cap[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+                r |= mf_bfs_label(v, uu, k, s_min, want, level_base, scnt, slist, hubs);
             }
         }
         if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k, level_base);

@@ -253,11 +253,11 @@ PGX_HD int mf_level_base(const MfView& v, int k) { return k <= 1 ? 0 : v.lvl[k -
 // of serialised L2 atomics each on a single address — 331 us for the level-1 pass and most of the ~42 us per level at
 // N = 1e6.
 PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want, int base = -1,
-                         int* stage_cnt = nullptr, int* stage_list = nullptr)
+                         int* stage_cnt = nullptr, int* stage_list = nullptr, bool hubs = true)
 {
     bool mine = false;
     if (want) mine = mf_cas32(&v.d[u], kMfInf, k);
-    if (mine) {
+    if (mine && hubs) {   // hubs == false: the caller knows that no hub exists in this move (saves the label gather)
         const int lu = v.labels[u];
         if (v.hub_exists[lu]) mf_acc_min(&hub_acc[lu], k + 1);      // y_beta -> u has infinite capacity
         if (v.has_alpha_hub[0] && mf_load64(&v.g[u]) > 0) {          // y_alpha -> u has residual g[u]
