@@ -183,11 +183,28 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
     // grid-stride over 256-site chunks: a workgroup ends with up to L atomicMin on the hub heights (~20 ns each, serialised
     // per address) - with one workgroup per chunk that was 3 906 of them per label at N = 1e6, most of the 70 us a sweep
     // over all sites took there (12 k such sweeps per find6DPoses call)
+    // A site takes part only if it holds excess or its hub is in play (holds excess: members pull and report their heights);
+    // everything else returns from the per-site body without side effects - after three dependent gathers and two workgroup
+    // barriers.  Here label and excess are loaded up front (two independent coalesced loads), the "hub in play" flags sit in
+    // LDS, and a chunk without a live site costs one barrier.  (The gates are the same plain, possibly stale reads the body
+    // makes; a push arriving later in this sweep is picked up by the next one, as before.)
+    __shared__ int s_hub_live[kMfMaxLabels];
+    if (threadIdx.x < kMfMaxLabels)
+        s_hub_live[threadIdx.x] = (int)threadIdx.x < v.L && v.hub_exists[threadIdx.x] && v.hub_e[threadIdx.x] > 0;
+    const bool hub_a = v.has_alpha_hub[0] != 0;
+    __syncthreads();
     bool r = false;
     const int64_t chunks = (v.n + kMfBlock - 1) / kMfBlock;
     for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const int64_t u = c * kMfBlock + threadIdx.x;
-        r |= mf_sweep_step(v, u < v.n ? u : -1, prev, cur, false, s, nullptr);
+        bool live = false;
+        if (u < v.n) {
+            const int lu = v.labels[u];
+            const long long e = v.ex[u];
+            live = lu != v.alpha && (hub_a || s_hub_live[lu] || e > 0);
+        }
+        if (!__syncthreads_or(live)) continue;
+        r |= mf_sweep_step(v, live ? u : -1, prev, cur, false, s, nullptr);
     }
     mf_sweep_flush(v, cur, false, s, r);
 }
