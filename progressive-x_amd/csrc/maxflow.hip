@@ -576,13 +576,20 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
 {
     const int l = (int)threadIdx.x;   // one wave, L <= 64
     const int prev = (cur + 2) % 3;
+    // every load up front (one round trip): the kernel is nothing but its dependent-load chain
+    const bool in = l < v.L;
+    const int exists = in ? v.hub_exists[l] : 0;
+    const long long he = in ? v.hub_e[l] : 0;
+    int mc = in ? v.hub_min[cur * v.L + l] : kMfInf;
+    const int mp = in ? v.hub_min[prev * v.L + l] : kMfInf;
+    const int work = v.flags[1];
+    const int hub_a = v.has_alpha_hub[0];
+    const long long hae = v.hubA_e[0];
+    const unsigned long long ham = v.hubA_min[cur];
     bool hub_act = false;
-    if (l < v.L) {
-        const int exists = v.hub_exists[l];
-        const long long he = v.hub_e[l];
-        int mc = v.hub_min[cur * v.L + l];
+    if (in) {
         if (exists && (consumed >= 0 || he <= 0) && mc == kMfInf) {   // no scan was requested: keep the last known height
-            mc = v.hub_min[prev * v.L + l];
+            mc = mp;
             v.hub_min[cur * v.L + l] = mc;
         }
         v.hub_min[next * v.L + l] = kMfInf;
@@ -590,9 +597,9 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
     }
     const bool any = __ballot(hub_act) != 0;
     if (l == 0) {
-        int act = v.flags[1];
+        int act = work;
         if (any) act = 1;
-        if (v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.hubA_min[cur] != ~0ull) act = 1;
+        if (hub_a && hae > 0 && ham != ~0ull) act = 1;
         v.hubA_min[next] = ~0ull;
         v.hubA_want[next] = 0;
         v.flags[4] = act;
