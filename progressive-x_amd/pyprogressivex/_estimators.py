@@ -206,6 +206,27 @@ def _hartley_from_moments(G, cnt):
     return Ts[0], Ts[1], np.array(prm), cnt
 
 
+def _hartley_batch(G, cnt):
+    """`_hartley_from_moments` for a stack of Gram matrices G [B, 5, 5] with a common count: (T1 [B,3,3], T2 [B,3,3],
+    params [B,6]) - elementwise the same arithmetic, so every selection gets bitwise the single-call result."""
+    B = G.shape[0]
+    c = G[:, 0, 1:] / cnt
+    var = np.maximum(np.diagonal(G, axis1=1, axis2=2)[:, 1:] / cnt - c * c, 0.0)
+    Ts, prm = [], []
+    for k in (0, 2):
+        rms = np.sqrt(var[:, k] + var[:, k + 1])
+        sc = np.where(rms > 0, np.sqrt(2.0) / np.where(rms > 0, rms, 1.0), 1.0)
+        T = np.zeros((B, 3, 3))
+        T[:, 0, 0] = sc
+        T[:, 0, 2] = -sc * c[:, k]
+        T[:, 1, 1] = sc
+        T[:, 1, 2] = -sc * c[:, k + 1]
+        T[:, 2, 2] = 1.0
+        Ts.append(T)
+        prm += [sc, c[:, k], c[:, k + 1]]
+    return Ts[0], Ts[1], np.stack(prm, axis=1)
+
+
 def _smallest_eigenvector(G):
     evals, evecs = np.linalg.eigh(G)
     return evecs[:, 0]
@@ -250,6 +271,29 @@ class HomographyEstimator(Estimator):
         return [(H / H[2, 2]).reshape(-1)]
 
 
+    def _fit_batch(self, ctx, index, weights, init):
+        """`_fit` for B selections at once: two pgx_gram_batch launches, stacked eigh / inv (numpy runs LAPACK per matrix, so
+        each selection's model is bitwise the single-call one)."""
+        B, m = index.shape
+        if B == 0 or m < 4:
+            return [[] for _ in range(B)]
+        G, _ = ctx.gram_batch(_lib.GRAM_AFFINE, index, params=None, weights=None, wpow=2)
+        T1, T2, prm = _hartley_batch(G, m)
+        AtA, _ = ctx.gram_batch(_lib.GRAM_DLT_H, index, params=prm, weights=weights, wpow=2)
+        out = [[] for _ in range(B)]
+        fin = np.isfinite(AtA).all(axis=(1, 2)) & np.isfinite(T2).all(axis=(1, 2)) & (np.abs(np.linalg.det(np.where(np.isfinite(T2), T2, 0.0))) > 0)
+        if not fin.any():
+            return out
+        idx = np.nonzero(fin)[0]
+        Hn = np.linalg.eigh(AtA[idx])[1][:, :, 0].reshape(-1, 3, 3)
+        H = np.linalg.inv(T2[idx]) @ Hn @ T1[idx]
+        for k, b in enumerate(idx):
+            Hb = H[k]
+            if np.isfinite(Hb).all() and abs(Hb[2, 2]) >= 1e-300:
+                out[b] = [(Hb / Hb[2, 2]).reshape(-1)]
+        return out
+
+
 class SymmetricHomographyEstimator(HomographyEstimator):
     """Same solvers; the model carried to the kernels is [H | H^-1] (symmetric transfer error switch)."""
     model_type = _lib.HOMOGRAPHY_SYM
@@ -275,6 +319,9 @@ class SymmetricHomographyEstimator(HomographyEstimator):
     def _fit(self, init):
         res = yield from super()._fit(init)
         return [m for m in self._augment(np.array(res).reshape(-1, 9))[0]]
+
+    def _fit_batch(self, ctx, index, weights, init):
+        return [[m for m in self._augment(np.array(res).reshape(-1, 9))[0]] for res in super()._fit_batch(ctx, index, weights, init)]
 
     def output(self, model):
         return np.asarray(model[:9], dtype=np.float64).reshape(3, 3)
@@ -358,6 +405,37 @@ class FundamentalEstimator(Estimator):
         if not np.isfinite(nrm) or nrm == 0:
             return []
         return [(F / nrm).reshape(-1)]
+
+    def _fit_batch(self, ctx, index, weights, init):
+        """`_fit` for B selections at once (a local-optimisation round refits 50 samples: 5 200 eigh + svd calls were a third of
+        findTwoViewMotions' proposal time at C3): two pgx_gram_batch launches, stacked eigh / svd - LAPACK per matrix, so each
+        selection's model is bitwise the single-call one."""
+        B, m = index.shape
+        if B == 0 or m < 8:
+            return [[] for _ in range(B)]
+        G, _ = ctx.gram_batch(_lib.GRAM_AFFINE, index, params=None, weights=None, wpow=2)
+        T1, T2, prm = _hartley_batch(G, m)
+        AtA, _ = ctx.gram_batch(_lib.GRAM_EPI_F, index, params=prm, weights=weights, wpow=2)
+        out = [[] for _ in range(B)]
+        fin = np.isfinite(AtA).all(axis=(1, 2))
+        if not fin.any():
+            return out
+        idx = np.nonzero(fin)[0]
+        F = np.linalg.eigh(AtA[idx])[1][:, :, 0].reshape(-1, 3, 3)
+        okf = np.isfinite(F).all(axis=(1, 2))
+        idx, F = idx[okf], F[okf]
+        if idx.size == 0:
+            return out
+        u, sv, v = np.linalg.svd(F)
+        D = np.zeros_like(F)
+        D[:, 0, 0], D[:, 1, 1] = sv[:, 0], sv[:, 1]
+        F = u @ D @ v
+        F = T2[idx].transpose(0, 2, 1) @ F @ T1[idx]
+        for k, b in enumerate(idx):
+            nrm = np.linalg.norm(F[k])
+            if np.isfinite(nrm) and nrm != 0:
+                out[b] = [(F[k] / nrm).reshape(-1)]
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
