@@ -177,6 +177,26 @@ class VanishingPointEstimator(Estimator):
         n = np.linalg.norm(v)
         return [v / n] if n > 0 else []
 
+    def _fit_batch(self, ctx, index, weights, init):
+        """`_fit` for B selections at once: one pgx_gram_batch launch, stacked 3x3 eigh (LAPACK per matrix: bitwise the
+        single-call models)."""
+        B, m = index.shape
+        if B == 0 or m < 2:
+            return [[] for _ in range(B)]
+        AtA, _ = ctx.gram_batch(_lib.GRAM_VP, index, params=None, weights=weights, wpow=2)
+        out = [[] for _ in range(B)]
+        idx = np.nonzero(np.isfinite(AtA).all(axis=(1, 2)))[0]
+        if idx.size == 0:
+            return out
+        evals, evecs = np.linalg.eigh(AtA[idx])
+        pick = np.argmin(evals, axis=1)
+        for k, b in enumerate(idx):
+            v = evecs[k][:, int(pick[k])]
+            n = np.linalg.norm(v)
+            if n > 0:
+                out[b] = [v / n]
+        return out
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # homography (DefaultHomographyEstimator, progressivex_python.cpp:252)  [UPSTREAM-MEMORY]: 4-point, h33 = 1

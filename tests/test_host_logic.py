@@ -164,6 +164,22 @@ def test_batched_refits_equal_single_refits_on_the_oracle_context():
         for b in range(len(picks)):
             single = est.nonminimal(ctx, ("index", picks[b]), w)
             assert len(single) == len(batch[b]) == 1 and np.array_equal(single[0], batch[b][0])
+    # vanishing points (one Gram pass, stacked 3x3 eigh) and the symmetric-homography wrapper: bitwise as well
+    segs, _, _ = datasets.make_vanishing_points(n_inliers=600, n_vps=3, n_outliers=200, seed=2)
+    ctx = _octx(_lib.VANISHING_POINT, segs)
+    est = _estimators.VanishingPointEstimator()
+    vpicks = np.array([np.sort(rng.choice(len(segs), 14, replace=False)) for _ in range(7)])
+    w = rng.random(len(segs)) + 0.5
+    batch = est.nonminimal_batch(ctx, vpicks, w)
+    for b in range(7):
+        single = est.nonminimal(ctx, ("index", vpicks[b]), w)
+        assert len(single) == len(batch[b]) == 1 and np.array_equal(single[0], batch[b][0])
+    est = _estimators.SymmetricHomographyEstimator()
+    ctx = _octx(_lib.HOMOGRAPHY_SYM, pts)
+    batch = est.nonminimal_batch(ctx, picks, None)
+    for b in range(len(picks)):
+        single = est.nonminimal(ctx, ("index", picks[b]), None)
+        assert len(single) == len(batch[b]) == 1 and np.array_equal(single[0], batch[b][0])
     # PnP: selections converge after different numbers of Gauss-Newton steps; an un-initialised fit returns nothing
     x1p, x2p, K, gtp, poses = datasets.make_poses(n_per_object=300, n_objects=1, n_outliers=0, seed=2)
     norm, f = datasets.normalize_pnp(x1p, x2p, K)
