@@ -51,6 +51,24 @@ class Estimator:
         every step is ONE pgx_gram_labels launch for all labels (PEARL refits every instance per iteration; one host round
         trip per instance and step made that loop latency-bound).  Labels in `skip` are not fitted.  The Gram matrices
         are bit-identical to the single-label calls, so the results are those of K separate `nonminimal` calls."""
+        if hasattr(self, "_fit_many"):          # refit vectorised over the instances (same Gram launches, stacked small solves)
+            live = [k for k in range(K) if k not in skip]
+            out = [[] for _ in range(K)]
+            if not live:
+                return out
+
+            def gram(kind, prm, use_w, wpow, rows):
+                sel = [live[r] for r in rows]
+                full = None
+                if prm is not None:
+                    full = np.zeros((K, prm.shape[1]))
+                    full[sel] = prm
+                G, cnt, bad = ctx.gram_labels(kind, K, params=full, weights=weights if use_w else None, wpow=wpow)
+                return G[sel], cnt[sel], bad[sel]
+            res = self._fit_many(gram, len(live), [None if inits is None else inits[k] for k in live])
+            for r, k in enumerate(live):
+                out[k] = res[r]
+            return out
         gens = {k: self._fit(None if inits is None else inits[k]) for k in range(K) if k not in skip}
         results, pending = {k: [] for k in range(K)}, {}
         for k, g in gens.items():
@@ -82,8 +100,11 @@ class Estimator:
         lockstep, each step is ONE pgx_gram_batch launch.  Returns a list of B model lists."""
         index = np.asarray(index)
         B, m = index.shape
-        if hasattr(self, "_fit_batch"):          # an estimator whose refit is vectorised over the batch (PnP)
-            return self._fit_batch(ctx, index, weights, init)
+        if hasattr(self, "_fit_many"):           # refit vectorised over the batch (same Gram launches, stacked small solves)
+            def gram(kind, prm, use_w, wpow, rows):
+                G, bad = ctx.gram_batch(kind, index[rows], params=prm, weights=weights if use_w else None, wpow=wpow)
+                return G, np.full(len(rows), m, dtype=np.int64), bad
+            return self._fit_many(gram, B, [init] * B)
         gens = [self._fit(init) for _ in range(B)]
         results, pending = [None] * B, {}
         for b, g in enumerate(gens):
@@ -177,15 +198,12 @@ class VanishingPointEstimator(Estimator):
         n = np.linalg.norm(v)
         return [v / n] if n > 0 else []
 
-    def _fit_batch(self, ctx, index, weights, init):
-        """`_fit` for B selections at once: one pgx_gram_batch launch, stacked 3x3 eigh (LAPACK per matrix: bitwise the
-        single-call models)."""
-        B, m = index.shape
-        if B == 0 or m < 2:
-            return [[] for _ in range(B)]
-        AtA, _ = ctx.gram_batch(_lib.GRAM_VP, index, params=None, weights=weights, wpow=2)
+    def _fit_many(self, gram, B, inits):
+        """`_fit` for B items at once (gram = the Gram provider of nonminimal_batch / nonminimal_labels): one launch, stacked
+        3x3 eigh (LAPACK per matrix: bitwise the single-call models)."""
         out = [[] for _ in range(B)]
-        idx = np.nonzero(np.isfinite(AtA).all(axis=(1, 2)))[0]
+        AtA, cnt, _ = gram(_lib.GRAM_VP, None, True, 2, np.arange(B))
+        idx = np.nonzero((cnt >= 2) & np.isfinite(AtA).all(axis=(1, 2)))[0]
         if idx.size == 0:
             return out
         evals, evecs = np.linalg.eigh(AtA[idx])
@@ -227,9 +245,10 @@ def _hartley_from_moments(G, cnt):
 
 
 def _hartley_batch(G, cnt):
-    """`_hartley_from_moments` for a stack of Gram matrices G [B, 5, 5] with a common count: (T1 [B,3,3], T2 [B,3,3],
-    params [B,6]) - elementwise the same arithmetic, so every selection gets bitwise the single-call result."""
+    """`_hartley_from_moments` for a stack of Gram matrices G [B, 5, 5] with counts cnt [B] (all >= 1): (T1 [B,3,3],
+    T2 [B,3,3], params [B,6]) - elementwise the same arithmetic, so every item gets bitwise the single-call result."""
     B = G.shape[0]
+    cnt = np.asarray(cnt, dtype=np.float64).reshape(B, 1)
     c = G[:, 0, 1:] / cnt
     var = np.maximum(np.diagonal(G, axis1=1, axis2=2)[:, 1:] / cnt - c * c, 0.0)
     Ts, prm = [], []
@@ -291,26 +310,26 @@ class HomographyEstimator(Estimator):
         return [(H / H[2, 2]).reshape(-1)]
 
 
-    def _fit_batch(self, ctx, index, weights, init):
-        """`_fit` for B selections at once: two pgx_gram_batch launches, stacked eigh / inv (numpy runs LAPACK per matrix, so
-        each selection's model is bitwise the single-call one)."""
-        B, m = index.shape
-        if B == 0 or m < 4:
-            return [[] for _ in range(B)]
-        G, _ = ctx.gram_batch(_lib.GRAM_AFFINE, index, params=None, weights=None, wpow=2)
-        T1, T2, prm = _hartley_batch(G, m)
-        AtA, _ = ctx.gram_batch(_lib.GRAM_DLT_H, index, params=prm, weights=weights, wpow=2)
+    def _fit_many(self, gram, B, inits):
+        """`_fit` for B items at once: two Gram launches, stacked eigh / inv (numpy runs LAPACK per matrix, so each item's
+        model is bitwise the single-call one)."""
         out = [[] for _ in range(B)]
-        fin = np.isfinite(AtA).all(axis=(1, 2)) & np.isfinite(T2).all(axis=(1, 2)) & (np.abs(np.linalg.det(np.where(np.isfinite(T2), T2, 0.0))) > 0)
+        G, cnt, _ = gram(_lib.GRAM_AFFINE, None, False, 2, np.arange(B))
+        rows = np.nonzero((cnt >= 4) & np.isfinite(G).all(axis=(1, 2)))[0]
+        if rows.size == 0:
+            return out
+        T1, T2, prm = _hartley_batch(G[rows], cnt[rows])
+        AtA, _, _ = gram(_lib.GRAM_DLT_H, prm, True, 2, rows)
+        fin = np.isfinite(AtA).all(axis=(1, 2)) & np.isfinite(T2).all(axis=(1, 2))
         if not fin.any():
             return out
-        idx = np.nonzero(fin)[0]
-        Hn = np.linalg.eigh(AtA[idx])[1][:, :, 0].reshape(-1, 3, 3)
-        H = np.linalg.inv(T2[idx]) @ Hn @ T1[idx]
-        for k, b in enumerate(idx):
+        sel = np.nonzero(fin)[0]
+        Hn = np.linalg.eigh(AtA[sel])[1][:, :, 0].reshape(-1, 3, 3)
+        H = np.linalg.inv(T2[sel]) @ Hn @ T1[sel]
+        for k, r in enumerate(sel):
             Hb = H[k]
             if np.isfinite(Hb).all() and abs(Hb[2, 2]) >= 1e-300:
-                out[b] = [(Hb / Hb[2, 2]).reshape(-1)]
+                out[rows[r]] = [(Hb / Hb[2, 2]).reshape(-1)]
         return out
 
 
@@ -340,8 +359,8 @@ class SymmetricHomographyEstimator(HomographyEstimator):
         res = yield from super()._fit(init)
         return [m for m in self._augment(np.array(res).reshape(-1, 9))[0]]
 
-    def _fit_batch(self, ctx, index, weights, init):
-        return [[m for m in self._augment(np.array(res).reshape(-1, 9))[0]] for res in super()._fit_batch(ctx, index, weights, init)]
+    def _fit_many(self, gram, B, inits):
+        return [[m for m in self._augment(np.array(res).reshape(-1, 9))[0]] for res in super()._fit_many(gram, B, inits)]
 
     def output(self, model):
         return np.asarray(model[:9], dtype=np.float64).reshape(3, 3)
@@ -426,35 +445,34 @@ class FundamentalEstimator(Estimator):
             return []
         return [(F / nrm).reshape(-1)]
 
-    def _fit_batch(self, ctx, index, weights, init):
-        """`_fit` for B selections at once (a local-optimisation round refits 50 samples: 5 200 eigh + svd calls were a third of
-        findTwoViewMotions' proposal time at C3): two pgx_gram_batch launches, stacked eigh / svd - LAPACK per matrix, so each
-        selection's model is bitwise the single-call one."""
-        B, m = index.shape
-        if B == 0 or m < 8:
-            return [[] for _ in range(B)]
-        G, _ = ctx.gram_batch(_lib.GRAM_AFFINE, index, params=None, weights=None, wpow=2)
-        T1, T2, prm = _hartley_batch(G, m)
-        AtA, _ = ctx.gram_batch(_lib.GRAM_EPI_F, index, params=prm, weights=weights, wpow=2)
+    def _fit_many(self, gram, B, inits):
+        """`_fit` for B items at once (a local-optimisation round refits 50 samples, a PEARL iteration every instance: 5 200
+        eigh + svd calls were a third of findTwoViewMotions' proposal time at C3): two Gram launches, stacked eigh / svd -
+        LAPACK per matrix, so each item's model is bitwise the single-call one."""
         out = [[] for _ in range(B)]
-        fin = np.isfinite(AtA).all(axis=(1, 2))
-        if not fin.any():
+        G, cnt, _ = gram(_lib.GRAM_AFFINE, None, False, 2, np.arange(B))
+        rows = np.nonzero((cnt >= 8) & np.isfinite(G).all(axis=(1, 2)))[0]
+        if rows.size == 0:
             return out
-        idx = np.nonzero(fin)[0]
-        F = np.linalg.eigh(AtA[idx])[1][:, :, 0].reshape(-1, 3, 3)
+        T1, T2, prm = _hartley_batch(G[rows], cnt[rows])
+        AtA, _, _ = gram(_lib.GRAM_EPI_F, prm, True, 2, rows)
+        sel = np.nonzero(np.isfinite(AtA).all(axis=(1, 2)))[0]
+        if sel.size == 0:
+            return out
+        F = np.linalg.eigh(AtA[sel])[1][:, :, 0].reshape(-1, 3, 3)
         okf = np.isfinite(F).all(axis=(1, 2))
-        idx, F = idx[okf], F[okf]
-        if idx.size == 0:
+        sel, F = sel[okf], F[okf]
+        if sel.size == 0:
             return out
         u, sv, v = np.linalg.svd(F)
         D = np.zeros_like(F)
         D[:, 0, 0], D[:, 1, 1] = sv[:, 0], sv[:, 1]
         F = u @ D @ v
-        F = T2[idx].transpose(0, 2, 1) @ F @ T1[idx]
-        for k, b in enumerate(idx):
+        F = T2[sel].transpose(0, 2, 1) @ F @ T1[sel]
+        for k, r in enumerate(sel):
             nrm = np.linalg.norm(F[k])
             if np.isfinite(nrm) and nrm != 0:
-                out[b] = [(F[k] / nrm).reshape(-1)]
+                out[rows[r]] = [(F[k] / nrm).reshape(-1)]
         return out
 
 
@@ -585,29 +603,31 @@ class PnPEstimator(Estimator):
         return [out.reshape(-1)] if np.isfinite(out).all() else []
 
 
-    def _fit_batch(self, ctx, index, weights, init):
-        """`_fit` for B selections at once (nonminimal_batch): the same Gauss-Newton iteration with the 6x6 solves, the
-        rotation updates and the convergence tests done on [B, ...] arrays - 50 refits x 10 iterations per graph-cut round
-        were 13 us of lstsq + 15 us of small-array numpy each, a third of C4's proposal time.  The solve is the
-        pseudo-inverse with lstsq's cut-off (singular values below eps * 6 * s_max dropped), so a selection's iterates are
-        those of `_fit` up to rounding."""
-        B, m = index.shape
-        if init is None or B == 0:
-            return [[] for _ in range(B)]
-        P0 = np.asarray(init, dtype=np.float64).reshape(3, 4)
-        R = np.broadcast_to(P0[:, :3], (B, 3, 3)).copy()
-        t = np.broadcast_to(P0[:, 3], (B, 3)).copy()
-        running = np.ones(B, dtype=bool)        # still iterating
-        failed = np.zeros(B, dtype=bool)
+    def _fit_many(self, gram, B, inits):
+        """`_fit` for B items at once: the same Gauss-Newton iteration with the 6x6 solves, the rotation updates and the
+        convergence tests done on [B, ...] arrays - 50 refits x 10 iterations per graph-cut round were 13 us of lstsq + 15 us
+        of small-array numpy each, a third of C4's proposal time.  The solve is the pseudo-inverse with lstsq's cut-off
+        (singular values below eps * 6 * s_max dropped), so an item's iterates are those of `_fit` up to rounding."""
+        out = [[] for _ in range(B)]
+        have = np.array([ini is not None for ini in inits], dtype=bool)
+        if not have.any():
+            return out
+        R = np.zeros((B, 3, 3))
+        t = np.zeros((B, 3))
+        for b in np.nonzero(have)[0]:
+            P0 = np.asarray(inits[b], dtype=np.float64).reshape(3, 4)
+            R[b], t[b] = P0[:, :3], P0[:, 3]
+        running = have.copy()                   # still iterating
+        failed = ~have
         eye = np.eye(3)
         for _ in range(10):
             act = np.nonzero(running)[0]
             if act.size == 0:
                 break
             prm = np.concatenate([R[act], t[act][:, :, None]], axis=2).reshape(act.size, 12)
-            G, bad = ctx.gram_batch(_lib.GRAM_PNP_GN, index[act], params=prm, weights=weights, wpow=2)
+            G, cnt, bad = gram(_lib.GRAM_PNP_GN, prm, True, 2, act)
             A, b = G[:, :6, :6], -G[:, :6, 6]
-            ok = (bad == 0) & np.isfinite(A).all(axis=(1, 2)) & np.isfinite(b).all(axis=1) & (m >= 4)
+            ok = (bad == 0) & (cnt >= 4) & np.isfinite(A).all(axis=(1, 2)) & np.isfinite(b).all(axis=1)
             failed[act[~ok]] = True
             running[act[~ok]] = False
             if not ok.any():
@@ -626,9 +646,9 @@ class PnPEstimator(Estimator):
             R[act] = rot @ R[act]
             t[act] = t[act] + delta[:, 3:]
             running[act[np.linalg.norm(delta, axis=1) < 1e-12]] = False
-        out = np.concatenate([R, t[:, :, None]], axis=2).reshape(B, 12)
-        good = ~failed & np.isfinite(out).all(axis=1)
-        return [[out[b]] if good[b] else [] for b in range(B)]
+        P = np.concatenate([R, t[:, :, None]], axis=2).reshape(B, 12)
+        good = ~failed & np.isfinite(P).all(axis=1)
+        return [[P[b]] if good[b] else [] for b in range(B)]
 
 
 ESTIMATORS = {

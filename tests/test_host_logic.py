@@ -205,6 +205,45 @@ def test_batched_refits_equal_single_refits_on_the_oracle_context():
             assert np.allclose(single[0], batch[b][0], rtol=1e-6, atol=1e-9)
 
 
+def test_label_refits_in_one_pass_equal_per_label_refits_on_the_oracle_context():
+    # PEARL::parameterEstimation refits every instance per iteration: nonminimal_labels (one Gram launch per step for all
+    # labels, stacked small solves) must return what K separate nonminimal(("label", k)) calls return - bitwise for the
+    # closed-form solvers, up to rounding for the PnP Gauss-Newton (pseudo-inverse instead of lstsq)
+    from pyprogressivex import _estimators, _lib, datasets
+    rng = np.random.default_rng(4)
+    cases = []
+    pts, gt, models = datasets.make_homographies(n_per_plane=150, n_planes=3, n_outliers=60, seed=2)
+    cases.append((_estimators.HomographyEstimator(), _lib.HOMOGRAPHY, pts, gt, None, True))
+    cases.append((_estimators.FundamentalEstimator(), _lib.FUNDAMENTAL, pts, gt, None, True))
+    segs, gts, _ = datasets.make_vanishing_points(n_inliers=450, n_vps=3, n_outliers=100, seed=2)
+    cases.append((_estimators.VanishingPointEstimator(), _lib.VANISHING_POINT, segs, gts, None, True))
+    x1p, x2p, K, gtp, poses = datasets.make_poses(n_per_object=200, n_objects=3, n_outliers=50, seed=2)
+    norm, f = datasets.normalize_pnp(x1p, x2p, K)
+    inits = [p + 1e-3 * rng.normal(size=12) for p in poses]
+    cases.append((_estimators.PnPEstimator(), _lib.PNP, norm, gtp, inits, False))
+    for est, mt, data, labels_gt, inits, bitwise in cases:
+        ctx = _octx(mt, data)
+        Kl = int(labels_gt.max())
+        lab = np.where(labels_gt > 0, labels_gt - 1, Kl).astype(np.int32)    # instance k -> label k, outliers -> label K
+        lab[:5] = Kl + 1                                                     # a label with 5 points only (too few for H / F)
+        ctx.set_labels(lab)
+        w = rng.random(len(data)) + 0.5
+        n_lab = Kl + 2
+        ini = None if inits is None else list(inits) + [inits[0], inits[0]]
+        many = est.nonminimal_labels(ctx, n_lab, w, inits=ini, skip=(1,))
+        assert many[1] == []
+        for k in range(n_lab):
+            if k == 1:
+                continue
+            single = est.nonminimal(ctx, ("label", k), w, init=None if ini is None else ini[k])
+            assert len(single) == len(many[k]), (type(est).__name__, k)
+            if single:
+                if bitwise:
+                    assert np.array_equal(single[0], many[k][0]), (type(est).__name__, k)
+                elif k < Kl:   # (on the outlier label / a 5-point label Gauss-Newton diverges: rounding differences are amplified)
+                    assert np.allclose(single[0], many[k][0], rtol=1e-9, atol=1e-12)
+
+
 def test_preference_slots_are_recycled(oracle_backend):
     """Rejected proposals and instances removed by PEARL give their preference slot back (each is N * 8 bytes on the
     device): the slot index never exceeds the number of live models."""
