@@ -744,7 +744,7 @@ struct HipBackend {
     }
     void bfs_level(const MfView& v, int k)
     {
-        const unsigned g = blocks < (unsigned)kBfsLevelBlocks ? blocks : (unsigned)kBfsLevelBlocks;
+        const unsigned g = blocks < bfs_level_blocks ? blocks : bfs_level_blocks;
         hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k, stage_margin());
         check();
     }
@@ -823,6 +823,7 @@ struct HipBackend {
         return s;
     }
     void build_list(const MfView& v, int stamp) { site(mf_k_build_list, v, stamp); }
+    unsigned bfs_level_blocks = (unsigned)kBfsLevelBlocks;   // PGX_MF_LEVEL_BLOCKS
     unsigned bfs_init_blocks = 256;  // every workgroup ends with one atomic on the level counter and up to L on the hub distances:
                                      // ~20 ns each, serialised per address (PGX_MF_INIT_BLOCKS)
     int tail_cap = 0;            // longest work list the one-workgroup sweep kernel takes (PGX_MF_TAIL=<sites>; 0 = off, the default:
@@ -1060,6 +1061,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
     tune.bfs_hint = st->bfs_hint;
+    if (const char* e = std::getenv("PGX_MF_LEVEL_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_level_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_INIT_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_init_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_SWEEP_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.sweep_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_TAIL")) { const int x = std::atoi(e); if (x >= 0) be.tail_cap = x; }
