@@ -104,6 +104,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SETPOINTS_HOST")) ctx->setpoints_host = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_WG")) ctx->score_wg = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_GC_FLIP")) ctx->gc_flip = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_DENSE")) { int v = std::atoi(b); if (v >= 1 && v <= 65) ctx->score_dense_min = v; }
     if (const char* b = std::getenv("PGX_SCORE_EXW")) { int v = std::atoi(b); if (v >= 1 && v <= 16) ctx->score_exact_waves = v; }
     if (const char* b = std::getenv("PGX_SCORE_CULL_SEGS")) { int v = std::atoi(b); if (v >= 1 && v <= 65535) ctx->score_cull_segs = v; }

@@ -115,13 +115,14 @@ struct SweepLds {
     unsigned long long want[kMfMaxLabels + 1];
     long long got[kMfMaxLabels + 1];
     unsigned long long pushA;
+    int moved;
 };
 
 __device__ __forceinline__ void sweep_lds_init(SweepLds& s)
 {
     if (threadIdx.x < kMfMaxLabels) s.min[threadIdx.x] = kMfInf;
     if (threadIdx.x <= kMfMaxLabels) { s.want[threadIdx.x] = 0; s.got[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s.pushA = 0;
+    if (threadIdx.x == 0) { s.pushA = 0; s.moved = 0; }
     __syncthreads();
 }
 
@@ -158,6 +159,7 @@ __device__ __forceinline__ bool mf_sweep_step(const MfView& v, int64_t u, int pr
         }
         r = mf_body_sweep(v, u, prev, cur, s.min, &io);
         if (io.pushedA > 0) atomicAdd(&s.pushA, (unsigned long long)io.pushedA);
+        if (io.moved) s.moved = 1;
         if (pushed_to) *pushed_to = io.pushed_to;
     }
     return r;
@@ -171,6 +173,7 @@ __device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool li
     if (threadIdx.x == 0) {
         if (s.pushA > 0) atomicAdd((unsigned long long*)v.hubA_e, s.pushA);
         if (count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s.moved) __hip_atomic_store(&v.flags[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(kTailBlock) void mf_k_sweep_tail(MfView v, int swee
             if (threadIdx.x == 0) s_ctl[0] = __hip_atomic_load(&v.acnt[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (threadIdx.x < kMfMaxLabels) s.min[threadIdx.x] = kMfInf;
             if (threadIdx.x <= kMfMaxLabels) { s.want[threadIdx.x] = 0; s.got[threadIdx.x] = 0; }
-            if (threadIdx.x == 0) s.pushA = 0;
+            if (threadIdx.x == 0) { s.pushA = 0; s.moved = 0; }
             __syncthreads();
             const int cnt = s_ctl[0];
             if (cnt > cap) break;
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(kTailBlock) void mf_k_sweep_tail(MfView v, int swee
             const int work = __syncthreads_count(any ? 1 : 0);   // also: every append of this sweep has been issued
             if (threadIdx.x == 0) {
                 v.flags[1] = work > 0 ? 1 : 0;
+                v.flags[8] = s.moved;
                 mf_body_sweep_epilogue(v, cur, next, parity);    // latches flags[4], clears flags[1] and the consumed list
                 s_ctl[1] = (v.flags[4] == 0 || __hip_atomic_load(&v.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
             }
@@ -545,6 +549,44 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave_persist(MfView v, int ksta
     }
 }
 
+// ---- minimal SOURCE side (source_reach mode) ---------------------------------------------------------------------------
+// apply() hands alpha to every site that cannot reach t - the complement of the minimal sink side, which is what BK's
+// what_segment(default = SOURCE) yields for an expansion move.  The inlier / outlier cut of the local optimisation is stated
+// the other way round ("inliers = the sites that reach t", ties -> outlier), and solving it in that orientation makes 95 % of
+// the sites hold excess.  Solved with the terminals swapped (every site "outlier", alpha = "inlier") the same answer is the
+// set the SOURCE reaches in the residual graph of the maximum flow: exactly the sites reachable from the excess that stayed
+// stranded (returning it to s only frees arcs back towards its origins, which are reachable from where it sits), while a site
+// that neither reaches t nor is reached from s stays "outlier" - as in the original orientation, where it does not reach t.
+// Jacobi-style growth over the source-side sites (d == kMfInf): a handful of rounds, the stranded sites are dense in the set.
+__global__ __launch_bounds__(kMfBlock) void mf_k_src_seed(MfView v, int stamp, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    if (u >= v.n || v.labels[u] == v.alpha) return;
+    if (v.d[u] == kMfInf && v.ex[u] > 0) v.mark[u] = stamp;
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_src_grow(MfView v, int stamp, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    bool grew = false;
+    if (u < v.n && v.labels[u] != v.alpha && v.d[u] == kMfInf && __hip_atomic_load(&v.mark[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
+        for (int a = v.off[u]; a < v.off[u + 1]; ++a) {
+            const int w = v.idx[a];
+            // residual of w -> u = cap[rev[a]] = tot[a] - cap[a]; w is on the list iff marked (inactive sites never are)
+            if (v.tot[a] - v.cap[a] > 0 && __hip_atomic_load(&v.mark[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp) { grew = true; break; }
+        }
+        if (grew) __hip_atomic_store(&v.mark[u], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__syncthreads_or(grew) && threadIdx.x == 0) __hip_atomic_store(&v.flags[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kMfBlock) void mf_k_src_finish(MfView v, int stamp, int)
+{
+    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
+    if (u >= v.n || v.labels[u] == v.alpha) return;
+    if (v.d[u] == kMfInf && v.mark[u] != stamp) v.d[u] = kMfInf - 1;   // not reached from s: keeps its label
+}
+
 // stranded excess of the sites (maxflow_body.cuh mf_body_stuck_excess): per-workgroup sum, one atomic per workgroup
 __global__ __launch_bounds__(kMfBlock) void mf_k_stuck(MfView v, unsigned long long* __restrict__ out, int)
 {
@@ -583,6 +625,7 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
     int mc = in ? v.hub_min[cur * v.L + l] : kMfInf;
     const int mp = in ? v.hub_min[prev * v.L + l] : kMfInf;
     const int work = v.flags[1];
+    const int moved = v.flags[8], stall = v.flags[11];
     const int hub_a = v.has_alpha_hub[0];
     const long long hae = v.hubA_e[0];
     const unsigned long long ham = v.hubA_min[cur];
@@ -604,6 +647,8 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
         v.hubA_want[next] = 0;
         v.flags[4] = act;
         v.flags[1] = 0;
+        v.flags[11] = moved ? 0 : stall + 1;   // as mf_body_sweep_epilogue
+        v.flags[8] = 0;
         if (consumed >= 0) v.acnt[consumed] = 0;
     }
 }
@@ -749,12 +794,12 @@ struct HipBackend {
         check();
     }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
-    void read_flags(const MfView& v, int out[8])
+    void read_flags(const MfView& v, int out[kMfFlags])
     {
-        hipError_t e = hipMemcpyAsync(st->h_flags, v.flags, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(st->h_flags, v.flags, kMfFlags * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
-        for (int k = 0; k < 8; ++k) out[k] = st->h_flags[k];
+        for (int k = 0; k < kMfFlags; ++k) out[k] = st->h_flags[k];
     }
     void wave(const MfView& v, int k)
     {
@@ -854,6 +899,18 @@ struct HipBackend {
         return total;
     }
     void apply(const MfView& v) { agg(mf_k_agg<kApply>, v); }
+    void keep_source_reachable_only(const MfView& v)
+    {
+        const int stamp = take_stamps(v, 1);
+        site(mf_k_src_seed, v, stamp);
+        for (int round = 0; round < 1 << 20; ++round) {
+            hipError_t e = hipMemsetAsync(v.flags + 5, 0, sizeof(int), ctx->stream);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            for (int r = 0; r < 4; ++r) site(mf_k_src_grow, v, stamp);   // four rounds per read-back
+            if (read_int(v.flags + 5) == 0 || err != hipSuccess) break;
+        }
+        site(mf_k_src_finish, v, stamp);
+    }
 };
 
 }  // namespace
@@ -979,8 +1036,9 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
 // One expansion move on caller-chosen tables: dq [L][n] label-major, labels [n], and optionally per-arc weights wq [E]
 // (used by the binary inlier/outlier cut of gclo.hip, whose pairwise weights depend on both end points).
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq,
-                    int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
+                    int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed, bool source_reach)
 {
+    if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
     if (!ctx->mf) {
@@ -1006,7 +1064,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
         st->mark_n = n;
         st->next_stamp = 1;
     }
-    const size_t small_bytes = (size_t)(L + 1 + 3 + 4) * 8 + (size_t)(9 * L + 2 + 3 + 8 + 2) * 4 + 64;
+    const size_t small_bytes = (size_t)(L + 1 + 3 + 4) * 8 + (size_t)(9 * L + 2 + 3 + kMfFlags + 2) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
     MfView v;
@@ -1061,6 +1119,8 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
     if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
     tune.bfs_hint = st->bfs_hint;
+    tune.source_reach = source_reach ? 1 : 0;
+    if (const char* e = std::getenv("PGX_MF_STALL")) tune.stall_sweeps = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_LEVEL_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_level_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_INIT_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_init_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_SWEEP_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.sweep_blocks = (unsigned)x; }

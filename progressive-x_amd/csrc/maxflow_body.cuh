@@ -42,6 +42,7 @@ namespace pgx {
 
 constexpr int kMfInf = 0x3fffffff;
 constexpr int kMfDead = -1;  // height of a site that is already alpha (not part of the move's graph)
+constexpr int kMfFlags = 12;  // ints in MfView::flags
 
 struct MfView {
     int64_t n;
@@ -81,7 +82,8 @@ struct MfView {
     int* act[2];                   // [n] each: work lists of the list-mode sweeps (read one, write the other)
     int* acnt;                     // [2] their sizes
     int* mark;                     // [n] stamp of the last list a site was appended to (stamps only grow)
-    int* flags;                    // [8]: 0 last BFS level that labelled a site, 1 work-left (boolean, being
+    int* flags;                    // [kMfFlags]: 8 flow reached t in the sweep being run, 11 sweeps since flow last reached t (epilogue);
+                                   //      0 last BFS level that labelled a site, 1 work-left (boolean, being
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep,
                                    //      6 a list-mode sweep pushed into a beta hub (all members must take part again)
     int hmax;                      // heights >= hmax are treated as unreachable
@@ -201,7 +203,7 @@ PGX_HD void mf_body_hub_setup(const MfView& v)
     v.hubA_want[0] = v.hubA_want[1] = v.hubA_want[2] = 0;
     v.bfs_hubA_d[0] = kMfInf;
     for (int r = 0; r < 3; ++r) v.hubA_min[r] = ~0ull;
-    for (int k = 0; k < 8; ++k) v.flags[k] = 0;
+    for (int k = 0; k < kMfFlags; ++k) v.flags[k] = 0;
 }
 
 PGX_HD void mf_body_init_site(const MfView& v, int64_t u)
@@ -282,6 +284,8 @@ PGX_HD void mf_body_bfs_reset(const MfView& v)
     v.flags[1] = 0;
     v.flags[3] = 0;
     v.flags[4] = 1;  // "work left": the sweeps of this round run until an epilogue clears it (mf_sweep_idle)
+    v.flags[8] = 0;
+    v.flags[11] = 0;
     v.flags[6] = 0;
     v.flags[7] = 0;
     v.acnt[0] = v.acnt[1] = 0;
@@ -513,6 +517,7 @@ struct MfSweepIo {
     bool list_mode = false;  // in
     int pushed_to = -1;      // out: site that received flow along an n-link
     long long pushedA = 0;   // out: flow pushed into the alpha hub (the caller adds it to hubA_e)
+    bool moved = false;      // out: this site delivered flow to t (its own t-link or the alpha hub's)
 };
 
 PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, MfSweepIo* io)
@@ -550,6 +555,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                 v.rt[u] -= dl;
                 mf_add64(&v.ex[u], -dl);
                 e -= dl;
+                io->moved = true;
             }
             if (e > 0) {
                 int best_h = kMfInf, best_a = -1, kind = 0;  // kind 1 n-link, 2 alpha hub, 3 beta hub
@@ -591,7 +597,7 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
                             if (!mf_elect(true)) work = true;
                             else {
                                 const long long got = mf_reserve(v.hubA_rt, e);
-                                if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); }
+                                if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); io->moved = true; }
                                 work = true;
                             }
                         } else {                            // into the hub; members one below it pull it out again
@@ -644,6 +650,8 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next, int consu
     v.hubA_want[next] = 0;
     v.flags[4] = act;
     v.flags[1] = 0;
+    v.flags[11] = v.flags[8] ? 0 : v.flags[11] + 1;   // sweeps in a row without any flow reaching t (the driver then searches again)
+    v.flags[8] = 0;
     if (consumed >= 0) v.acnt[consumed] = 0;
 }
 

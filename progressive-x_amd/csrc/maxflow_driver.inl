@@ -20,6 +20,8 @@ struct MfTuning {
     int wave_max = 24;        // ... only after searches at most this deep (0 = always; PGX_MF_WAVE_MAX), or from the 12th relabel of a move on
     int list_div = 8;         // sweeps visit a work list instead of all sites when <= n / list_div sites are active (0 = never)
     int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
+    int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never; PGX_MF_STALL)
+    int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
@@ -41,7 +43,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         be.bfs_init(v);
         int level = 1, last = 1;
         const int slot = (sweep_id + 2) % 3;
-        int fl[8];
+        int fl[kMfFlags];
         if (be.persistent()) {
             // all levels + the one-thread epilogue in ONE cooperative launch (grid barrier between levels); the level
             // counters come back with the flags: [5] = last level run, [0] = last level that labelled a site
@@ -125,6 +127,11 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             if ((s + 1) % tune.sweep_check != 0) continue;
             be.read_flags(v, fl);
             if (fl[4] == 0) break;
+            // No flow has reached t for longer than the search was deep (a site `last` levels out needs that many sweeps to
+            // deliver): what still moves is excess bouncing between sites that cannot reach t any more, climbing a level or two
+            // per bounce towards "unreachable" - the next search settles that at once.  (The inlier / outlier cut of a 10^6-point
+            // pose problem spent ~80 of the 96 list sweeps of a round this way.)
+            if (tune.stall_sweeps > 0 && fl[11] >= (tune.stall_sweeps > last + 2 ? tune.stall_sweeps : last + 2)) break;
             if (list_mode && fl[6] != 0) list_mode = false;
         }
     }
@@ -133,6 +140,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // alpha is not in use: taking it costs h once.  Worth it iff the stranded excess (sites + hubs) reaches h.
         if (be.stuck_excess(v) < v.h_q) return 0;
     }
+    if (tune.source_reach) be.keep_source_reachable_only(v);   // (label costs are not supported in this mode: h_q == 0)
     be.apply(v);
     *changed = be.read_flag(v, 2);
     stats[4] += *changed;

@@ -55,6 +55,7 @@ struct pgx_ctx {
     pgx::DevBuf pts_s, pts32_s, pmax_s, comp_s, pperm, gbounds, masks_s;
     pgx::DevBuf pts_g, p32_g;    // group-blocked SoA copies of the sorted rows: [group][coordinate][64] (group-major kernel)
     int setpoints_host = 0;      // PGX_SETPOINTS_HOST=1: round 1's host preprocessing in pgx_set_points (A/B, cross-check)
+    int gc_flip = 1;             // PGX_GC_FLIP=0: the inlier / outlier cut in its original orientation (pointwise.hip gc_labeling_launch)
     int score_wg = 0;            // PGX_SCORE_WG=1: workgroup variant of the group-major kernel (constants staged once per chunk of groups)
     int score_dense_min = 32;    // steps with at least this many candidates of 64 are evaluated in place, not queued (PGX_SCORE_DENSE; 65 = never)
     int score_exact_waves = 1;   // waves per segment of the candidate queue in score_exact_kernel (PGX_SCORE_EXW)
@@ -167,7 +168,7 @@ int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams,
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
 int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated);  // lambda = 0: all labels, one read-back
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq, int64_t lambda_q,
-                    int64_t h_q, int alpha, int64_t* changed);
+                    int64_t h_q, int alpha, int64_t* changed, bool source_reach = false);
 void maxflow_free(pgx_ctx* ctx);
 void comm_free(pgx_ctx* ctx);
 

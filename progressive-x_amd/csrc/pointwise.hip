@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kPwBlock) void gc_energy_kernel(const double* __res
 __global__ __launch_bounds__(kPwBlock) void gc_terms_kernel(const double* __restrict__ e, int64_t n, const int* __restrict__ off,
                                                             const int* __restrict__ idx, double lambda, long long lambda_q,
                                                             long long* __restrict__ dq, long long* __restrict__ wq,
-                                                            int* __restrict__ labels)
+                                                            int* __restrict__ labels, int start_label)
 {
     const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
     if (i >= n) return;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kPwBlock) void gc_terms_kernel(const double* __rest
     }
     dq[i] = out;                                                                    // label 0 = outlier (alpha)
     dq[n + i] = inl ? 0 : (long long)__builtin_nearbyint(oml * ei * 4294967296.0);  // label 1 = inlier
-    labels[i] = 1;
+    labels[i] = start_label;
 }
 
 int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
@@ -311,14 +311,20 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
     }
     PGX_HIP(ctx, hipGetLastError());
     const long long lambda_q = quantize_lambda(lambda);
+    // Orientation.  As stated above every site starts "inlier" and alpha = "outlier": then every site beyond the threshold
+    // holds excess (95 % of the sites of a 10^6-point pose problem: 64-level searches, sweeps over all sites).  The same cut with
+    // the terminals swapped - every site starts "outlier", alpha = "inlier", and alpha goes to the sites the SOURCE reaches
+    // (maxflow.hip mf_k_src_*: the minimal source side, i.e. exactly "reaches t" of the original orientation, ties -> outlier) -
+    // has the ~5 % near the model as its excess sites.  Same flags bit for bit (PGX_GC_FLIP=0 for A/B; GPU test).
+    const bool flip = ctx->gc_flip != 0;
     hipLaunchKernelGGL(gc_terms_kernel, g, b, 0, ctx->stream, e, n, ctx->goff.as<int>(), ctx->gidx.as<int>(), lambda, lambda_q, dq,
-                       wq, labels);
+                       wq, labels, flip ? 0 : 1);
     PGX_HIP(ctx, hipGetLastError());
     int64_t changed = 0;
-    PGX_TRY(expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, 0, &changed));
+    PGX_TRY(expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, flip ? 1 : 0, &changed, flip));
     PGX_HIP(ctx, hipMemcpyAsync(flags, labels, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (count) *count = n - changed;
+    if (count) *count = flip ? changed : n - changed;
     return PGX_OK;
 }
 

@@ -42,6 +42,7 @@ struct EmuBackend {
     bool persistent() const { return false; }      // the emulation runs the host-driven level loops
     void bfs_all(const MfView&, int) {}
     void wave_all(const MfView&, int) {}
+    void keep_source_reachable_only(const MfView&) {}   // device-only variant (gc_labeling flipped), never requested here
     int sweep_tail_cap() const { return 0; }       // device-only scheduling variants
     void sweep_tail(const MfView&, int, int, int, int) {}
     void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
@@ -62,7 +63,7 @@ struct EmuBackend {
         v.fcount[(k + 1) % 3] = 0;
     }
     int read_flag(const MfView& v, int i) { return v.flags[i]; }
-    void read_flags(const MfView& v, int out[8]) { for (int k = 0; k < 8; ++k) out[k] = v.flags[k]; }
+    void read_flags(const MfView& v, int out[kMfFlags]) { for (int k = 0; k < kMfFlags; ++k) out[k] = v.flags[k]; }
     void wave(const MfView& v, int k)
     {
         std::vector<int> lv(v.order + v.lvl[k], v.order + v.lvl[k + 1]);
@@ -88,6 +89,7 @@ struct EmuBackend {
         if (io.which == 2) { io.granted = mf_reserve(v.hubA_e, want); v.hubA_want[cur] += want; }
         const bool r = mf_body_sweep(v, u, prev, cur, v.hub_min + cur * v.L, &io);
         v.hubA_e[0] += io.pushedA;
+        if (io.moved) v.flags[8] = 1;
         if (pushed) *pushed = io.pushed_to;
         return r;
     }
@@ -189,7 +191,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     std::vector<long long> cap((size_t)(E > 0 ? E : 1)), ex((size_t)n), rt((size_t)n), f((size_t)n), g((size_t)n),
         hub_e((size_t)L), hubA_rt(1), hubA_e(1), hubA_want(3);
     std::vector<int> d((size_t)n), cnt((size_t)L), hub_exists((size_t)L), has_alpha(1), bfs_hub_d((size_t)L),
-        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 160)), fcount(3), flags(8), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
+        bfs_hubA_d(1), hub_min((size_t)3 * L), order((size_t)n), lvl((size_t)(n + L + 160)), fcount(3), flags(kMfFlags), act0((size_t)n), act1((size_t)n), acnt(2), mark((size_t)n, 0);
     std::vector<unsigned long long> hubA_min(3);
     MfView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;

@@ -1011,6 +1011,47 @@ def test_gc_labeling_matches_oracle(gpu_ctx, oracle, name, n, lam):
     assert np.array_equal(gpu_ctx.gc_labeling(bad, T2, lam), oracle.gc_labeling(mt, pts, bad, T2, lam, graph))
 
 
+def test_gc_labeling_orientations_agree_including_ties(oracle, monkeypatch):
+    """The cut is solved with the terminals swapped (every site starts "outlier", alpha = "inlier", alpha goes to the minimal
+    SOURCE side - maxflow.hip mf_k_src_*) because the stated orientation makes 95 % of the sites hold excess; PGX_GC_FLIP=0
+    keeps the stated one.  Both must give the oracle's flags bit for bit - also where min cuts are NOT unique: duplicated
+    points, integer lattices (exact ties between unary and pairwise terms), lambda = 0.5, models exactly through points."""
+    monkeypatch.setenv("PGX_GC_FLIP", "0")
+    plain = _lib.Context(0)
+    monkeypatch.setenv("PGX_GC_FLIP", "1")
+    flipped = _lib.Context(0)
+    rng = np.random.default_rng(31)
+    try:
+        for trial in range(24):
+            n = int(rng.choice([2, 7, 64, 500, 3000, 12000]))
+            kind = trial % 4
+            if kind == 0:      # integer lattice + the line x = k: residuals are integers, T2 an integer: ties galore
+                pts = rng.integers(0, 12, (n, 2)).astype(np.float64)
+                mt, model, T2 = _lib.LINE2D, np.array([1.0, 0.0, -float(rng.integers(0, 12))]), float(rng.choice([1.0, 4.0, 9.0]))
+            elif kind == 1:    # heavy duplication
+                mt, p0, models, thr = make_case("homography", max(4, n // 10), 3, seed=trial)
+                pts = p0[rng.integers(0, len(p0), n)]
+                model, T2 = models[0], 2.25 * thr * thr
+            else:
+                name = ["pnp", "fundamental", "vanishing_point", "line"][trial % 4]
+                mt, pts, models, thr = make_case(name, n, 3, seed=100 + trial)
+                model, T2 = models[trial % 3], 2.25 * thr * thr
+            lam = float(rng.choice([0.5, 0.25, 0.1, 0.75]))
+            k = min(6, max(1, n - 1))
+            for ctx in (plain, flipped):
+                ctx.set_points(mt, pts)
+            graph = plain.graph_build(pts, _lib.GRAPH_KNN, k=k)
+            flipped.graph_build(pts, _lib.GRAPH_KNN, k=k, fetch=False)
+            ref = oracle.gc_labeling(mt, pts, model, T2, lam, graph)
+            a = plain.gc_labeling(model, T2, lam)
+            b = flipped.gc_labeling(model, T2, lam)
+            assert np.array_equal(a, ref), (trial, "stated orientation", int((a != ref).sum()))
+            assert np.array_equal(b, ref), (trial, "swapped terminals", int((b != ref).sum()))
+    finally:
+        plain.close()
+        flipped.close()
+
+
 def test_gc_labeling_smooths_and_keeps_the_pearl_state(gpu_ctx, oracle):
     # the pairwise term changes the outcome of plain thresholding (points just beyond the threshold inside an inlier
     # neighbourhood are pulled in) but not wholesale; a following expansion still sees its own tables
