@@ -1112,6 +1112,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     MfTuning tune;
     if (const char* e = std::getenv("PGX_MF_WAVE")) tune.wave = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_WAVE_MAX")) tune.wave_max = std::atoi(e);
+    if (const char* e = std::getenv("PGX_MF_WAVE_SMALL")) tune.wave_small = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_LIST_DIV")) tune.list_div = std::atoi(e);
     if (const char* e = std::getenv("PGX_MF_SWEEPS_LIST")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_list = x; }
     if (tune.list_div > 0) be.list_blocks = (unsigned)((n / tune.list_div + kMfBlock - 1) / kMfBlock + 1);
