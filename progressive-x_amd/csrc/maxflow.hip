@@ -132,25 +132,31 @@ __device__ __forceinline__ bool mf_sweep_step(const MfView& v, int64_t u, int pr
     io.list_mode = list_mode;
     long long want = 0, before = 0;
     int slot = 0;
-    if (u >= 0) {
-        want = mf_body_pull_want(v, u, prev, &io.which);
-        if (io.which != 0) {
-            slot = io.which == 1 ? v.labels[u] : kMfMaxLabels;
-            before = (long long)atomicAdd(&s.want[slot], (unsigned long long)want);
+    // Work-list rounds start with no beta hub able to deliver (the driver's precondition) and end when one comes back into
+    // play (flags[6]), so without an alpha hub nobody can pull: the pull phase - three dependent gathers and two workgroup
+    // barriers per pass - is skipped (workgroup-uniform condition).
+    const bool pulls = !list_mode || v.has_alpha_hub[0] != 0;
+    if (pulls) {
+        if (u >= 0) {
+            want = mf_body_pull_want(v, u, prev, &io.which);
+            if (io.which != 0) {
+                slot = io.which == 1 ? v.labels[u] : kMfMaxLabels;
+                before = (long long)atomicAdd(&s.want[slot], (unsigned long long)want);
+            }
         }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x <= kMfMaxLabels && s.want[threadIdx.x] > 0) {
-        const long long w = (long long)s.want[threadIdx.x];
-        if ((int)threadIdx.x == kMfMaxLabels) {
-            s.got[threadIdx.x] = mf_reserve(v.hubA_e, w);
-            atomicAdd((unsigned long long*)&v.hubA_want[cur], (unsigned long long)w);
-        } else {
-            s.got[threadIdx.x] = mf_reserve(&v.hub_e[threadIdx.x], w);
+        __syncthreads();
+        if ((int)threadIdx.x <= kMfMaxLabels && s.want[threadIdx.x] > 0) {
+            const long long w = (long long)s.want[threadIdx.x];
+            if ((int)threadIdx.x == kMfMaxLabels) {
+                s.got[threadIdx.x] = mf_reserve(v.hubA_e, w);
+                atomicAdd((unsigned long long*)&v.hubA_want[cur], (unsigned long long)w);
+            } else {
+                s.got[threadIdx.x] = mf_reserve(&v.hub_e[threadIdx.x], w);
+            }
+            s.want[threadIdx.x] = 0;
         }
-        s.want[threadIdx.x] = 0;
+        __syncthreads();
     }
-    __syncthreads();
     bool r = false;
     if (u >= 0) {
         if (io.which != 0) {
