@@ -518,12 +518,21 @@ struct MfSweepIo {
     int pushed_to = -1;      // out: site that received flow along an n-link
     long long pushedA = 0;   // out: flow pushed into the alpha hub (the caller adds it to hubA_e)
     bool moved = false;      // out: this site delivered flow to t (its own t-link or the alpha hub's)
+    bool listed = false;     // out: the site still belongs on the work list (mf_listed with the values this step ended on)
 };
 
 PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hub_acc, MfSweepIo* io)
 {
     const bool list_mode = io->list_mode;
+    // Everything that depends on u alone is requested up front - ONE round trip instead of a chain of six (label -> excess ->
+    // height -> t-link -> row start -> row end: measured 7.6 us per pass of a work-list sweep, as much again as its list
+    // maintenance) - and the excess is tracked locally from here on: what a neighbour pushes to u meanwhile is that
+    // neighbour's "work" and puts u on the next list through `pushed_to`, exactly as when it arrived just after the old reload.
     const int lu = v.labels[u];
+    long long e = mf_load64(&v.ex[u]);
+    int du = v.d[u];
+    const long long rtu = v.rt[u];
+    const int a_lo = v.off ? v.off[u] : 0, a_hi = v.off ? v.off[u + 1] : 0;
     if (lu == v.alpha) return false;
     bool work = false;
     const bool hub_b = v.hub_exists[lu] != 0;
@@ -538,97 +547,101 @@ PGX_HD bool mf_body_sweep(const MfView& v, int64_t u, int prev, int cur, int* hu
         }
         else mf_add64(&v.g[u], -io->granted);
         mf_add64(&v.ex[u], io->granted);
+        e += io->granted;
         work = true;
     }
     const bool scan_b = !list_mode && hub_b && v.hub_e[lu] > 0;  // plain (cached) read: a gate, not a synchronisation
-    if (!scan_b && mf_load64(&v.ex[u]) <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
-    int du = v.d[u];
+    if (!scan_b && e <= 0 && !(hub_a && mf_load64(&v.g[u]) > 0)) return false;
     // hub heights as published by the previous scan
     int hb = kMfInf;
     if (hub_b) { const int m = v.hub_min[prev * v.L + lu]; hb = m == kMfInf ? kMfInf : m + 1; }
     const int ha = hub_a ? mf_hubA_height(v, prev) : kMfInf;
-    if (du != kMfInf) {
-        long long e = mf_load64(&v.ex[u]);
+    if (du != kMfInf && e > 0) {
+        if (rtu > 0) {  // u -> t
+            const long long dl = e < rtu ? e : rtu;
+            v.rt[u] = rtu - dl;
+            mf_add64(&v.ex[u], -dl);
+            e -= dl;
+            io->moved = true;
+        }
         if (e > 0) {
-            if (v.rt[u] > 0) {  // u -> t
-                const long long dl = e < v.rt[u] ? e : v.rt[u];
-                v.rt[u] -= dl;
-                mf_add64(&v.ex[u], -dl);
-                e -= dl;
-                io->moved = true;
-            }
-            if (e > 0) {
-                int best_h = kMfInf, best_a = -1, kind = 0;  // kind 1 n-link, 2 alpha hub, 3 beta hub
-                if (v.off) {
-                    // lowest residual neighbour.  Loads are issued in batches of eight arcs (capacities and heads, then
-                    // the heads' heights): one arc at a time is a chain of ~2 memory round trips per arc, which is what
-                    // a sweep over a short work list spends its time on.
-                    const int end = v.off[u + 1];
-                    for (int a0 = v.off[u]; a0 < end; a0 += 8) {
-                        long long c[8];
-                        int w[8], h[8];
-                        for (int j = 0; j < 8; ++j) {
-                            const bool in = a0 + j < end;
-                            c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
-                            w[j] = in ? v.idx[a0 + j] : 0;
-                        }
-                        for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
-                        for (int j = 0; j < 8; ++j)
-                            if (h[j] < best_h) { best_h = h[j]; best_a = a0 + j; kind = 1; }
-                    }
+            int best_h = kMfInf, best_a = -1, kind = 0;  // kind 1 n-link, 2 alpha hub, 3 beta hub
+            long long best_c = 0;
+            // lowest residual neighbour.  Loads are issued in batches of eight arcs (capacities and heads, then the heads'
+            // heights): one arc at a time is a chain of ~2 memory round trips per arc, which is what a sweep over a short
+            // work list spends its time on.
+            for (int a0 = a_lo; a0 < a_hi; a0 += 8) {
+                long long c[8];
+                int w[8], h[8];
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = a0 + j < a_hi;
+                    c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
+                    w[j] = in ? v.idx[a0 + j] : 0;
                 }
-                if (hub_a && ha < best_h) { best_h = ha; kind = 2; }
-                if (hub_b && v.f[u] > 0 && hb < best_h) { best_h = hb; kind = 3; }
-                if (kind == 0 || best_h == kMfInf) {
-                    du = kMfInf;  // no residual arc leads anywhere that reaches t
-                    mf_store32(&v.d[u], du);
-                } else if (du > best_h) {
-                    if (kind == 1) {
-                        const long long c = mf_load64(&v.cap[best_a]);
-                        const long long dl = e < c ? e : c;
-                        mf_add64(&v.cap[best_a], -dl);
-                        mf_add64(&v.cap[v.rev[best_a]], dl);
-                        mf_add64(&v.ex[u], -dl);
-                        mf_add64(&v.ex[v.idx[best_a]], dl);
-                        io->pushed_to = v.idx[best_a];
-                        work = true;
-                    } else if (kind == 2) {
-                        if (ha == 1 && v.hubA_rt[0] > 0) {  // budget y_alpha -> t still open: one contender per wave
-                            if (!mf_elect(true)) work = true;
-                            else {
-                                const long long got = mf_reserve(v.hubA_rt, e);
-                                if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); io->moved = true; }
-                                work = true;
-                            }
-                        } else {                            // into the hub; members one below it pull it out again
-                            mf_add64(&v.g[u], e);
-                            mf_add64(&v.ex[u], -e);
-                            io->pushedA += e;
+                for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
+                for (int j = 0; j < 8; ++j)
+                    if (h[j] < best_h) { best_h = h[j]; best_a = a0 + j; best_c = c[j]; kind = 1; }
+            }
+            if (hub_a && ha < best_h) { best_h = ha; kind = 2; }
+            if (hub_b && v.f[u] > 0 && hb < best_h) { best_h = hb; kind = 3; }
+            if (kind == 0 || best_h == kMfInf) {
+                du = kMfInf;  // no residual arc leads anywhere that reaches t
+                mf_store32(&v.d[u], du);
+            } else if (du > best_h) {
+                if (kind == 1) {
+                    // best_c as loaded above: only this site lowers the capacity of its own arcs, so the value can only have grown
+                    const long long dl = e < best_c ? e : best_c;
+                    const int to = v.idx[best_a];
+                    mf_add64(&v.cap[best_a], -dl);
+                    mf_add64(&v.cap[v.rev[best_a]], dl);
+                    mf_add64(&v.ex[u], -dl);
+                    mf_add64(&v.ex[to], dl);
+                    e -= dl;
+                    io->pushed_to = to;
+                    work = true;
+                } else if (kind == 2) {
+                    if (ha == 1 && v.hubA_rt[0] > 0) {  // budget y_alpha -> t still open: one contender per wave
+                        if (!mf_elect(true)) work = true;
+                        else {
+                            const long long got = mf_reserve(v.hubA_rt, e);
+                            if (got > 0) { mf_add64(&v.g[u], got); mf_add64(&v.ex[u], -got); e -= got; io->moved = true; }
                             work = true;
                         }
-                    } else {  // back into the beta hub
-                        const long long dl = e < v.f[u] ? e : v.f[u];
-                        v.f[u] -= dl;
-                        mf_add64(&v.ex[u], -dl);
-                        mf_add64(&v.hub_e[lu], dl);
-                        if (list_mode) mf_store32(&v.flags[6], 1);
+                    } else {                            // into the hub; members one below it pull it out again
+                        mf_add64(&v.g[u], e);
+                        mf_add64(&v.ex[u], -e);
+                        io->pushedA += e;
+                        e = 0;
                         work = true;
                     }
-                } else {
-                    du = best_h + 1;
-                    if (du >= v.hmax) du = kMfInf;
-                    mf_store32(&v.d[u], du);
+                } else {  // back into the beta hub
+                    const long long dl = e < v.f[u] ? e : v.f[u];
+                    v.f[u] -= dl;
+                    mf_add64(&v.ex[u], -dl);
+                    mf_add64(&v.hub_e[lu], dl);
+                    e -= dl;
+                    if (list_mode) mf_store32(&v.flags[6], 1);
+                    work = true;
                 }
+            } else {
+                du = best_h + 1;
+                if (du >= v.hmax) du = kMfInf;
+                mf_store32(&v.d[u], du);
             }
         }
     }
     // contribute to the next hub height scan with the final height
     if (scan_b && du != kMfInf) mf_acc_min(&hub_acc[lu], du);
-    if (hub_a && du != kMfInf && mf_load64(&v.g[u]) > 0) {
-        const unsigned long long pk = mf_pack(du, (int)u);
-        if (pk < v.hubA_min[cur]) mf_minu64(&v.hubA_min[cur], pk);
+    bool lent = false;
+    if (hub_a && du != kMfInf) {
+        lent = mf_load64(&v.g[u]) > 0;
+        if (lent) {
+            const unsigned long long pk = mf_pack(du, (int)u);
+            if (pk < v.hubA_min[cur]) mf_minu64(&v.hubA_min[cur], pk);
+        }
     }
-    if (du != kMfInf && mf_load64(&v.ex[u]) > 0) work = true;
+    if (du != kMfInf && e > 0) work = true;
+    io->listed = du != kMfInf && (e > 0 || lent);
     return work;
 }
 
