@@ -403,6 +403,10 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_l0_apply_dev(const long long* _
 // Eight lanes share one frontier site and stride over its arcs ("virtual warp"): a lane-per-site loop is a chain of
 // ~5 dependent gathers per arc (measured ~45 us per level for frontiers of a few thousand sites).
 constexpr int kBfsLevelBlocks = 256;
+// lanes that share one frontier site: 4 (two arcs each at the usual degree of ~6) instead of 8 doubles the sites per pass - the
+// frontiers of a find6DPoses call average 19 000 sites, i.e. 2.3 passes of 8 192 - and measured 14.2 vs 17.1 us per large level
+constexpr int kBfsLanesLog = 2;
+constexpr int kBfsLanes = 1 << kBfsLanesLog;
 
 // level 1: every site with residual capacity to t
 __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_init(MfView v, int, int)
@@ -436,7 +440,7 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
                                                int stage_margin, int* s_min, Stage& s_stage)
 {
     bool r = false;
-    const int sub = (int)(threadIdx.x & 7);
+    const int sub = (int)(threadIdx.x & (kBfsLanes - 1));
     // no hub at all in this move (label cost 0: the inlier / outlier cut of the local optimisation; or every label but alpha
     // unused): labelling a site then needs neither its label nor the hub table - one dependent gather less per pass
     bool hubs = v.has_alpha_hub[0] != 0;
@@ -446,12 +450,12 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
     int* const scnt = stage_margin > 0 ? &s_stage.count : nullptr;
     int* const slist = stage_margin > 0 ? s_stage.list : nullptr;
     const int full = kStageCap - (stage_margin > 256 ? stage_margin : 256);
-    // workgroup-uniform loops (stage_flush has barriers): every pass handles nthreads / 8 frontier sites
-    for (int64_t q0 = 0; v.off != nullptr && q0 < F; q0 += nthreads >> 3) {
-        const int64_t q = q0 + (gtid >> 3);
+    // workgroup-uniform loops (stage_flush has barriers): every pass handles nthreads / kBfsLanes frontier sites
+    for (int64_t q0 = 0; v.off != nullptr && q0 < F; q0 += nthreads >> kBfsLanesLog) {
+        const int64_t q = q0 + (gtid >> kBfsLanesLog);
         if (q < F) {
             const int w = __hip_atomic_load(&fin[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int a = v.off[w] + sub; a < v.off[w + 1]; a += 8) {
+            for (int a = v.off[w] + sub; a < v.off[w + 1]; a += kBfsLanes) {
                 const int uu = v.idx[a];
                 // residual of the reverse arc uu -> w without the gather through rev[a]; label test folded into d (kMfDead).
                 // The compare-and-swap itself tests "still unlabelled" (no load of d first: one round trip less per pass;
@@ -747,8 +751,8 @@ struct HipBackend {
     bool persistent() const { return persist; }
     int stage_margin() const
     {
-        // staging needs room for everything one pass can append: 256 threads x ceil(max degree / 8) arcs each
-        const int per_pass = kMfBlock * ((ctx->max_degree + 7) / 8);
+        // staging needs room for everything one pass can append: 256 threads x ceil(max degree / kBfsLanes) arcs each
+        const int per_pass = kMfBlock * ((ctx->max_degree + kBfsLanes - 1) / kBfsLanes);
         return per_pass <= kStageCap / 2 ? (per_pass > 0 ? per_pass : kMfBlock) : 0;
     }
     void bfs_all(const MfView& v, int slot)

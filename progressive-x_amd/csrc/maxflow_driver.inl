@@ -11,7 +11,8 @@
 namespace pgx {
 
 struct MfTuning {
-    int bfs_batch = 8;        // BFS levels issued between two flag read-backs
+    int bfs_batch = 8;        // BFS levels issued before the first flag read-back (without a depth hint)
+    int bfs_next = 8;         // ... before the second; 16 from then on
     int sweeps_per_relabel = 24;  // over all sites (48 before the BFS got cheaper: C4 end-to-end 3.13 -> 2.99 s)
     int sweep_check = 8;      // read the work-left flag every this many sweeps
     int max_relabels = 4096;  // hard cap on global relabels per move
@@ -64,7 +65,9 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
             if (hint && *hint > 0) first = *hint + 2 < 64 ? *hint + 2 : 64;
             for (int round = 0;; ++round) {
-                const int batch = round == 0 ? first : (round == 1 ? 4 : (4 << (round - 1) < 64 ? 4 << (round - 1) : 64));
+                // later batches of a fixed 16: doubling up to 64 overshot deep searches by dozens of launches on empty frontiers
+                // (26 % of all level launches of a find6DPoses + findVanishingPoints run; an empty level costs ~5 us, a read-back ~25)
+                const int batch = round == 0 ? first : (round == 1 ? tune.bfs_next : 16);
                 for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
                 last = be.read_flag(v, 0);
                 if (last <= level - 2 || level >= v.hmax) break;
