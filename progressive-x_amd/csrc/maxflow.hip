@@ -450,6 +450,26 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
     int* const scnt = stage_margin > 0 ? &s_stage.count : nullptr;
     int* const slist = stage_margin > 0 ? s_stage.list : nullptr;
     const int full = kStageCap - (stage_margin > 256 ? stage_margin : 256);
+    // Level 2, bottom-up.  Level 1 is every site with residual capacity to t - 94 % of the sites in the steady-state moves of
+    // PEARL - and expanding it top-down walks all their arcs to find the few unlabelled neighbours: 250-300 us at N = 1e6,
+    // 56 us at 2e5, once per search (a quarter of all BFS time of a find6DPoses call).  Here the UNLABELLED sites look for a
+    // level-1 neighbour they have a residual arc to instead (u -> w residual = cap of u's own arc: the same test the
+    // top-down step makes through tot - cap of w's arc): one pass over d[], arcs only for the few that are unlabelled.
+    if (k == 2 && ev == 0 && v.off != nullptr && (int64_t)F * 4 > v.n) {
+        const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;
+        for (int64_t u0 = (int64_t)blockIdx.x * kMfBlock; u0 < rounded; u0 += nthreads) {
+            const int64_t u = u0 + threadIdx.x;
+            bool want = false;
+            if (u < v.n && v.d[u] == kMfInf) {   // active and unlabelled (inactive sites carry kMfDead)
+                for (int a = v.off[u]; a < v.off[u + 1] && !want; ++a)
+                    want = v.cap[a] > 0 && v.d[v.idx[a]] == 1;
+            }
+            r |= mf_bfs_label(v, u < v.n ? u : 0, k, s_min, want, level_base, scnt, slist, hubs);
+            if (__syncthreads_or(s_stage.count > full)) stage_flush(v, s_stage, k, level_base);
+        }
+        stage_flush(v, s_stage, k, level_base);
+        return r;
+    }
     // workgroup-uniform loops (stage_flush has barriers): every pass handles nthreads / kBfsLanes frontier sites
     for (int64_t q0 = 0; v.off != nullptr && q0 < F; q0 += nthreads >> kBfsLanesLog) {
         const int64_t q = q0 + (gtid >> kBfsLanesLog);
