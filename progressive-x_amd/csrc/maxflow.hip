@@ -31,6 +31,18 @@ struct MaxflowState {
 
 constexpr int kMfMaxLabels = 64;
 
+// What a workgroup reports when it retires - a minimum per label, a "something happened" flag - lands on a handful of
+// addresses, and same-address atomics serialise at ~20 ns each: 512 workgroups reporting the same hub height cost 10 us at
+// the tail of a sweep over all sites.  Nearly all of them report what is already there: look first (a load is not serialised).
+__device__ __forceinline__ void mf_report_min(int* p, int val)
+{
+    if (val < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, val);
+}
+__device__ __forceinline__ void mf_report_flag(int* p, int val)
+{
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != val) __hip_atomic_store(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(kMfBlock) void mf_k_count(MfView v, int, int)
 {
     // per-block LDS histogram, one global atomic per (block, label present); grid-stride: same-address atomics cost ~20 ns
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
     const int count = s_count;
     if (WHAT == kCountActive) {
         if (threadIdx.x == 0 && count > 0) {
-            __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mf_report_flag(&v.flags[1], 1);
             atomicAdd(&v.flags[3], count);  // number of active sites after this global relabel (diagnostics)
         }
     } else {
@@ -177,14 +189,15 @@ __device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool li
 {
     const int count = __syncthreads_count(any ? 1 : 0);
     if (!list_mode && (int)threadIdx.x < v.L && s.min[threadIdx.x] != kMfInf)
-        atomicMin(&v.hub_min[cur * v.L + threadIdx.x], s.min[threadIdx.x]);
+        mf_report_min(&v.hub_min[cur * v.L + threadIdx.x], s.min[threadIdx.x]);
     if (threadIdx.x == 0) {
         if (s.pushA > 0) atomicAdd((unsigned long long*)v.hubA_e, s.pushA);
-        if (count > 0) __hip_atomic_store(&v.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s.moved) __hip_atomic_store(&v.flags[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (count > 0) mf_report_flag(&v.flags[1], 1);
+        if (s.moved) mf_report_flag(&v.flags[8], 1);
     }
 }
 
+constexpr int kSweepList = 8 * kMfBlock;   // live sites a workgroup collects before it runs the step over them
 // sweep over all sites
 __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
 {
@@ -204,19 +217,36 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
         s_hub_live[threadIdx.x] = (int)threadIdx.x < v.L && v.hub_exists[threadIdx.x] && v.hub_e[threadIdx.x] > 0;
     const bool hub_a = v.has_alpha_hub[0] != 0;
     __syncthreads();
+    // Two phases per workgroup: its chunks are scanned back to back (no barrier in between: the loads pipeline) and the live
+    // sites collected in LDS; then the push-relabel step runs over that compact list, 256 sites per pass.  In-kernel timers on
+    // a find6DPoses call: 23 of 256 sites of a chunk are live, and a pass over a chunk with ONE live site costs the same 4 us
+    // (two barriers, the gather chain) as a full one - 1.8 to 8 such passes per workgroup became one.
+    __shared__ int s_list[kSweepList];
+    __shared__ int s_nlist;
+    if (threadIdx.x == 0) s_nlist = 0;
+    __syncthreads();
     bool r = false;
+    auto run_list = [&]() {
+        __syncthreads();
+        const int nl = s_nlist;
+        for (int i = (int)threadIdx.x; i < (nl + kMfBlock - 1) / kMfBlock * kMfBlock; i += kMfBlock)
+            r |= mf_sweep_step(v, i < nl ? s_list[i] : -1, prev, cur, false, s, nullptr);
+        __syncthreads();
+        if (threadIdx.x == 0) s_nlist = 0;
+        __syncthreads();
+    };
     const int64_t chunks = (v.n + kMfBlock - 1) / kMfBlock;
+    int pending = 0;   // chunks scanned since the list was last emptied (workgroup-uniform)
     for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const int64_t u = c * kMfBlock + threadIdx.x;
-        bool live = false;
         if (u < v.n) {
             const int lu = v.labels[u];
             const long long e = v.ex[u];
-            live = lu != v.alpha && (hub_a || s_hub_live[lu] || e > 0);
+            if (lu != v.alpha && (hub_a || s_hub_live[lu] || e > 0)) s_list[atomicAdd(&s_nlist, 1)] = (int)u;
         }
-        if (!__syncthreads_or(live)) continue;
-        r |= mf_sweep_step(v, live ? u : -1, prev, cur, false, s, nullptr);
+        if (++pending == kSweepList / kMfBlock) { run_list(); pending = 0; }   // the list cannot overflow
     }
+    if (pending > 0) run_list();
     mf_sweep_flush(v, cur, false, s, r);
 }
 
@@ -429,8 +459,8 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_init(MfView v, int, int)
     }
     stage_flush(v, s_stage, 1);
     const int count = __syncthreads_count(r ? 1 : 0);
-    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
-    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) mf_report_min(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+    if (threadIdx.x == 0 && count > 0) mf_report_flag(&v.flags[0], 1);
 }
 
 // One BFS level for the calling workgroup (all of its threads): the frontier part (F sites of level k-1 at `fin`), then the
@@ -513,8 +543,8 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
         v.fcount[(k + 1) % 3] = 0;  // slot of the level after this one
     }
     const int count = __syncthreads_count(r ? 1 : 0);
-    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
-    if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) mf_report_min(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
+    if (threadIdx.x == 0 && count > 0) mf_report_flag(&v.flags[0], k);
 }
 
 // ---- persistent kernels: all BFS levels / all wave levels of one global relabel in ONE launch ---------------------------
