@@ -467,14 +467,12 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_init(MfView v, int, int)
 // hub part when a hub received distance k-1 (`ev`).  level_base = where level k starts in `order`.  Returns "labelled".
 // stage_margin: the most one pass can append (256 threads x arcs per thread); 0 = append straight to `order`
 __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, const int* __restrict__ fin, int level_base, int ev,
-                                               int stage_margin, int* s_min, Stage& s_stage)
+                                               int stage_margin, int* s_min, Stage& s_stage, bool hubs)
 {
     bool r = false;
     const int sub = (int)(threadIdx.x & (kBfsLanes - 1));
     // no hub at all in this move (label cost 0: the inlier / outlier cut of the local optimisation; or every label but alpha
     // unused): labelling a site then needs neither its label nor the hub table - one dependent gather less per pass
-    bool hubs = v.has_alpha_hub[0] != 0;
-    for (int l = 0; l < v.L; ++l) hubs |= v.hub_exists[l] != 0;
     const int64_t nthreads = (int64_t)gridDim.x * kMfBlock;
     const int64_t gtid = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
     int* const scnt = stage_margin > 0 ? &s_stage.count : nullptr;
@@ -529,15 +527,39 @@ __device__ __forceinline__ bool bfs_level_body(const MfView& v, int k, int F, co
     return r;
 }
 
+// "which hub events fire at level k" (mf_bfs_hub_events) and "does any hub exist" with one lane per label: the scalar loops over
+// the labels were a chain of ~2 L dependent loads at the head of every level (1.7 us of the ~11 a level over 10^4 sites takes).
+// s_flag[0] = events, s_flag[1] = any hub.  All threads call it; ends with a barrier.
+__device__ __forceinline__ void bfs_hub_flags(const MfView& v, int k, int* s_flag, bool coherent)
+{
+    if (threadIdx.x == 0) {
+        const int ha = v.has_alpha_hub[0];
+        const int da = ha ? (coherent ? __hip_atomic_load(&v.bfs_hubA_d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v.bfs_hubA_d[0]) : kMfInf;
+        s_flag[0] = (ha && da == k - 1) ? 1 : 0;
+        s_flag[1] = ha != 0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < v.L) {
+        const int ex = v.hub_exists[threadIdx.x];
+        if (ex) {
+            atomicOr(&s_flag[1], 1);
+            const int hd = coherent ? __hip_atomic_load(&v.bfs_hub_d[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v.bfs_hub_d[threadIdx.x];
+            if (ex == 2 && hd == k - 1) atomicOr(&s_flag[0], 2);   // == 2: some member holds f > 0 (mf_bfs_hub_events)
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int stage_margin)
 {
     __shared__ int s_min[kMfMaxLabels];
     __shared__ Stage s_stage;
     if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
+    __shared__ int s_flag[2];
     if (threadIdx.x == 0) s_stage.count = 0;
-    __syncthreads();
-    const bool r = bfs_level_body(v, k, v.fcount[(k - 1) % 3], v.order + v.lvl[k - 1], mf_level_base(v, k), mf_bfs_hub_events(v, k),
-                                  stage_margin, s_min, s_stage);
+    bfs_hub_flags(v, k, s_flag, false);   // (plain reads: a hub's distance k-1 was written by an earlier kernel, see mf_bfs_hub_events)
+    const bool r = bfs_level_body(v, k, v.fcount[(k - 1) % 3], v.order + v.lvl[k - 1], mf_level_base(v, k), s_flag[0],
+                                  stage_margin, s_min, s_stage, s_flag[1] != 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         v.lvl[k] = mf_level_base(v, k);
         v.fcount[(k + 1) % 3] = 0;  // slot of the level after this one
@@ -603,7 +625,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_persist(MfView v, int stage
             v.lvl[k] = level_base;
             __hip_atomic_store(&v.fcount[(k + 1) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // free since level k-1 ended
         }
-        const bool r = bfs_level_body(v, k, F, v.order + base_prev, level_base, ev, stage_margin, s_min, s_stage);
+        const bool r = bfs_level_body(v, k, F, v.order + base_prev, level_base, ev, stage_margin, s_min, s_stage, true);
         const int count = __syncthreads_count(r ? 1 : 0);
         if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
         if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
