@@ -198,8 +198,30 @@ __device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool li
 }
 
 constexpr int kSweepList = 8 * kMfBlock;   // live sites a workgroup collects before it runs the step over them
+template <bool COH> __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed);
+
+// The one-wave epilogue of a sweep as the LAST act of the sweep kernel itself (fused != 0): every participating workgroup
+// waits for its own memory operations, takes a ticket, and the one that draws the last ticket runs the epilogue - reading what
+// the others reported through device-scope loads.  Saves the 4.5 us launch that followed every sweep (a kernel that loads and
+// stores anything does not finish sooner); the tickets are `nb` atomics on one word, spread over the time the workgroups
+// take to finish.  All threads of the workgroup call it.  MEASURED: find6DPoses PEARL 2.07-2.11 s fused vs 1.98-2.04 s with the
+// separate launch, findVanishingPoints 2.27-2.31 vs 2.10-2.29 s - identical labels, opt-in only.
+__device__ __forceinline__ void mf_sweep_retire(const MfView& v, int cur, int consumed, unsigned nb)
+{
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores and atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = (unsigned)__hip_atomic_fetch_add(&v.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == nb - 1;
+        if (s_last) __hip_atomic_store(&v.flags[9], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) mf_sweep_epilogue_wave<true>(v, cur, (cur + 1) % 3, consumed);
+}
+
 // sweep over all sites
-__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur, int fused)
 {
     if (mf_sweep_idle(v)) return;
     __shared__ SweepLds s;
@@ -248,6 +270,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
     }
     if (pending > 0) run_list();
     mf_sweep_flush(v, cur, false, s, r);
+    if (fused) mf_sweep_retire(v, cur, -1, gridDim.x);
 }
 
 // Two conditional appends per lane (the site itself, the site it pushed to) with ONE reservation per wave: the list
@@ -276,12 +299,17 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_build_list(MfView v, int stamp,
     mf_list_append(v, 0, (int)u, want);
 }
 
-__global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp)
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp, int fused)
 {
     if (mf_sweep_idle(v)) return;
+    const int cnt = v.acnt[parity];
+    // workgroups beyond the list leave at once; the others (at least workgroup 0) take part in the retirement protocol
+    unsigned nb = (unsigned)((cnt + kMfBlock - 1) / kMfBlock);
+    if (nb > gridDim.x) nb = gridDim.x;
+    if (nb == 0) nb = 1;
+    if (blockIdx.x >= nb) return;
     __shared__ SweepLds s;
     sweep_lds_init(s);
-    const int cnt = v.acnt[parity];
     const int* __restrict__ in = v.act[parity];
     bool any = false;
     const int stride = (int)(gridDim.x * kMfBlock);
@@ -296,6 +324,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, 
         mf_append2(&v.acnt[1 - parity], v.act[1 - parity], u, again, pushed, fresh);
     }
     mf_sweep_flush(v, cur, true, s, any);
+    if (fused) mf_sweep_retire(v, cur, parity, nb);
 }
 
 // ---- list-mode sweeps of a SHORT work list: up to `budget` sweeps in one launch of one workgroup --------------------------
@@ -715,21 +744,26 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
 
 // The sweep epilogue (maxflow_body.cuh mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
 // labels through a chain of dependent loads (~5.3 us; at C5 a call ran 80 k of them, 19 % of its GPU time).  Same result.
+template <bool COH>
 __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed)
 {
+    // COH: run by the last workgroup of the sweep itself (mf_sweep_retire) - what the other workgroups reported with
+    // atomics is read with device-scope loads
+    auto ld32 = [](const int* p) { return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    auto ld64 = [](const long long* p) { return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
     const int l = (int)threadIdx.x;   // one wave, L <= 64
     const int prev = (cur + 2) % 3;
     // every load up front (one round trip): the kernel is nothing but its dependent-load chain
     const bool in = l < v.L;
     const int exists = in ? v.hub_exists[l] : 0;
-    const long long he = in ? v.hub_e[l] : 0;
-    int mc = in ? v.hub_min[cur * v.L + l] : kMfInf;
+    const long long he = in ? ld64(&v.hub_e[l]) : 0;
+    int mc = in ? ld32(&v.hub_min[cur * v.L + l]) : kMfInf;
     const int mp = in ? v.hub_min[prev * v.L + l] : kMfInf;
-    const int work = v.flags[1];
-    const int moved = v.flags[8], stall = v.flags[11];
+    const int work = ld32(&v.flags[1]);
+    const int moved = ld32(&v.flags[8]), stall = v.flags[11];
     const int hub_a = v.has_alpha_hub[0];
-    const long long hae = v.hubA_e[0];
-    const unsigned long long ham = v.hubA_min[cur];
+    const long long hae = ld64(v.hubA_e);
+    const unsigned long long ham = COH ? __hip_atomic_load(&v.hubA_min[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v.hubA_min[cur];
     bool hub_act = false;
     if (in) {
         if (exists && (consumed >= 0 || he <= 0) && mc == kMfInf) {   // no scan was requested: keep the last known height
@@ -758,7 +792,7 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
 {
     if (blockIdx.x != 0) return;
     if (what == 3) {   // all 64 lanes
-        if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave(v, a0, a1, a2);
+        if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave<false>(v, a0, a1, a2);
         return;
     }
     if (threadIdx.x != 0) return;
@@ -953,10 +987,13 @@ struct HipBackend {
     unsigned sweep_blocks = 512;     // workgroups of a sweep over all sites (PGX_MF_SWEEP_BLOCKS)
     void sweep(const MfView& v, int prev, int cur)
     {
-        hipLaunchKernelGGL(mf_k_sweep, dim3(blocks < sweep_blocks ? blocks : sweep_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur);
+        hipLaunchKernelGGL(mf_k_sweep, dim3(blocks < sweep_blocks ? blocks : sweep_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur,
+                           fused_epilogue);
         check();
     }
-    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { single(v, 3, cur, next, consumed); }
+    int fused_epilogue = 0;          // PGX_MF_FUSED=1: the sweep kernels run their own epilogue (mf_sweep_retire).  Measured 2-4 % SLOWER than the
+                                     // separate one-wave launch (the wait + ticket + dependent loads at the tail of every sweep): off
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { if (!fused_epilogue) single(v, 3, cur, next, consumed); }
     int take_stamps(const MfView& v, int count)
     {
         if (st->next_stamp > 0x3fff0000 - count) {  // stamps only grow: start over with a clean mark array
@@ -983,7 +1020,7 @@ struct HipBackend {
     }
     void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
     {
-        hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
+        hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp, fused_epilogue);
         check();
     }
     long long stuck_excess(const MfView& v)
@@ -1226,6 +1263,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (const char* e = std::getenv("PGX_MF_LEVEL_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_level_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_INIT_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_init_blocks = (unsigned)x; }
     if (const char* e = std::getenv("PGX_MF_SWEEP_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.sweep_blocks = (unsigned)x; }
+    if (const char* e = std::getenv("PGX_MF_FUSED")) be.fused_epilogue = std::atoi(e) ? 1 : 0;
     if (const char* e = std::getenv("PGX_MF_TAIL")) { const int x = std::atoi(e); if (x >= 0) be.tail_cap = x; }
     if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) { tune.bfs_batch = x; tune.bfs_hint = nullptr; } }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);

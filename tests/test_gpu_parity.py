@@ -554,11 +554,13 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail"])
+@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail", "fused"])
 def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
     # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
     if forced == "list_sweeps":
         monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
+    if forced == "fused":        # the sweep kernels run their own epilogue (last workgroup by ticket)
+        monkeypatch.setenv("PGX_MF_FUSED", "1")
     if forced == "tail":         # list-mode sweeps back to back inside one workgroup (mf_k_sweep_tail)
         monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
         monkeypatch.setenv("PGX_MF_TAIL", "2048")
@@ -1237,8 +1239,9 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     assert arcs > 4 * n
     gpu_ctx.pearl_unary(poses[:9], 4.0 / f, lam)
     results = []
-    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}, {"PGX_MF_TAIL": "1024"}):
-        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST", "PGX_MF_TAIL"):
+    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}, {"PGX_MF_TAIL": "1024"},
+                {"PGX_MF_FUSED": "1"}, {"PGX_MF_WAVE_MAX": "0", "PGX_MF_STALL": "0"}):
+        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST", "PGX_MF_TAIL", "PGX_MF_FUSED", "PGX_MF_WAVE_MAX", "PGX_MF_STALL"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
