@@ -255,10 +255,10 @@ PGX_HD int mf_level_base(const MfView& v, int k) { return k <= 1 ? 0 : v.lvl[k -
 // of serialised L2 atomics each on a single address — 331 us for the level-1 pass and most of the ~42 us per level at
 // N = 1e6.
 PGX_HD bool mf_bfs_label(const MfView& v, int64_t u, int k, int* hub_acc, bool want, int base = -1,
-                         int* stage_cnt = nullptr, int* stage_list = nullptr, bool hubs = true)
+                         int* stage_cnt = nullptr, int* stage_list = nullptr, bool hubs = true, bool preclaimed = false)
 {
     bool mine = false;
-    if (want) mine = mf_cas32(&v.d[u], kMfInf, k);
+    if (want) mine = preclaimed ? true : mf_cas32(&v.d[u], kMfInf, k);   // preclaimed: the caller has written d[u] = k itself
     if (mine && hubs) {   // hubs == false: the caller knows that no hub exists in this move (saves the label gather)
         const int lu = v.labels[u];
         if (v.hub_exists[lu]) mf_acc_min(&hub_acc[lu], k + 1);      // y_beta -> u has infinite capacity
@@ -300,9 +300,11 @@ PGX_HD bool mf_sweep_idle(const MfView& v) { return v.flags[4] == 0; }
 // level 1: sites with residual capacity to t.  Returns true iff the site was labelled.
 PGX_HD bool mf_body_bfs_init(const MfView& v, int64_t u, int* hub_acc, int* stage_cnt = nullptr, int* stage_list = nullptr)
 {
+    // nobody else touches d[u] in this pass: one store of the final value instead of "unlabelled", then a compare-and-swap
     const bool active = v.labels[u] != v.alpha;
-    if (active) mf_store32(&v.d[u], kMfInf);
-    return mf_bfs_label(v, u, 1, hub_acc, active && v.rt[u] > 0, -1, stage_cnt, stage_list);
+    const bool first = active && v.rt[u] > 0;
+    if (active) mf_store32(&v.d[u], first ? 1 : kMfInf);
+    return mf_bfs_label(v, u, 1, hub_acc, first, -1, stage_cnt, stage_list, true, true);
 }
 
 // level k, frontier part: site w was labelled k-1; every active unlabelled neighbour u with residual u -> w gets k
