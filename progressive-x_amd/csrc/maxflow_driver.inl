@@ -130,6 +130,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             stats[1] += 1;
             if ((s + 1) % tune.sweep_check != 0) continue;
             be.read_flags(v, fl);
+            if (tune.debug == 5) std::fprintf(stderr, "[mf-sweeps] alpha=%d it=%d s=%d work=%d stall=%d hub=%d list=%d active0=%d\n", v.alpha, it, s + 1, fl[4], fl[11], fl[7], (int)list_mode, fl[3]);
             if (fl[4] == 0) break;
             // No flow has reached t for longer than the search was deep (a site `last` levels out needs that many sweeps to
             // deliver): what still moves is excess bouncing between sites that cannot reach t any more, climbing a level or two
