@@ -397,7 +397,12 @@ static void finish_scores(int n, int has_compound, int exponent, const double* v
     for (int m = 0; m < n; ++m) {
         // scoring_function_with_compound_model.h:110,120: subtract pow(shared, exponent) iff the compound instance
         // is non-empty; std::pow(double,int) promotes to pow(double,double).
-        scores[m] = has_compound ? values[m] - std::pow(shared[m], (double)exponent) : values[m];
+        // A hypothesis that shares no inlier with the compound instance (most of a batch) has shared == +0: pow(+0, e) = +0 and
+        // v - (+0) = v bit for bit, so libm's pow (12 ns a call: 25 us per 2048-hypothesis fetch, inside every proposal step)
+        // runs only where it can change the result.
+        const double sh = shared[m];
+        scores[m] = has_compound && !(sh == 0.0 && !std::signbit(sh) && exponent > 0) ? values[m] - std::pow(sh, (double)exponent)
+                                                                                       : values[m];
     }
 }
 

@@ -179,7 +179,8 @@ int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* val
     if (shared) memcpy(shared, s.data(), T * 8);
     if (scores)
         for (size_t m = 0; m < T; ++m)
-            scores[m] = ctx->score_has_compound ? v[m] - std::pow(s[m], (double)exponent) : v[m];
+            // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
+            scores[m] = ctx->score_has_compound && !(s[m] == 0.0 && !std::signbit(s[m]) && exponent > 0) ? v[m] - std::pow(s[m], (double)exponent) : v[m];
     return PGX_OK;
 }
 
