@@ -614,17 +614,27 @@ __global__ __launch_bounds__(kPwBlock) void greedy_init_kernel(long long* __rest
     if (i < n) { e[i] = kGreedyBig; labels[i] = 0; }
 }
 
+// Rounds without a host round trip: the choice of the label to open is made on the device (greedy_decide_kernel, one thread,
+// the same strict "<" over the labels in index order as the oracle), so the host enqueues all L rounds at once and reads the
+// result once - a round used to be three launches, a copy back and a synchronisation (~40 us; findTwoViewMotions at C3 runs
+// 244 such labellings).  state: [0] mask of opened labels, [1] label opened in this round, [2] count, [3] done.
+constexpr int kGreedyBlocks = 256;   // grid-stride: every workgroup ends with one atomic per label on L addresses
+
 __global__ __launch_bounds__(kPwBlock) void greedy_delta_kernel(const long long* __restrict__ dq, int64_t n, int L,
-                                                               const long long* __restrict__ e, unsigned long long open_mask,
+                                                               const long long* __restrict__ e,
+                                                               const unsigned long long* __restrict__ state,
                                                                unsigned long long* __restrict__ delta /*[L]*/)
 {
+    if (state[3]) return;
+    const unsigned long long open_mask = state[0];
     __shared__ long long lds[kPwBlock / 64];
-    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
-    const long long ei = i < n ? e[i] : 0;
     for (int l = 0; l < L; ++l) {
         if ((open_mask >> l) & 1ull) continue;  // uniform
         long long d = 0;
-        if (i < n) { d = dq[(int64_t)l * n + i] - ei; if (d > 0) d = 0; }
+        for (int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kPwBlock) {
+            const long long t = dq[(int64_t)l * n + i] - e[i];
+            if (t < 0) d += t;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
         __syncthreads();  // the previous label's partials have been read
@@ -638,9 +648,31 @@ __global__ __launch_bounds__(kPwBlock) void greedy_delta_kernel(const long long*
     }
 }
 
-__global__ __launch_bounds__(kPwBlock) void greedy_apply_kernel(const long long* __restrict__ dq, int64_t n, int alpha,
+__global__ void greedy_decide_kernel(int L, long long h_q, unsigned long long* __restrict__ state, unsigned long long* __restrict__ delta)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || state[3]) return;
+    const unsigned long long open_mask = state[0];
+    int best = -1;
+    long long best_delta = 0;
+    for (int l = 0; l < L; ++l) {
+        if (!((open_mask >> l) & 1ull)) {
+            const long long dl = (long long)delta[l] + h_q;
+            if (dl < best_delta) { best_delta = dl; best = l; }
+        }
+        delta[l] = 0;   // for the next round
+    }
+    if (best < 0) { state[3] = 1; return; }
+    state[0] = open_mask | (1ull << best);
+    state[1] = (unsigned long long)best;
+    state[2] += 1;
+}
+
+__global__ __launch_bounds__(kPwBlock) void greedy_apply_kernel(const long long* __restrict__ dq, int64_t n,
+                                                               const unsigned long long* __restrict__ state,
                                                                long long* __restrict__ e, int* __restrict__ labels)
 {
+    if (state[3]) return;
+    const int alpha = (int)state[1];
     const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
     if (i >= n) return;
     const long long d = dq[(int64_t)alpha * n + i];
@@ -681,33 +713,24 @@ int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* op
         PGX_HIP(ctx, hipGetLastError());
         count = -1;  // counted from the energy pass below
     } else {
-        PGX_TRY(ensure(ctx, ctx->gc, (size_t)n * sizeof(long long) + 64 * sizeof(long long)));  // e[n] | delta[64]
+        PGX_TRY(ensure(ctx, ctx->gc, (size_t)n * sizeof(long long) + 72 * sizeof(long long)));  // e[n] | delta[64] | state[4]
         long long* e = ctx->gc.as<long long>();
         unsigned long long* d_delta = (unsigned long long*)(e + n);
+        unsigned long long* d_state = d_delta + 64;
         hipLaunchKernelGGL(greedy_init_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, e, labels, n);
         PGX_HIP(ctx, hipGetLastError());
-        unsigned long long open_mask = 0;
-        long long h_delta[64];
-        for (int round = 0; round < L; ++round) {
-            PGX_HIP(ctx, hipMemsetAsync(d_delta, 0, 64 * sizeof(long long), ctx->stream));
-            hipLaunchKernelGGL(greedy_delta_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, L, e, open_mask,
-                               d_delta);
-            PGX_HIP(ctx, hipGetLastError());
-            PGX_HIP(ctx, hipMemcpyAsync(h_delta, d_delta, (size_t)L * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-            PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            int best = -1;
-            long long best_delta = 0;
-            for (int l = 0; l < L; ++l) {
-                if ((open_mask >> l) & 1ull) continue;
-                const long long delta = h_delta[l] + (long long)h_q;
-                if (delta < best_delta) { best_delta = delta; best = l; }
-            }
-            if (best < 0) break;
-            open_mask |= 1ull << best;
-            ++count;
-            hipLaunchKernelGGL(greedy_apply_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, best, e, labels);
-            PGX_HIP(ctx, hipGetLastError());
+        PGX_HIP(ctx, hipMemsetAsync(d_delta, 0, 72 * sizeof(long long), ctx->stream));
+        const unsigned gb = (unsigned)(blocks < kGreedyBlocks ? blocks : kGreedyBlocks);
+        for (int round = 0; round < L; ++round) {   // all rounds enqueued at once: finished rounds leave at their first instruction
+            hipLaunchKernelGGL(greedy_delta_kernel, dim3(gb), dim3(kPwBlock), 0, ctx->stream, dq, n, L, e, d_state, d_delta);
+            hipLaunchKernelGGL(greedy_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, L, (long long)h_q, d_state, d_delta);
+            hipLaunchKernelGGL(greedy_apply_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, dq, n, d_state, e, labels);
         }
+        PGX_HIP(ctx, hipGetLastError());
+        unsigned long long h_state[4];
+        PGX_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        count = (int)h_state[2];
     }
     int64_t eq = 0;
     PGX_TRY(energy_launch(ctx, 0, h_q, &eq));
