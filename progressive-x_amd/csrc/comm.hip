@@ -145,20 +145,17 @@ int pgx_comm_allreduce_max_f64(pgx_ctx* ctx, double* value)
     return PGX_OK;
 }
 
+// counts | values | shared of a launch are ONE allocation of 3 x Mpad words (score_launch): one all-gather of that block per
+// step (three grouped ones before) into [rank][3][Mpad], one copy back into pinned memory (three copies into pageable
+// vectors before: staged, ~15 us each).  Every rank scores a shard of the same padded length, so Mpad agrees across ranks.
 int pgx_score_allgather(pgx_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: communicator not initialised");
     if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: nothing launched");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t M = (size_t)ctx->M, G = (size_t)ctx->comm->nranks;
-    PGX_TRY(ensure(ctx, ctx->g_counts, G * M * 8));
-    PGX_TRY(ensure(ctx, ctx->g_values, G * M * 8));
-    PGX_TRY(ensure(ctx, ctx->g_shared, G * M * 8));
-    PGX_NCCL(ctx, g_rccl.GroupStart());
-    PGX_NCCL(ctx, g_rccl.AllGather(ctx->counts.p, ctx->g_counts.p, M, ncclInt64, ctx->comm->comm, ctx->stream));
-    PGX_NCCL(ctx, g_rccl.AllGather(ctx->values.p, ctx->g_values.p, M, ncclFloat64, ctx->comm->comm, ctx->stream));
-    PGX_NCCL(ctx, g_rccl.AllGather(ctx->shared.p, ctx->g_shared.p, M, ncclFloat64, ctx->comm->comm, ctx->stream));
-    PGX_NCCL(ctx, g_rccl.GroupEnd());
+    const size_t W = (size_t)3 * (size_t)ctx->Mpad, G = (size_t)ctx->comm->nranks;
+    PGX_TRY(ensure(ctx, ctx->g_counts, G * W * 8));
+    PGX_NCCL(ctx, g_rccl.AllGather(ctx->counts.p, ctx->g_counts.p, W, ncclInt64, ctx->comm->comm, ctx->stream));
     return PGX_OK;
 }
 
@@ -166,21 +163,30 @@ int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* val
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch_all: communicator not initialised");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t T = (size_t)ctx->M * (size_t)ctx->comm->nranks;
-    if (T == 0 || !ctx->g_counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch_all: nothing gathered");
-    std::vector<double> v(T), s(T);
-    std::vector<int64_t> c(T);
-    PGX_HIP(ctx, hipMemcpyAsync(c.data(), ctx->g_counts.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(v.data(), ctx->g_values.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(s.data(), ctx->g_shared.p, T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t M = (size_t)ctx->M, Mp = (size_t)ctx->Mpad, G = (size_t)ctx->comm->nranks;
+    const size_t T = M * G, need = G * 3 * Mp * 8;
+    if (T == 0 || !ctx->g_counts.p || ctx->g_counts.cap < need) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch_all: nothing gathered");
+    if (ctx->h_res_cap < need) {
+        if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+        ctx->h_res = nullptr; ctx->h_res_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&ctx->h_res, need * 2, hipHostMallocDefault));
+        ctx->h_res_cap = need * 2;
+    }
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->h_res, ctx->g_counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts) memcpy(counts, c.data(), T * 8);
-    if (values) memcpy(values, v.data(), T * 8);
-    if (shared) memcpy(shared, s.data(), T * 8);
-    if (scores)
-        for (size_t m = 0; m < T; ++m)
-            // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
-            scores[m] = ctx->score_has_compound && !(s[m] == 0.0 && !std::signbit(s[m]) && exponent > 0) ? v[m] - std::pow(s[m], (double)exponent) : v[m];
+    for (size_t r = 0; r < G; ++r) {   // rank-major [M] rows out of [rank][3][Mpad]
+        const int64_t* c = (const int64_t*)ctx->h_res + r * 3 * Mp;
+        const double* v = (const double*)ctx->h_res + r * 3 * Mp + Mp;
+        const double* s = (const double*)ctx->h_res + r * 3 * Mp + 2 * Mp;
+        if (counts) memcpy(counts + r * M, c, M * 8);
+        if (values) memcpy(values + r * M, v, M * 8);
+        if (shared) memcpy(shared + r * M, s, M * 8);
+        if (scores)
+            for (size_t m = 0; m < M; ++m)
+                // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
+                scores[r * M + m] = ctx->score_has_compound && !(s[m] == 0.0 && !std::signbit(s[m]) && exponent > 0)
+                                        ? v[m] - std::pow(s[m], (double)exponent) : v[m];
+    }
     return PGX_OK;
 }
 
