@@ -88,8 +88,12 @@ __device__ void cubic_roots(double a, double b, double c, double *r)
     double lo = -(1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)))), hi = -lo;
     for (int it = 0; it < 200; ++it) {
         const double mid = 0.5 * (lo + hi);
+        // once the midpoint rounds onto an end point this update either changes nothing or collapses the interval onto it; either
+        // way every later step reproduces the state: stopping after it gives the bits of all 200 steps (~60 are needed)
+        const bool last = mid == lo || mid == hi;
         const double pv = ((mid + a) * mid + b) * mid + c;
         if (pv < 0.0) lo = mid; else hi = mid;
+        if (last) break;
     }
     const double l0 = 0.5 * (lo + hi);
     r[0] = l0;
@@ -162,8 +166,10 @@ __device__ void solve_p3p(const double *pts, int64_t n, const int32_t *smp, doub
         const int rising = plo < 0.0;
         for (int it = 0; it < 200; ++it) {
             const double mid = 0.5 * (lo + hi);
+            const bool last = mid == lo || mid == hi;   // (see cubic_roots: the state is a fixed point after this update)
             const double pv = quartic_eval(m, mid);
             if ((pv < 0.0) == rising) lo = mid; else hi = mid;
+            if (last) break;
         }
         const double v = 0.5 * (lo + hi);
         if (!(v > 0.0)) continue;
@@ -343,8 +349,10 @@ __global__ __launch_bounds__(64) void solve_f7_kernel(const double* __restrict__
         double lo = -(1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)))), hi = -lo;  // Cauchy bound: p(lo) < 0 < p(hi)
         for (int it = 0; it < 200; ++it) {
             const double mid = 0.5 * (lo + hi);
+            const bool last = mid == lo || mid == hi;   // (see cubic_roots: the state is a fixed point after this update)
             const double pv = ((mid + a) * mid + b) * mid + c;
             if (pv < 0.0) lo = mid; else hi = mid;
+            if (last) break;
         }
         const double l0 = 0.5 * (lo + hi);
         roots[0] = l0;
