@@ -929,6 +929,13 @@ struct HipBackend {
         check();
     }
     int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
+    void read_flags_and_count(const MfView& v, int out[kMfFlags], int* cnt_alpha)
+    {
+        hipError_t e = hipMemcpyAsync(st->h_flags + kMfFlags, v.cnt + v.alpha, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        read_flags(v, out);
+        *cnt_alpha = st->h_flags[kMfFlags];
+    }
     void read_flags(const MfView& v, int out[kMfFlags])
     {
         hipError_t e = hipMemcpyAsync(st->h_flags, v.flags, kMfFlags * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);

@@ -347,6 +347,7 @@ PGX_HD int mf_bfs_hub_events(const MfView& v, int k)
 // one thread, after the BFS: publish hub heights for the sweeps (slot `slot`) and count active hubs
 PGX_HD void mf_body_bfs_finish(const MfView& v, int slot, int last_level)
 {
+    v.flags[3] = 0;   // the count of active sites follows (it is redone when the search turns out to need more levels)
     v.lvl[last_level + 1] = mf_level_base(v, last_level + 1);  // closes the level table for the wave pass
     for (int l = 0; l < v.L; ++l) {
         const int hd = v.bfs_hub_d[l];

@@ -33,8 +33,10 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
 {
     *changed = 0;
     be.count_and_setup(v);
-    const int cnt_alpha = be.read_count(v, v.alpha);
-    if ((int64_t)cnt_alpha == v.n) return 0;  // every site already carries alpha
+    // The number of sites that already carry alpha travels back with the first flag read-back of the move (a read-back of
+    // its own was a synchronisation per move: 5 % of a findVanishingPoints call).  If EVERY site carries alpha the move's
+    // graph is empty: the first search finds nothing and the move ends there, as the early return used to.
+    int cnt_alpha = -1;
     be.init_sites(v);
     stats[0] += 1;
     int sweep_id = 0;
@@ -64,19 +66,35 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             int first = tune.bfs_batch;
             int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
             if (hint && *hint > 0) first = *hint + 2 < 64 ? *hint + 2 : 64;
+            // The search's epilogue and the count of active sites are enqueued right behind the first batch and ONE read-back
+            // brings everything: with the batch sized by the hint the search is nearly always complete (two synchronisations
+            // per search before: 10 % of a findVanishingPoints call).  If it is not, more levels follow and both are redone
+            // (the epilogue restarts the count; everything else it writes only becomes more complete).
             for (int round = 0;; ++round) {
                 // later batches of a fixed 16: doubling up to 64 overshot deep searches by dozens of launches on empty frontiers
                 // (26 % of all level launches of a find6DPoses + findVanishingPoints run; an empty level costs ~5 us, a read-back ~25)
                 const int batch = round == 0 ? first : (round == 1 ? tune.bfs_next : 16);
                 for (int b = 0; b < batch; ++b) be.bfs_level(v, ++level);
-                last = be.read_flag(v, 0);
+                if (!v.gate) {   // a materialised alpha hub: its epilogue moves the BFS result slot and must run once, at the end
+                    last = be.read_flag(v, 0);
+                    if (last <= level - 2 || level >= v.hmax) break;
+                    continue;
+                }
+                be.bfs_finish(v, slot, level);
+                be.count_active(v);
+                if (cnt_alpha < 0) be.read_flags_and_count(v, fl, &cnt_alpha);
+                else be.read_flags(v, fl);
+                last = fl[0];
                 if (last <= level - 2 || level >= v.hmax) break;
             }
             if (hint) *hint = last > 1 ? last : 1;
-            be.bfs_finish(v, slot, level);
-            be.count_active(v);
-            be.read_flags(v, fl);
+            if (!v.gate) {
+                be.bfs_finish(v, slot, level);
+                be.count_active(v);
+                be.read_flags(v, fl);
+            }
         }
+        if (cnt_alpha < 0) cnt_alpha = be.read_count(v, v.alpha);   // (persistent mode)
         stats[2] += 1;
         stats[3] += level;
         if (fl[1] == 0) { converged = true; break; }

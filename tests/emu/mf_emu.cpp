@@ -64,6 +64,7 @@ struct EmuBackend {
     }
     int read_flag(const MfView& v, int i) { return v.flags[i]; }
     void read_flags(const MfView& v, int out[kMfFlags]) { for (int k = 0; k < kMfFlags; ++k) out[k] = v.flags[k]; }
+    void read_flags_and_count(const MfView& v, int out[kMfFlags], int* cnt_alpha) { read_flags(v, out); *cnt_alpha = v.cnt[v.alpha]; }
     void wave(const MfView& v, int k)
     {
         std::vector<int> lv(v.order + v.lvl[k], v.order + v.lvl[k + 1]);
