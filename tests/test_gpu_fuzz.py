@@ -1,0 +1,29 @@
+"""Differential fuzz of the alpha-expansion: random realistic problems, GPU against the CPU oracle's Dinic solver - labels,
+energy and cycle count identical.  (A longer one-off run of the same loop - 530 problems, 2 ... 20 000 sites - is on record in
+DESIGN.md 5.4; this is the committed slice.)"""
+import numpy as np
+import pytest
+
+from helpers import realistic_labeling_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_expansion_fuzz_against_the_oracle(gpu_ctx, oracle, seed):
+    rng = np.random.default_rng(seed)
+    for trial in range(30):
+        n = int(rng.choice([2, 7, 50, 300, 1500, 4000, 9000]))
+        L = int(rng.integers(2, 9))
+        lam = float(rng.choice([0.02, 0.1, 0.3, 0.6, 0.9]))
+        h = float(rng.choice([0.0, 0.5, 3.0, 20.0, 200.0]))
+        Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=int(rng.integers(1 << 30)))
+        lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+        start = rng.integers(0, L, n).astype(np.int32) if trial % 2 else np.zeros(n, np.int32)
+        ref, re, rc = oracle.expansion(Dq, graph, lq, hq, start.copy())
+        gpu_ctx.set_unary_q(Dq)
+        gpu_ctx.set_graph(*graph)
+        gpu_ctx.set_labels(start.copy())
+        eq, e, cyc = gpu_ctx.expansion(lam, h)
+        got = gpu_ctx.get_labels()
+        assert np.array_equal(got, ref) and eq == re and cyc == rc, (seed, trial, n, L, lam, h, int((got != ref).sum()))
