@@ -10,8 +10,7 @@ import sys
 import numpy as np
 sys.path.insert(0, "progressive-x_amd")
 sys.path.insert(0, ".")
-from pyprogressivex import datasets
-from oracle import pgx_oracle as po
+from pyprogressivex import datasets, _estimators
 
 pts, gt, models = datasets.make_two_view_motions(seed=0)
 n = len(pts)
@@ -20,8 +19,7 @@ K = int(gt.max())
 S = 200
 smp = np.array([rng.choice(np.nonzero(gt == 1 + r % K)[0], 7, replace=False) if r % 2 == 0 else rng.choice(n, 7, replace=False)
                 for r in range(S)], dtype=np.int32)
-out = po.solve_minimal(2, pts, smp)
-Fs = np.asarray(out[0] if isinstance(out, tuple) else out).reshape(-1, 9)
+Fs = np.asarray(_estimators.FundamentalEstimator().minimal(pts, smp)[0]).reshape(-1, 9)   # host 7-point solver of the package
 Fs = Fs[np.isfinite(Fs).all(1) & (np.abs(Fs).sum(1) > 0)]
 print("hypotheses", len(Fs))
 T = 1.5 * 0.75
@@ -49,7 +47,7 @@ def run(order, label):
     culled = 0; total = 0; inl = 0; near = 0
     for F in Fs:
         F = F.reshape(3, 3)
-        # oracle convention: r = x1^T F^T ... use the residual's own layout: rxc = f0 x2 + f3 y2 + f6 etc.
+        # the residual's own layout: rxc = f0 x2 + f3 y2 + f6 etc.
         x1 = np.column_stack([c[:, 0], c[:, 1], np.ones(G)])
         x2 = np.column_stack([c[:, 2], c[:, 3], np.ones(G)])
         l1 = x2 @ F          # (F^T x2): rxc, ryc, rwc
