@@ -51,7 +51,9 @@ template <> struct Filter<kPnP> {
         const double l0 = fabs(m[0]) + fabs(m[1]) + fabs(m[2]) + fabs(m[3]);
         const double l1 = fabs(m[4]) + fabs(m[5]) + fabs(m[6]) + fabs(m[7]);
         const double l2 = fabs(m[8]) + fabs(m[9]) + fabs(m[10]) + fabs(m[11]);
-        return {guard * fmax(l0, fmax(l1, l2))};
+        const double l = fmax(l0, fmax(l1, l2));
+        // the test squares pz: outside this range of scales it is not trusted at all (trust = c * pmax <= |pz| fails for c = inf)
+        return {(l > 1e-100 && l < 1e100) ? guard * l : 1.0 / 0.0};
     }
     template <class PT, class MD>
     static __device__ __forceinline__ bool reject(const PT& p, const MD& m, const Lane& ln, double pmax, double T2d) {
@@ -74,7 +76,8 @@ template <> struct Filter<kHomography> {
         const double l0 = fabs(h[0]) + fabs(h[1]) + fabs(h[2]);
         const double l1 = fabs(h[3]) + fabs(h[4]) + fabs(h[5]);
         const double l2 = fabs(h[6]) + fabs(h[7]) + fabs(h[8]);
-        return {guard * fmax(l0, fmax(l1, l2))};
+        const double l = fmax(l0, fmax(l1, l2));
+        return {(l > 1e-100 && l < 1e100) ? guard * l : 1.0 / 0.0};   // (see Filter<kPnP>)
     }
     template <class PT, class MD>
     static __device__ __forceinline__ bool reject(const PT& p, const MD& h, const Lane& ln, double pmax, double T2d) {
@@ -109,6 +112,27 @@ constexpr double kInflate = 1.000001;           // (float)(x * kInflate) >= x fo
 
 __device__ __forceinline__ float f32_up(double x) { return (float)(x * kInflate); }
 
+// The f32 tests below are homogeneous in the hypothesis (a residual does not change when its model is multiplied by a constant -
+// for lines the threshold scales along), but their intermediate SQUARES are not representable for every scale: a hypothesis
+// 1e-24 times a perfectly good one (tests/soak_scoring.py found it) made pz^2 underflow to 0 before the multiplication by T2,
+// and "lhs > 0" rejected true inliers.  Every f32 copy is therefore made from the hypothesis scaled by a power of two (exact)
+// that brings its largest entry into [0.5, 1): returns that factor (1 when the largest entry is 0, Inf or NaN).
+// *off: the hypothesis is outside the band of scales (largest entry in [1e-75, 1e75]) in which the EXACT path's own f64
+// arithmetic neither overflows nor underflows for coordinates up to 1e30 (the dispatch checks that): outside it the oracle's
+// residual is whatever IEEE makes of it (a vanishing point 1e158 away divides by inf and every segment becomes an "inlier"
+// with residual 0), and only the exact path reproduces that - such a hypothesis is never rejected or culled.
+template <int P, class MD> __device__ __forceinline__ double pow2_normaliser(const MD& m, bool* off)
+{
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) { const double a = fabs(m[k]); if (a > mx) mx = a; }   // NaN entries are skipped by the comparison
+    *off = !(mx >= 1e-75) || !(mx <= 1e75);
+    if (!(mx > 0.0) || !(mx < 1.7976931348623157e308)) return 1.0;
+    int e;
+    (void)frexp(mx, &e);
+    return ldexp(1.0, -e);
+}
+
 template <int MT> struct Filter32 {
     static constexpr bool enabled = false;
     static constexpr int kRowVals = 6;    // floats of a point's f32 row the filter reads
@@ -135,11 +159,14 @@ template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 6, kGroupVals = 9;
     struct Lane { float m[12]; float c1, c0; float n0, n1, n2; float nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double guard32, double) {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m0, double guard32, double) {
         Lane ln;
         bool nan = false;
+        bool off;
+        const double sc = pow2_normaliser<12>(m0, &off);
+        double m[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { ln.m[k] = (float)m[k]; nan |= !(m[k] == m[k]); }
+        for (int k = 0; k < 12; ++k) { m[k] = m0[k] * sc; ln.m[k] = (float)m[k]; nan |= !(m0[k] == m0[k]); }
         ln.nanh = nan ? 1.0f : 0.0f;  // a NaN entry makes every residual NaN (all 12 enter it): never an inlier
         ln.n0 = (float)(sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) * kGroupInflate);
         ln.n1 = (float)(sqrt(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) * kGroupInflate);
@@ -148,7 +175,7 @@ template <> struct Filter32<kPnP> {
                                fmax(fabs(m[4]) + fabs(m[5]) + fabs(m[6]), fabs(m[8]) + fabs(m[9]) + fabs(m[10])));
         const double t = fmax(fabs(m[3]), fmax(fabs(m[7]), fabs(m[11])));
         ln.c1 = f32_up(guard32 * l3);
-        ln.c0 = fmaxf(f32_up(guard32 * t), 1e-30f);
+        ln.c0 = off ? __builtin_inff() : fmaxf(f32_up(guard32 * t), 1e-30f);   // inf: the trust test never holds
         return ln;
     }
     // p = (u, v, X, Y, Z, scale, -, -) in f32
@@ -200,11 +227,14 @@ template <> struct Filter32<kHomography> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 6, kGroupVals = 9;
     struct Lane { float m[9]; float e1, e0; float n0, n1, n2; float nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h, double, double) {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& h0, double, double) {
         Lane ln;
         bool nan = false;
+        bool off;
+        const double sc = pow2_normaliser<9>(h0, &off);
+        double h[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { ln.m[k] = (float)h[k]; nan |= !(h[k] == h[k]); }
+        for (int k = 0; k < 9; ++k) { h[k] = h0[k] * sc; ln.m[k] = (float)h[k]; nan |= !(h0[k] == h0[k]); }
         ln.nanh = nan ? 1.0f : 0.0f;
         ln.n0 = (float)(sqrt(h[0] * h[0] + h[1] * h[1]) * kGroupInflate);
         ln.n1 = (float)(sqrt(h[3] * h[3] + h[4] * h[4]) * kGroupInflate);
@@ -213,7 +243,7 @@ template <> struct Filter32<kHomography> {
         const double t = fmax(fabs(h[2]), fmax(fabs(h[5]), fabs(h[8])));
         const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38;
         ln.e1 = f32_up(5.5 * u * l2 + 4.0 * eta);
-        ln.e0 = f32_up(5.5 * u * t + eta);
+        ln.e0 = off ? __builtin_inff() : f32_up(5.5 * u * t + eta);   // inf: every error term is infinite, nothing is rejected
         return ln;
     }
     // p = (x1, y1, x2, y2, -, P, -, -) in f32, P = max(|all four coordinates|, 1) rounded up
@@ -278,15 +308,18 @@ template <> struct Filter32<kVanishingPoint> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 7, kGroupVals = 12;
     struct Lane { float v[3]; float e2, e1, e0, e50, t2pp, invT, nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& v, double, double T2) {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& v0, double, double T2) {
         Lane ln;
+        bool off;
+        const double sc = pow2_normaliser<3>(v0, &off);
+        const double v[3] = {v0[0] * sc, v0[1] * sc, v0[2] * sc};
         ln.v[0] = (float)v[0]; ln.v[1] = (float)v[1]; ln.v[2] = (float)v[2];
-        ln.nanh = (v[0] == v[0] && v[1] == v[1] && v[2] == v[2]) ? 0.0f : 1.0f;
+        ln.nanh = (v0[0] == v0[0] && v0[1] == v0[1] && v0[2] == v0[2]) ? 0.0f : 1.0f;
         const double V1 = fabs(v[0]) + fabs(v[1]), V2 = fabs(v[2]), T = sqrt(T2);
         const double k38 = 3.637978807091713e-12 /* 2^-38 */, k11 = 4.8828125e-4 /* 2^-11 */;
         ln.e2 = f32_up(k38 * V2 / T * 1.001);
         ln.e1 = f32_up((k11 * V2 + k38 * V1 / T) * 1.001);
-        ln.e0 = fmaxf(f32_up(k11 * V1 * 1.001), 1e-37f);
+        ln.e0 = off ? __builtin_inff() : fmaxf(f32_up(k11 * V1 * 1.001), 1e-37f);   // inf: the trust test never holds
         ln.e50 = f32_up(8.881784197001252e-16 /* 2^-50 */ * V2 * 1.001);
         ln.t2pp = f32_up(T2 * (1.0 + 1.0 / 64.0));
         ln.invT = (float)(1.0 / (T * (1.0 + 1.0 / 64.0)) * 0.99999);  // rounded DOWN: 1 / T''
@@ -348,11 +381,15 @@ template <> struct Filter32<kFundamental> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 7, kGroupVals = 9;
     struct Lane { float f[9]; float e1, e0, n2, n1, n0, t2pp, nA, nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& f, double pscale2 /* max(|coordinate|, 1)^2 over the point set */, double T2) {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& f0, double pscale2 /* max(|coordinate|, 1)^2 over the point set */, double T2) {
         Lane ln;
         bool nan = false, big = false;
+        bool off;
+        const double sc = pow2_normaliser<9>(f0, &off);
+        big = off;
+        double f[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { ln.f[k] = (float)f[k]; nan |= !(f[k] == f[k]); big |= !(fabs(f[k]) * pscale2 <= 1e36); }
+        for (int k = 0; k < 9; ++k) { f[k] = f0[k] * sc; ln.f[k] = (float)f[k]; nan |= !(f0[k] == f0[k]); big |= !(fabs(f[k]) * pscale2 <= 1e36); }
         ln.nanh = nan ? 1.0f : 0.0f;
         const double A4 = fabs(f[0]) + fabs(f[1]) + fabs(f[3]) + fabs(f[4]), B4 = fabs(f[2]) + fabs(f[5]) + fabs(f[6]) + fabs(f[7]);
         const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38, itau = 1024.0;
@@ -423,16 +460,21 @@ template <> struct Filter32<kLine2D> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 6, kGroupVals = 4;
     struct Lane { float a, b, c, e1, e0, nrm, tpp, nanh; };
-    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m, double pscale /* max(|coordinate|, 1) over the set */, double T2) {
+    template <class MD> static __device__ __forceinline__ Lane prep(const MD& m0, double pscale /* max(|coordinate|, 1) over the set */, double T2) {
         Lane ln;
+        // r = |a x + b y + c| scales with the model: the scaled copy is tested against the scaled threshold (sc is a power of two)
+        bool off;
+        const double sc = pow2_normaliser<3>(m0, &off);
+        const double m[3] = {m0[0] * sc, m0[1] * sc, m0[2] * sc};
         ln.a = (float)m[0]; ln.b = (float)m[1]; ln.c = (float)m[2];
-        ln.nanh = (m[0] == m[0] && m[1] == m[1] && m[2] == m[2]) ? 0.0f : 1.0f;
-        const bool big = !(fabs(m[0]) * pscale <= 1e36) || !(fabs(m[1]) * pscale <= 1e36) || !(fabs(m[2]) <= 1e36);
+        ln.nanh = (m0[0] == m0[0] && m0[1] == m0[1] && m0[2] == m0[2]) ? 0.0f : 1.0f;
+        const double Ts = sqrt(T2) * sc;   // the threshold in the scaled model's units: must be an ordinary f32 as well
+        const bool big = !(fabs(m[0]) * pscale <= 1e36) || !(fabs(m[1]) * pscale <= 1e36) || !(fabs(m[2]) <= 1e36) || !(Ts > 1e-30) || !(Ts < 1e30) || off;
         const double u = 5.9604644775390625e-8, eta = 1.1754943508222875e-38;
         ln.e1 = f32_up(4.1 * u * (fabs(m[0]) + fabs(m[1])) + 4.0 * eta);
         ln.e0 = big ? __builtin_inff() : f32_up(4.1 * u * fabs(m[2]) + eta);
         ln.nrm = f32_up(sqrt(m[0] * m[0] + m[1] * m[1]) * 1.001);
-        ln.tpp = f32_up(sqrt(T2) * (1.0 + 1.0 / 64.0));
+        ln.tpp = f32_up(Ts * (1.0 + 1.0 / 64.0));
         return ln;
     }
     // p = (x, y, -, -, -, P, -, -) in f32
@@ -1439,6 +1481,9 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
         filt32 = ctx->filter_enabled == 1 && T2 > 1e-12 && T2 < 1e12 && std::isfinite(ctx->fscale);
         guard32 = ctx->fscale * ctx->fscale;   // Filter32<kFundamental>::prep: overflow guard of the f32 terms (fscale >= 1)
     }
+    // every filter's proof takes the exact path's f64 arithmetic as overflow-free: coordinates up to 1e30 with the
+    // per-hypothesis band of pow2_normaliser keep it so
+    if (!(ctx->fscale <= 1e30)) filt = filt32 = false;
     ctx->last_score_filtered = filt32 ? 2 : (filt ? 1 : 0);
     // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
     // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).

@@ -27,3 +27,12 @@ def test_expansion_fuzz_against_the_oracle(gpu_ctx, oracle, seed):
         eq, e, cyc = gpu_ctx.expansion(lam, h)
         got = gpu_ctx.get_labels()
         assert np.array_equal(got, ref) and eq == re and cyc == rc, (seed, trial, n, L, lam, h, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_scoring_soak_slice(oracle, seed):
+    """A bounded slice of tests/soak_scoring.py: random sizes and thresholds (some exactly on a residual), hypotheses a hair from
+    the truth, garbage, uniformly rescaled by up to 10^+-160 and with entries of wildly different magnitude, all six residuals -
+    counts, masks and values against the oracle.  (This loop is what found the two scale holes of DESIGN.md 5.2h.)"""
+    from soak_scoring import soak
+    assert soak(seed, 60, verbose=False) == 0

@@ -141,6 +141,10 @@ def test_score_filter_adversarial(gpu_ctx, oracle, name):
     models[45] = gt * 1e150          # entries that overflow f32 with mixed signs: inf - inf inside the f32 bound tests
     models[45, ::2] *= -1.0
     models[46] = -gt * 1e150
+    # scales that ARE representable in f32 but whose squares are not (found by tests/soak_scoring.py: pz^2 underflowed to 0 before
+    # the multiplication by T2 and "lhs > 0" rejected true inliers; the f32 copies are now made from a power-of-two-normalised model)
+    for k, sc in enumerate((1e-24, 1e-30, 1e-37, 1e22, 1e30, 1e-110, 1e110)):
+        models[47 + k] = gt * sc
     gpu_ctx.set_points(mt, pts)
     gpu_ctx.set_compound(None)
     sq0 = oracle.squared_residuals(mt, pts, gt)
@@ -199,6 +203,8 @@ def test_vanishing_point_filter_and_cull_adversarial(oracle, monkeypatch):
             models[38] = gt * 1e150
             models[39] = gt * 1e-150
             models[40:] = rng.normal(0, 1, (models.shape[0] - 40, 3)) * rng.choice([1e-3, 1.0, 1e3], (models.shape[0] - 40, 1))
+            for k, sc in enumerate((1e-24, 1e-30, 1e-37, 1e22, 1e30)):     # f32-representable, squares are not (soak_scoring.py)
+                models[40 + k] = gt * sc
             sq0 = oracle.squared_residuals(mt, pts, gt)
             finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
             T2s = [2.25 * thr * thr, 1e-30, 1e30]
@@ -283,6 +289,8 @@ def test_line_and_symmetric_filters_adversarial(oracle, name, monkeypatch):
             models[37] = gt * 1e33
             models[38] = gt * 1e-43
             models[40:] = rng.normal(0, 1, (models.shape[0] - 40, P)) * rng.choice([1e-3, 1.0, 1e3], (models.shape[0] - 40, 1))
+            for k, sc in enumerate((1e-24, 1e-30, 1e22, 1e30)):          # f32-representable, squares are not (soak_scoring.py)
+                models[40 + k] = gt * sc
             sq0 = oracle.squared_residuals(mt, pts, gt)
             finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
             T2s = [2.25 * thr * thr, 1e-30, 1e30, 1e-23, 1e23]
@@ -362,6 +370,8 @@ def test_fundamental_filter_and_cull_adversarial(oracle, monkeypatch):
             models[38] = gt * 1e-33
             models[39] = gt * 1e-43                   # denormal in f32
             models[40:] = rng.normal(0, 1, (models.shape[0] - 40, 9)) * rng.choice([1e-6, 1e-3, 1.0], (models.shape[0] - 40, 9))
+            for k, sc in enumerate((1e-24, 1e-30, 1e22, 1e30)):          # f32-representable, squares are not (soak_scoring.py)
+                models[40 + k] = gt * sc
             sq0 = oracle.squared_residuals(mt, pts, gt)
             finite = np.sort(sq0[np.isfinite(sq0) & (sq0 > 0)])
             T2s = [2.25 * thr * thr, 1e-30, 1e30, 1e-11, 1e11]
