@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kGBlock) void g_search_kernel(const double* __restr
                         s = s + df * df;
                     }
                     const int ci = t_idx[e];
-                    if (s <= r2 && ci != qi) best.offer(s, ci);
+                    // a squared distance that overflowed (coordinates ~1e155 and beyond) ranks nothing: no neighbour, as in the oracle
+                    if (s <= r2 && s < __builtin_inf() && ci != qi) best.offer(s, ci);
                 }
         }
     }

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q -x --tb=short < /dev/null 2>&1 | tail -8 > gpurun_out/gpu_suite.log
-timeout 300 python bench.py < /dev/null > gpurun_out/bench.log 2>&1
-for s in 41 42 43 44 45 46 47 48 49 50 51 52; do SOAK_DENSE=1 timeout 400 python tests/soak_scoring.py $s 200 < /dev/null 2>&1 | tail -8; done > gpurun_out/soak.log 2>&1
+for s in 31 32 33 34 35 36; do timeout 900 python tests/soak_pointwise.py $s 600 < /dev/null 2>&1 | tail -8 | cut -c1-400; done > gpurun_out/soak2.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_parity.py -k "graph" -q -x < /dev/null 2>&1 | tail -3 >> gpurun_out/soak2.log

@@ -36,3 +36,12 @@ def test_scoring_soak_slice(oracle, seed):
     counts, masks and values against the oracle.  (This loop is what found the two scale holes of DESIGN.md 5.2h.)"""
     from soak_scoring import soak
     assert soak(seed, 60, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [201, 202])
+def test_pointwise_soak_slice(oracle, seed):
+    """A bounded slice of tests/soak_pointwise.py: preference vectors, compound maximum, unary table, residual sums, minimal
+    solvers, neighbourhood graph, the inlier/outlier cut and the greedy labelling on the same wild hypotheses and point sets
+    (absurd scales, NaN / Inf / 1e200 coordinates, duplicates) - bit-exact against the oracle."""
+    from soak_pointwise import soak
+    assert soak(seed, 150, verbose=False) == 0
