@@ -45,3 +45,13 @@ def test_pointwise_soak_slice(oracle, seed):
     (absurd scales, NaN / Inf / 1e200 coordinates, duplicates) - bit-exact against the oracle."""
     from soak_pointwise import soak
     assert soak(seed, 150, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [301, 302])
+def test_api_soak_slice(oracle, seed):
+    """A bounded slice of tests/soak_api.py: the five drop-in calls with random arguments on random small problems, on the GPU
+    and through the same host code over the CPU oracle.  A differing call is replayed with every context call recorded and
+    classified: only a call that returns different integers (or floats beyond 1e-9) for bitwise identical inputs is a failure;
+    a Gauss-Newton refit that amplified the rounding of a Gram sum is reported and tolerated (2 of 3 000 calls)."""
+    from soak_api import soak
+    assert soak(seed, 40, verbose=False) == 0
