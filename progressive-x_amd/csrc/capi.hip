@@ -112,6 +112,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_SCORE_QUEUE")) ctx->score_queue = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_ABLATE")) { int v = std::atoi(b); if (v >= 0 && v <= 9) ctx->score_ablate = v; }
     if (const char* b = std::getenv("PGX_SCORE_PIPE")) { int v = std::atoi(b); if (v >= 0 && v <= 2) ctx->score_pipe = v; }
+    if (const char* b = std::getenv("PGX_SCORE_MIRROR")) ctx->score_mirror = std::atoi(b) != 0;
     if (const char* b = std::getenv("PGX_SCORE_SOA")) ctx->score_soa = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_SPLIT")) { int v = std::atoi(b); if (v >= 1 && v <= 1024) ctx->score_split = v; }
     if (const char* b = std::getenv("PGX_SCORE_NO_CULL")) ctx->score_cull = std::atoi(b) ? 0 : 1;
@@ -138,6 +139,7 @@ void pgx_destroy(pgx_ctx* ctx)
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
     for (int k = 0; k < 5; ++k) if (ctx->kev[k]) (void)hipEventDestroy(ctx->kev[k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -366,6 +368,8 @@ int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
             std::memcpy(sorted.data() + (size_t)m * P, models + (size_t)perm[(size_t)m] * P, (size_t)P * sizeof(double));
         src = sorted.data();
     }
+    if (src == models) ctx->h_perm.clear();   // not reordered: identity
+    else ctx->h_perm.assign(perm.begin(), perm.end());
     ctx->Mpad = ((M + 255) / 256) * 256;
     perm.resize((size_t)ctx->Mpad, 0);
     PGX_TRY(ensure(ctx, ctx->models, (size_t)M * P * sizeof(double)));
@@ -380,6 +384,7 @@ int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
 int pgx_solve_minimal(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out)
 {
     CTX_GUARD(ctx);
+    ctx->h_perm.clear();   // device-generated batches stay in the caller's order
     return solve_minimal_launch(ctx, samples, S, models_out);
 }
 
@@ -423,14 +428,29 @@ int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values,
     int64_t* c = (int64_t*)ctx->h_res;
     double* v = (double*)ctx->h_res + Mp;
     double* s = (double*)ctx->h_res + 2 * Mp;
-    // counts | values | shared are one allocation of 3 x Mpad words (score_launch): one copy
-    PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
+    const bool mirrored = ctx->mirror_valid && ctx->h_mirror_cap >= need;
+    // counts | values | shared are one allocation of 3 x Mpad words (score_launch): one copy - or none, when the last
+    // kernel of the launch has already written them to the host mirror
+    if (!mirrored) PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
     if (masks) {
         if (!ctx->have_masks) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: masks were not requested at launch");
         PGX_HIP(ctx, hipMemcpyAsync(masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t),
                                     hipMemcpyDeviceToHost, ctx->stream));
     }
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (mirrored) {   // device order -> the caller's order
+        const int64_t* mc = (const int64_t*)ctx->h_mirror;
+        const double* mv = (const double*)ctx->h_mirror + Mp;
+        const double* ms = (const double*)ctx->h_mirror + 2 * Mp;
+        if (ctx->h_perm.size() >= (size_t)M) {
+            const int* pm = ctx->h_perm.data();
+            for (int m = 0; m < M; ++m) { const int o = pm[m]; c[o] = mc[m]; v[o] = mv[m]; s[o] = ms[m]; }
+        } else {
+            memcpy(c, mc, (size_t)M * sizeof(int64_t));
+            memcpy(v, mv, (size_t)M * sizeof(double));
+            memcpy(s, ms, (size_t)M * sizeof(double));
+        }
+    }
     if (counts) memcpy(counts, c, (size_t)M * sizeof(int64_t));
     if (values) memcpy(values, v, (size_t)M * sizeof(double));
     if (shared) memcpy(shared, s, (size_t)M * sizeof(double));

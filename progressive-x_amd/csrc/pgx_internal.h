@@ -106,6 +106,14 @@ struct pgx_ctx {
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
     void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
     size_t h_res_cap = 0;
+    // Host mirror of the score triples: score_finish_kernel also writes (count, value, shared) in the batch's device order
+    // straight into this pinned, device-mapped allocation (coalesced 512 B runs over PCIe), so pgx_score_fetch needs no
+    // copy command on the stream - it waits for the kernel and un-permutes on the host (h_perm; empty = identity).
+    void* h_mirror = nullptr;
+    size_t h_mirror_cap = 0;
+    int mirror_valid = 0;        // the last launch wrote the mirror
+    int score_mirror = 1;        // PGX_SCORE_MIRROR=0: read the triples back with a copy instead
+    std::vector<int> h_perm;     // host copy of `perm` for an uploaded, locality-sorted batch
     pgx::DevBuf fit_scratch;  // pgx_gram: partials | result | counters | index list
     pgx::DevBuf weights;      // resident per-point weights of the weighted refits (pgx_set_weights), weights_n == n when valid
     int64_t weights_n = 0;

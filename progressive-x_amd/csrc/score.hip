@@ -1266,7 +1266,8 @@ __global__ __launch_bounds__(64) void score_exact_kernel(
 
 __global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long long* __restrict__ acc, int M, int Mpad, double qscale,
                                                            const int* __restrict__ perm, long long* __restrict__ counts,
-                                                           double* __restrict__ values, double* __restrict__ shared, int nrep)
+                                                           double* __restrict__ values, double* __restrict__ shared, int nrep,
+                                                           long long* __restrict__ mirror /* pinned host memory or nullptr */)
 {
     const int m = (int)(blockIdx.x * 256 + threadIdx.x);
     if (m >= M) return;
@@ -1279,9 +1280,15 @@ __global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long l
         v += a[(int64_t)Mpad + m];
         sh += a[2 * (int64_t)Mpad + m];
     }
+    const double val = (double)(long long)v / qscale, shv = (double)(long long)sh / qscale;
     counts[o] = (long long)c;
-    values[o] = (double)(long long)v / qscale;
-    shared[o] = (double)(long long)sh / qscale;
+    values[o] = val;
+    shared[o] = shv;
+    if (mirror != nullptr) {  // the same triples in device order, contiguous per wave: pgx_score_fetch reads them without a copy
+        mirror[m] = (long long)c;
+        reinterpret_cast<double*>(mirror)[(int64_t)Mpad + m] = val;
+        reinterpret_cast<double*>(mirror)[2 * (int64_t)Mpad + m] = shv;
+    }
 }
 
 // ---- filtered variant with deferred exact evaluation ------------------------------------------------
@@ -1571,10 +1578,23 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                 PGX_HIP(ctx, hipGetLastError());
             }
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream));
+            long long* mirror = nullptr;
+            if (ctx->score_mirror && !want_masks) {
+                const size_t need = (size_t)ctx->Mpad * 24;
+                if (ctx->h_mirror_cap < need) {
+                    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // an earlier launch may still be writing the old one
+                    if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
+                    ctx->h_mirror = nullptr; ctx->h_mirror_cap = 0;
+                    PGX_HIP(ctx, hipHostMalloc(&ctx->h_mirror, need * 2, hipHostMallocMapped | hipHostMallocCoherent));
+                    ctx->h_mirror_cap = need * 2;
+                }
+                mirror = (long long*)ctx->h_mirror;
+            }
             hipLaunchKernelGGL(score_finish_kernel, dim3((unsigned)((ctx->M + 255) / 256)), dim3(256), 0, ctx->stream, acc, ctx->M,
                                ctx->Mpad, qscale, ctx->perm.as<int>(), ctx->counts.as<long long>(), ctx->values.as<double>(),
-                               ctx->shared.as<double>(), nrep);
+                               ctx->shared.as<double>(), nrep, mirror);
             PGX_HIP(ctx, hipGetLastError());
+            ctx->mirror_valid = mirror != nullptr;
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
             ctx->last_score_path = 2;
             return PGX_OK;
@@ -1770,6 +1790,7 @@ static int score_launch_typed(pgx_ctx* ctx, double T2, int has_compound, int wan
 // while chunks stay multiples of 64 points (mask words never straddle blocks).
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
 {
+    ctx->mirror_valid = 0;   // set by the path whose last kernel writes the host mirror
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score: points not set");
     if (ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score: no hypotheses uploaded");
     const int groups = ctx->Mpad / kScoreBlock;
