@@ -663,11 +663,16 @@ template <int MT>
 __global__ __launch_bounds__(64 * kCullWaves) void score_cull_kernel(
     const double* __restrict__ models, int M, double T2, double guard32, const float* __restrict__ gbounds, int groups,
     int gps /* groups per segment */, int W, unsigned long long* __restrict__ keep, float* __restrict__ hyp32,
-    double* __restrict__ models_t /* [P][W * 64]: component-major copy for the gathers of the group kernel */)
+    double* __restrict__ models_t /* [P][W * 64]: component-major copy for the gathers of the group kernel */,
+    unsigned long long* __restrict__ zero /* the accumulators of the group kernel, zeroed here (one fill command less) */, int64_t zero_words)
 {
     using R = Residual<MT>;
     using F32 = Filter32<MT>;
     __shared__ __attribute__((aligned(16))) float s_gb[kCullTile + kCullTile / kSuper][kGroupRow];  // groups | their super-groups
+    {
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * (64 * kCullWaves);
+        for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * kCullWaves) + threadIdx.x; i < zero_words; i += nthreads) zero[i] = 0ull;
+    }
     const int lane = (int)(threadIdx.x & 63);
     const int w = (int)blockIdx.x * kCullWaves + (int)(threadIdx.x >> 6), seg = (int)blockIdx.y;
     const int m = w * 64 + lane;
@@ -1523,11 +1528,12 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             int lg = 0;
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
-            PGX_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)nrep * ctx->Mpad * 3 * sizeof(long long) + cnt_bytes, ctx->stream));
+            // the accumulators (and the queue counters behind them) are zeroed by the cull kernel, which runs before their first use
+            const int64_t zero_words = (int64_t)(((size_t)nrep * ctx->Mpad * 3 * sizeof(long long) + cnt_bytes) / sizeof(long long));
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
-                               ctx->cull_lists.as<unsigned long long>(), hyp32, models_t);
+                               ctx->cull_lists.as<unsigned long long>(), hyp32, models_t, acc, zero_words);
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream));
             const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
