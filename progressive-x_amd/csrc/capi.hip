@@ -759,10 +759,12 @@ static int flow_params(pgx_ctx* ctx, double lambda, double label_cost, int64_t* 
     *lambda_q = quantize_lambda(lambda);
     *h_q = quantize(label_cost);
     // Range check: every excess / capacity sum must stay far below 2^63.
-    const double per_site = 4.0 + 2.0 * lambda * (double)(ctx->gn > 0 ? ctx->max_row_mult : 0);
+    // (an injected table - pgx_set_unary_q - may hold costs beyond PEARL's 2 (1 - lambda) <= 2: dq_max is what counts)
+    const double dmax = (double)ctx->dq_max / 4294967296.0;
+    const double per_site = 2.0 * (dmax > 2.0 ? dmax : 2.0) + 2.0 * lambda * (double)(ctx->gn > 0 ? ctx->max_row_mult : 0);
     const double total = per_site * (double)(ctx->dq_n > 0 ? ctx->dq_n : 1) + label_cost * (double)(ctx->L + 1);
     if (total >= 1073741824.0)  // 2^30 * 2^32 = 2^62
-        return fail(ctx, PGX_ERR_RANGE, "fixed-point range exceeded: n*(4+2*lambda*row_mult)+L*h = %.3g >= 2^30", total);
+        return fail(ctx, PGX_ERR_RANGE, "fixed-point range exceeded: n*(2*max_cost+2*lambda*row_mult)+L*h = %.3g >= 2^30", total);
     return PGX_OK;
 }
 

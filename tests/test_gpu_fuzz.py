@@ -55,3 +55,12 @@ def test_api_soak_slice(oracle, seed):
     a Gauss-Newton refit that amplified the rounding of a Gram sum is reported and tolerated (2 of 3 000 calls)."""
     from soak_api import soak
     assert soak(seed, 40, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [401, 402])
+def test_expansion_soak_slice(oracle, seed):
+    """A bounded slice of tests/soak_expansion.py: long paths, stars, cliques, grids, disconnected and empty graphs, unary tables
+    of ties / zeros / identical rows / costs up to 2^40, lambda 0.001 ... 1, label costs 0 ... 1e5, 2 ... 12 labels - labels,
+    energy and cycle count identical to the oracle's Dinic solver (4 200 such problems on record: no mismatch)."""
+    from soak_expansion import soak
+    assert soak(seed, 120, verbose=False) == 0

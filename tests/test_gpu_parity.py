@@ -1195,6 +1195,13 @@ def test_abi_error_paths():
             ctx.expand_alpha(0.0, 1.0, 7)
         with pytest.raises(_lib.PgxError, match="fixed-point range"):
             ctx.energy(0.0, 1e12)                                     # label cost beyond the 2^30 budget
+        with pytest.raises(_lib.PgxError, match="fixed-point range"):
+            big = np.zeros((100, 2), np.int64)
+            big[0, 0] = 1 << 61                                       # an injected table whose sums would not fit int64
+            ctx.set_unary_q(big)
+            ctx.set_labels(np.zeros(100, np.int32))
+            ctx.energy(0.0, 0.0)
+        ctx.pearl_unary(np.array([[1.0, 0.0, -0.5]]), 0.1, 0.2)
         with pytest.raises(_lib.PgxError, match="slot"):
             ctx.compound_update([5])
         with pytest.raises(_lib.PgxError, match="at most"):
