@@ -8,6 +8,11 @@ import os
 
 import numpy as np
 
+# Multi-process GPU work (one rank per GPU over RCCL) needs dmabuf IPC on hosts whose driver has no legacy IPC: without this
+# RCCL's bootstrap fails with "hipIpcGetMemHandle: invalid argument".  Set before the HIP runtime initialises; a value the
+# launcher exported wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGX_LIBPGX") or os.path.join(_HERE, "libpgx.so")   # PGX_LIBPGX: A/B of kernel builds
 
