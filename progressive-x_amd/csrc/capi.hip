@@ -140,6 +140,8 @@ void pgx_destroy(pgx_ctx* ctx)
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
+    if (ctx->h_samples) (void)hipHostFree(ctx->h_samples);
+    if (ctx->ev_samples) (void)hipEventDestroy(ctx->ev_samples);
     for (int k = 0; k < 5; ++k) if (ctx->kev[k]) (void)hipEventDestroy(ctx->kev[k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

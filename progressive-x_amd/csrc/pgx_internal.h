@@ -109,6 +109,10 @@ struct pgx_ctx {
     // Host mirror of the score triples: score_finish_kernel also writes (count, value, shared) in the batch's device order
     // straight into this pinned, device-mapped allocation (coalesced 512 B runs over PCIe), so pgx_score_fetch needs no
     // copy command on the stream - it waits for the kernel and un-permutes on the host (h_perm; empty = identity).
+    void* h_samples = nullptr;   // pinned staging of pgx_solve_minimal's sample indices (solve.hip upload_samples)
+    size_t h_samples_cap = 0;
+    hipEvent_t ev_samples = nullptr;
+    int h_samples_busy = 0;
     void* h_mirror = nullptr;
     size_t h_mirror_cap = 0;
     int mirror_valid = 0;        // the last launch wrote the mirror

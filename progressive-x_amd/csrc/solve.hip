@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 
 #include "pgx_internal.h"
 
@@ -393,6 +394,28 @@ __global__ __launch_bounds__(64) void solve_f7_kernel(const double* __restrict__
 
 }  // namespace
 
+// The sample indices go through a pinned staging buffer owned by the context: the caller's array is consumed before the
+// call returns, so a launch that hands nothing back (models_out == NULL: the batch stays resident for pgx_score_launch) needs
+// no synchronisation at all - the host goes straight on to enqueue the scoring kernels behind the solver.  An event guards
+// the staging buffer against the next call.
+static int upload_samples(pgx_ctx* ctx, const int32_t* samples, size_t bytes)
+{
+    if (ctx->h_samples_busy) { PGX_HIP(ctx, hipEventSynchronize(ctx->ev_samples)); ctx->h_samples_busy = 0; }
+    if (ctx->h_samples_cap < bytes) {
+        if (ctx->h_samples) (void)hipHostFree(ctx->h_samples);
+        ctx->h_samples = nullptr; ctx->h_samples_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&ctx->h_samples, bytes * 2, hipHostMallocDefault));
+        ctx->h_samples_cap = bytes * 2;
+    }
+    if (!ctx->ev_samples) PGX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_samples, hipEventDisableTiming));
+    std::memcpy(ctx->h_samples, samples, bytes);
+    PGX_TRY(ensure(ctx, ctx->scratch, bytes));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, ctx->h_samples, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipEventRecord(ctx->ev_samples, ctx->stream));
+    ctx->h_samples_busy = 1;
+    return PGX_OK;
+}
+
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: points not set");
@@ -405,15 +428,14 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((Mtot + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)Mtot * 9 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * 7 * sizeof(int32_t)));
-        PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, samples, (size_t)S * 7 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 7 * sizeof(int32_t)));
         const unsigned blocks = (unsigned)((S + 63) / 64);
         hipLaunchKernelGGL(solve_f7_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->M = Mtot;
         return PGX_OK;
     }
@@ -422,14 +444,13 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((Mtot + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)Mtot * 12 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * 3 * sizeof(int32_t)));
-        PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, samples, (size_t)S * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 3 * sizeof(int32_t)));
         hipLaunchKernelGGL(solve_p3p_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->M = Mtot;
         return PGX_OK;
     }
@@ -438,14 +459,13 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((S + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 9 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * 4 * sizeof(int32_t)));
-        PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, samples, (size_t)S * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 4 * sizeof(int32_t)));
         hipLaunchKernelGGL(solve_h4_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->M = S;
         return PGX_OK;
     }
@@ -454,8 +474,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     ctx->Mpad = ((S + 255) / 256) * 256;
     PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 3 * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-    PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * 2 * sizeof(int32_t)));
-    PGX_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, samples, (size_t)S * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PGX_TRY(upload_samples(ctx, samples, (size_t)S * 2 * sizeof(int32_t)));
     const unsigned blocks = (unsigned)((ctx->Mpad + kSolveBlock - 1) / kSolveBlock);
     if (ctx->model_type == kLine2D)
         hipLaunchKernelGGL((solve_kernel<kLine2D>), dim3(blocks), dim3(kSolveBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
@@ -466,7 +485,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     PGX_HIP(ctx, hipGetLastError());
     if (models_out)
         PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->M = S;
     return PGX_OK;
 }
