@@ -78,13 +78,13 @@ def odd_unary(rng, n, L, lam):
     return np.ascontiguousarray(D.astype(np.int64))
 
 
-def soak(seed, trials, verbose=True):
+def soak(seed, trials, verbose=True, max_n=9000):
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
     bad = 0
     t0 = time.time()
     for trial in range(trials):
-        n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 2500, 9000]))
+        n = min(max_n, int(rng.choice([1, 2, 3, 17, 64, 65, 300, 1000, 2500, 9000])))
         L = int(rng.integers(2, 13))
         lam = float(rng.choice([0.001, 0.02, 0.1, 0.3, 0.6, 0.9, 0.99, 1.0]))
         h = float(rng.choice([0.0, 0.0, 1e-6, 0.5, 3.0, 20.0, 200.0, 1e5]))
