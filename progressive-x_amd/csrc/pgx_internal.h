@@ -109,6 +109,10 @@ struct pgx_ctx {
     // Host mirror of the score triples: score_finish_kernel also writes (count, value, shared) in the batch's device order
     // straight into this pinned, device-mapped allocation (coalesced 512 B runs over PCIe), so pgx_score_fetch needs no
     // copy command on the stream - it waits for the kernel and un-permutes on the host (h_perm; empty = identity).
+    void* h_models = nullptr;    // pinned staging of pgx_score_upload's (reordered) batch + permutation
+    size_t h_models_cap = 0;
+    hipEvent_t ev_models = nullptr;
+    int h_models_busy = 0;
     void* h_samples = nullptr;   // pinned staging of pgx_solve_minimal's sample indices (solve.hip upload_samples)
     size_t h_samples_cap = 0;
     hipEvent_t ev_samples = nullptr;

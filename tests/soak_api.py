@@ -77,14 +77,26 @@ def classify(fn, args, kw, gpu):
     for i, (a, b) in enumerate(zip(*logs)):
         if a[0] != b[0]:
             return "bug", f"call {i}: {a[0]} on the device, {b[0]} on the oracle, identical inputs so far"
-        if _differ(a[3], b[3], 1e-9):
-            return "bug", f"call {i} {a[0]}: identical inputs so far, results differ"
         if _differ(a[1], b[1], 0.0) or _differ(a[2], b[2], 0.0):
-            return "fp-order", f"call {i} {a[0]} is the first whose arguments differ (in rounding: every result before it agreed to 1e-9)"
+            return "fp-order", f"call {i} {a[0]} is the first whose arguments differ (in rounding, or in the sign of a homogeneous model: every result before it agreed to 1e-9)"
+        if _differ(a[3], b[3], 1e-9):
+            if os.environ.get("SOAK_DUMP"):   # the arguments of the call and where the two results part
+                np.set_printoptions(precision=17, linewidth=220)
+                print("   call", i, a[0], "kwargs", {k: v for k, v in a[2].items() if not isinstance(v, np.ndarray)})
+                ra, rb = (a[3], b[3]) if isinstance(a[3], dict) else ({"result": a[3]}, {"result": b[3]})
+                for k in ra:
+                    if k in rb and _differ(ra[k], rb[k], 1e-9):
+                        x, y = np.asarray(ra[k]), np.asarray(rb[k])
+                        w = np.nonzero(~np.isclose(x, y, rtol=1e-9, atol=0, equal_nan=True))[0] if x.shape == y.shape else []
+                        print("   field", k, "differs at", w[:6], "device", x[w[:6]] if len(w) else x, "oracle", y[w[:6]] if len(w) else y)
+                        if len(w) and a[1] and isinstance(a[1][0], np.ndarray) and a[1][0].ndim == 2:
+                            print("   hypotheses", a[1][0][w[:3]], "other positional args", [v for v in a[1][1:] if not isinstance(v, np.ndarray)])
+                np.save(os.environ["SOAK_DUMP"] + f"_call{i}_arg0.npy", a[1][0]) if a[1] and isinstance(a[1][0], np.ndarray) else None
+            return "bug", f"call {i} {a[0]}: identical inputs so far, results differ"
     return "fp-order", "every call agreed to 1e-9; the returned arrays differ beyond the soak's 1e-7"
 
 
-def soak(seed, trials, verbose=True):
+def soak(seed, trials, verbose=True, only=None):
     rng = np.random.default_rng(seed)
     bad = 0
     chaos = 0
@@ -134,6 +146,8 @@ def soak(seed, trials, verbose=True):
                 kw.pop(k, None)
             kw.update(threshold=float(rng.choice([2.0, 4.0, 8.0])), minimum_point_number=int(rng.choice([6, 30])),
                       neighborhood_ball_radius=float(rng.choice([20.0, 60.0])))
+        if only is not None and not (only[0] <= trial <= only[1]):
+            continue
         try:
             with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
                 _api._ctx = gpu
@@ -144,12 +158,22 @@ def soak(seed, trials, verbose=True):
         finally:
             _api._ctx = gpu
         found += M.shape[0]
-        ok = np.array_equal(lab, labr) and M.shape == Mr.shape and np.allclose(M, Mr, rtol=1e-7, atol=1e-9)
+        ok = np.array_equal(lab, labr) and M.shape == Mr.shape
+        if ok and M.size:
+            # lines, vanishing points, homographies and fundamental matrices are homogeneous: a refit's eigenvector comes with
+            # either sign (the Gram sums' rounding decides), so those are compared up to the sign of each model
+            rows = 3 if which in (1, 2, 4) else 1
+            A, B = M.reshape(-1, rows * M.shape[1]), Mr.reshape(-1, rows * M.shape[1])
+            tol = 1e-7 * np.abs(B).max(axis=1, keepdims=True) + 1e-9
+            same = np.all(np.abs(A - B) <= tol, axis=1)
+            if which != 4:
+                same |= np.all(np.abs(A + B) <= tol, axis=1)
+            ok = bool(same.all())
         if not ok:
             kind, why = classify(fn, args, kw, gpu)
             bad += kind == "bug"
             chaos += kind != "bug"
-            print("MISMATCH" if kind == "bug" else "fp-order divergence", "-", why, "|", fn.__name__, "data seed", s, "K", K, "per", per, "nout", nout, kw, "models", M.shape, Mr.shape,
+            print("MISMATCH" if kind == "bug" else "fp-order divergence", "trial", trial, "-", why, "|", fn.__name__, "data seed", s, "K", K, "per", per, "nout", nout, kw, "models", M.shape, Mr.shape,
                   "labels differing", int((lab != labr).sum()) if lab.shape == labr.shape else "shape",
                   "max model diff", float(np.abs(M - Mr).max()) if M.shape == Mr.shape and M.size else None, flush=True)
     if verbose:
@@ -158,4 +182,4 @@ def soak(seed, trials, verbose=True):
 
 
 if __name__ == "__main__":
-    soak(int(sys.argv[1]), int(sys.argv[2]))
+    soak(int(sys.argv[1]), int(sys.argv[2]), only=(int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None)   # optional: first and last trial to run
