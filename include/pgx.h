@@ -77,6 +77,8 @@ int pgx_get_compound(pgx_ctx *ctx, double *compound);
  *   count + 1 < best_inlier_number  =>  Score()   in hypothesis order (see pyprogressivex/_proposal.py). */
 int pgx_score(pgx_ctx *ctx, const double *models, int M, double T2, int has_compound, int exponent,
               int64_t *counts, double *values, double *shared, double *scores, uint64_t *masks);
+/* pgx_score_upload: `models` is consumed before the call returns (copied, in locality order, into a pinned staging buffer of
+ * the context); the transfer itself is asynchronous on the context's stream, as is everything that follows it there. */
 int pgx_score_upload(pgx_ctx *ctx, const double *models, int M);
 /* ---- SURVEY 8f "next", rank 1 (first slice): batched minimal solvers on the resident points.  samples[S][2] are point
  * indices; hypothesis s is generated straight into the resident hypothesis buffer (as after pgx_score_upload, in the
@@ -86,7 +88,8 @@ int pgx_score_upload(pgx_ctx *ctx, const double *models, int M);
  * DefaultHomographyEstimator progressivex_python.cpp:252, absent upstream), the 7-point fundamental matrix solver (samples[S][7], THREE model slots per
  * sample: 3S x 9, DefaultFundamentalMatrixEstimator progressivex_python.cpp:616, absent upstream), P3P (samples[S][3],
  * FOUR slots per sample: 4S x 12 [R|t], DefaultPnPEstimator progressivex_python.cpp:119, absent upstream); a degenerate sample
- * or an absent root yields a NaN model (never an inlier).  Other model types: PGX_ERR_INVALID. */
+ * or an absent root yields a NaN model (never an inlier).  Other model types: PGX_ERR_INVALID.  `samples` is consumed before the
+ * call returns; with models_out == NULL the call does not wait for the solver (the batch stays on the device). */
 int pgx_solve_minimal(pgx_ctx *ctx, const int32_t *samples, int S, double *models_out);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
