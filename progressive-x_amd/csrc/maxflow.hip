@@ -8,6 +8,9 @@
 // per-site int64 excess / sink residual / hub flows, int32 heights.  The kernels are latency/HBM bound irregular
 // gathers; cross-workgroup communication is through device-scope atomics only, and every kernel
 // boundary is a full synchronisation point, so no in-launch release/acquire protocol is needed.
+#include <atomic>
+#include <chrono>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -22,6 +25,9 @@ constexpr int kMfBlock = 256;
 struct MaxflowState {
     DevBuf cap, tot, ex, rt, d, f, g, small, front;
     int* h_flags = nullptr;  // pinned host mirror for flag read-backs
+    int* h_pub = nullptr;    // device-mapped host words the last kernel before a read-back publishes the flags into (mf_publish):
+                             // [0 .. kMfFlags) flags, [kMfFlags] cnt[alpha], [15] sequence number the host spins on
+    int pub_seq = 0;
     DevBuf lists;            // act[2][n] | mark[n]
     DevBuf bar;              // grid barrier of the persistent kernels: arrivals | generation (zeroed once)
     int next_stamp = 1;
@@ -92,8 +98,20 @@ __device__ __forceinline__ void stage_flush(const MfView& v, Stage& st, int k, i
 // LDS and flushed with at most (L + 1) global operations per block.
 enum { kCountActive = 2, kApply = 4 };
 
+// A read-back used to be a 48-byte copy command plus hipStreamSynchronize behind the kernel that finished the flags (~9 us on
+// top of that kernel, 12 000 times per findVanishingPoints call).  Instead that kernel's last wave stores the flags straight
+// into device-mapped host memory, fences, and stores a sequence number the host spins on: ~3 us.  Called by one whole wave.
+__device__ __forceinline__ void mf_publish(const MfView& v, int* pub, int seq)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane < kMfFlags) __hip_atomic_store(&pub[lane], __hip_atomic_load(&v.flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (lane == kMfFlags) __hip_atomic_store(&pub[lane], __hip_atomic_load(&v.cnt[v.alpha], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(&pub[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int WHAT>
-__global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
+__global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1, int* pub, int* ticket, int seq)
 {
     __shared__ int s_min[kMfMaxLabels];
     if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
@@ -116,6 +134,17 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_agg(MfView v, int a0, int a1)
         }
     } else {
         if (threadIdx.x == 0 && count > 0) atomicAdd(&v.flags[2], count);
+    }
+    if (pub != nullptr) {   // the last workgroup to get here publishes the finished flags to the host (workgroup-uniform branch)
+        __shared__ int s_last;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int t = atomicAdd(ticket, 1);
+            s_last = t == (int)gridDim.x - 1;
+            if (s_last) atomicExch(ticket, 0);
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < 64) mf_publish(v, pub, seq);
     }
 }
 
@@ -788,11 +817,12 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
     }
 }
 
-__global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2)
+__global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub, int seq)
 {
     if (blockIdx.x != 0) return;
     if (what == 3) {   // all 64 lanes
         if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave<false>(v, a0, a1, a2);
+        if (pub != nullptr) mf_publish(v, pub, seq);   // a read-back follows this sweep
         return;
     }
     if (threadIdx.x != 0) return;
@@ -888,10 +918,34 @@ struct HipBackend {
         hipLaunchKernelGGL(k, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, a0, a1);
         check();
     }
-    void single(const MfView& v, int what, int a0 = 0, int a1 = 0, int a2 = 0)
+    void single(const MfView& v, int what, int a0 = 0, int a1 = 0, int a2 = 0, int* pub = nullptr, int seq = 0)
     {
-        hipLaunchKernelGGL(mf_k_single, dim3(1), dim3(64), 0, ctx->stream, v, what, a0, a1, a2);
+        hipLaunchKernelGGL(mf_k_single, dim3(1), dim3(64), 0, ctx->stream, v, what, a0, a1, a2, pub, seq);
         check();
+    }
+    int publish = 1;             // PGX_MF_PUBLISH=0: read the flags back with a copy + hipStreamSynchronize instead
+    bool pub_pending = false;    // the last kernel enqueued publishes the flags under sequence number st->pub_seq
+    // waits for the published flags; false if nothing was published or the wait gave up (the caller falls back to a copy)
+    bool take_published(int out[kMfFlags], int* cnt_alpha)
+    {
+        if (!pub_pending) return false;
+        pub_pending = false;
+        volatile int* p = st->h_pub;
+        const int want = st->pub_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0; p[15] != want; ++spin) {
+            if ((spin & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                // a kernel that faulted never publishes: let the runtime report it
+                hipError_t e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess && err == hipSuccess) err = e;
+                if (p[15] != want) return false;
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int k = 0; k < kMfFlags; ++k) out[k] = p[k];
+        if (cnt_alpha) *cnt_alpha = p[kMfFlags];
+        return true;
     }
     int read_int(const int* dptr)
     {
@@ -901,9 +955,9 @@ struct HipBackend {
         return st->h_flags[0];
     }
     static constexpr unsigned kAggBlocks = 512;   // kernels that end with per-workgroup atomics on a few addresses
-    template <class K> void agg(K k, const MfView& v)
+    template <class K, class... A> void agg(K k, const MfView& v, A... extra)
     {
-        hipLaunchKernelGGL(k, dim3(blocks < kAggBlocks ? blocks : kAggBlocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
+        hipLaunchKernelGGL(k, dim3(blocks < kAggBlocks ? blocks : kAggBlocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0, extra...);
         check();
     }
     void count_and_setup(const MfView& v)
@@ -928,9 +982,15 @@ struct HipBackend {
         hipLaunchKernelGGL(mf_k_bfs_level, dim3(g), dim3(kMfBlock), 0, ctx->stream, v, k, stage_margin());
         check();
     }
-    int read_flag(const MfView& v, int i) { return read_int(v.flags + i); }
+    int read_flag(const MfView& v, int i)
+    {
+        int fl[kMfFlags];
+        if (take_published(fl, nullptr)) return fl[i];
+        return read_int(v.flags + i);
+    }
     void read_flags_and_count(const MfView& v, int out[kMfFlags], int* cnt_alpha)
     {
+        if (take_published(out, cnt_alpha)) return;
         hipError_t e = hipMemcpyAsync(st->h_flags + kMfFlags, v.cnt + v.alpha, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
         read_flags(v, out);
@@ -938,6 +998,7 @@ struct HipBackend {
     }
     void read_flags(const MfView& v, int out[kMfFlags])
     {
+        if (take_published(out, nullptr)) return;
         hipError_t e = hipMemcpyAsync(st->h_flags, v.flags, kMfFlags * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess && err == hipSuccess) err = e;
@@ -990,7 +1051,14 @@ struct HipBackend {
                      n_stuck, s_stuck / 4294967296.0, n_exit, s_rt / 4294967296.0, n_relay);
     }
     void bfs_finish(const MfView& v, int slot, int last_level) { single(v, 2, slot, last_level); }
-    void count_active(const MfView& v) { agg(mf_k_agg<kCountActive>, v); }
+    void count_active(const MfView& v)   // always followed by a read-back (maxflow_driver.inl): its last workgroup publishes
+    {
+        if (!publish || !st->h_pub) { agg(mf_k_agg<kCountActive>, v, (int*)nullptr, (int*)nullptr, 0); return; }
+        hipLaunchKernelGGL(mf_k_agg<kCountActive>, dim3(blocks < kAggBlocks ? blocks : kAggBlocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0,
+                           st->h_pub, st->bar.as<int>() + 8, ++st->pub_seq);
+        check();
+        pub_pending = true;
+    }
     unsigned sweep_blocks = 512;     // workgroups of a sweep over all sites (PGX_MF_SWEEP_BLOCKS)
     void sweep(const MfView& v, int prev, int cur)
     {
@@ -1000,7 +1068,12 @@ struct HipBackend {
     }
     int fused_epilogue = 0;          // PGX_MF_FUSED=1: the sweep kernels run their own epilogue (mf_sweep_retire).  Measured 2-4 % SLOWER than the
                                      // separate one-wave launch (the wait + ticket + dependent loads at the tail of every sweep): off
-    void sweep_epilogue(const MfView& v, int cur, int next, int consumed) { if (!fused_epilogue) single(v, 3, cur, next, consumed); }
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed, bool read_follows = false)
+    {
+        if (fused_epilogue) return;
+        if (read_follows && publish && st->h_pub) { single(v, 3, cur, next, consumed, st->h_pub, ++st->pub_seq); pub_pending = true; }
+        else single(v, 3, cur, next, consumed);
+    }
     int take_stamps(const MfView& v, int count)
     {
         if (st->next_stamp > 0x3fff0000 - count) {  // stamps only grow: start over with a clean mark array
@@ -1043,7 +1116,12 @@ struct HipBackend {
             if (peek(v.hub_exists + l)) { const long long he = peek(v.hub_e + l); if (he > 0) total += he; }
         return total;
     }
-    void apply(const MfView& v) { agg(mf_k_agg<kApply>, v); }
+    void apply(const MfView& v)   // followed by the read-back of the number of relabelled sites (flags[2]): published as well
+    {
+        if (!publish || !st->h_pub) { agg(mf_k_agg<kApply>, v, (int*)nullptr, (int*)nullptr, 0); return; }
+        agg(mf_k_agg<kApply>, v, st->h_pub, st->bar.as<int>() + 8, ++st->pub_seq);
+        pub_pending = true;
+    }
     void keep_source_reachable_only(const MfView& v)
     {
         const int stamp = take_stamps(v, 1);
@@ -1067,6 +1145,7 @@ void maxflow_free(pgx_ctx* ctx)
     release(st->cap); release(st->tot); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
     release(st->small); release(st->front); release(st->lists); release(st->bar);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
+    if (st->h_pub) (void)hipHostFree(st->h_pub);
     delete st;
     ctx->mf = nullptr;
 }
@@ -1242,10 +1321,15 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.gate = std::getenv("PGX_MF_NO_GATE") ? 0 : 1;
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
-    if (!st->bar.p) {
+    if (!st->bar.p) {   // grid barrier of the persistent kernels (words 0-1) | ticket of the publishing count kernel (word 8)
         PGX_TRY(ensure(ctx, st->bar, 64));
         PGX_HIP(ctx, hipMemsetAsync(st->bar.p, 0, 64, ctx->stream));
     }
+    if (!st->h_pub) {
+        PGX_HIP(ctx, hipHostMalloc((void**)&st->h_pub, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(st->h_pub, 0, 64);
+    }
+    if (const char* e = std::getenv("PGX_MF_PUBLISH")) be.publish = std::atoi(e) ? 1 : 0;
     {
         const char* e = std::getenv("PGX_MF_PERSIST");
         // opt-in: measured equal-to-slower than one launch per level (a grid barrier over 256 workgroups on 8 XCDs costs what

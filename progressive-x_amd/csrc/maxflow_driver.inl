@@ -135,14 +135,15 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         }
         for (; s < budget && !round_done; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
+            const bool read_follows = (s + 1) % tune.sweep_check == 0;   // the epilogue then hands the flags to the host itself
             if (list_mode) {
                 be.sweep_list(v, prev, cur, parity, stamp + 1 + s);
-                be.sweep_epilogue(v, cur, next, parity);
+                be.sweep_epilogue(v, cur, next, parity, read_follows);
                 parity ^= 1;
                 stats[6] += 1;
             } else {
                 be.sweep(v, prev, cur);
-                be.sweep_epilogue(v, cur, next, -1);
+                be.sweep_epilogue(v, cur, next, -1, read_follows);
             }
             ++sweep_id;
             stats[1] += 1;

@@ -125,7 +125,7 @@ struct EmuBackend {
             std::fprintf(stderr, "  u=%lld l=%d d=%d ex=%lld rt=%lld f=%lld g=%lld\n", (long long)u, v.labels[u], v.d[u], (long long)v.ex[u],
                          (long long)v.rt[u], (long long)v.f[u], (long long)v.g[u]);
     }
-    void sweep_epilogue(const MfView& v, int cur, int next, int consumed)
+    void sweep_epilogue(const MfView& v, int cur, int next, int consumed, bool = false)
     {
         if (mf_sweep_idle(v)) return;
         mf_body_sweep_epilogue(v, cur, next, consumed);
