@@ -564,7 +564,7 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail", "fused"])
+@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail", "fused", "copied_readbacks"])
 def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
     # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
     if forced == "list_sweeps":
@@ -579,6 +579,8 @@ def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
         monkeypatch.setenv("PGX_MF_LIST_DIV", "0")
     if forced == "persistent":   # BFS / wave level loops inside cooperative kernels with a grid barrier
         monkeypatch.setenv("PGX_MF_PERSIST", "1")
+    if forced == "copied_readbacks":   # flags read back by copy + synchronisation instead of published by the kernels
+        monkeypatch.setenv("PGX_MF_PUBLISH", "0")
     rng = np.random.default_rng(2024)
     for trial in range(60):
         n = int(rng.integers(2, 300))
