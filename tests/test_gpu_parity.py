@@ -466,7 +466,7 @@ def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch, ora
     T2 = 2.25 * thr * thr
     comp = np.random.default_rng(3).random(len(pts))
     configs = [{"PGX_SCORE_SPLIT": s} for s in ("1", "3", "8", "16")] + [
-        {"PGX_SCORE_GROUP_XCD": "1"}, {"PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_SPLIT": "2"}, {"PGX_SCORE_NREP": "64"},
+        {"PGX_SCORE_GROUP_XCD": "1"}, {"PGX_SCORE_GROUP_XCD": "0"}, {"PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_SPLIT": "2"}, {"PGX_SCORE_NREP": "64"},
         {"PGX_SCORE_SOA": "0"}, {"PGX_SCORE_PIPE": "1"}, {"PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_DENSE": "65"}, {"PGX_SCORE_DENSE": "1"},
         {"PGX_SCORE_DENSE": "8", "PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_WG": "1"}, {"PGX_SCORE_WG": "1", "PGX_SCORE_SPLIT": "3", "PGX_SCORE_DENSE": "65"},
         {"PGX_NO_SORT": "1"},
