@@ -5,7 +5,7 @@ set -x
 TAG=${1:-run}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"
+B="python $R/bench.py --no-cpu-baseline --no-legs"   # the default steps / warm-up: the kernel averages are those of the bench line
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_${TAG}_stats -o bench -- $B > $R/gpurun_out/p_${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/p_${TAG}_fetch -o bench -- $B > $R/gpurun_out/p_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/p_${TAG}_write -o bench -- $B > $R/gpurun_out/p_${TAG}_write.log 2>&1
