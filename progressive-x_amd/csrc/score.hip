@@ -812,7 +812,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // 2^-q fixed point BEFORE any summation, so the accumulated integers do not depend on how pairs were batched:
     // results are bit-reproducible and independent of the launch geometry.  Equal hypotheses are adjacent in the queue
     // (pairs are appended hypothesis by hypothesis): a segmented shuffle reduction leaves one atomic set per run.
-    auto drain = [&](int c) {
+    auto drain = [&](int c) __attribute__((always_inline)) {
         if (ablate >= 1) return;
         const bool act = lane < c;
         const unsigned e = act ? s_queue[wv][lane] : 0u;
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // the mask-producing variant for every step and by the queued variant for DENSE steps (>= dense_min candidates of 64):
     // through the queue such a step would pay the shuffles, the model gather and the segmented reduction per pair for
     // nothing - its 64 pairs already sit in 64 lanes.  The same per-pair integers as the queued path: bitwise equal sums.
-    auto direct = [&](int m, bool cand) {
+    auto direct = [&](int m, bool cand) __attribute__((always_inline)) {
         double sc = 0.0, shv = 0.0;
         bool inl = false;
         if (cand) {  // exact path: oracle operation order, no contraction
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // exact FP64 evaluation then runs in score_exact_kernel with all 64 lanes busy, instead of here where a wave's last
     // batch is on average 40 % full and every batch ends the wave's work with a dependent gather + atomics.  A full
     // segment makes the wave evaluate in place (the reserved slots are marked empty).
-    auto flush = [&](int c) {
+    auto flush = [&](int c) __attribute__((always_inline)) {
         if (MASK || STATS || cand == nullptr) { drain(c); return; }
         if (ablate >= 1) return;
         // a wave's successive batches go to different segments (a dense group would otherwise fill one): segments end up
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             // are requested from LDS before the current one is evaluated, so the ~100-cycle LDS round trip overlaps the
             // filter arithmetic instead of heading every step's dependency chain (ISA of the plain loop: s_ff1 -> ds_read
             // x4 -> s_waitcnt -> 18 VALU -> ballot -> branch, strictly serial; VALU 56 % busy).
-            auto append = [&](int h, bool cand) {
+            auto append = [&](int h, bool cand) __attribute__((always_inline)) {
                 const unsigned long long cm = __ballot(cand);
                 if (cm == 0) return;
                 const int m = w * 64 + h;
