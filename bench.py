@@ -93,17 +93,24 @@ def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
 
 
 def timed_steps(ctx, step, steps, warmup):
-    """(seconds per step by the wall clock, mean HIP-event ms of the three scoring kernels) of `step` on one context"""
+    """(seconds per step by the wall clock, mean HIP-event ms of the scoring kernels) of `step` on one context.  The wall clock
+    runs with the events off - two event records around every kernel cost ~30 us of a step - and five more steps with the
+    events on give the per-kernel split."""
+    ctx.score_profile(0)
     for _ in range(warmup):
         step()
     ctx.sync()
-    kt = []
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-        kt.append(ctx.score_kernel_times())
     ctx.sync()
-    return (time.perf_counter() - t0) / steps, np.mean(np.array(kt), axis=0)
+    wall = (time.perf_counter() - t0) / steps
+    ctx.score_profile(2)
+    kt = []
+    for _ in range(6):
+        step()
+        kt.append(ctx.score_kernel_times())
+    return wall, np.mean(np.array(kt[1:]), axis=0)
 
 
 def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warmup):
@@ -325,27 +332,33 @@ def main():
 
     fetch_buf = None if use_comm else ctx.score_buffers()   # reused every step (results are consumed before the next one)
 
-    def step():
+    # HIP events around the dominant kernel on every EVENT_EVERY-th step of the timed region: a pair of event records costs
+    # ~9 us of a 0.25 ms step, so timing every launch would put 3.5 % of measurement into the number being measured
+    EVENT_EVERY = 5
+
+    def step(sample=True):
+        ctx.score_profile(1 if sample else 0)
         ctx.score_launch(T2, has_compound=True)
         if use_comm:
             ctx.score_allgather()
             res = ctx.score_fetch_all(exponent=2)
         else:
             res = ctx.score_fetch(exponent=2, out=fetch_buf)
-        kt = ctx.score_kernel_times()    # the fetch synchronised the stream: the events are complete
+        kt = ctx.score_kernel_times() if sample else None    # (waits for the launch's last event)
         best = parallel.select_best(res["scores"], res["counts"])
         return kt, best, res
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i % EVENT_EVERY == 0)
     if use_comm:
         ctx.comm_barrier()
     ctx.sync()
     t0 = time.perf_counter()
     kernel_ms = []
-    for _ in range(args.steps):
-        kms, best, res = step()
-        kernel_ms.append(kms)
+    for i in range(args.steps):
+        kms, best, res = step(i % EVENT_EVERY == 0)
+        if kms is not None:
+            kernel_ms.append(kms)
     if use_comm:
         ctx.comm_barrier()
     ctx.sync()
@@ -391,6 +404,8 @@ def main():
                          "traffic": PMC_TRAFFIC_DEFAULT if default_workload else None,
                          "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes, {PMC['source']}",
                          "kernel": "pgx::score_group_kernel<PnP>", "kernel_ms": k_ms,
+                         "kernel_ms_samples": len(kernel_ms),
+                         "kernel_ms_how": f"HIP events around the kernel on every {EVENT_EVERY}th launch of the timed region, on the context's stream",
                          "launch_kernels_ms": {"cull": float(kt[0]), "group_major": float(kt[1]), "finish": float(kt[2]),
                                                "exact_queue": float(kt[3]), "sum": launch_ms,
                                                "note": "breakdown from 5 extra steps with events around every kernel (an event costs "
