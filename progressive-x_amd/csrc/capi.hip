@@ -101,6 +101,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SP_KD")) ctx->sp_kd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SETPOINTS_HOST")) ctx->setpoints_host = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SCORE_WG")) ctx->score_wg = std::atoi(b) ? 1 : 0;
@@ -135,7 +136,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
-                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->cand};
+                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->cand, &ctx->weights_scratch};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);

@@ -111,6 +111,97 @@ __global__ __launch_bounds__(kSpBlock) void sp_keys_kernel(const double* __restr
     vals[i] = (unsigned)i;
 }
 
+
+// ---- k-d order (PGX_SP_KD, pose problems): median splits of the widest dimension instead of a Morton curve ----------------
+// The group bound's slack is (radius of the 3-D part) x (projection scale) + (half extent of the observed part): a Morton cell
+// is as wide in every normalised coordinate, a k-d leaf is balanced by construction (every split halves the widest extent,
+// whole groups of 64 on either side) and adapts to the density - 89-99 surviving hypotheses per group against 135
+// (scripts/analysis_cull_bound.py).  Built level by level: the segment boundaries depend on n alone (host), a level is a
+// segmented min/max, a key (node << 32 | coordinate along the node's widest dimension) and one stable radix sort of the pairs.
+__device__ __forceinline__ unsigned f32_ord(float x)
+{
+    const unsigned b = __float_as_uint(x);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ int kd_node_of(const int* __restrict__ seg, int nseg, int pos)   // last s with seg[s] <= pos
+{
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+struct KdScale { double s[5]; };
+
+__global__ __launch_bounds__(kSpBlock) void sp_kd_extent_kernel(const double* __restrict__ pts, int64_t n, int d, KdScale sc,
+                                                                const unsigned* __restrict__ order, const int* __restrict__ seg, int nseg,
+                                                                unsigned* __restrict__ mn /* [nseg][5] */, unsigned* __restrict__ mx)
+{
+    const int64_t pos = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    const bool live = pos < n;
+    const int node = live ? kd_node_of(seg, nseg, (int)pos) : -1;
+    __shared__ int s_first, s_same;
+    __shared__ unsigned s_mn[5], s_mx[5];
+    if (threadIdx.x == 0) { s_first = node; s_same = 1; }
+    if (threadIdx.x < 5) { s_mn[threadIdx.x] = 0xffffffffu; s_mx[threadIdx.x] = 0u; }
+    __syncthreads();
+    if (live && node != s_first) s_same = 0;   // (benign race: every writer stores 0)
+    __syncthreads();
+    unsigned key[5];
+    if (live) {
+        const unsigned i = order[pos];
+        for (int k = 0; k < d; ++k) key[k] = f32_ord((float)(pts[(int64_t)i * d + k] * sc.s[k]));
+    }
+    if (s_same) {   // the whole workgroup inside one node (the first levels): one set of global atomics per workgroup
+        if (live)
+            for (int k = 0; k < d; ++k) { atomicMin(&s_mn[k], key[k]); atomicMax(&s_mx[k], key[k]); }
+        __syncthreads();
+        if ((int)threadIdx.x < d && s_first >= 0) {
+            atomicMin(&mn[s_first * 5 + threadIdx.x], s_mn[threadIdx.x]);
+            atomicMax(&mx[s_first * 5 + threadIdx.x], s_mx[threadIdx.x]);
+        }
+    } else if (live) {
+        for (int k = 0; k < d; ++k) { atomicMin(&mn[node * 5 + k], key[k]); atomicMax(&mx[node * 5 + k], key[k]); }
+    }
+}
+
+__device__ __forceinline__ float ord_f32(unsigned k)
+{
+    const unsigned b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(kSpBlock) void sp_kd_keys_kernel(const double* __restrict__ pts, int64_t n, int d, KdScale sc,
+                                                              const unsigned* __restrict__ order, const int* __restrict__ seg, int nseg,
+                                                              const unsigned* __restrict__ mn, const unsigned* __restrict__ mx,
+                                                              unsigned* __restrict__ keys, int qbits)
+{
+    const int64_t pos = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (pos >= n) return;
+    const int node = kd_node_of(seg, nseg, (int)pos);
+    int best = 0;
+    float ext = -1.0f, lo = 0.0f;
+    for (int k = 0; k < d; ++k) {   // widest extent (first among equals); a NaN extent never wins
+        const float a = ord_f32(mn[node * 5 + k]), e = ord_f32(mx[node * 5 + k]) - a;
+        if (e > ext) { ext = e; best = k; lo = a; }
+    }
+    // position along that dimension, quantised to qbits inside the node's own extent: (node, position) fits a 32-bit key and
+    // the sort needs half the passes of a 64-bit one; equal positions keep their order (stable sort)
+    const unsigned i = order[pos];
+    const float x = (float)(pts[(int64_t)i * d + best] * sc.s[best]);
+    const float qmax = (float)((1u << qbits) - 1u);
+    float t = ext > 0.0f ? (x - lo) / ext * qmax : 0.0f;
+    t = t > 0.0f ? (t < qmax ? t : qmax) : 0.0f;   // (NaN -> 0)
+    keys[pos] = ((unsigned)node << qbits) | (unsigned)t;
+}
+
+__global__ __launch_bounds__(kSpBlock) void sp_iota_kernel(unsigned* __restrict__ v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    if (i < n) v[i] = (unsigned)i;
+}
+
 // sorted copies: AoS rows (chunked kernel, exact kernel), f32 rows, scales, and the group-blocked SoA copies
 __global__ __launch_bounds__(kSpBlock) void sp_gather_kernel(const double* __restrict__ pts, const float* __restrict__ p32,
                                                              const double* __restrict__ pmax, const unsigned* __restrict__ order,
@@ -561,9 +652,79 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     unsigned* v_in = (unsigned*)((char*)ctx->fit_scratch.p + 2 * arr);
     unsigned* v_out = (unsigned*)((char*)ctx->fit_scratch.p + 3 * arr);
     void* tmp = (char*)ctx->fit_scratch.p + 4 * arr;
-    hipLaunchKernelGGL(sp_keys_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, m, k_in, v_in);
-    PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)(m.bits * d), ctx->stream));
+    bool kd_done = false;
+    if (ctx->sp_kd && model_type == kPnP && n > 128 && n < (1ll << 31)) {
+        // segment boundaries of every level (they depend on n alone): a segment of m > 64 points sends the first
+        // 64 * ((m / 64) / 2) (at least 64) to the left
+        std::vector<std::vector<int>> levels;
+        std::vector<int> cur = {0, (int)n};
+        for (;;) {
+            std::vector<int> nxt;
+            bool split = false;
+            for (size_t q = 0; q + 1 < cur.size(); ++q) {
+                const int a = cur[q], mseg = cur[q + 1] - a;
+                nxt.push_back(a);
+                if (mseg > 64) {
+                    int nl = ((mseg / 64) / 2) * 64;
+                    if (nl <= 0) nl = 64;
+                    if (nl < mseg) { nxt.push_back(a + nl); split = true; }
+                }
+            }
+            nxt.push_back((int)n);
+            levels.push_back(cur);
+            if (!split) break;
+            cur.swap(nxt);
+        }
+        KdScale sc;
+        {   // one scale for the observed pair, one for the 3-D part: a quarter of what box normalisation would give the latter
+            double eo = 0.0, ei = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double e = key_f64(st[5 + k]) - key_f64(st[k]);
+                if (k < 2) eo = std::fmax(eo, e); else ei = std::fmax(ei, e);
+            }
+            for (int k = 0; k < d; ++k) sc.s[k] = k < 2 ? (eo > 0.0 ? 1.0 / eo : 0.0) : (ei > 0.0 ? 0.25 / ei : 0.0);
+            for (int k = d; k < 5; ++k) sc.s[k] = 0.0;
+        }
+        const size_t maxseg = levels.back().size();
+        int nodebits = 1;
+        while ((1ll << nodebits) < (long long)maxseg) ++nodebits;
+        const int qbits = 32 - nodebits < 16 ? 32 - nodebits : 16;
+        if (qbits >= 8) {
+            const size_t segbytes = (maxseg * sizeof(int) + 255) & ~(size_t)255, mmbytes = (maxseg * 5 * sizeof(unsigned) + 255) & ~(size_t)255;
+            PGX_TRY(ensure(ctx, ctx->weights_scratch, segbytes + 2 * mmbytes + 256));
+            int* d_seg = (int*)ctx->weights_scratch.p;
+            unsigned* d_mn = (unsigned*)((char*)d_seg + segbytes);
+            unsigned* d_mx = (unsigned*)((char*)d_mn + mmbytes);
+            hipLaunchKernelGGL(sp_iota_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, v_out, n);
+            unsigned* ord_cur = v_out;
+            unsigned* ord_nxt = v_in;
+            for (size_t lv = 0; lv + 1 < levels.size(); ++lv) {   // (`levels` outlives the copies: the stream is synchronised below)
+                const std::vector<int>& seg = levels[lv];
+                const int nseg = (int)seg.size() - 1;
+                PGX_HIP(ctx, hipMemcpyAsync(d_seg, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                PGX_HIP(ctx, hipMemsetAsync(d_mn, 0xff, (size_t)nseg * 5 * sizeof(unsigned), ctx->stream));
+                PGX_HIP(ctx, hipMemsetAsync(d_mx, 0, (size_t)nseg * 5 * sizeof(unsigned), ctx->stream));
+                hipLaunchKernelGGL(sp_kd_extent_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, d, sc, ord_cur, d_seg,
+                                   nseg, d_mn, d_mx);
+                hipLaunchKernelGGL(sp_kd_keys_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, d, sc, ord_cur, d_seg,
+                                   nseg, d_mn, d_mx, k_in, qbits);
+                PGX_HIP(ctx, hipGetLastError());
+                int nb = 1;
+                while ((1ll << nb) < nseg) ++nb;
+                PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, ord_cur, ord_nxt, (size_t)n, 0, (unsigned)(qbits + nb), ctx->stream));
+                std::swap(ord_cur, ord_nxt);
+            }
+            PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ord_cur != v_out)
+                PGX_HIP(ctx, hipMemcpyAsync(v_out, ord_cur, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+            kd_done = true;
+        }
+    }
+    if (!kd_done) {
+        hipLaunchKernelGGL(sp_keys_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, m, k_in, v_in);
+        PGX_HIP(ctx, hipGetLastError());
+        PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, (unsigned)(m.bits * d), ctx->stream));
+    }
     PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->pts32_s, (size_t)n * 8 * sizeof(float)));
     PGX_TRY(ensure(ctx, ctx->pmax_s, (size_t)n * sizeof(double)));

@@ -1335,6 +1335,7 @@ def test_set_points_device_equals_host_preprocessing(name, n, monkeypatch, oracl
         pts[11, 0] = pts[:, 0].max() * 3.0    # a far point: the quantisation range
     T2 = 2.25 * thr * thr
     got = {}
+    monkeypatch.setenv("PGX_SP_KD", "0")        # the host path orders by the Morton key: compare like with like (k-d order: next test)
     for mode in ("0", "1"):
         monkeypatch.setenv("PGX_SETPOINTS_HOST", mode)
         ctx = _lib.Context(0)
@@ -1351,6 +1352,36 @@ def test_set_points_device_equals_host_preprocessing(name, n, monkeypatch, oracl
         assert np.array_equal(got["0"]["score"][k], got["1"]["score"][k]), k
     ref = oracle.score(mt, pts, models, T2, want_masks=True)
     assert np.array_equal(got["0"]["score"]["counts"], ref["counts"]) and np.array_equal(got["0"]["score"]["masks"], ref["masks"])
+
+
+@pytest.mark.parametrize("n", [129, 130, 4097, 5000, 100003])
+def test_kd_order_of_pose_points_is_a_valid_grouping(n, monkeypatch, oracle):
+    """The k-d order of a pose problem's points (setpoints.hip, the default) is another permutation under the same group
+    bounds: a permutation of all points, duplicates and a far outlier included, and scores, counts and masks bitwise those of
+    the Morton order and equal to the oracle's - with no more surviving (hypothesis, group) steps at the larger sizes."""
+    mt, pts, models, thr = make_case("pnp", n, 70, seed=n)
+    pts[7] = pts[3]
+    pts[11, 0] = pts[:, 0].max() * 3.0
+    T2 = 2.25 * thr * thr
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PGX_SP_KD", mode)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(mt, pts)
+            got[mode] = {"order": ctx.score_debug_fetch("order"), "score": ctx.score(models, T2, want_masks=True),
+                         "steps": ctx.score_stats(T2)["surviving_group_steps"]}
+        finally:
+            ctx.close()
+    monkeypatch.delenv("PGX_SP_KD")
+    assert np.array_equal(np.sort(got["1"]["order"]), np.arange(n))
+    assert not np.array_equal(got["0"]["order"], got["1"]["order"])
+    for k in ("counts", "values", "masks"):
+        assert np.array_equal(got["0"]["score"][k], got["1"]["score"][k]), k
+    ref = oracle.score(mt, pts, models, T2, want_masks=True)
+    assert np.array_equal(got["1"]["score"]["counts"], ref["counts"]) and np.array_equal(got["1"]["score"]["masks"], ref["masks"])
+    if n >= 100000:
+        assert got["1"]["steps"] <= got["0"]["steps"]
 
 
 def test_set_points_device_non_finite_points_disable_the_sorted_path(oracle):
