@@ -138,31 +138,31 @@ __global__ __launch_bounds__(kSpBlock) void sp_kd_extent_kernel(const double* __
                                                                 const unsigned* __restrict__ order, const int* __restrict__ seg, int nseg,
                                                                 unsigned* __restrict__ mn /* [nseg][5] */, unsigned* __restrict__ mx)
 {
+    // Every segment starts at a multiple of 64 positions (the splits send whole groups to the left), so the 64 positions of a
+    // wave lie in ONE node: a shuffle reduction per wave, then one atomic per (wave, dimension) instead of one per point.
     const int64_t pos = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
+    const int64_t wave0 = pos & ~(int64_t)63;
+    if (wave0 >= n) return;
     const bool live = pos < n;
-    const int node = live ? kd_node_of(seg, nseg, (int)pos) : -1;
-    __shared__ int s_first, s_same;
-    __shared__ unsigned s_mn[5], s_mx[5];
-    if (threadIdx.x == 0) { s_first = node; s_same = 1; }
-    if (threadIdx.x < 5) { s_mn[threadIdx.x] = 0xffffffffu; s_mx[threadIdx.x] = 0u; }
-    __syncthreads();
-    if (live && node != s_first) s_same = 0;   // (benign race: every writer stores 0)
-    __syncthreads();
-    unsigned key[5];
+    const int node = kd_node_of(seg, nseg, (int)wave0);
+    unsigned lo[5], hi[5];
+    for (int k = 0; k < 5; ++k) { lo[k] = 0xffffffffu; hi[k] = 0u; }
     if (live) {
         const unsigned i = order[pos];
-        for (int k = 0; k < d; ++k) key[k] = f32_ord((float)(pts[(int64_t)i * d + k] * sc.s[k]));
+        for (int k = 0; k < d; ++k) lo[k] = hi[k] = f32_ord((float)(pts[(int64_t)i * d + k] * sc.s[k]));
     }
-    if (s_same) {   // the whole workgroup inside one node (the first levels): one set of global atomics per workgroup
-        if (live)
-            for (int k = 0; k < d; ++k) { atomicMin(&s_mn[k], key[k]); atomicMax(&s_mx[k], key[k]); }
-        __syncthreads();
-        if ((int)threadIdx.x < d && s_first >= 0) {
-            atomicMin(&mn[s_first * 5 + threadIdx.x], s_mn[threadIdx.x]);
-            atomicMax(&mx[s_first * 5 + threadIdx.x], s_mx[threadIdx.x]);
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < d; ++k) {
+            const unsigned a = __shfl_xor(lo[k], off, 64), b = __shfl_xor(hi[k], off, 64);
+            lo[k] = a < lo[k] ? a : lo[k];
+            hi[k] = b > hi[k] ? b : hi[k];
         }
-    } else if (live) {
-        for (int k = 0; k < d; ++k) { atomicMin(&mn[node * 5 + k], key[k]); atomicMax(&mx[node * 5 + k], key[k]); }
+    const int lane = (int)(threadIdx.x & 63);
+    if (lane < d) {
+        unsigned vlo = lo[0], vhi = hi[0];
+        for (int k = 1; k < d; ++k) if (lane == k) { vlo = lo[k]; vhi = hi[k]; }
+        atomicMin(&mn[node * 5 + lane], vlo);
+        atomicMax(&mx[node * 5 + lane], vhi);
     }
 }
 
