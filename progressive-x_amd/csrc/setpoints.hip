@@ -653,7 +653,7 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     unsigned* v_out = (unsigned*)((char*)ctx->fit_scratch.p + 3 * arr);
     void* tmp = (char*)ctx->fit_scratch.p + 4 * arr;
     bool kd_done = false;
-    if (ctx->sp_kd && model_type == kPnP && n > 128 && n < (1ll << 31)) {
+    if (ctx->sp_kd && (model_type == kPnP || (ctx->sp_kd >= 2 && !line)) && n > 128 && n < (1ll << 31)) {   // (2: experimental, every model type on this path)
         // segment boundaries of every level (they depend on n alone): a segment of m > 64 points sends the first
         // 64 * ((m / 64) / 2) (at least 64) to the left
         std::vector<std::vector<int>> levels;
@@ -682,7 +682,8 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
                 const double e = key_f64(st[5 + k]) - key_f64(st[k]);
                 if (k < 2) eo = std::fmax(eo, e); else ei = std::fmax(ei, e);
             }
-            for (int k = 0; k < d; ++k) sc.s[k] = k < 2 ? (eo > 0.0 ? 1.0 / eo : 0.0) : (ei > 0.0 ? 0.25 / ei : 0.0);
+            if (model_type != kPnP) eo = ei = std::fmax(eo, ei) * 4.0 > 0.0 ? std::fmax(eo, ei) : 0.0;   // correspondences: one scale for all four pixel coordinates
+            for (int k = 0; k < d; ++k) sc.s[k] = k < 2 ? (eo > 0.0 ? 1.0 / eo : 0.0) : (ei > 0.0 ? (model_type == kPnP ? 0.25 : 1.0) / ei : 0.0);
             for (int k = d; k < 5; ++k) sc.s[k] = 0.0;
         }
         const size_t maxseg = levels.back().size();
