@@ -101,6 +101,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
     const char* df = std::getenv("PGX_SCORE_DEFERRED");
     ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
+    if (const char* b = std::getenv("PGX_SP_KD_W")) { const double v = std::atof(b); if (v > 0.0 && v < 1e6) ctx->sp_kd_weight = v; }
     if (const char* b = std::getenv("PGX_SP_KD")) { const int v = std::atoi(b); ctx->sp_kd = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SETPOINTS_HOST")) ctx->setpoints_host = std::atoi(b) ? 1 : 0;

@@ -67,6 +67,7 @@ struct pgx_ctx {
     int score_pipe = 0;          // PGX_SCORE_PIPE: 0 plain survivor loop, 1 prefetch of the next hypothesis' constants, 2 two per step
     int score_soa = 1;           // PGX_SCORE_SOA=0: the group-major kernel reads the AoS copies (A/B)
     int score_cull = 1;          // cull + survivor kernels instead of in-kernel group skipping (PGX_SCORE_NO_CULL=1: A/B)
+    double sp_kd_weight = 0.25;  // PGX_SP_KD_W: weight of the 3-D part against the observed pair in the k-d order (1 = box normalisation)
     int sp_kd = 1;               // PGX_SP_KD=0: Morton order of the points of a pose problem instead of the k-d order (setpoints.hip)
     pgx::DevBuf weights_scratch; // scratch of the k-d build (64-bit keys, sort workspace, per-node extents)
     int score_group_xcd = -1;    // PGX_SCORE_GROUP_XCD: 1 = a group's workgroups on one XCD (8x less row fetch, per-XCD accumulator replicas), 0 = part p on XCD p;

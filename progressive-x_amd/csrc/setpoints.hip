@@ -683,7 +683,7 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
                 if (k < 2) eo = std::fmax(eo, e); else ei = std::fmax(ei, e);
             }
             if (model_type != kPnP) eo = ei = std::fmax(eo, ei) * 4.0 > 0.0 ? std::fmax(eo, ei) : 0.0;   // correspondences: one scale for all four pixel coordinates
-            for (int k = 0; k < d; ++k) sc.s[k] = k < 2 ? (eo > 0.0 ? 1.0 / eo : 0.0) : (ei > 0.0 ? (model_type == kPnP ? 0.25 : 1.0) / ei : 0.0);
+            for (int k = 0; k < d; ++k) sc.s[k] = k < 2 ? (eo > 0.0 ? 1.0 / eo : 0.0) : (ei > 0.0 ? (model_type == kPnP ? ctx->sp_kd_weight : 1.0) / ei : 0.0);
             for (int k = d; k < 5; ++k) sc.s[k] = 0.0;
         }
         const size_t maxseg = levels.back().size();
