@@ -1542,7 +1542,12 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                ctx->cull_lists.as<unsigned long long>(), hyp32, models_t, acc, zero_words);
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[1], ctx->stream));
-            const int split = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
+            // waves per group.  Spread mapping: 8 (part p = XCD p).  Co-located mapping: 5 - fewer, longer waves load a group's rows
+            // less often, and an ODD count keeps the heavy workgroups (a locality-ordered batch puts a group's survivors into two or
+            // three neighbouring hypothesis words) from falling into a period of the dispatch order: group kernel 169 (8), 157 (4),
+            // 146 (6), 140 (2) against 135-140 us (1, 3, 5, 7) on the metric batch.
+            const int split_cfg = ctx->score_split > 0 ? ctx->score_split : (group_xcd ? 5 : 8);
+            const int split = split_cfg < W ? split_cfg : W;
             const unsigned gblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
             if (want_masks) {
                 PGX_HIP(ctx, hipMemsetAsync(ctx->masks_s.p, 0, (size_t)ctx->M * (size_t)ctx->words * sizeof(uint64_t), ctx->stream));
@@ -1567,7 +1572,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                        qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
                                        (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep, ctx->score_dense_min);
                 };
-                const int parts = ctx->score_split < W ? (ctx->score_split > 0 ? ctx->score_split : 1) : W;
+                const int parts = split;
                 const int wpp = (W + parts - 1) / parts;
                 if (ctx->score_wg && !use_queue && pts_g != nullptr && wpp <= 8 && ctx->Mpad < (1 << 22)) {
                     // workgroup variant: grid = chunks x parts, workgroup id % parts = part (= XCD when parts == 8)
