@@ -1546,7 +1546,9 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             // less often, and an ODD count keeps the heavy workgroups (a locality-ordered batch puts a group's survivors into two or
             // three neighbouring hypothesis words) from falling into a period of the dispatch order: group kernel 169 (8), 157 (4),
             // 146 (6), 140 (2) against 135-140 us (1, 3, 5, 7) on the metric batch.
-            const int split_cfg = ctx->score_split > 0 ? ctx->score_split : (group_xcd ? 5 : 8);
+            // (pose problems take 5 with the spread mapping as well: RANSAC-like batch 0.371 -> 0.353 ms; Sampson and vanishing-point
+            // batches lose 15-20 % there and keep 8)
+            const int split_cfg = ctx->score_split > 0 ? ctx->score_split : ((group_xcd || MT == kPnP) ? 5 : 8);
             const int split = split_cfg < W ? split_cfg : W;
             const unsigned gblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
             if (want_masks) {
