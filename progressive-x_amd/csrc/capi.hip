@@ -121,6 +121,17 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_NO_XCD")) ctx->score_xcd_map = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
+    if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_ORDER")) ctx->tile_order = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_MULTI")) ctx->tile_multi = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_HARD")) { const int v = std::atoi(b); if (v >= 0 && v <= (1 << 20)) ctx->tile_hard_div = v; }
+    if (const char* b = std::getenv("PGX_TILE_SINGLE")) { const int v = std::atoi(b); if (v >= 0 && v <= 8192) ctx->tile_single_max = v; }
+    if (const char* b = std::getenv("PGX_TILE_POLLS")) { const int v = std::atoi(b); if (v >= 1 && v <= 65536) ctx->tile_polls = v; }
+    if (const char* b = std::getenv("PGX_TILE_BATCH")) { const int v = std::atoi(b); if (v >= 2 && v <= 32) ctx->tile_phase_batch = v; }
+    if (const char* b = std::getenv("PGX_TILE_SWEEPS")) { const int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->tile_sweeps = v; }
+    if (const char* b = std::getenv("PGX_TILE_LAZY")) ctx->tile_lazy = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_DISCHARGES")) { const int v = std::atoi(b); if (v >= 1 && v <= 64) ctx->tile_discharges = v; }
+    if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
 }
@@ -132,6 +143,8 @@ void pgx_destroy(pgx_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     comm_free(ctx);
     maxflow_free(ctx);
+    tile_free(ctx);
+    release(ctx->gorder);
     DevBuf* bufs[] = {&ctx->pts, &ctx->comp, &ctx->pmax, &ctx->pts32, &ctx->perm, &ctx->models, &ctx->pcnt, &ctx->pval, &ctx->psh, &ctx->counts,
                       &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
@@ -751,6 +764,7 @@ int pgx_set_graph(pgx_ctx* ctx, int64_t n, const int32_t* off, const int32_t* id
     }
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gn = n; ctx->gE = E; ctx->max_degree = maxdeg; ctx->max_row_mult = max_row;
+    ctx->gorder_n = 0;   // no coordinates: the tile path orders the sites like the resident points (or not at all)
     return graph_build_reverse(ctx);
 }
 

@@ -18,11 +18,13 @@
 // (LDS reads are broadcasts: all lanes look at the same candidate).  FP64-VALU/LDS bound: N * (points per 3x3 block)
 // pair tests of 3d flops.  Lists -> CSR: reciprocity test, degree scan, fill with atomically placed reverse entries,
 // per-row sort (rows come out sorted, so the result does not depend on atomic order).
-#include <hip/hip_runtime.h>
-
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 
 #include "pgx_internal.h"
 
@@ -390,6 +392,84 @@ void launch_ball(pgx_ctx* ctx, GraphScratch& gs, const GridSpec& g, int cells, i
                        (unsigned long long*)(gs.small.as<int>() + 2));
 }
 
+// ---- site order for the tile-resident min-cut (maxflow_tile.hip): Morton code of the coordinates the graph was built on,
+// quantised with ONE cell size for all coordinates (the ball's radius: neighbours are at most one cell apart in every
+// coordinate), most significant bits first, coordinates with fewer cells contributing fewer bits
+struct MortonSpec {
+    double mn[5];
+    double inv_cell;
+    int bits[5];
+    int d, maxb;
+};
+
+__global__ __launch_bounds__(kGBlock) void g_morton_kernel(const double* __restrict__ pts, int64_t n, MortonSpec m,
+                                                           unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * kGBlock + threadIdx.x;
+    if (i >= n) return;
+    int q[5];
+    for (int k = 0; k < m.d; ++k) {
+        const double x = (pts[i * m.d + k] - m.mn[k]) * m.inv_cell;
+        int c = x > 0.0 ? (x < 2147483000.0 ? (int)x : 2147483000) : 0;   // NaN -> 0
+        const int top = (1 << m.bits[k]) - 1;
+        q[k] = c > top ? top : c;
+    }
+    unsigned long long key = 0;
+    for (int level = m.maxb - 1; level >= 0; --level)
+        for (int k = 0; k < m.d; ++k)
+            if (level < m.bits[k]) key = (key << 1) | (unsigned long long)((q[k] >> level) & 1);
+    keys[i] = key;
+    vals[i] = (int)i;
+}
+
+int graph_site_order(pgx_ctx* ctx, const double* d_pts, int64_t n, int d, const double* mn, const double* mx, double cell)
+{
+    ctx->gorder_n = 0;
+    MortonSpec m;
+    m.d = d;
+    double ext = 0.0;
+    for (int k = 0; k < d; ++k) { m.mn[k] = mn[k]; ext = std::fmax(ext, mx[k] - mn[k]); }
+    if (!(cell > 0.0) || !std::isfinite(cell)) cell = ext / 1024.0;
+    if (!(cell > 0.0) || !std::isfinite(ext)) return PGX_OK;   // all points identical (or not finite): the caller's order
+    const int cap = 62 / d;
+    int total = 0;
+    for (;;) {
+        total = 0;
+        m.maxb = 0;
+        bool fits = true;
+        for (int k = 0; k < d; ++k) {
+            const double cells = std::floor((mx[k] - mn[k]) / cell) + 1.0;
+            int b = 0;
+            while (b < 31 && (double)(1u << b) < cells) ++b;
+            if (b > cap) fits = false;
+            m.bits[k] = b;
+            total += b;
+            m.maxb = b > m.maxb ? b : m.maxb;
+        }
+        if (fits) break;
+        cell *= 2.0;
+    }
+    if (total == 0) return PGX_OK;
+    m.inv_cell = 1.0 / cell;
+    size_t tmp_bytes = 0;
+    unsigned long long* nullk = nullptr;
+    int* nullv = nullptr;
+    PGX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, nullk, nullk, nullv, nullv, (size_t)n, 0, (unsigned)total, ctx->stream));
+    const size_t ka = ((size_t)n * 8 + 255) & ~(size_t)255, va = ((size_t)n * 4 + 255) & ~(size_t)255;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, 2 * ka + va + tmp_bytes + 256));
+    PGX_TRY(ensure(ctx, ctx->gorder, (size_t)n * sizeof(int)));
+    char* base = (char*)ctx->fit_scratch.p;
+    unsigned long long* k_in = (unsigned long long*)base;
+    unsigned long long* k_out = (unsigned long long*)(base + ka);
+    int* v_in = (int*)(base + 2 * ka);
+    void* tmp = base + 2 * ka + va;
+    hipLaunchKernelGGL(g_morton_kernel, dim3((unsigned)((n + kGBlock - 1) / kGBlock)), dim3(kGBlock), 0, ctx->stream, d_pts, n, m, k_in, v_in);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, ctx->gorder.as<int>(), (size_t)n, 0, (unsigned)total, ctx->stream));
+    ctx->gorder_n = n;
+    return PGX_OK;
+}
+
 void free_scratch(GraphScratch& gs)
 {
     DevBuf* all[] = {&gs.key, &gs.count, &gs.start, &gs.cursor, &gs.sidx, &gs.spts, &gs.blk, &gs.nbr, &gs.m1,
@@ -466,11 +546,12 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
     if (kind != PGX_GRAPH_KNN && !(radius > 0.0)) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: radius must be > 0");
     if (k > n - 1) k = (int)(n - 1);
     // extent of the two grid coordinates (host pass: the caller's buffer is in host memory anyway)
-    double mn[2] = {pts[0], pts[1]}, mx[2] = {pts[0], pts[1]};
+    double mn[5] = {pts[0], pts[1], 0, 0, 0}, mx[5] = {pts[0], pts[1], 0, 0, 0};
+    for (int c = 2; c < d; ++c) mn[c] = mx[c] = pts[c];
     for (int64_t i = 0; i < n; ++i)
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < d; ++c) {
             const double v = pts[i * d + c];
-            if (!(v == v) || std::isinf(v)) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: non-finite coordinate in row %lld", (long long)i);
+            if (c < 2 && (!(v == v) || std::isinf(v))) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_build: non-finite coordinate in row %lld", (long long)i);
             if (v < mn[c]) mn[c] = v;
             if (v > mx[c]) mx[c] = v;
         }
@@ -595,6 +676,9 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
         return graph_build_reverse(ctx);
     };
     rc = body();
+    ctx->gorder_n = 0;
+    if (rc == PGX_OK && ctx->tile_order)   // (gs.dpts still holds the caller's rows)
+        rc = graph_site_order(ctx, gs.dpts.as<double>(), n, d, mn, mx, kind == PGX_GRAPH_KNN ? 0.0 : radius);
     (void)hipStreamSynchronize(ctx->stream);
     free_scratch(gs);
     if (rc != PGX_OK) { ctx->gn = 0; ctx->gE = 0; }

@@ -852,6 +852,7 @@ __global__ __launch_bounds__(kMfBlock) void graph_reverse_kernel(int64_t n, cons
 
 int graph_build_reverse(pgx_ctx* ctx)
 {
+    ctx->graph_version += 1;
     if (ctx->gE == 0) return PGX_OK;
     PGX_TRY(ensure(ctx, ctx->scratch, 64));
     PGX_HIP(ctx, hipMemsetAsync(ctx->scratch.p, 0, 4, ctx->stream));
@@ -1265,6 +1266,12 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
+    if (ctx->mf_tile && !source_reach && wq == nullptr && !std::getenv("PGX_MF_NO_GATE")) {
+        const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed);
+        if (r != PGX_TILE_FALLBACK) return r;
+        ctx->stats[7] += 0;   // (fallbacks are rare: a hub that only reaches t through members without t-links, round caps)
+        ctx->tile_fallbacks += 1;
+    }
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();
         PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));

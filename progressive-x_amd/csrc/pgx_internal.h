@@ -20,6 +20,7 @@ struct DevBuf {
 };
 
 struct MaxflowState;  // maxflow.hip
+struct TileState;     // maxflow_tile.hip
 struct CommState;     // comm.cpp
 
 }  // namespace pgx
@@ -106,6 +107,23 @@ struct pgx_ctx {
     int64_t max_row_mult = 0;
     pgx::DevBuf goff, gidx, gmult, grev;
     pgx::MaxflowState* mf = nullptr;
+    // tile-resident min-cut (maxflow_tile.hip), the default path of an expansion move
+    pgx::TileState* tile = nullptr;
+    int64_t graph_version = 0;   // bumped whenever the resident graph changes (graph_build_reverse)
+    pgx::DevBuf gorder;          // sites in the Morton order of the coordinates the graph was built on (graph.hip); gorder_n == gn when valid
+    int64_t gorder_n = 0;
+    int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
+    int tile_order = 1;          // PGX_TILE_ORDER=0: tiles over the caller's site order (A/B)
+    int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
+    int tile_multi = 0;          // PGX_TILE_MULTI=1: graphs beyond one workgroup on the tile path too (measured slower: opt-in)
+    int tile_hard_div = 64;      // a move with more than n / this sites holding excess that reaches t goes to maxflow.hip (PGX_TILE_HARD; 0 = never)
+    int tile_polls = 4096;       // cap on the re-scans of one relax launch (it normally ends by the all-idle rule)
+    int tile_phase_batch = 3;    // relax launches enqueued per host read-back (reset + local, cooperative, verifying)
+    int tile_lazy = 1;           // PGX_TILE_LAZY=0: exact distances in multi-tile relax launches (A/B)
+    int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
+    int tile_discharges = 1;     // discharge launches per global relabel
+    int64_t tile_fallbacks = 0;  // moves the tile path handed back to maxflow.hip
+    int tile_debug = 0;          // PGX_MF_DEBUG: one stderr line per global relabel
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
     void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
@@ -190,6 +208,10 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq, int64_t lambda_q,
                     int64_t h_q, int alpha, int64_t* changed, bool source_reach = false);
 void maxflow_free(pgx_ctx* ctx);
+constexpr int PGX_TILE_FALLBACK = 1000;   // expand_alpha_tile: not handled, run the level-synchronous path (labels untouched)
+int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha,
+                      int64_t* changed);
+void tile_free(pgx_ctx* ctx);
 void comm_free(pgx_ctx* ctx);
 
 }  // namespace pgx

@@ -3,6 +3,7 @@
 on the BASELINE configs' shapes.  Prints one JSON line per config.  Not the driver's bench — numbers go to DESIGN.md."""
 import json
 import os
+import zlib
 import sys
 import time
 
@@ -17,9 +18,16 @@ import pgx_oracle as O  # noqa: E402
 
 
 def run(name, mt, pts, models, thr, lam, h, graph, with_oracle=True):
+    """graph: a host CSR (off, idx, mult), or (points, kind, radius, k) to build it on the device as the API does (the sites
+    of the tile-resident min-cut are then ordered along the Morton curve of those points)"""
     ctx = _lib.Context(0)
     ctx.set_points(mt, pts)
-    ctx.set_graph(*graph)
+    if len(graph) == 4:
+        t0 = time.perf_counter()
+        graph = ctx.graph_build(graph[0], graph[1], radius=graph[2], k=graph[3])
+        print(json.dumps(dict(note=name + ": device graph build + fetch", seconds=time.perf_counter() - t0)), flush=True)
+    else:
+        ctx.set_graph(*graph)
     n = pts.shape[0]
     t0 = time.perf_counter()
     ctx.pearl_unary(models, thr, lam)
@@ -33,7 +41,7 @@ def run(name, mt, pts, models, thr, lam, h, graph, with_oracle=True):
     labels = ctx.get_labels()
     out = dict(config=name, n=n, K=len(models), arcs=int(graph[0][-1]), lam=lam, h=h, gpu_unary_ms=1e3 * t_unary,
                gpu_expansion_ms=1e3 * t_gpu, cycles=cycles, energy=e, **st,
-               gpu_ms_per_mincut=1e3 * t_gpu / max(1, st["mincuts"]))
+               gpu_ms_per_mincut=1e3 * t_gpu / max(1, st["mincuts"]), labels_crc=zlib.crc32(labels.tobytes()))
     if with_oracle and "--no-oracle" not in sys.argv:
         t0 = time.perf_counter()
         Dq = O.unary_q(mt, pts, models, thr, lam)
@@ -52,20 +60,17 @@ if __name__ == "__main__":
     # --no-oracle: skip the Dinic reference (minutes at C4 size)
     if "C2" in which:
         pts, gt, models = datasets.make_homographies(seed=0)
-        run("C2 homography 5k/5 planes", _lib.HOMOGRAPHY, pts, models, 3.0, 0.05, 10.0, _graph.flann_like_graph(pts, 200.0))
+        run("C2 homography 5k/5 planes", _lib.HOMOGRAPHY, pts, models, 3.0, 0.05, 10.0, (pts, _lib.GRAPH_KNN_IN_BALL, 200.0, 5))
     if "C3" in which:
         pts, gt, models = datasets.make_two_view_motions(seed=0)
-        run("C3 two-view 1e5/8 motions", _lib.FUNDAMENTAL, pts, models, 0.75, 0.1, 14.0, _graph.flann_like_graph(pts, 50.0))
+        run("C3 two-view 1e5/8 motions", _lib.FUNDAMENTAL, pts, models, 0.75, 0.1, 14.0, (pts, _lib.GRAPH_KNN_IN_BALL, 50.0, 5))
     if "C5" in which:
         pts, gt, models = datasets.make_vanishing_points(seed=0)
         mid = 0.5 * (pts[:, :2] + pts[:, 2:])
         run("C5 vanishing points 2e5/6 VPs, k-NN(8) on midpoints", _lib.VANISHING_POINT, pts, models, 1.5, 0.1, 20.0,
-            _graph.knn_graph(mid, 8))
+            (mid, _lib.GRAPH_KNN, 0.0, 8))
     if "C4" in which:
         x1, x2, K, gt, poses = datasets.make_poses(seed=0)
         pts, f = datasets.normalize_pnp(x1, x2, K)
         raw = np.column_stack([x1, x2])
-        t0 = time.perf_counter()
-        g = _graph.flann_like_graph(raw, 20.0)
-        print(json.dumps(dict(note="C4 host graph build (scipy cKDTree)", seconds=time.perf_counter() - t0)), flush=True)
-        run("C4 6D pose 1e6/10 of 16 objects", _lib.PNP, pts, poses[:10], 4.0 / f, 0.1, 6.0, g)
+        run("C4 6D pose 1e6/10 of 16 objects", _lib.PNP, pts, poses[:10], 4.0 / f, 0.1, 6.0, (raw, _lib.GRAPH_KNN_IN_BALL, 20.0, 5))
