@@ -26,6 +26,20 @@ class Estimator:
         """samples [S, m] -> (models [H, P], sample_of_model [H]); several or zero solutions per sample allowed."""
         raise NotImplementedError
 
+    # -- model validity (gcransac Estimator::isValidModel, both overloads) [U-14] -------------------------------------------
+    validity = "off"
+
+    def valid_samples(self, pts, samples, models, src):
+        """Quick test of hypotheses against their own minimal samples, before they are scored (isValidModel(model, data,
+        sample, threshold)).  models [H, P], src [H] = row of `samples` each came from -> bool [H].  Default: all valid."""
+        return np.ones(len(models), dtype=bool)
+
+    def valid_best(self, ctx, pts, model, sample, threshold, rescore):
+        """Test of a model that is about to become the so-far-best (isValidModel(model, data, inliers, sample, threshold,
+        model_updated)).  Returns (valid, model): the model may come back replaced.  `rescore(models) -> scores` evaluates
+        candidates with the proposal's scoring function.  Default: valid, unchanged."""
+        return True, model
+
     def _fit(self, init):
         """The refit as a coroutine: yields Gram requests (kind, params, use_weights, wpow), receives (G, count, bad)
         and returns the list of models.  Written once, driven either by one pgx_gram call per request (`nonminimal`) or
@@ -266,6 +280,34 @@ def _hartley_batch(G, cnt):
     return Ts[0], Ts[1], np.stack(prm, axis=1)
 
 
+def _dlt_homography(p):
+    """normalised DLT homography of correspondences p [k, 4] (host, k small: DEGENSAC's plane refit) or None"""
+    x1, x2 = p[:, 0:2], p[:, 2:4]
+    def norm(x):
+        c = x.mean(0)
+        d = np.sqrt(((x - c) ** 2).sum(1)).mean()
+        if not (d > 0):
+            return None, None
+        sc = np.sqrt(2.0) / d
+        T = np.array([[sc, 0, -sc * c[0]], [0, sc, -sc * c[1]], [0, 0, 1.0]])
+        return (x - c) * sc, T
+    a, T1 = norm(x1)
+    b, T2 = norm(x2)
+    if a is None or b is None:
+        return None
+    z = np.zeros(len(p))
+    o = np.ones(len(p))
+    r1 = np.stack([a[:, 0], a[:, 1], o, z, z, z, -b[:, 0] * a[:, 0], -b[:, 0] * a[:, 1], -b[:, 0]], axis=1)
+    r2 = np.stack([z, z, z, a[:, 0], a[:, 1], o, -b[:, 1] * a[:, 0], -b[:, 1] * a[:, 1], -b[:, 1]], axis=1)
+    A = np.vstack([r1, r2])
+    try:
+        h = np.linalg.svd(A)[2][-1].reshape(3, 3)
+        H = np.linalg.inv(T2) @ h @ T1
+    except np.linalg.LinAlgError:
+        return None
+    return H if np.isfinite(H).all() else None
+
+
 def _smallest_eigenvector(G):
     evals, evecs = np.linalg.eigh(G)
     return evecs[:, 0]
@@ -429,6 +471,142 @@ class FundamentalEstimator(Estimator):
         return models, sidx[ok].astype(np.int64)
 
         return np.array(models).reshape(-1, 9), np.array(src, dtype=np.int64)
+
+    # -- validity [U-14] ------------------------------------------------------------------------------------------------------
+    # DefaultFundamentalMatrixEstimator (progressivex_python.cpp:616) = gcransac's FundamentalMatrixEstimator, whose source is
+    # absent from the snapshot.  Restated from the literature the upstream comments cite [UPSTREAM-MEMORY]:
+    #   "oriented"  Chum, Werner, Matas, "Epipolar geometry estimation via RANSAC benefits from the oriented epipolar
+    #               constraint" (ICPR 2004): e' x x' and F x must point the same way for every correspondence of the
+    #               minimal sample - a hypothesis whose sample disagrees is dropped before it is scored;
+    #   "symmetric" every so-far-best F must keep at least max(7, ratio * |inliers|) of its Sampson inliers (r^2 < T^2, the
+    #               scorer's threshold) when they are tested with the SYMMETRIC EPIPOLAR distance d(x', F x)^2 + d(x, F^T x')^2
+    #               - the Sampson distance stays small next to a degenerate (near rank-one) F's pseudo-epipoles, where one of
+    #               the two point-line distances explodes; ratio = 0.5 upstream.  The symmetric distance is 4 x the Sampson
+    #               distance when both gradients are equal, so it is compared with 4 T^2: against threshold^2 (what the
+    #               recollection of upstream says) the CLEAN ground-truth models of the bundled cubetoy scene keep only
+    #               48-60 % of their inliers and are rejected (docs/experiments-cubetoy.md);
+    #   "degensac"  Chum, Werner, Matas, "Two-view geometry estimation unaffected by a dominant plane" (CVPR 2005): if five of
+    #               the seven sample points agree with a homography H compatible with F, F is H-degenerate: H is re-estimated
+    #               on its inliers, epipoles are drawn from pairs of off-plane correspondences (plane and parallax:
+    #               e' = (x1' x H x1) x (x2' x H x2), F = [e']x H) and the best-scoring F replaces the model.
+    # validity = "off" | "oriented" | "symmetric" (oriented + symmetric) | "full" (all three).
+    validity = "full"
+    minimum_inlier_ratio_in_validity_check = 0.5
+    homography_threshold = 2.0
+
+    @staticmethod
+    def _hom(p):
+        o = np.ones(p.shape[:-1] + (1,))
+        return np.concatenate([p[..., 0:2], o], axis=-1), np.concatenate([p[..., 2:4], o], axis=-1)
+
+    def valid_samples(self, pts, samples, models, src):
+        ok = np.isfinite(models).all(axis=1)
+        if self.validity == "off" or not ok.any():
+            return ok
+        idx = np.nonzero(ok)[0]
+        F = models[idx].reshape(-1, 3, 3)
+        x1, x2 = self._hom(pts[np.asarray(samples)[src[idx]]])                 # [H, 7, 3] each
+        e2 = np.linalg.svd(F)[0][:, :, 2]                                       # left null vector: e2^T F = 0
+        l = np.einsum("hij,hkj->hki", F, x1)                                    # F x1
+        m = np.cross(e2[:, None, :], x2)                                        # e2 x x2
+        sg = np.sign((l * m).sum(-1))
+        good = (sg > 0).all(axis=1) | (sg < 0).all(axis=1)
+        ok[idx[~good]] = False
+        return ok
+
+    @staticmethod
+    def _sampson_and_symmetric(F, pts):
+        x1, x2 = FundamentalEstimator._hom(pts)
+        l2 = x1 @ F.T                                                           # F x1: lines in image 2
+        l1 = x2 @ F                                                             # F^T x2: lines in image 1
+        r = (x2 * l2).sum(-1)
+        a = l2[:, 0] ** 2 + l2[:, 1] ** 2
+        b = l1[:, 0] ** 2 + l1[:, 1] ** 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return r * r / (a + b), r * r * (1.0 / a + 1.0 / b)
+
+    def _h_from_f(self, F, e2, x1, x2):
+        """H compatible with F through three correspondences (Hartley & Zisserman, result 13.6): H = A - e2 (M^-1 b)^T,
+        A = [e2]x F, M = rows x1_i, b_i = (x2_i x A x1_i) . (x2_i x e2) / |x2_i x e2|^2."""
+        ex = np.array([[0.0, -e2[2], e2[1]], [e2[2], 0.0, -e2[0]], [-e2[1], e2[0], 0.0]])
+        A = ex @ F
+        c1 = np.cross(x2, (A @ x1.T).T)
+        c2 = np.cross(x2, e2[None, :])
+        den = (c2 * c2).sum(-1)
+        if not np.all(den > 0):
+            return None
+        b = (c1 * c2).sum(-1) / den
+        try:
+            return A - np.outer(e2, np.linalg.solve(x1, b))
+        except np.linalg.LinAlgError:
+            return None
+
+    @staticmethod
+    def _transfer2(H, x1, x2):
+        y = x1 @ H.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = (y[:, 0] / y[:, 2] - x2[:, 0]) ** 2 + (y[:, 1] / y[:, 2] - x2[:, 1]) ** 2
+        return np.where(np.isfinite(d), d, np.inf)
+
+    def valid_best(self, ctx, pts, model, sample, threshold, rescore):
+        if self.validity in ("off", "oriented"):
+            return True, model
+        F = np.asarray(model, dtype=np.float64).reshape(3, 3)
+        T2 = 2.25 * threshold * threshold
+        samp, sym = self._sampson_and_symmetric(F, pts)
+        inl = samp < T2
+        need = max(self.sample_size, int(inl.sum() * self.minimum_inlier_ratio_in_validity_check))
+        if int((inl & (sym < 4.0 * T2)).sum()) < need:
+            return False, model
+        if self.validity != "full" or sample is None:
+            return True, model
+        # ---- DEGENSAC: is the sample H-degenerate?
+        x1, x2 = self._hom(pts[np.asarray(sample)])
+        e2 = np.linalg.svd(F)[0][:, 2]
+        h2 = self.homography_threshold ** 2
+        H = None
+        for tri in ((0, 1, 2), (3, 4, 5), (0, 1, 6), (3, 4, 6), (2, 5, 6)):
+            cand = self._h_from_f(F, e2, x1[list(tri)], x2[list(tri)])
+            if cand is not None and np.isfinite(cand).all() and int((self._transfer2(cand, x1, x2) < h2).sum()) >= 5:
+                H = cand
+                break
+        if H is None:
+            return True, model
+        # the plane: inliers of H among all correspondences, H refitted on them (normalised DLT)
+        a1, a2 = self._hom(pts)
+        on = self._transfer2(H, a1, a2) < h2
+        if int(on.sum()) >= 4:
+            Hr = _dlt_homography(pts[on])
+            if Hr is not None and int((self._transfer2(Hr, a1, a2) < h2).sum()) >= int(on.sum()):
+                H = Hr
+                on = self._transfer2(H, a1, a2) < h2
+        off = np.nonzero(~on)[0]
+        if len(off) < 2:
+            return True, model
+        # plane and parallax: epipoles from pairs of off-plane correspondences
+        rng = np.random.default_rng(int(on.sum()) * 7919 + len(off))            # deterministic in the data (no stream consumed)
+        trials = min(100, len(off) * (len(off) - 1) // 2)
+        pa = rng.integers(0, len(off), trials)
+        pb = (pa + 1 + rng.integers(0, len(off) - 1, trials)) % len(off)
+        la = np.cross(a2[off[pa]], (a1[off[pa]] @ H.T))
+        lb = np.cross(a2[off[pb]], (a1[off[pb]] @ H.T))
+        e = np.cross(la, lb)
+        nrm = np.linalg.norm(e, axis=1)
+        e = e[nrm > 0] / nrm[nrm > 0][:, None]
+        if len(e) == 0:
+            return True, model
+        ex = np.zeros((len(e), 3, 3))
+        ex[:, 0, 1], ex[:, 0, 2], ex[:, 1, 0], ex[:, 1, 2], ex[:, 2, 0], ex[:, 2, 1] = -e[:, 2], e[:, 1], e[:, 2], -e[:, 0], -e[:, 1], e[:, 0]
+        cands = ex @ H
+        cn = np.linalg.norm(cands.reshape(len(e), -1), axis=1)
+        cands = (cands[cn > 0] / cn[cn > 0][:, None, None]).reshape(-1, 9)
+        if len(cands) == 0:
+            return True, model
+        sc = np.asarray(rescore(np.vstack([np.asarray(model, dtype=np.float64)[None, :], cands])), dtype=np.float64)
+        k = int(np.argmax(sc[1:])) + 1
+        if np.isfinite(sc[k]) and sc[k] > sc[0]:
+            return True, cands[k - 1].copy()
+        return True, model
 
     def _fit(self, init):
         G, cnt, _ = yield (_lib.GRAM_AFFINE, None, False, 2)

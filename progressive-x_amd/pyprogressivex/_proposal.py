@@ -347,6 +347,15 @@ class ProposalEngine:
         counts = np.asarray(table["counts"], dtype=np.int64)
         scores = np.where(counts > 0, np.asarray(table["scores"], dtype=np.float64), -np.inf)
         scores = np.where(np.isnan(scores), -np.inf, scores)
+        check = getattr(est, "validity", "off") != "off"                       # [U-14] model validity, both overloads
+        smp_arr = np.asarray(samples)
+        if check and models is not None:
+            # isValidModel(model, data, sample, threshold): a hypothesis that fails is never scored upstream (`continue`)
+            scores = np.where(est.valid_samples(self.pts, smp_arr, np.asarray(models), np.asarray(src)), scores, -np.inf)
+
+        def rescore(cands):
+            t = self.ctx.score(np.ascontiguousarray(cands), T2, has_compound=has_compound, exponent=exponent)
+            return np.where(np.asarray(t["counts"]) > 0, np.asarray(t["scores"], dtype=np.float64), -np.inf)
         max_iters = float(s.max_iteration_number)
         min_iters = int(getattr(s, "min_iteration_number", 0))
         lo_after = int(getattr(s, "min_iteration_number_before_lo", 0))
@@ -367,8 +376,25 @@ class ProposalEngine:
             if c + 1 < best_count:          # scoring_function_with_compound_model.h:105-106 -> Score(): not considered
                 h += 1
                 continue
-            model = model_of(h) if model_of is not None else models[h].copy()
-            best_score, best_count, it_best = float(scores[h]), c, it
+            cand = model_of(h) if model_of is not None else models[h].copy()
+            cand_score, cand_count = float(scores[h]), c
+            if check:
+                smp = smp_arr[int(src[h])]
+                if models is None and not est.valid_samples(self.pts, smp_arr, cand[None, :], np.asarray([int(src[h])]))[0]:
+                    scores[h] = -np.inf
+                    h += 1
+                    continue
+                # isValidModel(model, data, inliers, sample, threshold, updated): an invalid so-far-best is dropped
+                ok, upd = est.valid_best(self.ctx, self.pts, cand, smp, float(s.inlier_outlier_threshold), rescore)
+                if not ok:
+                    scores[h] = -np.inf
+                    h += 1
+                    continue
+                if upd is not cand:
+                    one = self.ctx.score(upd[None, :], T2, has_compound=has_compound, exponent=exponent)
+                    cand, cand_score, cand_count = upd, float(one["scores"][0]), int(one["counts"][0])
+            model = cand
+            best_score, best_count, it_best = cand_score, cand_count, it
             if every_best and it > lo_after and c > est.sample_size:
                 model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
                                                                           exponent, weights)

@@ -2,6 +2,7 @@
 code driven by the CPU oracle for the same seed (= the same hypothesis lists), and recovers the structures of the
 reference's bundled scenes (data files copied verbatim from /root/reference/build/data as fixtures)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -112,26 +113,18 @@ def test_example_notebook_two_view_call_finds_the_recorded_number_of_motions():
     assert int(np.median(counts)) == 2, counts   # (no error is recorded for this call; at threshold 0.5 ours is 0.14-0.26)
 
 
-def test_bundled_cubetoy_explained_miss():
-    """cubetoy (recorded 0.012) is the one bundled scene where the recorded number is NOT reached reliably (0.09-0.6 over
-    seeds and samplers, profiles/round2_scenes.txt).  Why, pinned here: the two motions share most of their epipolar
-    geometry - ONE fundamental matrix explains dozens of points of EACH motion within the threshold and outscores either
-    pure motion (MSAC), so whichever run samples it accepts it first, and PEARL at lambda = 0.5 cannot split it afterwards.
-    The recorded value is one stochastic run of a sampler / validity-test combination that is absent from the snapshot."""
-    corrs, gt = datasets.load_points_with_labels(os.path.join(SCENES, "cubetoy.txt"))
-    kw = dict(threshold=0.75, conf=0.5, spatial_coherence_weight=0.5, neighborhood_ball_radius=50.0,
-              maximum_tanimoto_similarity=0.4, max_iters=10000, minimum_point_number=7, sampler_id=0, scoring_exponent=1.0)
-    mixed, mes = 0, []
-    for seed in range(4):
-        F, lab = px.findTwoViewMotions(corrs, 1024, 768, 1024, 768, maximum_model_number=1, seed=seed, **kw)
-        inl = lab == 0                                            # exactly one model: 0 = inlier (progressive_x.h:382-384)
-        a, b = int((inl & (gt == 1)).sum()), int((inl & (gt == 2)).sum())
-        mixed += min(a, b) >= 20
-        F, lab = px.findTwoViewMotions(corrs, 1024, 768, 1024, 768, maximum_model_number=4, seed=seed, **kw)
-        mes.append(round(float(datasets.misclassification(lab, gt)), 4))
-        print(f"cubetoy seed {seed}: first model holds {a} + {b} points of the two motions; 4-model run ME {mes[-1]}")
-    assert mixed >= 2, "the explanation no longer holds: the first accepted model is not the shared-geometry one"
-    assert min(mes) < 0.35
+@pytest.mark.xfail(strict=False, reason="cubetoy: one F out-scores both clean motions at this threshold (docs/experiments-cubetoy.md); "
+                                        "the ingredient that keeps upstream from accepting it first is in the absent submodule")
+def test_bundled_cubetoy_recorded_band():
+    """cubetoy, recorded 0.012 (adelaideF.ipynb:149-157), with the notebook's exact arguments: the same <= 3 x band as the other
+    bundled scenes.  NOT reached (median 0.30-0.36 over seeds; docs/experiments-cubetoy.md isolates why: a single fundamental
+    matrix explains 50 + 43 points of the two objects and out-scores either clean motion, 72 against 62 / 51).  Expected failure,
+    non-strict: the test turns green by itself when the missing proposal-stage ingredient is supplied."""
+    sys.path.insert(0, os.path.join(os.path.dirname(SCENES), "..", "..", "scripts"))
+    import eval_scenes
+    mes = [float(eval_scenes.two_view_scene("cubetoy", seed)[0]) for seed in range(6)]
+    print(f"cubetoy: misclassification per seed {np.round(mes, 3).tolist()} (recorded 0.012)")
+    assert float(np.median(mes)) <= 3 * 0.012
 
 
 def test_bundled_tless_poses():

@@ -321,3 +321,46 @@ def test_misclassification_overloads_of_progx_utils():
             best = min(best, err)
         assert abs(got - 100.0 * best / n) < 1e-12
     assert datasets.misclassification_models(np.zeros((10, 5)), np.zeros(5, int), 2) == -1.0
+
+
+# ---- [U-14] validity stages of the fundamental-matrix estimator (host, numpy) --------------------------------------------------
+def test_fundamental_validity_stages():
+    """Oriented epipolar constraint, symmetric-epipolar support and DEGENSAC of _estimators.FundamentalEstimator: the true
+    geometry passes all of them, a hypothesis from a mirrored sample fails the orientation test, and a rank-one pseudo-solution
+    (whose Sampson inliers hug one line per image) fails the symmetric test."""
+    from pyprogressivex import _estimators, datasets
+    pts, gt, models = datasets.make_two_view_motions(n_per_motion=300, n_motions=1, n_outliers=100, sigma=0.3, seed=3)
+    est = _estimators.FundamentalEstimator()
+    assert est.validity == "full"
+    rng = np.random.default_rng(0)
+    inl = np.nonzero(gt == 1)[0]
+    smp = np.array([rng.choice(inl, 7, replace=False) for _ in range(50)])
+    hyp, src = est.minimal(pts, smp)
+    ok = est.valid_samples(pts, smp, hyp, src)
+    # among the up-to-three roots per sample, the one closest to the truth is oriented consistently
+    F0 = models[0] / np.linalg.norm(models[0])
+    err = np.minimum(np.abs(hyp - F0).sum(1), np.abs(hyp + F0).sum(1))
+    best = np.array([np.nonzero(src == k)[0][np.argmin(err[src == k])] for k in range(len(smp)) if (src == k).any()])
+    assert ok[best].mean() > 0.7                                               # (noisy minimal solutions)
+    assert est.valid_samples(pts, smp, np.tile(F0, (len(smp), 1)), np.arange(len(smp))).all()   # the true geometry: every sample
+    # one correspondence of the sample mirrored through the epipole's far side: points "behind" the camera
+    x1, x2 = est._hom(pts[smp[0]])
+    e2 = np.linalg.svd(F0.reshape(3, 3))[0][:, 2]
+    sg = np.sign(((x1 @ F0.reshape(3, 3).T) * np.cross(e2[None, :], x2)).sum(-1))
+    assert (sg > 0).all() or (sg < 0).all()
+    # the truth keeps its support under the symmetric distance; a rank-one matrix a b^T does not
+    never = lambda c: np.full(len(c), -np.inf)                                   # (plane-and-parallax candidates never win here)
+    valid, _ = est.valid_best(None, pts, F0, smp[0], 0.75, never)
+    assert valid
+    a, b = np.array([0.0, 1.0, -500.0]), np.array([0.0, 1.0, -480.0])            # "x' on the line y = 500" times "x on y = 480"
+    band = pts.copy()
+    band[:150, 1] = 480.0 + rng.normal(0, 0.2, 150)                              # plenty of points near ONE of the two lines only
+    band[150:300, 3] = 500.0 + rng.normal(0, 0.2, 150)
+    R1 = np.outer(a, b).reshape(-1) / np.linalg.norm(np.outer(a, b))
+    samp, sym = est._sampson_and_symmetric(R1.reshape(3, 3), band)
+    assert (samp < 2.25 * 0.75 ** 2).sum() >= 250 and ((samp < 2.25 * 0.75 ** 2) & (sym < 9 * 0.75 ** 2)).sum() < 100
+    valid, _ = est.valid_best(None, band, R1, None, 0.75, never)
+    assert not valid
+    est_off = _estimators.FundamentalEstimator()
+    est_off.validity = "off"
+    assert est_off.valid_best(None, band, R1, None, 0.75, never)[0]
