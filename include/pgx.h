@@ -111,6 +111,12 @@ int pgx_score_profile(pgx_ctx *ctx, int on);
  * host version bit for bit): what = 0 sorted order (n int32), 1 group + super-group rows ((groups + supers) x 12 f32),
  * 2 / 3 the group-blocked f64 / f32 row copies, 4 the sorted f32 rows.  bytes must match exactly. */
 int pgx_score_debug_fetch(pgx_ctx *ctx, int what, void *out, int64_t bytes);
+/* Test hook: launch geometry of the group-major score path (results must not depend on it - integer accumulation of per-pair
+ * fixed point; tests/test_gpu_parity.py).  what = 0 waves per 64-point group (0 = automatic), 1 a group's waves on one XCD
+ * (-1 automatic, 0, 1), 2 replicas of the accumulators (0 = automatic, else a multiple of 8), 3 candidates of 64 from which a
+ * step is evaluated in place instead of queued (1..65), 4 segments of groups per hypothesis word in the cull kernel.  Not an
+ * environment switch: nothing in the product path calls it. */
+int pgx_score_debug_geometry(pgx_ctx *ctx, int what, int value);
 int pgx_score_kernel_times(pgx_ctx *ctx, float ms[4]);
 
 /* ---- a2/a3: Model::setPreferenceVector (progx_model.h:70-87) + the three reductions of isPutativeModelValid

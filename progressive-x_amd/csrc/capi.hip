@@ -99,38 +99,18 @@ int pgx_create(int device_id, pgx_ctx** out)
     const char* nf = std::getenv("PGX_NO_FILTER");
     ctx->filter_enabled = (nf && nf[0] == '1') ? 0 : ((nf && nf[0] == '2') ? 2 : 1);
     if (const char* ns = std::getenv("PGX_NO_SORT")) ctx->score_sort = (ns[0] == '1') ? 0 : 1;
-    const char* df = std::getenv("PGX_SCORE_DEFERRED");
-    ctx->score_deferred = (df && df[0] == '1') ? 1 : 0;
-    if (const char* b = std::getenv("PGX_SP_KD_W")) { const double v = std::atof(b); if (v > 0.0 && v < 1e6) ctx->sp_kd_weight = v; }
     if (const char* b = std::getenv("PGX_SP_KD")) { const int v = std::atoi(b); ctx->sp_kd = v < 0 ? 0 : (v > 2 ? 2 : v); }
-    if (const char* b = std::getenv("PGX_SCORE_GROUP_XCD")) ctx->score_group_xcd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_SETPOINTS_HOST")) ctx->setpoints_host = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_SCORE_WG")) ctx->score_wg = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_GC_FLIP")) ctx->gc_flip = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_SCORE_DENSE")) { int v = std::atoi(b); if (v >= 1 && v <= 65) ctx->score_dense_min = v; }
-    if (const char* b = std::getenv("PGX_SCORE_EXW")) { int v = std::atoi(b); if (v >= 1 && v <= 16) ctx->score_exact_waves = v; }
-    if (const char* b = std::getenv("PGX_SCORE_CULL_SEGS")) { int v = std::atoi(b); if (v >= 1 && v <= 65535) ctx->score_cull_segs = v; }
-    if (const char* b = std::getenv("PGX_SCORE_NREP")) { int v = std::atoi(b); if (v >= 0 && v <= 1024) ctx->score_nrep = v; }
-    if (const char* b = std::getenv("PGX_SCORE_QUEUE")) ctx->score_queue = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_SCORE_ABLATE")) { int v = std::atoi(b); if (v >= 0 && v <= 9) ctx->score_ablate = v; }
-    if (const char* b = std::getenv("PGX_SCORE_PIPE")) { int v = std::atoi(b); if (v >= 0 && v <= 2) ctx->score_pipe = v; }
     if (const char* b = std::getenv("PGX_SCORE_MIRROR")) ctx->score_mirror = std::atoi(b) != 0;
-    if (const char* b = std::getenv("PGX_SCORE_SOA")) ctx->score_soa = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_SCORE_SPLIT")) { int v = std::atoi(b); if (v >= 1 && v <= 1024) ctx->score_split = v; }
     if (const char* b = std::getenv("PGX_SCORE_NO_CULL")) ctx->score_cull = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
-    if (const char* b = std::getenv("PGX_SCORE_NO_XCD")) ctx->score_xcd_map = std::atoi(b) ? 0 : 1;
-    if (const char* b = std::getenv("PGX_SCORE_BLOCKS_PER_CU")) { int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->score_blocks_per_cu = v; }
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_TILE_ORDER")) ctx->tile_order = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_TILE_MULTI")) ctx->tile_multi = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_TILE_HARD")) { const int v = std::atoi(b); if (v >= 0 && v <= (1 << 20)) ctx->tile_hard_div = v; }
-    if (const char* b = std::getenv("PGX_TILE_SINGLE")) { const int v = std::atoi(b); if (v >= 0 && v <= 8192) ctx->tile_single_max = v; }
-    if (const char* b = std::getenv("PGX_TILE_POLLS")) { const int v = std::atoi(b); if (v >= 1 && v <= 65536) ctx->tile_polls = v; }
-    if (const char* b = std::getenv("PGX_TILE_BATCH")) { const int v = std::atoi(b); if (v >= 2 && v <= 32) ctx->tile_phase_batch = v; }
-    if (const char* b = std::getenv("PGX_TILE_SWEEPS")) { const int v = std::atoi(b); if (v >= 1 && v <= 4096) ctx->tile_sweeps = v; }
-    if (const char* b = std::getenv("PGX_TILE_LAZY")) ctx->tile_lazy = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_TILE_DISCHARGES")) { const int v = std::atoi(b); if (v >= 1 && v <= 64) ctx->tile_discharges = v; }
+    if (const char* b = std::getenv("PGX_TILE_MULTI")) {   // 1: graphs beyond one workgroup on the tile path; 2 (tests): tiles for every graph, no hand-back
+        const int v = std::atoi(b);
+        ctx->tile_multi = v ? 1 : 0;
+        if (v == 2) { ctx->tile_single_max = 0; ctx->tile_hard_div = 0; }
+    }
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -150,7 +130,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
-                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->cand, &ctx->weights_scratch};
+                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->weights_scratch};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -288,11 +268,11 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
     ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
     ctx->weights_n = 0;  // weights belong to a point set
-    if (!ctx->setpoints_host) {
-        // upload + every derived copy on the device (setpoints.hip): filter scales, f32 rows, Morton order, group bounds
-        PGX_TRY(set_points_device(ctx, model_type, points, n));
-    } else {
-        PGX_TRY(set_points_host(ctx, model_type, points, n, d));
+    // upload + every derived copy on the device (setpoints.hip): filter scales, f32 rows, Morton order, group bounds
+    const int rc = !ctx->setpoints_host ? set_points_device(ctx, model_type, points, n) : set_points_host(ctx, model_type, points, n, d);
+    if (rc != PGX_OK) {   // half-built copies (an allocation failed midway): no resident problem, every later call fails cleanly
+        ctx->n = 0; ctx->model_type = -1; ctx->D = 0; ctx->P = 0; ctx->point_sort = 0; ctx->mirror_valid = 0;
+        return rc;
     }
     for (DevBuf& b : ctx->slots) release(b);
     ctx->slots.clear();
@@ -391,6 +371,9 @@ int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
     if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: points not set");
     if (!models || M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_upload: empty hypothesis batch");
     const int P = ctx->P;
+    // the host mirror of an earlier launch is un-permuted with THAT launch's order: from here on h_perm belongs to this batch, so a
+    // fetch of the earlier launch's results must come from the device copy (the finish kernel scattered it through the device perm)
+    ctx->mirror_valid = 0;
     std::vector<int> perm((size_t)M);
     for (int m = 0; m < M; ++m) perm[(size_t)m] = m;
     std::vector<uint64_t> keys;
@@ -433,6 +416,7 @@ int pgx_solve_minimal(pgx_ctx* ctx, const int32_t* samples, int S, double* model
 {
     CTX_GUARD(ctx);
     ctx->h_perm.clear();   // device-generated batches stay in the caller's order
+    ctx->mirror_valid = 0; // (see pgx_score_upload: the mirror of an earlier launch goes with that launch's order)
     return solve_minimal_launch(ctx, samples, S, models_out);
 }
 
@@ -526,6 +510,19 @@ int pgx_score_algorithmic_bytes(pgx_ctx* ctx, int want_masks, int64_t* bytes, in
     if (bytes) *bytes = b;
     if (pairs) *pairs = ctx->n * (int64_t)ctx->M;
     return PGX_OK;
+}
+
+int pgx_score_debug_geometry(pgx_ctx* ctx, int what, int value)
+{
+    CTX_GUARD(ctx);
+    switch (what) {
+    case 0: if (value < 0 || value > 1024) break; ctx->score_split = value; return PGX_OK;
+    case 1: if (value < -1 || value > 1) break; ctx->score_group_xcd = value; return PGX_OK;
+    case 2: if (value < 0 || value > 1024 || value % 8) break; ctx->score_nrep = value; return PGX_OK;
+    case 3: if (value < 1 || value > 65) break; ctx->score_dense_min = value; return PGX_OK;
+    case 4: if (value < 1 || value > 65535) break; ctx->score_cull_segs = value; return PGX_OK;
+    }
+    return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_geometry: what = %d, value = %d out of range", what, value);
 }
 
 int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)

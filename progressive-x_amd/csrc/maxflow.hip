@@ -29,7 +29,7 @@ struct MaxflowState {
                              // [0 .. kMfFlags) flags, [kMfFlags] cnt[alpha], [15] sequence number the host spins on
     int pub_seq = 0;
     DevBuf lists;            // act[2][n] | mark[n]
-    DevBuf bar;              // grid barrier of the persistent kernels: arrivals | generation (zeroed once)
+    DevBuf bar;              // word 8: arrival ticket of the kernels that publish the flags to the host (zeroed once)
     int next_stamp = 1;
     int64_t mark_n = 0;
     int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
@@ -85,7 +85,6 @@ __device__ __forceinline__ void stage_flush(const MfView& v, Stage& st, int k, i
     if (n > 0) {
         if (threadIdx.x == 0) st.base = (level_base >= 0 ? level_base : mf_level_base(v, k)) + atomicAdd(&v.fcount[k % 3], n);
         __syncthreads();
-        // device-scope (write-through) stores: the persistent BFS reads the entries in the same kernel from other XCDs
         for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x)
             __hip_atomic_store(&v.order[st.base + i], st.list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -227,30 +226,9 @@ __device__ __forceinline__ void mf_sweep_flush(const MfView& v, int cur, bool li
 }
 
 constexpr int kSweepList = 8 * kMfBlock;   // live sites a workgroup collects before it runs the step over them
-template <bool COH> __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed);
-
-// The one-wave epilogue of a sweep as the LAST act of the sweep kernel itself (fused != 0): every participating workgroup
-// waits for its own memory operations, takes a ticket, and the one that draws the last ticket runs the epilogue - reading what
-// the others reported through device-scope loads.  Saves the 4.5 us launch that followed every sweep (a kernel that loads and
-// stores anything does not finish sooner); the tickets are `nb` atomics on one word, spread over the time the workgroups
-// take to finish.  All threads of the workgroup call it.  MEASURED: find6DPoses PEARL 2.07-2.11 s fused vs 1.98-2.04 s with the
-// separate launch, findVanishingPoints 2.27-2.31 vs 2.10-2.29 s - identical labels, opt-in only.
-__device__ __forceinline__ void mf_sweep_retire(const MfView& v, int cur, int consumed, unsigned nb)
-{
-    __shared__ int s_last;
-    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores and atomics have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = (unsigned)__hip_atomic_fetch_add(&v.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == nb - 1;
-        if (s_last) __hip_atomic_store(&v.flags[9], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x < 64) mf_sweep_epilogue_wave<true>(v, cur, (cur + 1) % 3, consumed);
-}
 
 // sweep over all sites
-__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur, int fused)
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int cur)
 {
     if (mf_sweep_idle(v)) return;
     __shared__ SweepLds s;
@@ -299,7 +277,6 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep(MfView v, int prev, int c
     }
     if (pending > 0) run_list();
     mf_sweep_flush(v, cur, false, s, r);
-    if (fused) mf_sweep_retire(v, cur, -1, gridDim.x);
 }
 
 // Two conditional appends per lane (the site itself, the site it pushed to) with ONE reservation per wave: the list
@@ -328,7 +305,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_build_list(MfView v, int stamp,
     mf_list_append(v, 0, (int)u, want);
 }
 
-__global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp, int fused)
+__global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, int cur, int parity, int stamp)
 {
     if (mf_sweep_idle(v)) return;
     const int cnt = v.acnt[parity];
@@ -353,63 +330,6 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, 
         mf_append2(&v.acnt[1 - parity], v.act[1 - parity], u, again, pushed, fresh);
     }
     mf_sweep_flush(v, cur, true, s, any);
-    if (fused) mf_sweep_retire(v, cur, parity, nb);
-}
-
-// ---- list-mode sweeps of a SHORT work list: up to `budget` sweeps in one launch of one workgroup --------------------------
-// A list-mode sweep over a few hundred sites is two launches (sweep + one-thread epilogue, ~23 us) for ~3 us of dependent
-// gathers, and a round issues up to 96 of them: at C4 33 400 of the 43 700 sweeps of a find6DPoses call, median list 700
-// sites.  Here ONE workgroup of 1024 threads runs the sweeps back to back - sweep, epilogue by thread 0, next sweep - with
-// workgroup barriers in between: its waves share the CU's vector L1 (write-through, coherent within the workgroup), so
-// plain stores of one sweep are visible to the plain loads of the next after a barrier, and everything contended is an
-// atomic at L2 as before.  No grid barrier, no device-scope fence (the two things that sank the persistent kernels,
-// DESIGN.md 5.4).  The kernel stops when the round is finished (no work left), when a site pushed back into a beta hub
-// (flags[6]: every member must take part again - the host switches to full sweeps), when the list outgrows `cap`, or when
-// the budget is spent; flags[5] = sweeps done.  Same bodies, same rotation of slots / lists / stamps as the host loop: a
-// pure scheduling change (labels are those of the unique minimal sink side either way).  MEASURED: no gain - opt-in only.
-constexpr int kTailBlock = 1024;
-
-__global__ __launch_bounds__(kTailBlock) void mf_k_sweep_tail(MfView v, int sweep_id, int parity, int stamp, int budget, int cap)
-{
-    __shared__ SweepLds s;
-    __shared__ int s_ctl[4];  // list size, stop
-    int done = 0;
-    if (v.has_alpha_hub[0] == 0) {   // (the alpha hub's words are read as uniform gates by the bodies: not in this kernel)
-        for (; done < budget; ++done) {
-            if (threadIdx.x == 0) s_ctl[0] = __hip_atomic_load(&v.acnt[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (threadIdx.x < kMfMaxLabels) s.min[threadIdx.x] = kMfInf;
-            if (threadIdx.x <= kMfMaxLabels) { s.want[threadIdx.x] = 0; s.got[threadIdx.x] = 0; }
-            if (threadIdx.x == 0) { s.pushA = 0; s.moved = 0; }
-            __syncthreads();
-            const int cnt = s_ctl[0];
-            if (cnt > cap) break;
-            const int cur = (sweep_id + done) % 3, prev = (sweep_id + done + 2) % 3, next = (sweep_id + done + 1) % 3;
-            const int st = stamp + 1 + done;
-            const int* __restrict__ in = v.act[parity];
-            bool any = false;
-            const int rounded = (cnt + kTailBlock - 1) / kTailBlock * kTailBlock;
-            for (int i = (int)threadIdx.x; i < rounded; i += kTailBlock) {
-                const int u = i < cnt ? in[i] : -1;
-                int pushed = -1;
-                bool listed = false;
-                any |= mf_sweep_step(v, u, prev, cur, true, s, &pushed, &listed);
-                const bool again = u >= 0 && listed && mf_list_claim(v, u, st);
-                const bool fresh = pushed >= 0 && mf_list_claim(v, pushed, st);
-                mf_append2(&v.acnt[1 - parity], v.act[1 - parity], u, again, pushed, fresh);
-            }
-            const int work = __syncthreads_count(any ? 1 : 0);   // also: every append of this sweep has been issued
-            if (threadIdx.x == 0) {
-                v.flags[1] = work > 0 ? 1 : 0;
-                v.flags[8] = s.moved;
-                mf_body_sweep_epilogue(v, cur, next, parity);    // latches flags[4], clears flags[1] and the consumed list
-                s_ctl[1] = (v.flags[4] == 0 || __hip_atomic_load(&v.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
-            }
-            parity ^= 1;
-            __syncthreads();
-            if (s_ctl[1]) { ++done; break; }
-        }
-    }
-    if (threadIdx.x == 0) v.flags[5] = done;
 }
 
 // ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
@@ -627,87 +547,6 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_bfs_level(MfView v, int k, int 
     if (threadIdx.x == 0 && count > 0) mf_report_flag(&v.flags[0], k);
 }
 
-// ---- persistent kernels: all BFS levels / all wave levels of one global relabel in ONE launch ---------------------------
-// The level loop used to be driven by the host: one launch per level (median 11 us for frontiers of a few thousand sites, 55
-// levels per relabel in the moves that hand a new instance its points) plus a flag read-back every 8-64 levels.  Here the
-// workgroups of a co-resident grid (cooperative launch, one workgroup per CU) run the levels back to back and meet at a
-// grid barrier: arrival counter + generation word, relaxed device-scope atomics.  NO cache-wide fence: a release / acquire
-// pair at device scope writes back and invalidates the whole L2 of every XCD on gfx950 (measured: ~60 us per level, 3x
-// slower than the launches it replaced).  Instead everything one level hands to the next across workgroups is written
-// with device-scope (write-through) stores or atomics and read with device-scope loads - the frontier entries, the level
-// counters, the hub distances, d[], cap[], ex[] - and a workgroup arrives only after all of its memory operations have
-// been acknowledged (s_waitcnt 0 before the workgroup barrier).
-__device__ __forceinline__ void mf_grid_barrier(unsigned* bar, unsigned nblocks)
-{
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores and atomics have completed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_waitcnt(0);
-            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-}
-
-// levels 2 .. until two consecutive levels label nothing (what the host loop tested through flags[0]).  flags[5] = the last
-// level run, flags[0] = the last level that labelled a site; the one-thread epilogue (mf_body_bfs_finish) follows in its own
-// launch (it reads the hub distances with plain loads).
-__global__ __launch_bounds__(kMfBlock) void mf_k_bfs_persist(MfView v, int stage_margin, int slot, unsigned* bar)
-{
-    __shared__ int s_min[kMfMaxLabels];
-    __shared__ Stage s_stage;
-    __shared__ int s_ctl[4];  // frontier size, hub events, stop
-    int base_prev = 0;        // lvl[k - 1]: level 1 starts at 0
-    int k = 1;
-    for (;;) {
-        ++k;
-        if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
-        if (threadIdx.x == 0) {
-            s_stage.count = 0;
-            s_ctl[0] = __hip_atomic_load(&v.fcount[(k - 1) % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int ev = 0;  // mf_bfs_hub_events with device-scope loads (the distances were written earlier in THIS kernel)
-            if (v.has_alpha_hub[0] && __hip_atomic_load(&v.bfs_hubA_d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 1;
-            for (int l = 0; l < v.L; ++l)
-                if (v.hub_exists[l] == 2 && __hip_atomic_load(&v.bfs_hub_d[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k - 1) ev |= 2;
-            s_ctl[1] = ev;
-        }
-        __syncthreads();
-        const int F = s_ctl[0], ev = s_ctl[1];
-        const int level_base = base_prev + F;  // level k starts behind level k-1
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            v.lvl[k] = level_base;
-            __hip_atomic_store(&v.fcount[(k + 1) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // free since level k-1 ended
-        }
-        const bool r = bfs_level_body(v, k, F, v.order + base_prev, level_base, ev, stage_margin, s_min, s_stage, true);
-        const int count = __syncthreads_count(r ? 1 : 0);
-        if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], s_min[threadIdx.x]);
-        if (threadIdx.x == 0 && count > 0) __hip_atomic_store(&v.flags[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mf_grid_barrier(bar, gridDim.x);
-        if (threadIdx.x == 0)
-            s_ctl[2] = __hip_atomic_load(&v.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= k - 2 || k >= v.hmax;
-        __syncthreads();
-        base_prev = level_base;
-        if (s_ctl[2]) break;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) v.flags[5] = k;
-}
-
-// wave pass: levels kstart .. 1, farthest first, a grid barrier between levels (level k pushes into level k-1)
-__global__ __launch_bounds__(kMfBlock) void mf_k_wave_persist(MfView v, int kstart, unsigned* bar)
-{
-    for (int k = kstart; k >= 1; --k) {
-        const int lo = v.lvl[k], hi = v.lvl[k + 1];
-        for (int i = lo + (int)(blockIdx.x * kMfBlock + threadIdx.x); i < hi; i += (int)(gridDim.x * kMfBlock))
-            mf_body_wave(v, v.order[i], k);
-        if (k > 1) mf_grid_barrier(bar, gridDim.x);
-    }
-}
-
 // ---- minimal SOURCE side (source_reach mode) ---------------------------------------------------------------------------
 // apply() hands alpha to every site that cannot reach t - the complement of the minimal sink side, which is what BK's
 // what_segment(default = SOURCE) yields for an expansion move.  The inlier / outlier cut of the local optimisation is stated
@@ -773,13 +612,10 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
 
 // The sweep epilogue (maxflow_body.cuh mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
 // labels through a chain of dependent loads (~5.3 us; at C5 a call ran 80 k of them, 19 % of its GPU time).  Same result.
-template <bool COH>
 __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed)
 {
-    // COH: run by the last workgroup of the sweep itself (mf_sweep_retire) - what the other workgroups reported with
-    // atomics is read with device-scope loads
-    auto ld32 = [](const int* p) { return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
-    auto ld64 = [](const long long* p) { return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    auto ld32 = [](const int* p) { return *p; };          // (everything read here was written by earlier kernels)
+    auto ld64 = [](const long long* p) { return *p; };
     const int l = (int)threadIdx.x;   // one wave, L <= 64
     const int prev = (cur + 2) % 3;
     // every load up front (one round trip): the kernel is nothing but its dependent-load chain
@@ -792,7 +628,7 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
     const int moved = ld32(&v.flags[8]), stall = v.flags[11];
     const int hub_a = v.has_alpha_hub[0];
     const long long hae = ld64(v.hubA_e);
-    const unsigned long long ham = COH ? __hip_atomic_load(&v.hubA_min[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v.hubA_min[cur];
+    const unsigned long long ham = v.hubA_min[cur];
     bool hub_act = false;
     if (in) {
         if (exists && (consumed >= 0 || he <= 0) && mc == kMfInf) {   // no scan was requested: keep the last known height
@@ -821,7 +657,7 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub
 {
     if (blockIdx.x != 0) return;
     if (what == 3) {   // all 64 lanes
-        if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave<false>(v, a0, a1, a2);
+        if (!mf_sweep_idle(v)) mf_sweep_epilogue_wave(v, a0, a1, a2);
         if (pub != nullptr) mf_publish(v, pub, seq);   // a read-back follows this sweep
         return;
     }
@@ -830,7 +666,6 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
-    case 4: mf_body_bfs_finish(v, a0, v.flags[5]); break;  // after mf_k_bfs_persist: the level count is on the device
     }
 }
 
@@ -873,7 +708,6 @@ int graph_build_reverse(pgx_ctx* ctx)
 
 namespace {
 
-static int ctx_debug_level() { const char* e = std::getenv("PGX_MF_DEBUG"); return e ? std::atoi(e) : 0; }
 
 struct HipBackend {
     pgx_ctx* ctx;
@@ -881,36 +715,13 @@ struct HipBackend {
     unsigned blocks;
     bool v_has_graph;
     unsigned list_blocks;
-    bool persist = false;        // level loops inside persistent cooperative kernels (PGX_MF_PERSIST=0: one launch per level)
-    unsigned coop_blocks = 0;    // co-resident grid of the persistent kernels: one workgroup per CU
     hipError_t err = hipSuccess;
 
-    bool persistent() const { return persist; }
     int stage_margin() const
     {
         // staging needs room for everything one pass can append: 256 threads x ceil(max degree / kBfsLanes) arcs each
         const int per_pass = kMfBlock * ((ctx->max_degree + kBfsLanes - 1) / kBfsLanes);
         return per_pass <= kStageCap / 2 ? (per_pass > 0 ? per_pass : kMfBlock) : 0;
-    }
-    void bfs_all(const MfView& v, int slot)
-    {
-        MfView vv = v;
-        int margin = stage_margin();
-        unsigned* bar = st->bar.as<unsigned>();
-        void* args[] = {&vv, &margin, &slot, &bar};
-        hipError_t e = hipLaunchCooperativeKernel((const void*)mf_k_bfs_persist, dim3(coop_blocks), dim3(kMfBlock), args, 0, ctx->stream);
-        if (e != hipSuccess && err == hipSuccess) err = e;
-        check();
-        single(v, 4, slot);
-    }
-    void wave_all(const MfView& v, int kstart)
-    {
-        MfView vv = v;
-        unsigned* bar = st->bar.as<unsigned>();
-        void* args[] = {&vv, &kstart, &bar};
-        hipError_t e = hipLaunchCooperativeKernel((const void*)mf_k_wave_persist, dim3(coop_blocks), dim3(kMfBlock), args, 0, ctx->stream);
-        if (e != hipSuccess && err == hipSuccess) err = e;
-        check();
     }
 
     void check() { if (err == hipSuccess) err = hipGetLastError(); }
@@ -1023,7 +834,7 @@ struct HipBackend {
             if (peek(v.hub_exists + l))
                 std::fprintf(stderr, "    hub %d: e=%lld d=%d cnt=%d\n", l, peek(v.hub_e + l), peek(v.bfs_hub_d + l), peek(v.cnt + l));
         if (peek(v.has_alpha_hub)) std::fprintf(stderr, "    hubA: rt=%lld d=%d\n", peek(v.hubA_rt), peek(v.bfs_hubA_d));
-        if (ctx_debug_level() == 4) {  // level sizes of the BFS that just ran (nact carries the last level)
+        if (ctx->tile_debug == 4) {  // level sizes of the BFS that just ran (nact carries the last level)
             std::vector<int> lv((size_t)nact + 2);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipMemcpy(lv.data(), v.lvl, sizeof(int) * lv.size(), hipMemcpyDeviceToHost);
@@ -1032,7 +843,7 @@ struct HipBackend {
             std::fprintf(stderr, "\n");
             return;
         }
-        if (ctx_debug_level() < 3) return;
+        if (ctx->tile_debug < 3) return;
         std::vector<long long> ex((size_t)v.n), rt((size_t)v.n);
         std::vector<int> d((size_t)v.n), lab((size_t)v.n);
         (void)hipMemcpy(ex.data(), v.ex, sizeof(long long) * (size_t)v.n, hipMemcpyDeviceToHost);
@@ -1063,15 +874,11 @@ struct HipBackend {
     unsigned sweep_blocks = 512;     // workgroups of a sweep over all sites (PGX_MF_SWEEP_BLOCKS)
     void sweep(const MfView& v, int prev, int cur)
     {
-        hipLaunchKernelGGL(mf_k_sweep, dim3(blocks < sweep_blocks ? blocks : sweep_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur,
-                           fused_epilogue);
+        hipLaunchKernelGGL(mf_k_sweep, dim3(blocks < sweep_blocks ? blocks : sweep_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur);
         check();
     }
-    int fused_epilogue = 0;          // PGX_MF_FUSED=1: the sweep kernels run their own epilogue (mf_sweep_retire).  Measured 2-4 % SLOWER than the
-                                     // separate one-wave launch (the wait + ticket + dependent loads at the tail of every sweep): off
     void sweep_epilogue(const MfView& v, int cur, int next, int consumed, bool read_follows = false)
     {
-        if (fused_epilogue) return;
         if (read_follows && publish && st->h_pub) { single(v, 3, cur, next, consumed, st->h_pub, ++st->pub_seq); pub_pending = true; }
         else single(v, 3, cur, next, consumed);
     }
@@ -1090,18 +897,9 @@ struct HipBackend {
     unsigned bfs_level_blocks = (unsigned)kBfsLevelBlocks;   // PGX_MF_LEVEL_BLOCKS
     unsigned bfs_init_blocks = 256;  // every workgroup ends with one atomic on the level counter and up to L on the hub distances:
                                      // ~20 ns each, serialised per address (PGX_MF_INIT_BLOCKS)
-    int tail_cap = 0;            // longest work list the one-workgroup sweep kernel takes (PGX_MF_TAIL=<sites>; 0 = off, the default:
-                                 // measured equal within noise at 256-512 sites, 3-15 % slower at 1024-2048 - a sweep is a chain of ~10
-                                 // dependent L2 round trips either way)
-    int sweep_tail_cap() const { return tail_cap; }
-    void sweep_tail(const MfView& v, int sweep_id, int parity, int stamp, int budget)
-    {
-        hipLaunchKernelGGL(mf_k_sweep_tail, dim3(1), dim3(kTailBlock), 0, ctx->stream, v, sweep_id, parity, stamp, budget, tail_cap);
-        check();
-    }
     void sweep_list(const MfView& v, int prev, int cur, int parity, int stamp)
     {
-        hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp, fused_epilogue);
+        hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
         check();
     }
     long long stuck_excess(const MfView& v)
@@ -1266,10 +1064,9 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
-    if (ctx->mf_tile && !source_reach && wq == nullptr && !std::getenv("PGX_MF_NO_GATE")) {
+    if (ctx->mf_tile && !source_reach && wq == nullptr) {
         const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed);
         if (r != PGX_TILE_FALLBACK) return r;
-        ctx->stats[7] += 0;   // (fallbacks are rare: a hub that only reaches t through members without t-links, round caps)
         ctx->tile_fallbacks += 1;
     }
     if (!ctx->mf) {
@@ -1325,10 +1122,10 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
-    v.gate = std::getenv("PGX_MF_NO_GATE") ? 0 : 1;
+    v.gate = 1;   // an unused alpha is handled by the stranded-excess test (maxflow_body.cuh); the materialised hub stays in the bodies for the CPU emulation
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
-    if (!st->bar.p) {   // grid barrier of the persistent kernels (words 0-1) | ticket of the publishing count kernel (word 8)
+    if (!st->bar.p) {
         PGX_TRY(ensure(ctx, st->bar, 64));
         PGX_HIP(ctx, hipMemsetAsync(st->bar.p, 0, 64, ctx->stream));
     }
@@ -1336,34 +1133,11 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
         PGX_HIP(ctx, hipHostMalloc((void**)&st->h_pub, 64, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(st->h_pub, 0, 64);
     }
-    if (const char* e = std::getenv("PGX_MF_PUBLISH")) be.publish = std::atoi(e) ? 1 : 0;
-    {
-        const char* e = std::getenv("PGX_MF_PERSIST");
-        // opt-in: measured equal-to-slower than one launch per level (a grid barrier over 256 workgroups on 8 XCDs costs what
-        // a launch costs); unstaged appends use plain stores, so staging is a precondition
-        be.persist = e && e[0] == '1' && be.stage_margin() > 0;
-        const unsigned cus = ctx->cu_count > 0 ? (unsigned)ctx->cu_count : 64u;
-        be.coop_blocks = be.blocks < cus ? be.blocks : cus;
-    }
-    MfTuning tune;
-    if (const char* e = std::getenv("PGX_MF_WAVE")) tune.wave = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_WAVE_MAX")) tune.wave_max = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_WAVE_SMALL")) tune.wave_small = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_LIST_DIV")) tune.list_div = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_SWEEPS_LIST")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_list = x; }
+    MfTuning tune;   // the schedule constants of maxflow_driver.inl (measured: DESIGN.md 5.4)
     if (tune.list_div > 0) be.list_blocks = (unsigned)((n / tune.list_div + kMfBlock - 1) / kMfBlock + 1);
-    if (const char* e = std::getenv("PGX_MF_DEBUG")) tune.debug = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_SWEEPS")) { const int x = std::atoi(e); if (x > 0) tune.sweeps_per_relabel = x; }
-    if (const char* e = std::getenv("PGX_MF_CHECK")) { const int x = std::atoi(e); if (x > 0) tune.sweep_check = x; }
+    tune.debug = ctx->tile_debug;
     tune.bfs_hint = st->bfs_hint;
     tune.source_reach = source_reach ? 1 : 0;
-    if (const char* e = std::getenv("PGX_MF_STALL")) tune.stall_sweeps = std::atoi(e);
-    if (const char* e = std::getenv("PGX_MF_LEVEL_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_level_blocks = (unsigned)x; }
-    if (const char* e = std::getenv("PGX_MF_INIT_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.bfs_init_blocks = (unsigned)x; }
-    if (const char* e = std::getenv("PGX_MF_SWEEP_BLOCKS")) { const int x = std::atoi(e); if (x > 0) be.sweep_blocks = (unsigned)x; }
-    if (const char* e = std::getenv("PGX_MF_FUSED")) be.fused_epilogue = std::atoi(e) ? 1 : 0;
-    if (const char* e = std::getenv("PGX_MF_TAIL")) { const int x = std::atoi(e); if (x >= 0) be.tail_cap = x; }
-    if (const char* e = std::getenv("PGX_MF_BFS_BATCH")) { const int x = std::atoi(e); if (x > 0) { tune.bfs_batch = x; tune.bfs_hint = nullptr; } }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);
     if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
     if (r != 0)

@@ -16,13 +16,12 @@ struct MfTuning {
     int sweeps_per_relabel = 24;  // over all sites (48 before the BFS got cheaper: C4 end-to-end 3.13 -> 2.99 s)
     int sweep_check = 8;      // read the work-left flag every this many sweeps
     int max_relabels = 4096;  // hard cap on global relabels per move
-    int debug = 0;            // PGX_MF_DEBUG=1: one stderr line per global relabel
+    int debug = 0;            // PGX_MF_DEBUG: one stderr line per global relabel
     int wave = 1;             // run the level-ordered wave pass after each global relabel
-    int wave_small = 0;       // ... or when at most this many sites are active (PGX_MF_WAVE_SMALL)
     int wave_max = 24;        // ... only after searches at most this deep (0 = always; PGX_MF_WAVE_MAX), or from the 12th relabel of a move on
     int list_div = 8;         // sweeps visit a work list instead of all sites when <= n / list_div sites are active (0 = never)
     int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
-    int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never; PGX_MF_STALL)
+    int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
     int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
@@ -48,15 +47,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         int level = 1, last = 1;
         const int slot = (sweep_id + 2) % 3;
         int fl[kMfFlags];
-        if (be.persistent()) {
-            // all levels + the one-thread epilogue in ONE cooperative launch (grid barrier between levels); the level
-            // counters come back with the flags: [5] = last level run, [0] = last level that labelled a site
-            be.bfs_all(v, slot);
-            be.count_active(v);
-            be.read_flags(v, fl);
-            level = fl[5];
-            last = fl[0];
-        } else {
+        {
             // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
             // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
             // The first batch is sized by the depth of the previous search of the same kind - the first search of a move (from
@@ -94,7 +85,6 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
                 be.read_flags(v, fl);
             }
         }
-        if (cnt_alpha < 0) cnt_alpha = be.read_count(v, v.alpha);   // (persistent mode)
         stats[2] += 1;
         stats[3] += level;
         if (fl[1] == 0) { converged = true; break; }
@@ -105,10 +95,9 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // One launch per level: after a deep search (86 levels at C4) the pass costs more than the list sweeps it saves
         // (find6DPoses PEARL 2.96 -> 2.70 s without it), after a shallow one (7 levels at C5) it pays (2.7 vs 3.2 s).  A move
         // that still needs many relabels gets it back: it is what moved excess along 100-arc paths in round 1.
-        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12 || fl[3] <= tune.wave_small)) {
+        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {
             const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
-            if (be.persistent()) be.wave_all(v, kstart);
-            else for (int k = kstart; k >= 1; --k) be.wave(v, k);
+            for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
         }
         // ---- push-relabel sweeps: over all sites, or over a work list while few sites are active and no beta hub can
@@ -119,20 +108,6 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         if (list_mode) be.build_list(v, stamp);
         int parity = 0, s = 0;
         bool round_done = false;
-        if (list_mode && be.sweep_tail_cap() > 0 && fl[3] <= be.sweep_tail_cap()) {
-            // short work list: the sweeps run back to back inside one workgroup (maxflow.hip mf_k_sweep_tail) until the
-            // round is finished, the list outgrows the workgroup, a hub comes back into play, or the budget is spent
-            be.sweep_tail(v, sweep_id, parity, stamp, budget);
-            be.read_flags(v, fl);
-            const int done = fl[5];
-            s = done;
-            sweep_id += done;
-            parity ^= done & 1;
-            stats[1] += done;
-            stats[6] += done;
-            if (fl[4] == 0) round_done = true;
-            else if (fl[6] != 0) list_mode = false;
-        }
         for (; s < budget && !round_done; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
             const bool read_follows = (s + 1) % tune.sweep_check == 0;   // the epilogue then hands the flags to the host itself

@@ -47,7 +47,6 @@ struct pgx_ctx {
     int last_score_path = 0;       // 1 = chunked kernel (every pair visited), 2 = cull + group-major
     int score_stats = 0;           // set by pgx_score_stats for one launch: work counters in stats_buf
     pgx::DevBuf stats_buf;
-    int score_deferred = 0;        // PGX_SCORE_DEFERRED=1: filtered kernel with per-lane candidate queues (slower, kept for A/B)
     // spatially sorted copies for the score kernel (group-level rejection); aliases of the originals
     // when point_sort is off
     int point_sort = 0;          // 1: pts_s / pts32_s / pmax_s / comp_s hold the points in Morton order, pperm maps back
@@ -57,16 +56,9 @@ struct pgx_ctx {
     pgx::DevBuf pts_g, p32_g;    // group-blocked SoA copies of the sorted rows: [group][coordinate][64] (group-major kernel)
     int setpoints_host = 0;      // PGX_SETPOINTS_HOST=1: round 1's host preprocessing in pgx_set_points (A/B, cross-check)
     int gc_flip = 1;             // PGX_GC_FLIP=0: the inlier / outlier cut in its original orientation (pointwise.hip gc_labeling_launch)
-    int score_wg = 0;            // PGX_SCORE_WG=1: workgroup variant of the group-major kernel (constants staged once per chunk of groups)
     int score_dense_min = 32;    // steps with at least this many candidates of 64 are evaluated in place, not queued (PGX_SCORE_DENSE; 65 = never)
-    int score_exact_waves = 1;   // waves per segment of the candidate queue in score_exact_kernel (PGX_SCORE_EXW)
     int score_cull_segs = 256;   // segments of groups per hypothesis word in the cull kernel (PGX_SCORE_CULL_SEGS; 8192 waves at M = 2048)
     int score_nrep = 0;         // replicas of the integer accumulators (PGX_SCORE_NREP, multiple of 8); 0 = automatic: 8 when a group's waves share an XCD, else 1
-    int score_queue = 0;         // PGX_SCORE_QUEUE=1: candidates go to a global queue and are evaluated by score_exact_kernel (measured slower; A/B)
-    pgx::DevBuf cand;            // global candidate queue [kCandSegs][qcap] of (hypothesis, sorted point index)
-    int score_ablate = 0;        // PGX_SCORE_ABLATE (measurement only, wrong results): 1 skips the exact evaluation, 2 the filter loop too
-    int score_pipe = 0;          // PGX_SCORE_PIPE: 0 plain survivor loop, 1 prefetch of the next hypothesis' constants, 2 two per step
-    int score_soa = 1;           // PGX_SCORE_SOA=0: the group-major kernel reads the AoS copies (A/B)
     int score_cull = 1;          // cull + survivor kernels instead of in-kernel group skipping (PGX_SCORE_NO_CULL=1: A/B)
     double sp_kd_weight = 0.25;  // PGX_SP_KD_W: weight of the 3-D part against the observed pair in the k-d order (1 = box normalisation)
     int sp_kd = 1;               // PGX_SP_KD=0: Morton order of the points of a pose problem instead of the k-d order (setpoints.hip)
@@ -113,15 +105,12 @@ struct pgx_ctx {
     pgx::DevBuf gorder;          // sites in the Morton order of the coordinates the graph was built on (graph.hip); gorder_n == gn when valid
     int64_t gorder_n = 0;
     int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
-    int tile_order = 1;          // PGX_TILE_ORDER=0: tiles over the caller's site order (A/B)
+    int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
     int tile_multi = 0;          // PGX_TILE_MULTI=1: graphs beyond one workgroup on the tile path too (measured slower: opt-in)
-    int tile_hard_div = 64;      // a move with more than n / this sites holding excess that reaches t goes to maxflow.hip (PGX_TILE_HARD; 0 = never)
-    int tile_polls = 4096;       // cap on the re-scans of one relax launch (it normally ends by the all-idle rule)
-    int tile_phase_batch = 3;    // relax launches enqueued per host read-back (reset + local, cooperative, verifying)
-    int tile_lazy = 1;           // PGX_TILE_LAZY=0: exact distances in multi-tile relax launches (A/B)
+    int tile_hard_div = 64;      // a move with more than n / this sites holding excess that reaches t goes to maxflow.hip (0 = never)
+    int tile_lazy = 1;           // multi-tile searches accept only substantial improvements of finite heights (maxflow_tile.hip)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
-    int tile_discharges = 1;     // discharge launches per global relabel
     int64_t tile_fallbacks = 0;  // moves the tile path handed back to maxflow.hip
     int tile_debug = 0;          // PGX_MF_DEBUG: one stderr line per global relabel
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};

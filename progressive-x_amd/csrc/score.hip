@@ -727,10 +727,8 @@ __device__ __forceinline__ long long to_fixed(double x)
 }
 
 constexpr int kGroupWaves = 1;  // waves per workgroup of the group-major kernel
-constexpr int kCandSegs = 16384;   // segments of the global candidate queue (power of two; one reservation counter each)
-constexpr int kCandStride = 8;     // counters 32 B apart
 
-template <int MT, bool MASK, bool STATS = false, int PIPE = 0>
+template <int MT, bool MASK, bool STATS = false>
 __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     const double* __restrict__ pts, const float* __restrict__ pts32, const double* __restrict__ comp, int64_t n, int groups,
     const double* __restrict__ models, int W, double T2, int has_comp, const unsigned long long* __restrict__ keep,
@@ -738,9 +736,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     int Mpad, unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm, int split, int xcd_local, const double* __restrict__ models_t,
     unsigned long long* __restrict__ stats /* STATS: [0] surviving (hypothesis, group) steps, [1] exact evaluations, [2] inlier pairs */,
     const double* __restrict__ pts_g /* [groups][D][64]: group-blocked SoA copy of the rows (nullptr: AoS) */,
-    const float* __restrict__ p32_g /* [groups][8][64] */,
-    unsigned long long* __restrict__ cand /* [kCandSegs][qcap] global candidate queue (nullptr: exact evaluation in place) */,
-    unsigned* __restrict__ cand_cnt /* [kCandSegs * kCandStride] */, int qcap, int nrep, int dense_min)
+    const float* __restrict__ p32_g /* [groups][8][64] */, int nrep, int dense_min)
 {
     // split: waves per group, each takes every split-th word of 64 hypotheses (shorter waves: better tail)
     using R = Residual<MT>;
@@ -753,8 +749,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     // group's workgroups on one XCD (FETCH_SIZE 165 -> 45 MiB but 0.51 ms); one wave per workgroup with 8 parts per
     // group: 0.28 ms (16 parts: 250 k workgroups, the dispatcher limits at ~1.3 ns per workgroup).
     const int wv = 0;
-    const int ablate = xcd_local >> 4;  // measurement only (PGX_SCORE_ABLATE): 1 = no exact evaluation, 2 = no filter loop either
-    xcd_local &= 1;
     int g, part;
     if (xcd_local) {  // workgroup ids go round-robin over the 8 XCDs: all parts of a group on one XCD (its L2 fetches the rows once)
         const int slot = (int)(blockIdx.x >> 3);
@@ -806,14 +800,12 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     __shared__ unsigned s_queue[kGroupWaves][128];
     int qn = 0;  // queued candidate pairs of this wave (wave-uniform)
     unsigned long long st_steps = 0, st_exact = 0, st_inl = 0;  // STATS only (wave-uniform / per-lane partials)
-    int nflush = 0;  // batches this wave has handed to the global candidate queue
     // Exact evaluation of up to 64 queued (hypothesis, point) pairs, one per lane.  A pair's point lives in the registers
     // of lane `src` of this wave (shuffles), its model is gathered from global memory.  Every contribution is converted to
     // 2^-q fixed point BEFORE any summation, so the accumulated integers do not depend on how pairs were batched:
     // results are bit-reproducible and independent of the launch geometry.  Equal hypotheses are adjacent in the queue
     // (pairs are appended hypothesis by hypothesis): a segmented shuffle reduction leaves one atomic set per run.
     auto drain = [&](int c) __attribute__((always_inline)) {
-        if (ablate >= 1) return;
         const bool act = lane < c;
         const unsigned e = act ? s_queue[wv][lane] : 0u;
         const int m = act ? (int)(e >> 6) : -1 - lane;
@@ -887,28 +879,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             if (MASK) masks[(int64_t)perm[m] * words + g] = bm;  // rows start zeroed
         }
     };
-    // Hand-over of `c` queued candidates to the global queue (one segment per workgroup id, one reservation per flush): the
-    // exact FP64 evaluation then runs in score_exact_kernel with all 64 lanes busy, instead of here where a wave's last
-    // batch is on average 40 % full and every batch ends the wave's work with a dependent gather + atomics.  A full
-    // segment makes the wave evaluate in place (the reserved slots are marked empty).
-    auto flush = [&](int c) __attribute__((always_inline)) {
-        if (MASK || STATS || cand == nullptr) { drain(c); return; }
-        if (ablate >= 1) return;
-        // a wave's successive batches go to different segments (a dense group would otherwise fill one): segments end up
-        // equally loaded, which is what the consumer's one-wave-per-segment schedule needs
-        const unsigned seg = ((unsigned)blockIdx.x + (unsigned)(nflush++) * 7919u) & (unsigned)(kCandSegs - 1);
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&cand_cnt[seg * kCandStride], (unsigned)c);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        const bool fits = base + (unsigned)c <= (unsigned)qcap;
-        if (lane < c && base + (unsigned)lane < (unsigned)qcap) {
-            const unsigned e = s_queue[wv][lane];
-            const unsigned long long entry = fits ? (((unsigned long long)(e >> 6) << 32) | (unsigned long long)((unsigned)g * 64u + (e & 63u)))
-                                                  : ~0ull;
-            cand[(size_t)seg * (size_t)qcap + base + lane] = entry;
-        }
-        if (!fits) drain(c);
-    };
     for (int w = part; w < W; w += split) {
         unsigned long long todo = keep[(int64_t)g * W + w];  // wave-uniform -> scalar load
         if (todo == 0) continue;
@@ -920,61 +890,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             for (int k = 0; k < kHypRow; ++k) s_h32[wv][lane][k] = hyp32[ml * kHypRow + k];
         }
         __builtin_amdgcn_wave_barrier();
-        if (ablate >= 2) continue;
-        if constexpr (!MASK && PIPE > 0) {
-            // Software-pipelined walk over the survivors: the constants of the NEXT hypothesis (PIPE == 2: of the next two)
-            // are requested from LDS before the current one is evaluated, so the ~100-cycle LDS round trip overlaps the
-            // filter arithmetic instead of heading every step's dependency chain (ISA of the plain loop: s_ff1 -> ds_read
-            // x4 -> s_waitcnt -> 18 VALU -> ballot -> branch, strictly serial; VALU 56 % busy).
-            auto append = [&](int h, bool cand) __attribute__((always_inline)) {
-                const unsigned long long cm = __ballot(cand);
-                if (cm == 0) return;
-                const int m = w * 64 + h;
-                if (__popcll(cm) >= dense_min) { direct(m, cand); return; }
-                if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
-                    ((unsigned)m << 6) | (unsigned)lane;
-                qn += __popcll(cm);
-                if (qn >= 64) {
-                    __builtin_amdgcn_wave_barrier();
-                    flush(64);
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned mv = s_queue[wv][64 + lane];
-                    __builtin_amdgcn_wave_barrier();
-                    s_queue[wv][lane] = mv;
-                    qn -= 64;
-                }
-            };
-            if constexpr (PIPE == 1) {
-                int hA = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                LaneT lnA = lane_load<LaneT>(&s_h32[wv][hA][0]);
-                for (;;) {
-                    const bool more = todo != 0;
-                    const int hB = more ? __builtin_ctzll(todo) : hA;
-                    todo &= todo - 1;  // 0 stays 0
-                    const LaneT lnB = lane_load<LaneT>(&s_h32[wv][hB][0]);  // in flight while A is evaluated
-                    append(hA, valid && !F32::reject(p32, lnA, T2d32));
-                    if (!more) break;
-                    hA = hB;
-                    lnA = lnB;
-                }
-            } else {
-                while (todo != 0) {  // two hypotheses per step: two independent FMA chains, one loop overhead
-                    const int hA = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const bool two = todo != 0;
-                    const int hB = two ? __builtin_ctzll(todo) : hA;
-                    todo &= todo - 1;
-                    const LaneT lnA = lane_load<LaneT>(&s_h32[wv][hA][0]);
-                    const LaneT lnB = lane_load<LaneT>(&s_h32[wv][hB][0]);
-                    const bool cA = valid && !F32::reject(p32, lnA, T2d32);
-                    const bool cB = two && valid && !F32::reject(p32, lnB, T2d32);
-                    append(hA, cA);
-                    append(hB, cB);
-                }
-            }
-            continue;
-        }
         while (todo != 0) {
             const int h = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -991,7 +906,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
                 qn += __popcll(cm);
                 if (qn >= 64) {
                     __builtin_amdgcn_wave_barrier();
-                    flush(64);
+                    drain(64);
                     __builtin_amdgcn_wave_barrier();
                     const unsigned mv = s_queue[wv][64 + lane];
                     __builtin_amdgcn_wave_barrier();
@@ -1005,7 +920,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     }
     if (!MASK && qn > 0) {
         __builtin_amdgcn_wave_barrier();
-        flush(qn);
+        drain(qn);
     }
     if (STATS) {  // one set of atomics per wave
 #pragma unroll
@@ -1017,254 +932,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
             atomicAdd(&stats[0], st_steps);
             atomicAdd(&stats[1], st_exact);
             atomicAdd(&stats[2], st_inl);
-        }
-    }
-}
-
-// Exact FP64 evaluation of the queued candidate pairs, 64 per wave step with every lane busy: the point row and the model
-// are gathered from memory (the rows of a producer's batch are neighbours in the sorted copy, its hypotheses form runs),
-// the residual is the oracle's operation order, every contribution becomes 2^-q fixed point BEFORE any summation and goes
-// to the hypothesis' integer accumulators - the same integers the in-place path adds, so the results do not depend on
-// which path a pair took.
-// ---- workgroup variant of the group-major kernel (PGX_SCORE_WG=1) --------------------------------------------------------
-// What the ablation of score_group_kernel says: a third of its time is per-wave start-up plus the four
-// dependent global -> LDS round trips that stage the constants of a word's survivors, and the exact batches at the end of
-// 125 k short-lived waves are 40 % full.  Here a 4-wave workgroup owns (a chunk of kWgChunk consecutive groups, part p):
-// the f32 constants of ALL of the part's hypotheses are staged in LDS ONCE per workgroup, the waves take groups from an LDS
-// counter, and a wave's candidate queue lives across its groups - a queued pair names (hypothesis, group, lane) and the
-// exact evaluation gathers its point row from the group-blocked copy instead of shuffling registers - so batches are full
-// except the wave's last.  Same per-pair fixed point, same integer atomics: bitwise the results of the other kernels.
-constexpr int kWgChunk = 16;   // groups per workgroup
-constexpr int kWgWaves = 4;
-constexpr int kWgRow = 20;     // floats per hypothesis in LDS (= kHypRow: the rows of hyp32 as they are, 80 bytes)
-
-template <int MT>
-__global__ __launch_bounds__(64 * kWgWaves) void score_group_kernel_wg(
-    const double* __restrict__ comp, int64_t n, int groups, const double* __restrict__ models, int W, int wpp /* words per part */,
-    double T2, int has_comp, const unsigned long long* __restrict__ keep, const float* __restrict__ hyp32, double qscale,
-    unsigned long long* __restrict__ acc, int Mpad, const double* __restrict__ models_t, const double* __restrict__ pts_g,
-    const float* __restrict__ p32_g, int nrep, int dense_min, int parts)
-{
-    using R = Residual<MT>;
-    using F32 = Filter32<MT>;
-    using LaneT = typename F32::Lane;
-    static_assert(sizeof(LaneT) / 4 <= kWgRow, "Filter32 lane constants must fit an LDS row");
-    extern __shared__ float s_dyn[];                       // [wpp * 64][kWgRow] constants of the part's hypotheses
-    __shared__ unsigned s_queue[kWgWaves][128];
-    __shared__ int s_next;
-    const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-    const int part = (int)(blockIdx.x % (unsigned)parts), chunk = (int)(blockIdx.x / (unsigned)parts);
-    // this part's words of 64 hypotheses: part, part + parts, ... (INTERLEAVED: the batch is in locality order, a contiguous
-    // range of words would give one part all hypotheses of an object and the other parts nothing to do for its groups)
-    const int nw = part < W ? (W - part + parts - 1) / parts : 0;
-    acc += (size_t)(blockIdx.x % (unsigned)nrep) * 3 * (size_t)Mpad;
-    // stage the constants once (all threads; 64-byte rows)
-    for (int e = (int)threadIdx.x; e < nw * 64 * (kWgRow / 4); e += 64 * kWgWaves) {
-        const int hyp = e / (kWgRow / 4), q4 = e % (kWgRow / 4);
-        const int64_t mg = (int64_t)(part + (hyp >> 6) * parts) * 64 + (hyp & 63);   // global hypothesis of local slot `hyp`
-        const float4 v = *reinterpret_cast<const float4*>(hyp32 + mg * kHypRow + q4 * 4);
-        *reinterpret_cast<float4*>(s_dyn + (size_t)hyp * kWgRow + q4 * 4) = v;
-    }
-    if (threadIdx.x == 0) s_next = 0;
-    __syncthreads();
-    const float T2d32 = f32_up(T2 * (1.0 + kFilter32Delta));
-    const int g0 = chunk * kWgChunk;
-    int qn = 0;
-    // exact evaluation of c queued pairs, one per lane: rows gathered from the group-blocked copies (just read by this wave)
-    auto drain = [&](int c) {
-        const bool act = lane < c;
-        const unsigned e = act ? s_queue[wv][lane] : 0u;
-        const int m = act ? (int)(e >> 10) : -1 - lane;
-        long long cnt = 0, val = 0, shq = 0;
-        if (act) {
-            const int64_t g = g0 + (int)((e >> 6) & 15u);
-            const int sl = (int)(e & 63u);
-            double pt[R::D], mdl[R::P];
-#pragma unroll
-            for (int k = 0; k < R::D; ++k) pt[k] = pts_g[(g * R::D + k) * 64 + sl];
-#pragma unroll
-            for (int k = 0; k < R::P; ++k) mdl[k] = models_t[(int64_t)k * Mpad + m];
-            const double sq = R::squared(pt, mdl);
-            if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
-                const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
-                cnt = 1;
-                val = to_fixed(sc * qscale);
-                if (has_comp) {
-                    const int64_t j = g * 64 + sl < n ? g * 64 + sl : n - 1;
-                    shq = to_fixed(cv_min(comp[j], sc) * qscale);                   // :115-117
-                }
-            }
-        }
-        const int mp = __shfl_up(m, 1, 64);
-        const bool head = lane == 0 || mp != m;
-        const unsigned long long heads = __ballot(head);
-        const int rs = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));  // first lane of this lane's run
-        for (int off = 1; off < 64; off <<= 1) {
-            const int ro = __shfl_down(rs, off, 64);
-            const bool same = lane + off < 64 && ro == rs;
-            if (__ballot(same) == 0) break;
-            const long long c2 = __shfl_down(cnt, off, 64), v2 = __shfl_down(val, off, 64), s2 = __shfl_down(shq, off, 64);
-            if (same) { cnt += c2; val += v2; shq += s2; }
-        }
-        if (act && head && cnt > 0) {
-            atomicAdd(&acc[m], (unsigned long long)cnt);
-            atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
-            if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
-        }
-    };
-    for (;;) {
-        int gi = 0;
-        if (lane == 0) gi = atomicAdd(&s_next, 1);
-        gi = __builtin_amdgcn_readfirstlane(gi);
-        const int g = g0 + gi;
-        if (gi >= kWgChunk || g >= groups) break;
-        unsigned long long todo[8];   // wpp <= 8 words per part
-        unsigned long long any = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { todo[k] = k < nw ? keep[(int64_t)g * W + part + k * parts] : 0ull; any |= todo[k]; }
-        if (any == 0) continue;
-        const int64_t j = (int64_t)g * 64 + lane;
-        const bool valid = j < n;
-        double pt[R::D];
-        float p32[8];
-#pragma unroll
-        for (int q = 0; q < R::D; ++q) pt[q] = pts_g[((int64_t)g * R::D + q) * 64 + lane];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) p32[q] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < F32::kRowVals; ++q) p32[q] = p32_g[((int64_t)g * 8 + q) * 64 + lane];
-        const double cmp = has_comp ? comp[valid ? j : n - 1] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            unsigned long long td = todo[k];
-            while (td != 0) {
-                const int h = __builtin_ctzll(td);
-                td &= td - 1;
-                const int hl = k * 64 + h;              // hypothesis index inside the part
-                const int m = (part + k * parts) * 64 + h;
-                const LaneT ln = lane_load<LaneT>(s_dyn + (size_t)hl * kWgRow);   // LDS broadcast
-                const bool cand = valid && !F32::reject(p32, ln, T2d32);
-                const unsigned long long cm = __ballot(cand);
-                if (cm == 0) continue;
-                if (__popcll(cm) >= dense_min) {        // dense step: in place (same integers as the queued path)
-                    double sc = 0.0, shv = 0.0;
-                    bool inl = false;
-                    if (cand) {
-                        double mdl[R::P];
-#pragma unroll
-                        for (int q = 0; q < R::P; ++q) mdl[q] = models[(int64_t)m * R::P + q];
-                        const double sq = R::squared(pt, mdl);
-                        inl = sq < T2;
-                        if (inl) {
-                            sc = cv_max(0.0, 1.0 - sq / T2);
-                            if (has_comp) shv = cv_min(cmp, sc);
-                        }
-                    }
-                    const unsigned long long bm = __ballot(inl);
-                    if (bm == 0) continue;
-                    long long val = inl ? to_fixed(sc * qscale) : 0, shq = (inl && has_comp) ? to_fixed(shv * qscale) : 0;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        val += __shfl_down(val, off, 64);
-                        shq += __shfl_down(shq, off, 64);
-                    }
-                    if (lane == 0) {
-                        atomicAdd(&acc[m], (unsigned long long)__popcll(bm));
-                        atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
-                        if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
-                    }
-                    continue;
-                }
-                if (cand) s_queue[wv][qn + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] =
-                    ((unsigned)m << 10) | ((unsigned)gi << 6) | (unsigned)lane;
-                qn += __popcll(cm);
-                if (qn >= 64) {
-                    __builtin_amdgcn_wave_barrier();
-                    drain(64);
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned mv = s_queue[wv][64 + lane];
-                    __builtin_amdgcn_wave_barrier();
-                    s_queue[wv][lane] = mv;
-                    qn -= 64;
-                }
-            }
-        }
-    }
-    if (qn > 0) {
-        __builtin_amdgcn_wave_barrier();
-        drain(qn);
-    }
-}
-
-constexpr int kExactUnroll = 4;  // batches of 64 pairs a wave has in flight
-
-template <int MT>
-__global__ __launch_bounds__(64) void score_exact_kernel(
-    const double* __restrict__ pts_s, const double* __restrict__ comp, const double* __restrict__ models_t, int Mpad, double T2,
-    int has_comp, double qscale, const unsigned long long* __restrict__ cand, const unsigned* __restrict__ cand_cnt, int qcap,
-    unsigned long long* __restrict__ acc, int nrep, int kExactWaves, int ablate)
-{
-    using R = Residual<MT>;
-    const int lane = (int)threadIdx.x;
-    // kExactWaves waves share a segment; a wave takes kExactUnroll consecutive batches per step and issues the entry loads,
-    // then the row / model gathers of ALL of them before any arithmetic: the chain count -> entries -> rows/models ->
-    // arithmetic is three dependent memory round trips (the rows were written by another XCD: L2 misses), and with one
-    // batch in flight per wave the kernel was nothing but that latency.
-    const unsigned seg = (unsigned)blockIdx.x / (unsigned)kExactWaves, k = (unsigned)blockIdx.x % (unsigned)kExactWaves;
-    unsigned cnt = cand_cnt[seg * kCandStride];
-    if (cnt > (unsigned)qcap) cnt = (unsigned)qcap;
-    acc += (size_t)(blockIdx.x % (unsigned)nrep) * 3 * (size_t)Mpad;
-    const unsigned long long* q = cand + (size_t)seg * (size_t)qcap;
-    for (unsigned base = k * 64u * kExactUnroll; base < cnt; base += 64u * kExactUnroll * (unsigned)kExactWaves) {
-        unsigned long long e[kExactUnroll];
-#pragma unroll
-        for (int u = 0; u < kExactUnroll; ++u) e[u] = base + 64u * u + lane < cnt ? q[base + 64u * u + lane] : ~0ull;
-        double pt[kExactUnroll][R::D], mdl[kExactUnroll][R::P], cj[kExactUnroll];
-#pragma unroll
-        for (int u = 0; u < kExactUnroll; ++u) {
-            const bool act = e[u] != ~0ull;
-            const unsigned j = act ? (unsigned)e[u] : 0u, m = act ? (unsigned)(e[u] >> 32) : 0u;
-            const double* __restrict__ row = pts_s + (size_t)j * R::D;
-#pragma unroll
-            for (int qq = 0; qq < R::D; ++qq) pt[u][qq] = row[qq];
-#pragma unroll
-            for (int qq = 0; qq < R::P; ++qq) mdl[u][qq] = models_t[(size_t)qq * (unsigned)Mpad + m];
-            cj[u] = has_comp ? comp[j] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kExactUnroll; ++u) {
-            if (base + 64u * u >= cnt) break;  // uniform
-            const bool act = e[u] != ~0ull;
-            const int m = act ? (int)(e[u] >> 32) : -1 - lane;
-            long long c1 = 0, val = 0, shq = 0;
-            if (act) {
-                const double sq = R::squared(pt[u], mdl[u]);
-                if (sq < T2) {  // strict, scoring_function_with_compound_model.h:85
-                    const double sc = cv_max(0.0, 1.0 - sq / T2);                       // :94
-                    c1 = 1;
-                    val = to_fixed(sc * qscale);
-                    if (has_comp) shq = to_fixed(cv_min(cj[u], sc) * qscale);           // :115-117
-                }
-            }
-            // segmented sums over RUNS of equal hypotheses.  A segment concatenates the batches of several producer waves, so
-            // the same hypothesis may come back after other ones: runs are identified by their first lane (from the ballot
-            // of the run heads), not by the hypothesis index, so that only contiguous entries are combined.
-            const int mp = __shfl_up(m, 1, 64);
-            const bool head = lane == 0 || mp != m;
-            const unsigned long long heads = __ballot(head);
-            const int rs = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));  // first lane of this lane's run
-            for (int off = 1; off < 64; off <<= 1) {
-                const int ro = __shfl_down(rs, off, 64);
-                const bool same = lane + off < 64 && ro == rs;
-                if (__ballot(same) == 0) break;
-                const long long c2 = __shfl_down(c1, off, 64), v2 = __shfl_down(val, off, 64), s2 = __shfl_down(shq, off, 64);
-                if (same) { c1 += c2; val += v2; shq += s2; }
-            }
-            if (act && head && c1 > 0 && ablate != 4) {
-                atomicAdd(&acc[m], (unsigned long long)c1);
-                atomicAdd(&acc[(int64_t)Mpad + m], (unsigned long long)val);
-                if (has_comp) atomicAdd(&acc[2 * (int64_t)Mpad + m], (unsigned long long)shq);
-            }
         }
     }
 }
@@ -1294,109 +961,6 @@ __global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long l
         reinterpret_cast<double*>(mirror)[(int64_t)Mpad + m] = val;
         reinterpret_cast<double*>(mirror)[2 * (int64_t)Mpad + m] = shv;
     }
-}
-
-// ---- filtered variant with deferred exact evaluation ------------------------------------------------
-// The filter leaves only a few candidate pairs per lane, but a wave pays for the exact path whenever ANY of its 64
-// hypotheses has a candidate at the current point (the union over lanes).  Here a lane instead appends the point index
-// of each of its candidates to a private LDS queue (wave ballot decides when some queue is nearly full), and the wave
-// drains all queues together, one entry per lane per step, each lane gathering its own point with vector loads: the
-// number of exact-path wave steps drops from |union of candidates| to max-over-lanes |candidates|.  Every lane still
-// processes its candidates in ascending point order, so sums are bit-identical to the unfiltered kernel.
-constexpr int kQueue = 24;  // u16 entries per lane: 256 x 24 x 2 B = 12 KiB LDS per block (8 blocks/CU stay resident)
-
-template <int MT, bool MASK>
-__global__ __launch_bounds__(kScoreBlock) void score_kernel_deferred(
-    const double* __restrict__ pts, int64_t n, const double* __restrict__ models, int M, int Mpad,
-    double T2, const double* __restrict__ comp, int has_comp, int64_t chunk,
-    const double* __restrict__ pmax, double guard,
-    unsigned* __restrict__ pcnt, double* __restrict__ pval, double* __restrict__ psh,
-    unsigned long long* __restrict__ masks, int64_t words, const int* __restrict__ perm)
-{
-    using R = Residual<MT>;
-    using F = Filter<MT>;
-    __shared__ unsigned short queue[kQueue][kScoreBlock];
-    const int tid = threadIdx.x;
-    const int m = blockIdx.x * kScoreBlock + tid;
-    const bool live = m < M;
-    const int64_t i0 = (int64_t)blockIdx.y * chunk;
-    const int64_t i1 = (i0 + chunk < n) ? (i0 + chunk) : n;
-
-    double mdl[R::P];
-#pragma unroll
-    for (int k = 0; k < R::P; ++k)
-        mdl[k] = live ? models[(int64_t)m * R::P + k] : __builtin_nan("");
-    const typename F::Lane flane = F::prep(mdl, guard);
-    const double T2d = T2 * (1.0 + kFilterDelta);
-
-    unsigned cnt = 0, qn = 0;
-    double val = 0.0, sh = 0.0;
-    unsigned long long word = 0;
-
-    auto drain = [&]() {
-        for (unsigned j = 0; __any(j < qn); ++j) {
-            if (j < qn) {
-                const int64_t i = i0 + queue[j][tid];
-                const double* __restrict__ prow = pts + i * R::D;  // per-lane gather (recently streamed: L2 hits)
-                double pt[R::D];
-#pragma unroll
-                for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
-                const double sq = R::squared(pt, mdl);            // exact path: oracle order, no contraction
-                if (sq < T2) {                                    // strict, scoring_function_with_compound_model.h:85
-                    ++cnt;                                        // :91
-                    const double s = cv_max(0.0, 1.0 - sq / T2);  // :94
-                    val += s;                                     // :97
-                    if (has_comp) sh += cv_min(comp[i], s);       // :115-117
-                    if (MASK) word |= 1ull << (i & 63);           // :88
-                }
-            }
-        }
-        qn = 0;
-    };
-    auto filter_step = [&](int64_t i, const double (&pt)[R::D], double pm) {
-        if (live && !F::reject(pt, mdl, flane, pm, T2d)) {
-            queue[qn][tid] = (unsigned short)(i - i0);
-            ++qn;
-        }
-    };
-    auto boundary = [&](int64_t last) {  // `last` = index of the last point handled so far
-        const bool word_end = MASK && ((last & 63) == 63 || last == i1 - 1);
-        if (word_end || __any(qn > kQueue - 4)) drain();
-        if (word_end) {
-            if (live) masks[(int64_t)perm[m] * words + (last >> 6)] = word;
-            word = 0;
-        }
-    };
-
-    constexpr int kUnroll = 4;
-    int64_t i = i0;
-    for (; i + kUnroll <= i1; i += kUnroll) {
-        const double* __restrict__ prow = pts + i * R::D;  // wave-uniform address -> scalar loads
-        double pt[kUnroll][R::D];
-        double pm[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-#pragma unroll
-            for (int k = 0; k < R::D; ++k) pt[u][k] = prow[u * R::D + k];
-            pm[u] = pmax[i + u];
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) filter_step(i + u, pt[u], pm[u]);
-        boundary(i + kUnroll - 1);  // chunks start at multiples of 64, so a 64-point word never straddles a group
-    }
-    for (; i < i1; ++i) {
-        const double* __restrict__ prow = pts + i * R::D;
-        double pt[R::D];
-#pragma unroll
-        for (int k = 0; k < R::D; ++k) pt[k] = prow[k];
-        filter_step(i, pt, pmax[i]);
-        boundary(i);
-    }
-    drain();
-    const int64_t o = (int64_t)blockIdx.y * Mpad + m;
-    pcnt[o] = cnt;
-    pval[o] = val;
-    psh[o] = sh;
 }
 
 // Adds the chunk partials of each hypothesis in a FIXED order (bit-reproducible): 64 hypotheses per block, 16 waves
@@ -1429,20 +993,6 @@ __global__ __launch_bounds__(64 * kReduceWaves) void score_reduce_kernel(
         values[o] = v;
         shared[o] = s;
     }
-}
-
-template <int MT, bool MASK>
-static void score_launch_deferred(pgx_ctx* ctx, double T2, int has_compound, double guard)
-{
-    dim3 grid((unsigned)(ctx->Mpad / kScoreBlock), (unsigned)ctx->chunks);
-    const bool srt = ctx->point_sort != 0;
-    hipLaunchKernelGGL((score_kernel_deferred<MT, MASK>), grid, dim3(kScoreBlock), 0, ctx->stream,
-                       (srt ? ctx->pts_s : ctx->pts).as<double>(), ctx->n, ctx->models.as<double>(), ctx->M, ctx->Mpad, T2,
-                       (srt ? ctx->comp_s : ctx->comp).as<double>(), has_compound, ctx->chunk,
-                       (srt ? ctx->pmax_s : ctx->pmax).as<double>(), guard,
-                       ctx->pcnt.as<unsigned>(), ctx->pval.as<double>(), ctx->psh.as<double>(),
-                       MASK ? (srt ? ctx->masks_s : ctx->masks).as<unsigned long long>() : (unsigned long long*)nullptr, ctx->words,
-                       ctx->perm.as<int>());
 }
 
 template <int MT, bool MASK, int FILT>
@@ -1497,11 +1047,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     // per-hypothesis band of pow2_normaliser keep it so
     if (!(ctx->fscale <= 1e30)) filt = filt32 = false;
     ctx->last_score_filtered = filt32 ? 2 : (filt ? 1 : 0);
-    // Deferred exact evaluation measured 8 % SLOWER than the plain filtered kernel on the metric batch (per-lane
-    // gathers + serialised drain latency outweigh the fewer exact steps): opt-in only (PGX_SCORE_DEFERRED=1).
-    const bool deferred = filt && ctx->score_deferred;
     if constexpr (Filter32<MT>::enabled) {
-        if (filt32 && !deferred && ctx->point_sort && ctx->score_cull) {
+        if (filt32 && ctx->point_sort && ctx->score_cull) {
             // ---- cull, then score group-major
             const int groups = (int)((ctx->n + 63) / 64);
             const int kCullSegs = ctx->score_cull_segs;
@@ -1515,27 +1062,18 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             // 0.42 -> 0.50 ms) on a batch in arbitrary order, where all of them do - so the order of the batch decides.
             const int group_xcd = ctx->score_group_xcd >= 0 ? ctx->score_group_xcd : (ctx->h_perm.empty() ? 0 : 1);
             const int nrep = ctx->score_nrep > 0 ? ctx->score_nrep : (group_xcd ? 8 : 1);
-            const int xcd_local = (group_xcd ? 1 : 0) | ((ctx->score_ablate < 4 ? ctx->score_ablate : 0) << 4);  // per-XCD replicas of the accumulators when a group's waves share an XCD
-            // global candidate queue (exact evaluation in its own dense kernel): kCandSegs segments, capacity from the batch size
-            const bool use_queue = ctx->score_queue && !want_masks && !ctx->score_stats;
-            int qcap = 256;
-            while ((int64_t)qcap * kCandSegs * 64 < ctx->n * (int64_t)ctx->M && qcap < 8192) qcap *= 2;  // ~1/64 of the pairs
-            if (const char* b = std::getenv("PGX_SCORE_QCAP")) { const int v = std::atoi(b); if (v >= 64 && v <= 65536) qcap = v; }
-            const size_t cnt_bytes = use_queue ? (size_t)kCandSegs * kCandStride * sizeof(unsigned) : 0;
-            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + (size_t)nrep * 3 * sizeof(long long) + Residual<MT>::P * sizeof(double)) + cnt_bytes));  // hyp32 | acc[nrep] | cand_cnt | models_t
-            if (use_queue) PGX_TRY(ensure(ctx, ctx->cand, (size_t)kCandSegs * (size_t)qcap * sizeof(unsigned long long)));
+            const int xcd_local = group_xcd ? 1 : 0;   // per-XCD replicas of the accumulators when a group's waves share an XCD
+            PGX_TRY(ensure(ctx, ctx->cull_counts, (size_t)ctx->Mpad * (kHypRow * sizeof(float) + (size_t)nrep * 3 * sizeof(long long) + Residual<MT>::P * sizeof(double))));  // hyp32 | acc[nrep] | models_t
             float* hyp32 = ctx->cull_counts.as<float>();
             unsigned long long* acc = (unsigned long long*)(ctx->cull_counts.as<char>() + (size_t)ctx->Mpad * kHypRow * sizeof(float));
-            unsigned* cand_cnt = (unsigned*)(acc + (size_t)nrep * 3 * (size_t)ctx->Mpad);  // zeroed by the same memset as acc
-            double* models_t = (double*)((char*)cand_cnt + cnt_bytes);
-            unsigned long long* cand = use_queue ? ctx->cand.as<unsigned long long>() : (unsigned long long*)nullptr;
-            const double* pts_g = ctx->score_soa && ctx->pts_g.p ? ctx->pts_g.as<double>() : (const double*)nullptr;
-            const float* p32_g = ctx->score_soa && ctx->pts_g.p ? ctx->p32_g.as<float>() : (const float*)nullptr;
+            double* models_t = (double*)(acc + (size_t)nrep * 3 * (size_t)ctx->Mpad);
+            const double* pts_g = ctx->pts_g.p ? ctx->pts_g.as<double>() : (const double*)nullptr;   // group-blocked SoA copies of the rows
+            const float* p32_g = ctx->pts_g.p ? ctx->p32_g.as<float>() : (const float*)nullptr;
             int lg = 0;
             while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
-            // the accumulators (and the queue counters behind them) are zeroed by the cull kernel, which runs before their first use
-            const int64_t zero_words = (int64_t)(((size_t)nrep * ctx->Mpad * 3 * sizeof(long long) + cnt_bytes) / sizeof(long long));
+            // the accumulators are zeroed by the cull kernel, which runs before their first use
+            const int64_t zero_words = (int64_t)nrep * ctx->Mpad * 3;
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
             hipLaunchKernelGGL((score_cull_kernel<MT>), dim3((unsigned)((W + kCullWaves - 1) / kCullWaves), kCullSegs), dim3(64 * kCullWaves), 0,
                                ctx->stream, ctx->models.as<double>(), ctx->M, T2, guard32, ctx->gbounds.as<float>(), groups, gps, W,
@@ -1557,7 +1095,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   (unsigned long long*)nullptr, pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep, 65);
+                                   (unsigned long long*)nullptr, pts_g, p32_g, nrep, 65);
             } else if (ctx->score_stats) {  // pgx_score_stats: the same launch with work counters (never timed)
                 PGX_TRY(ensure(ctx, ctx->stats_buf, 8 * sizeof(unsigned long long)));
                 PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
@@ -1565,37 +1103,16 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
                                    qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                   ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, (unsigned long long*)nullptr, (unsigned*)nullptr, 0, nrep, ctx->score_dense_min);
+                                   ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, nrep, ctx->score_dense_min);
             } else {
-                auto launch = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
-                                       ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
-                                       ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                       qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
-                                       (unsigned long long*)nullptr, pts_g, p32_g, cand, cand_cnt, qcap, nrep, ctx->score_dense_min);
-                };
-                const int parts = split;
-                const int wpp = (W + parts - 1) / parts;
-                if (ctx->score_wg && !use_queue && pts_g != nullptr && wpp <= 8 && ctx->Mpad < (1 << 22)) {
-                    // workgroup variant: grid = chunks x parts, workgroup id % parts = part (= XCD when parts == 8)
-                    const unsigned chunks = (unsigned)((groups + kWgChunk - 1) / kWgChunk);
-                    hipLaunchKernelGGL((score_group_kernel_wg<MT>), dim3(chunks * (unsigned)parts), dim3(64 * kWgWaves),
-                                       (size_t)wpp * 64 * kWgRow * sizeof(float), ctx->stream, ctx->comp_s.as<double>(), ctx->n, groups,
-                                       ctx->models.as<double>(), W, wpp, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
-                                       qscale, acc, ctx->Mpad, models_t, pts_g, p32_g, nrep, ctx->score_dense_min, parts);
-                }
-                else if (ctx->score_pipe == 2) launch(score_group_kernel<MT, false, false, 2>);
-                else if (ctx->score_pipe == 1) launch(score_group_kernel<MT, false, false, 1>);
-                else launch(score_group_kernel<MT, false, false, 0>);
+                hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
+                                   ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
+                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
+                                   qscale, acc, ctx->Mpad, (unsigned long long*)nullptr, ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
+                                   (unsigned long long*)nullptr, pts_g, p32_g, nrep, ctx->score_dense_min);
             }
             PGX_HIP(ctx, hipGetLastError());
             if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[2], ctx->stream));
-            if (use_queue) {
-                hipLaunchKernelGGL((score_exact_kernel<MT>), dim3((unsigned)(kCandSegs * ctx->score_exact_waves)), dim3(64), 0, ctx->stream,
-                                   ctx->pts_s.as<double>(), ctx->comp_s.as<double>(), models_t, ctx->Mpad, T2, has_compound, qscale, cand,
-                                   cand_cnt, qcap, acc, nrep, ctx->score_exact_waves, ctx->score_ablate);
-                PGX_HIP(ctx, hipGetLastError());
-            }
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[4], ctx->stream));
             long long* mirror = nullptr;
             if (ctx->score_mirror && !want_masks) {
@@ -1623,13 +1140,11 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
     if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
     if constexpr (Filter<MT>::enabled) {
         if (want_masks) {
-            if (deferred) score_launch_deferred<MT, true>(ctx, T2, has_compound, guard);
-            else if (filt32) score_launch_one<MT, true, 2>(ctx, T2, has_compound, guard, guard32);
+            if (filt32) score_launch_one<MT, true, 2>(ctx, T2, has_compound, guard, guard32);
             else if (filt) score_launch_one<MT, true, 1>(ctx, T2, has_compound, guard);
             else score_launch_one<MT, true, 0>(ctx, T2, has_compound, guard);
         } else {
-            if (deferred) score_launch_deferred<MT, false>(ctx, T2, has_compound, guard);
-            else if (filt32) score_launch_one<MT, false, 2>(ctx, T2, has_compound, guard, guard32);
+            if (filt32) score_launch_one<MT, false, 2>(ctx, T2, has_compound, guard, guard32);
             else if (filt) score_launch_one<MT, false, 1>(ctx, T2, has_compound, guard);
             else score_launch_one<MT, false, 0>(ctx, T2, has_compound, guard);
         }

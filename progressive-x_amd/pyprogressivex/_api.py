@@ -6,6 +6,8 @@ findTwoViewMotions ignores scoring_exponent, findLines ignores weights, only fin
 
 Extensions that do not change the reference behaviour when left at their defaults (keyword-only):
   seed=None                     reproducible sampling (the reference seeds from std::random_device)
+  distributed=None              True: shard the proposal batches over the ranks of this launch (every rank must make the same
+                                call on the same data; checked).  None: only if PGX_MULTI_GPU=1.  Never implicit.
   max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
   residual="transfer"           findHomographies: "symmetric" switches to the symmetric transfer error (U-1 switch)
   neighborhood="flann_like"     U-7 switch: "flann_like" (<= 5 nearest neighbours inside the ball, what upstream's
@@ -72,20 +74,23 @@ def _unknown_sampler(sampler_id):
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
          do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-         local_optimization="auto", labeling_l0="greedy"):
+         local_optimization="auto", labeling_l0="greedy", distributed=None):
     n = pts.shape[0]
     if getattr(sampler_factory, "unknown", False):
         # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
         _unknown_sampler(sampler_factory.sampler_id)
         return [], np.zeros(n, dtype=np.int32), None
     ctx = _context()
-    # multi-GPU (one process per GPU, WORLD_SIZE > 1): the proposal batches are sharded over the ranks and the score triples
-    # all-gathered over RCCL (parallel.py); everything else runs replicated, so every rank returns the same result.  All
-    # ranks must draw the same samples: an unset seed is replaced by one the launch agrees on.
+    # multi-GPU, OPT-IN (distributed=True or PGX_MULTI_GPU=1, one process per GPU, WORLD_SIZE > 1): the proposal batches are
+    # sharded over the ranks and the score triples all-gathered over RCCL (parallel.py); everything else runs replicated, so
+    # every rank returns the same result.  Every rank must make this call with the same data (checked) and draw the same
+    # samples: an unset seed is replaced by one the launch agrees on.
     from . import parallel
-    exchange = parallel.default_exchange(ctx)
-    if exchange is not None and seed is None:
-        seed = parallel.shared_seed()
+    exchange = parallel.default_exchange(ctx, distributed)
+    if exchange is not None:
+        parallel.check_same_problem(exchange, pts)
+        if seed is None:
+            seed = parallel.shared_seed()
     rng = np.random.default_rng(seed)
     # FlannNeighborhoodGraph(&points, radius) [U-7]: built on the GPU (pgx_graph_build) and left resident there; the
     # CSR comes back for the neighbourhood samplers.
@@ -146,7 +151,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                      do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -165,7 +170,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed)
     return _stack(est, models, 3), labels
 
 
@@ -173,7 +178,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -192,7 +197,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed)
     return _stack(est, models, 3), labels
 
 
@@ -203,7 +208,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                         do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -220,7 +225,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
                              weights=_weights(weights, n), seed=seed, max_outer_iterations=max_outer_iterations,
-                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
+                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed)
     return _stack(est, models, 3), labels
 
 
@@ -228,7 +233,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
               do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -246,7 +251,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed)
     return _stack(est, models, 3), labels
 
 
@@ -254,7 +259,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
                 minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
                 neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
     import time
     x1 = _as_f64(x1y1)
@@ -288,5 +293,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed)
     return _stack(est, models, 4), labels

@@ -116,13 +116,20 @@ class Pearl:
         self.ctx.pearl_unary(desc, self.threshold, self.lam)          # PEARL.h:512-519 data term
         lam = self.lam if self.lam > 0.0 else 0.0                     # :523-525, :532 smooth term only if > 0
         h = self.model_complexity_weight if self.model_complexity_weight > 0.0 else 0.0   # :528-529
-        if lam == 0.0 and self.labeling_l0 == "greedy":
-            # [U-8] no setSmoothCost / setNeighbors call was made (:523-536), so GCO-v3's expansion() (:550-551) leaves
-            # through solveSpecialCases(): per-site argmin without label costs, greedy facility location with them -
-            # not alpha-expansion.  labeling_l0="expansion" runs the closed-form alpha-expansion moves instead.
-            eq, e, opened = self.ctx.greedy_labeling(h)
-            cycles = 1
-        else:
+        greedy = lam == 0.0 and self.labeling_l0 == "greedy" and K + 1 <= 64   # (pgx_greedy_labeling: label sets as 64-bit masks)
+        if greedy:
+            # [U-8, UNVERIFIED recollection of GCO-v3] no setSmoothCost / setNeighbors call was made (:523-536), so expansion()
+            # (:550-551) leaves through solveSpecialCases(): per-site argmin without label costs, greedy facility location with
+            # them - not alpha-expansion.  labeling_l0="expansion" runs the closed-form alpha-expansion moves instead; so does a
+            # run with more than 63 instances (max_outer_iterations extension) or a greedy call that fails.
+            try:
+                eq, e, opened = self.ctx.greedy_labeling(h)
+                cycles = 1
+            except Exception as ex:                                   # PgxError / oracle error: fall back, do not abort the run
+                if self.do_logging:
+                    print(f"[Optimization] greedy labelling unavailable ({ex}); alpha-expansion instead.")
+                greedy = False
+        if not greedy:
             eq, e, cycles = self.ctx.expansion(lam, h, 1000)          # :550-551
         self.has_engine = True
         self.cycles += cycles

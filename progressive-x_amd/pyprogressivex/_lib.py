@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pgx_version", "pgx_device_count", "pgx_global_error", "pgx_create", "pgx_destroy", "pgx_last_error",
     "pgx_model_dims", "pgx_sync", "pgx_timer_start", "pgx_timer_stop", "pgx_timer_mark", "pgx_timer_elapsed", "pgx_device_info",
     "pgx_set_points", "pgx_set_compound", "pgx_get_compound",
-    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch",
+    "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch", "pgx_score_debug_geometry",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats",
@@ -283,6 +283,12 @@ class Context:
         self._ck(self._lib.pgx_score_debug_fetch(self._h, C.c_int(spec[0]), out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)),
                  "pgx_score_debug_fetch")
         return out
+
+    def score_debug_geometry(self, **kw):
+        """pgx_score_debug_geometry (test hook): split=, group_xcd=, nrep=, dense_min=, cull_segs="""
+        keys = {"split": 0, "group_xcd": 1, "nrep": 2, "dense_min": 3, "cull_segs": 4}
+        for k, v in kw.items():
+            self._ck(self._lib.pgx_score_debug_geometry(self._h, C.c_int(keys[k]), C.c_int(int(v))), "pgx_score_debug_geometry")
 
     def score_profile(self, on=1):
         """0 off; 1 = HIP events around the dominant scoring kernel only; 2 (or True) = around every kernel of a launch"""

@@ -207,15 +207,25 @@ class RcclExchange:
 _process_exchange = None
 
 
-def default_exchange(ctx):
-    """The exchange the drop-in API uses: None on one GPU; with WORLD_SIZE > 1 (one process per GPU, launched by
-    torch.distributed.run or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE) the node-wide RCCL communicator, created
-    once per process.  PGX_FORCE_COMM=1 puts RCCL on the path with a single rank (tests, bench leg)."""
+def default_exchange(ctx, distributed=None):
+    """The exchange the drop-in API uses.  Sharding is OPT-IN: `distributed=True` on the call, or PGX_MULTI_GPU=1 in the
+    environment; a torch.distributed.run job whose ranks call the API independently (different data, different call counts)
+    gets None even though WORLD_SIZE > 1 - every proposal runs a collective, so ranks that do not make the same calls on the
+    same data would deadlock or merge unrelated score tables.  With the opt-in and WORLD_SIZE > 1 (one process per GPU, any
+    launcher that sets RANK / LOCAL_RANK / WORLD_SIZE) the node-wide RCCL communicator is created once per process; the ranks
+    must sit on ONE node (the unique id travels through a local file).  PGX_FORCE_COMM=1 puts RCCL on the path with a single
+    rank (tests, bench leg)."""
     global _process_exchange
     rank, world, _ = rank_env()
     force = os.environ.get("PGX_FORCE_COMM") == "1"
-    if world == 1 and not force:
+    want = distributed if distributed is not None else os.environ.get("PGX_MULTI_GPU") == "1"
+    if not force and (world == 1 or not want):
         return None
+    local_world = os.environ.get("LOCAL_WORLD_SIZE")
+    nnodes = os.environ.get("GROUP_WORLD_SIZE") or os.environ.get("NNODES")
+    if (local_world is not None and int(local_world) != world) or (nnodes is not None and nnodes.isdigit() and int(nnodes) > 1):
+        raise RuntimeError(f"pyprogressivex: hypothesis sharding needs all {world} ranks on one node (LOCAL_WORLD_SIZE = {local_world}): "
+                           "the RCCL unique id is exchanged through a node-local file")
     if _process_exchange is None or _process_exchange.ctx is not ctx:
         if getattr(ctx, "nranks", 1) != world or not getattr(ctx, "_comm_ready", False):
             init_rccl(ctx, rank, world)
@@ -223,6 +233,22 @@ def default_exchange(ctx):
         ctx.force_comm = force
         _process_exchange = RcclExchange(ctx)
     return _process_exchange
+
+
+def check_same_problem(exchange, pts):
+    """Every rank of a sharded call must hold the same points: max and min over the ranks of a 52-bit digest of (shape, bytes)
+    must agree.  Raises on every rank alike (the reduction is collective), before any proposal is exchanged."""
+    import hashlib
+    if exchange is None or exchange.world == 1 or not hasattr(exchange.ctx, "comm_allreduce_max"):
+        return
+    a = np.ascontiguousarray(pts)
+    h = hashlib.sha256(repr(a.shape).encode() + a.tobytes()).digest()
+    v = float(int.from_bytes(h[:8], "little") >> 12)            # exact in a double
+    hi = exchange.ctx.comm_allreduce_max(v)
+    lo = -exchange.ctx.comm_allreduce_max(-v)
+    if hi != lo:
+        raise RuntimeError("pyprogressivex: the ranks of this sharded call hold different point sets (or shapes); sharding needs every "
+                           "rank to make the same call on the same data - unset PGX_MULTI_GPU / distributed= for independent calls")
 
 
 def shared_seed():

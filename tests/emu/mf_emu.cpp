@@ -39,12 +39,7 @@ struct EmuBackend {
         mf_body_hub_setup(v);
     }
     int read_count(const MfView& v, int l) { return v.cnt[l]; }
-    bool persistent() const { return false; }      // the emulation runs the host-driven level loops
-    void bfs_all(const MfView&, int) {}
-    void wave_all(const MfView&, int) {}
     void keep_source_reachable_only(const MfView&) {}   // device-only variant (gc_labeling flipped), never requested here
-    int sweep_tail_cap() const { return 0; }       // device-only scheduling variants
-    void sweep_tail(const MfView&, int, int, int, int) {}
     void init_sites(const MfView& v) { each([&](int64_t u) { mf_body_init_site(v, u); }); }
     void bfs_reset(const MfView& v) { mf_body_bfs_reset(v); }
     void bfs_init(const MfView& v) { each([&](int64_t u) { if (mf_body_bfs_init(v, u, v.bfs_hub_d)) v.flags[0] = 1; }); }

@@ -29,6 +29,33 @@ def test_expansion_fuzz_against_the_oracle(gpu_ctx, oracle, seed):
         assert np.array_equal(got, ref) and eq == re and cyc == rc, (seed, trial, n, L, lam, h, int((got != ref).sum()))
 
 
+def test_expansion_fuzz_on_forced_tiles(oracle, monkeypatch):
+    """The same loop with every graph cut into 4096-site tiles and solved by the co-operative multi-workgroup launch
+    (PGX_TILE_MULTI=2: tiles even for small graphs, hard moves not handed back) - the path that is opt-in for large graphs."""
+    from pyprogressivex import _lib
+    monkeypatch.setenv("PGX_TILE_MULTI", "2")
+    ctx = _lib.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        for trial in range(24):
+            n = int(rng.choice([50, 1500, 5000, 9000, 20000]))
+            L = int(rng.integers(2, 9))
+            lam = float(rng.choice([0.02, 0.1, 0.3, 0.6]))
+            h = float(rng.choice([0.0, 3.0, 20.0]))
+            Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=int(rng.integers(1 << 30)))
+            lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+            start = rng.integers(0, L, n).astype(np.int32) if trial % 2 else np.zeros(n, np.int32)
+            ref, re, rc = oracle.expansion(Dq, graph, lq, hq, start.copy())
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(start.copy())
+            eq, e, cyc = ctx.expansion(lam, h)
+            got = ctx.get_labels()
+            assert np.array_equal(got, ref) and eq == re and cyc == rc, (trial, n, L, lam, h, int((got != ref).sum()))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_scoring_soak_slice(oracle, seed):
     """A bounded slice of tests/soak_scoring.py: random sizes and thresholds (some exactly on a residual), hypotheses a hair from

@@ -459,36 +459,30 @@ def test_group_culling_never_changes_a_count(oracle, name, monkeypatch):
 @pytest.mark.parametrize("name", ["pnp", "homography", "fundamental", "homography_sym", "line"])
 def test_group_path_is_independent_of_the_launch_geometry(name, monkeypatch, oracle):
     # per-pair fixed point + integer accumulation: the results of the group-major path do not depend on how many waves share
-    # a group, on queue boundaries, on the order in which groups finish, on where a pair is evaluated (in the producing wave
-    # or, through the global candidate queue, in score_exact_kernel - including segments that overflow), on how many
-    # accumulator replicas there are, on the row layout or on the survivor-loop variant: bitwise equal across every switch
+    # a group, on queue boundaries, on the order in which groups finish, on whether a step is evaluated in place or through the
+    # wave's candidate queue, on how many accumulator replicas there are or on the order of the batch: bitwise equal
     mt, pts, models, thr = make_case(name, 50000, 700, seed=21)
     T2 = 2.25 * thr * thr
     comp = np.random.default_rng(3).random(len(pts))
-    configs = [{"PGX_SCORE_SPLIT": s} for s in ("1", "3", "8", "16")] + [
-        {"PGX_SCORE_GROUP_XCD": "1"}, {"PGX_SCORE_GROUP_XCD": "0"}, {"PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_SPLIT": "2"}, {"PGX_SCORE_NREP": "64"},
-        {"PGX_SCORE_SOA": "0"}, {"PGX_SCORE_PIPE": "1"}, {"PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_DENSE": "65"}, {"PGX_SCORE_DENSE": "1"},
-        {"PGX_SCORE_DENSE": "8", "PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_WG": "1"}, {"PGX_SCORE_WG": "1", "PGX_SCORE_SPLIT": "3", "PGX_SCORE_DENSE": "65"},
-        {"PGX_NO_SORT": "1"},
-        {"PGX_SCORE_QUEUE": "1"}, {"PGX_SCORE_QUEUE": "1", "PGX_SCORE_QCAP": "64", "PGX_SCORE_EXW": "3"},
-        {"PGX_SCORE_QUEUE": "1", "PGX_SCORE_GROUP_XCD": "1", "PGX_SCORE_PIPE": "2"}, {"PGX_SCORE_CULL_SEGS": "31"}]
-    keys = sorted({k for c in configs for k in c})
+    configs = [dict(split=s) for s in (1, 3, 8, 16)] + [
+        dict(group_xcd=1), dict(group_xcd=0), dict(group_xcd=1, split=2), dict(nrep=64), dict(dense_min=65), dict(dense_min=1),
+        dict(dense_min=8, split=5), dict(cull_segs=31), dict(no_sort=1)]
     outs = []
     for cfg in configs:
-        for k in keys:
-            monkeypatch.delenv(k, raising=False)
-        for k, v in cfg.items():
-            monkeypatch.setenv(k, v)
+        cfg = dict(cfg)
+        monkeypatch.delenv("PGX_NO_SORT", raising=False)
+        if cfg.pop("no_sort", 0):
+            monkeypatch.setenv("PGX_NO_SORT", "1")       # hypotheses scored in the caller's order instead of locality order
         ctx = _lib.Context(0)
         try:
+            ctx.score_debug_geometry(**cfg)
             ctx.set_points(mt, pts)
             ctx.set_compound(comp)
             outs.append(ctx.score(models, T2, has_compound=True, exponent=2))
             outs.append(ctx.score(models, T2, has_compound=True, exponent=2))
         finally:
             ctx.close()
-    for k in keys:
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("PGX_NO_SORT", raising=False)
     for o in outs[1:]:
         for key in ("counts", "values", "shared", "scores"):
             assert np.array_equal(o[key], outs[0][key]), key
@@ -564,23 +558,27 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("forced", ["default", "list_sweeps", "no_wave", "persistent", "tail", "fused", "copied_readbacks"])
-def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
-    # the max-flow schedule (work-list sweeps, wave pass) must not show in the result: the cut is unique
-    if forced == "list_sweeps":
-        monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
-    if forced == "fused":        # the sweep kernels run their own epilogue (last workgroup by ticket)
-        monkeypatch.setenv("PGX_MF_FUSED", "1")
-    if forced == "tail":         # list-mode sweeps back to back inside one workgroup (mf_k_sweep_tail)
-        monkeypatch.setenv("PGX_MF_LIST_DIV", "1")
-        monkeypatch.setenv("PGX_MF_TAIL", "2048")
-    if forced == "no_wave":
-        monkeypatch.setenv("PGX_MF_WAVE", "0")
-        monkeypatch.setenv("PGX_MF_LIST_DIV", "0")
-    if forced == "persistent":   # BFS / wave level loops inside cooperative kernels with a grid barrier
-        monkeypatch.setenv("PGX_MF_PERSIST", "1")
-    if forced == "copied_readbacks":   # flags read back by copy + synchronisation instead of published by the kernels
-        monkeypatch.setenv("PGX_MF_PUBLISH", "0")
+MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0"}, "tiles": {"PGX_TILE_MULTI": "2"}}
+
+
+@pytest.fixture
+def mincut_ctx(request, monkeypatch):
+    """A context per min-cut schedule (the switches are read when the context is created): the default (a graph of <= 8192
+    sites is one workgroup, one launch per move), maxflow.hip's level-synchronous launches for everything, and 4096-site tiles
+    with a co-operative launch even for small graphs."""
+    for key in ("PGX_MF_TILE", "PGX_TILE_MULTI"):
+        monkeypatch.delenv(key, raising=False)
+    for key, val in MINCUT_PATHS[request.param].items():
+        monkeypatch.setenv(key, val)
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("mincut_ctx", list(MINCUT_PATHS), indirect=True)
+def test_energy_and_moves_random_small(mincut_ctx, oracle):
+    # the max-flow schedule must not show in the result: the cut (minimal sink side) is unique
+    gpu_ctx = mincut_ctx
     rng = np.random.default_rng(2024)
     for trial in range(60):
         n = int(rng.integers(2, 300))
@@ -608,13 +606,10 @@ def test_energy_and_moves_random_small(gpu_ctx, oracle, forced, monkeypatch):
             labels = ref
 
 
-@pytest.mark.parametrize("list_div", ["8", "1", "tail"])
-@pytest.mark.parametrize("n,lam,h", [(3000, 0.3, 10.0), (3000, 0.0, 10.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0)])
-def test_full_expansion_matches_oracle(gpu_ctx, oracle, n, lam, h, list_div, monkeypatch):
-    if list_div == "tail":       # short work lists swept inside one workgroup; a cap of 300 sites also exercises the hand-back
-        monkeypatch.setenv("PGX_MF_TAIL", "300")
-        list_div = "1"
-    monkeypatch.setenv("PGX_MF_LIST_DIV", list_div)
+@pytest.mark.parametrize("mincut_ctx", list(MINCUT_PATHS), indirect=True)
+@pytest.mark.parametrize("n,lam,h", [(3000, 0.3, 10.0), (3000, 0.0, 10.0), (6000, 0.2, 3.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0)])
+def test_full_expansion_matches_oracle(mincut_ctx, oracle, n, lam, h):
+    gpu_ctx = mincut_ctx
     Dq, graph = realistic_labeling_problem(n, L=6, lam=lam, seed=n)
     lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
     labels0 = np.zeros(n, dtype=np.int32)
@@ -1258,16 +1253,26 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     assert arcs > 4 * n
     gpu_ctx.pearl_unary(poses[:9], 4.0 / f, lam)
     results = []
-    for env in ({}, {"PGX_MF_LIST_DIV": "0", "PGX_MF_WAVE": "0"}, {"PGX_MF_NO_GATE": "1"}, {"PGX_MF_PERSIST": "1"}, {"PGX_MF_TAIL": "1024"},
-                {"PGX_MF_FUSED": "1"}, {"PGX_MF_WAVE_MAX": "0", "PGX_MF_STALL": "0"}):
-        for key in ("PGX_MF_LIST_DIV", "PGX_MF_WAVE", "PGX_MF_NO_GATE", "PGX_MF_PERSIST", "PGX_MF_TAIL", "PGX_MF_FUSED", "PGX_MF_WAVE_MAX", "PGX_MF_STALL"):
+    gpu_ctx.set_labels(np.zeros(n, np.int32))
+    eq, e, cycles = gpu_ctx.expansion(lam, h)
+    results.append((eq, cycles, gpu_ctx.get_labels()))
+    assert gpu_ctx.energy(lam, h)[0] == eq
+    for env in ({"PGX_MF_TILE": "0"}, {"PGX_TILE_MULTI": "1"}):     # level-synchronous only / 4096-site tiles, co-operative launch
+        for key in ("PGX_MF_TILE", "PGX_TILE_MULTI"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
-        gpu_ctx.set_labels(np.zeros(n, np.int32))
-        eq, e, cycles = gpu_ctx.expansion(lam, h)
-        results.append((eq, cycles, gpu_ctx.get_labels()))
-        assert gpu_ctx.energy(lam, h)[0] == eq
+        other = _lib.Context(0)
+        try:
+            other.set_points(_lib.PNP, pts)
+            other.graph_build(np.column_stack([x1, x2]), _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+            other.pearl_unary(poses[:9], 4.0 / f, lam)
+            other.set_labels(np.zeros(n, np.int32))
+            eq, e, cycles = other.expansion(lam, h)
+            results.append((eq, cycles, other.get_labels()))
+            assert other.energy(lam, h)[0] == eq
+        finally:
+            other.close()
     for eq, cycles, labels in results[1:]:
         assert eq == results[0][0] and cycles == results[0][1] and np.array_equal(labels, results[0][2])
     eq2, _, cycles2 = gpu_ctx.expansion(lam, h)            # idempotent at the optimum

@@ -364,3 +364,30 @@ def test_fundamental_validity_stages():
     est_off = _estimators.FundamentalEstimator()
     est_off.validity = "off"
     assert est_off.valid_best(None, band, R1, None, 0.75, never)[0]
+
+
+def test_sharding_is_opt_in(monkeypatch):
+    """a torch.distributed.run job whose ranks call the API independently must not be pulled into a collective.
+    default_exchange returns None unless the call (distributed=True) or the environment (PGX_MULTI_GPU=1) opts in, and refuses a
+    launch that spans nodes before touching RCCL."""
+    from pyprogressivex import parallel
+    for key in ("PGX_MULTI_GPU", "PGX_FORCE_COMM", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "NNODES"):
+        monkeypatch.delenv(key, raising=False)
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+
+    class NoComm:      # a context without RCCL: reaching init_rccl would fail loudly
+        nranks = 1
+
+    assert parallel.default_exchange(NoComm()) is None
+    assert parallel.default_exchange(NoComm(), distributed=False) is None
+    monkeypatch.setenv("PGX_MULTI_GPU", "1")
+    assert parallel.default_exchange(NoComm(), distributed=False) is None       # the call wins over the environment
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")                                 # 4 ranks, 2 per node
+    import pytest
+    with pytest.raises(RuntimeError, match="one node"):
+        parallel.default_exchange(NoComm())
+    with pytest.raises(RuntimeError, match="one node"):
+        parallel.default_exchange(NoComm(), distributed=True)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert parallel.default_exchange(NoComm(), distributed=True) is None        # one rank: nothing to shard
