@@ -99,7 +99,9 @@ int pgx_score_algorithmic_bytes(pgx_ctx *ctx, int want_masks, int64_t *bytes, in
 /* Work counters of one scoring launch of the resident batch (a separate, untimed launch of the same kernels with counting
  * switched on): [0] (point, hypothesis) pairs, [1] (hypothesis, 64-point group) pairs, [2] group steps that survived the
  * bound test (64 f32 filter evaluations each), [3] exact FP64 residual evaluations (-1: not counted on this path),
- * [4] inlier pairs, [6] path (1 = every pair visited, 2 = cull + group-major), [7] filter (0 none, 1 f64, 2 f32). */
+ * [4] inlier pairs, [5] with PGX_VERIFY=1 in the environment at pgx_create: inlier pairs - by the exact residual over EVERY pair of
+ * the batch - that the group bound or the f32 filter discarded (must be 0: a hole in a filter proof otherwise), else -1,
+ * [6] path (1 = every pair visited, 2 = cull + group-major), [7] filter (0 none, 1 f64, 2 f32). */
 int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8]);
 /* Per-kernel HIP-event timing of the scoring launches on the context's stream (bench.py's roofline block).  on = 1: every
  * pgx_score_launch records two events around its DOMINANT kernel (group-major scoring, or the chunked kernel); on = 2:

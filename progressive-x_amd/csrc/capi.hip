@@ -105,6 +105,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_SCORE_MIRROR")) ctx->score_mirror = std::atoi(b) != 0;
     if (const char* b = std::getenv("PGX_SCORE_NO_CULL")) ctx->score_cull = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
+    if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_TILE_MULTI")) {   // 1: graphs beyond one workgroup on the tile path; 2 (tests): tiles for every graph, no hand-back
         const int v = std::atoi(b);
@@ -600,6 +601,9 @@ int pgx_score_stats(pgx_ctx* ctx, double T2, int has_compound, int64_t stats[8])
         stats[2] = (int64_t)h[0];             // surviving (hypothesis, group) steps: 64 f32 filter evaluations each
         stats[3] = (int64_t)h[1];             // exact FP64 residual evaluations
         stats[4] = (int64_t)h[2];             // inlier pairs
+        // PGX_VERIFY=1: inlier pairs (by the exact residual over EVERY pair) that the group bound or the f32 filter discarded
+        // (+ the difference between the exhaustive pass's inlier count and the scoring path's: equal unless something else is wrong)
+        stats[5] = ctx->verify ? (int64_t)(h[4] + h[5]) + ((int64_t)h[6] > stats[4] ? (int64_t)h[6] - stats[4] : stats[4] - (int64_t)h[6]) : -1;
     } else {
         PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         stats[3] = ctx->last_score_filtered ? -1 : stats[0];  // unfiltered chunked kernel: every pair is evaluated exactly

@@ -46,6 +46,7 @@ struct pgx_ctx {
     int last_score_filtered = 0;
     int last_score_path = 0;       // 1 = chunked kernel (every pair visited), 2 = cull + group-major
     int score_stats = 0;           // set by pgx_score_stats for one launch: work counters in stats_buf
+    int verify = 0;                // PGX_VERIFY=1: pgx_score_stats also re-decides every pair exactly and counts contradictions (score.hip)
     pgx::DevBuf stats_buf;
     // spatially sorted copies for the score kernel (group-level rejection); aliases of the originals
     // when point_sort is off

@@ -308,7 +308,7 @@ class Context:
         self._ck(self._lib.pgx_score_stats(self._h, C.c_double(T2), C.c_int(1 if has_compound else 0), _ptr(st, C.c_int64)),
                  "pgx_score_stats")
         return dict(pairs=int(st[0]), group_pairs=int(st[1]), surviving_group_steps=int(st[2]), exact_evaluations=int(st[3]),
-                    inlier_pairs=int(st[4]), path={1: "every pair", 2: "cull + group-major"}.get(int(st[6]), "?"),
+                    inlier_pairs=int(st[4]), contradictions=int(st[5]), path={1: "every pair", 2: "cull + group-major"}.get(int(st[6]), "?"),
                     filter={0: "none", 1: "f64", 2: "f32"}.get(int(st[7]), "?"))
 
     # -- preference / compound -------------------------------------------------------------------------------------

@@ -13,10 +13,24 @@ from pyprogressivex import _lib
 import pgx_oracle as O
 
 
-def soak(seed, trials, verbose=True):
+def soak(seed, trials, verbose=True, verify=True):
+    """verify: the context is created with PGX_VERIFY=1 and every batch is also re-decided pair by pair on the device
+    (pgx_score_stats[5]): a pair the group bound or the f32 filter discarded although the exact residual calls it an inlier is a
+    contradiction - a hole in a filter proof - whether or not it happens to change a count."""
     rng = np.random.default_rng(seed)
-    ctx = _lib.Context(0)
+    saved = os.environ.get("PGX_VERIFY")
+    if verify:
+        os.environ["PGX_VERIFY"] = "1"
+    try:
+        ctx = _lib.Context(0)
+    finally:
+        if saved is None:
+            os.environ.pop("PGX_VERIFY", None)
+        else:
+            os.environ["PGX_VERIFY"] = saved
     bad = 0
+    contradictions = 0
+    checked_pairs = 0
     t0 = time.time()
     for trial in range(trials):
         name = list(MODEL_CASES)[trial % len(MODEL_CASES)]
@@ -55,6 +69,14 @@ def soak(seed, trials, verbose=True):
             ok = np.array_equal(a["counts"], ref["counts"]) and np.array_equal(a["masks"], ref["masks"]) and np.array_equal(b["counts"], ref["counts"])
             tol = 1e-9 * np.maximum(np.abs(ref["values"]), 1e-4)
             ok = ok and np.all(np.abs(a["values"] - ref["values"]) <= tol) and np.all(np.abs(b["values"] - ref["values"]) <= tol)
+            if verify:
+                st = ctx.score_stats(float(T2), has_compound=True)
+                if st["contradictions"] >= 0:          # (-1: this batch went the dense / unsorted way: nothing is discarded there)
+                    checked_pairs += st["pairs"]
+                    if st["contradictions"] != 0:
+                        contradictions += st["contradictions"]
+                        ok = False
+                        print("CONTRADICTION", name, n, M, T2, st, flush=True)
             if not ok:
                 bad += 1
                 w = np.nonzero((a["counts"] != ref["counts"]) | (b["counts"] != ref["counts"]))[0]
@@ -69,7 +91,8 @@ def soak(seed, trials, verbose=True):
                     del os.environ["PGX_NO_GROUP"]
     ctx.close()
     if verbose:
-        print(f"soak done: seed {seed}, {trials} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+        print(f"soak done: seed {seed}, {trials} cases, {bad} mismatches, {contradictions} contradictions in {checked_pairs:.3g} verified pairs, "
+              f"{time.time() - t0:.0f} s")
     return bad
 
 
