@@ -234,7 +234,12 @@ int pgx_comm_barrier(pgx_ctx *ctx);
 int pgx_comm_allreduce_max_f64(pgx_ctx *ctx, double *value);                /* host scalar in/out, via device */
 int pgx_score_allgather(pgx_ctx *ctx);                                      /* after pgx_score_launch, asynchronous */
 int pgx_score_fetch_all(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
-                        double *scores);                                    /* nranks*M entries, rank-major */
+                        double *scores);                                    /* The same exchange, overlapped with the scoring of the NEXT batch (two batches in flight, slot = 0 / 1): _begin right behind
+ * pgx_score_launch copies the launch's result block aside and runs all-gather + copy to pinned memory on a second stream; _end
+ * waits for that slot and unpacks it like pgx_score_fetch_all (M = the launch's batch size).  Bitwise the serial results. */
+int pgx_score_allgather_begin(pgx_ctx *ctx, int slot);
+int pgx_score_allgather_end(pgx_ctx *ctx, int slot, int exponent, int64_t *counts, double *values, double *shared, double *scores);
+/* nranks*M entries, rank-major */
 int pgx_compound_allreduce_max(pgx_ctx *ctx);
 
 #ifdef __cplusplus

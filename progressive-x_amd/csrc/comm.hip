@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "pgx_internal.h"
@@ -58,10 +59,22 @@ static int load_rccl(pgx_ctx* ctx)
     return PGX_OK;
 }
 
+// One in-flight exchange (pgx_score_allgather_begin / _end): the (count | value | shared) block of a launch is copied aside on
+// the context's stream, all-gathered and copied into pinned memory on the EXCHANGE stream, so the next batch is scored meanwhile.
+struct ExchangeSlot {
+    DevBuf stage, gathered;
+    void* host = nullptr;
+    size_t host_cap = 0;
+    hipEvent_t scored = nullptr, done = nullptr;
+    int M = 0, Mpad = 0, has_compound = 0, busy = 0;
+};
+
 struct CommState {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     DevBuf tmp;
+    hipStream_t xstream = nullptr;
+    ExchangeSlot slot[2];
 };
 
 #define PGX_NCCL(ctx, call)                                                                              \
@@ -74,8 +87,17 @@ struct CommState {
 void comm_free(pgx_ctx* ctx)
 {
     if (!ctx->comm) return;
+    if (ctx->comm->xstream) (void)hipStreamSynchronize(ctx->comm->xstream);
     if (ctx->comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm->comm);
     release(ctx->comm->tmp);
+    for (ExchangeSlot& e : ctx->comm->slot) {
+        release(e.stage);
+        release(e.gathered);
+        if (e.host) (void)hipHostFree(e.host);
+        if (e.scored) (void)hipEventDestroy(e.scored);
+        if (e.done) (void)hipEventDestroy(e.done);
+    }
+    if (ctx->comm->xstream) (void)hipStreamDestroy(ctx->comm->xstream);
     delete ctx->comm;
     ctx->comm = nullptr;
 }
@@ -186,6 +208,67 @@ int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* val
                 // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
                 scores[r * M + m] = ctx->score_has_compound && !(s[m] == 0.0 && !std::signbit(s[m]) && exponent > 0)
                                         ? v[m] - std::pow(s[m], (double)exponent) : v[m];
+    }
+    return PGX_OK;
+}
+
+// ---- the same exchange, overlapped: two batches in flight ----------------------------------------------------------------------
+// begin(slot): right behind pgx_score_launch.  The result block is copied aside on the context's stream (48 KB, in order behind
+// the finish kernel: the next launch may overwrite the block at once), an event hands it to the exchange stream, which runs the
+// all-gather and the copy into the slot's pinned buffer.  end(slot) waits for that slot only and unpacks it.  Between the two
+// the caller uploads / generates and launches the NEXT batch: its scoring hides the exchange of this one (the all-gather of a
+// 48 KB block is latency - ~16-20 us with the copy - not bandwidth).  Results are those of pgx_score_allgather + _fetch_all.
+int pgx_score_allgather_begin(pgx_ctx* ctx, int slot)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: communicator not initialised");
+    if (slot < 0 || slot > 1) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: slot %d (0 or 1)", slot);
+    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: nothing launched");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    CommState* cs = ctx->comm;
+    ExchangeSlot& e = cs->slot[slot];
+    if (e.busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: slot %d is still in flight (call pgx_score_allgather_end)", slot);
+    if (!cs->xstream) PGX_HIP(ctx, hipStreamCreateWithFlags(&cs->xstream, hipStreamNonBlocking));
+    if (!e.scored) PGX_HIP(ctx, hipEventCreateWithFlags(&e.scored, hipEventDisableTiming));
+    if (!e.done) PGX_HIP(ctx, hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+    const size_t W = (size_t)3 * (size_t)ctx->Mpad, G = (size_t)cs->nranks, need = G * W * 8;
+    PGX_TRY(ensure(ctx, e.stage, W * 8));
+    PGX_TRY(ensure(ctx, e.gathered, need));
+    if (e.host_cap < need) {
+        if (e.host) (void)hipHostFree(e.host);
+        e.host = nullptr; e.host_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&e.host, need * 2, hipHostMallocDefault));
+        e.host_cap = need * 2;
+    }
+    PGX_HIP(ctx, hipMemcpyAsync(e.stage.p, ctx->counts.p, W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
+    PGX_HIP(ctx, hipStreamWaitEvent(cs->xstream, e.scored, 0));
+    PGX_NCCL(ctx, g_rccl.AllGather(e.stage.p, e.gathered.p, W, ncclInt64, cs->comm, cs->xstream));
+    PGX_HIP(ctx, hipMemcpyAsync(e.host, e.gathered.p, need, hipMemcpyDeviceToHost, cs->xstream));
+    PGX_HIP(ctx, hipEventRecord(e.done, cs->xstream));
+    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1;
+    return PGX_OK;
+}
+
+int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* counts, double* values, double* shared, double* scores)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_end: communicator not initialised");
+    if (slot < 0 || slot > 1 || !ctx->comm->slot[slot].busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_end: slot %d holds nothing", slot);
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    ExchangeSlot& e = ctx->comm->slot[slot];
+    PGX_HIP(ctx, hipEventSynchronize(e.done));
+    e.busy = 0;
+    const size_t M = (size_t)e.M, Mp = (size_t)e.Mpad, G = (size_t)ctx->comm->nranks;
+    for (size_t r = 0; r < G; ++r) {   // rank-major [M] rows out of [rank][3][Mpad]
+        const int64_t* c = (const int64_t*)e.host + r * 3 * Mp;
+        const double* v = (const double*)e.host + r * 3 * Mp + Mp;
+        const double* sh = (const double*)e.host + r * 3 * Mp + 2 * Mp;
+        if (counts) memcpy(counts + r * M, c, M * 8);
+        if (values) memcpy(values + r * M, v, M * 8);
+        if (shared) memcpy(shared + r * M, sh, M * 8);
+        if (scores)
+            for (size_t m = 0; m < M; ++m)
+                scores[r * M + m] = e.has_compound && !(sh[m] == 0.0 && !std::signbit(sh[m]) && exponent > 0)
+                                        ? v[m] - std::pow(sh[m], (double)exponent) : v[m];
     }
     return PGX_OK;
 }

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
-    "pgx_score_allgather", "pgx_score_fetch_all", "pgx_compound_allreduce_max",
+    "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
 ]
 
 
@@ -563,6 +563,23 @@ class Context:
         self._ck(self._lib.pgx_score_fetch_all(self._h, C.c_int(int(exponent)), _ptr(counts, C.c_int64),
                                                _ptr(values, C.c_double), _ptr(shared, C.c_double),
                                                _ptr(scores, C.c_double)), "pgx_score_fetch_all")
+        return dict(counts=counts, values=values, shared=shared, scores=scores)
+
+    def score_allgather_begin(self, slot):
+        """pgx_score_allgather_begin: the exchange of the launch just issued, on the exchange stream (slot 0 / 1)"""
+        self._ck(self._lib.pgx_score_allgather_begin(self._h, C.c_int(int(slot))), "pgx_score_allgather_begin")
+        self._slot_M = getattr(self, "_slot_M", {})
+        self._slot_M[int(slot)] = self.M
+
+    def score_allgather_end(self, slot, exponent=2):
+        T = self._slot_M[int(slot)] * self.nranks
+        counts = np.empty(T, dtype=np.int64)
+        values = np.empty(T, dtype=np.float64)
+        shared = np.empty(T, dtype=np.float64)
+        scores = np.empty(T, dtype=np.float64)
+        self._ck(self._lib.pgx_score_allgather_end(self._h, C.c_int(int(slot)), C.c_int(int(exponent)), _ptr(counts, C.c_int64),
+                                                   _ptr(values, C.c_double), _ptr(shared, C.c_double), _ptr(scores, C.c_double)),
+                 "pgx_score_allgather_end")
         return dict(counts=counts, values=values, shared=shared, scores=scores)
 
     def compound_allreduce_max(self):

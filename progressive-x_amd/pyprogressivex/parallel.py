@@ -203,6 +203,39 @@ class RcclExchange:
         self.ctx.score_launch(T2, has_compound=has_compound)
         return self.gather_scores(self.ctx, exponent)
 
+    # -- two batches in flight: the exchange of one overlaps the scoring of the next ------------------------------------------
+    def begin(self, slot, shard, T2, has_compound):
+        """upload + launch `shard`, start its exchange in `slot` (0 / 1) and return at once"""
+        self.ctx.score_upload(shard)
+        self.ctx.score_launch(T2, has_compound=has_compound)
+        self.ctx.score_allgather_begin(slot)
+
+    def end(self, slot, exponent):
+        """the rank-major table of the batch that was begun in `slot`"""
+        return self.ctx.score_allgather_end(slot, exponent)
+
+
+def score_shard_pipelined(exchange, shard, T2, has_compound, exponent, pieces=2):
+    """`exchange.score_shard(shard, ...)` with the shard cut into `pieces` consecutive parts whose exchanges overlap the scoring
+    of the following part (`begin` / `end`, two in flight).  Every hypothesis is scored independently of its batch, so the
+    rank-major table is bitwise the one `score_shard` returns."""
+    per = shard.shape[0]
+    pieces = max(1, min(int(pieces), per))
+    if pieces == 1 or not hasattr(exchange, "begin"):
+        return exchange.score_shard(shard, T2, has_compound, exponent)
+    cuts = [(per * k) // pieces for k in range(pieces + 1)]
+    tables = []
+    for k in range(pieces):
+        exchange.begin(k & 1, np.ascontiguousarray(shard[cuts[k]:cuts[k + 1]]), T2, has_compound)
+        if k >= 1:
+            tables.append(exchange.end((k - 1) & 1, exponent))
+    tables.append(exchange.end((pieces - 1) & 1, exponent))
+    out = {}
+    for key in ("counts", "values", "shared", "scores"):      # [rank][piece rows] per piece -> [rank][all rows of the rank]
+        parts = [np.asarray(t[key]).reshape(exchange.world, cuts[k + 1] - cuts[k]) for k, t in enumerate(tables)]
+        out[key] = np.concatenate(parts, axis=1).reshape(-1)
+    return out
+
 
 _process_exchange = None
 
@@ -283,6 +316,9 @@ def score_sharded(exchange, models, T2, has_compound=False, exponent=2):
     models = np.ascontiguousarray(models, dtype=np.float64)
     M = models.shape[0]
     shard, lo, hi = shard_hypotheses(models, exchange.world, exchange.rank)
-    gathered = exchange.score_shard(shard, T2, has_compound, exponent)
+    # two pieces in flight once a rank's shard is large enough for the second piece's scoring to hide the first one's exchange
+    comm_on = exchange.world > 1 or getattr(getattr(exchange, "ctx", None), "force_comm", False)
+    pieces = 2 if comm_on and shard.shape[0] >= 256 else 1
+    gathered = score_shard_pipelined(exchange, shard, T2, has_compound, exponent, pieces)
     keys = {k: gathered[k] for k in ("counts", "values", "shared", "scores")}
     return merge_gathered(keys, M, exchange.world)

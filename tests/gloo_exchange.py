@@ -27,3 +27,31 @@ class GlooExchange:
 
     def score_shard(self, shard, T2, has_compound, exponent):
         return self._gather(self.scorer(shard, T2, has_compound, exponent))
+
+    # -- the pipelined interface of RcclExchange (two batches in flight): begin() scores and starts an ASYNCHRONOUS all_gather,
+    #    end() waits for that slot only
+    def begin(self, slot, shard, T2, has_compound):
+        import torch
+        import torch.distributed as dist
+        local = self.scorer(shard, T2, has_compound, self._exponent)
+        self._inflight = getattr(self, "_inflight", {})
+        assert slot not in self._inflight, "slot still in flight"
+        work = {}
+        for key in ("counts", "values", "shared", "scores"):
+            t = torch.from_numpy(np.ascontiguousarray(local[key]))
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            h = dist.all_gather(parts, t, async_op=True) if self.world > 1 else None
+            work[key] = (h, parts if self.world > 1 else [t])
+        self._inflight[slot] = work
+
+    def end(self, slot, exponent):
+        import torch
+        work = self._inflight.pop(slot)
+        out = {}
+        for key, (h, parts) in work.items():
+            if h is not None:
+                h.wait()
+            out[key] = torch.cat(parts).numpy()
+        return out
+
+    _exponent = 2

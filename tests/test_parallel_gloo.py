@@ -36,6 +36,12 @@ best = parallel.select_best(table["scores"], table["counts"])
 assert best == parallel.select_best(full["scores"], full["counts"])
 shard, lo, hi = parallel.shard_hypotheses(models, world, rank)
 assert shard.shape[0] == 19 and np.isnan(shard[hi - lo:]).all()
+# two batches in flight (asynchronous all_gather per piece, the next piece scored meanwhile): bitwise the serial exchange
+serial = ex.score_shard(shard, T2, True, 2)
+for pieces in (2, 3, 19):
+    piped = parallel.score_shard_pipelined(ex, shard, T2, True, 2, pieces=pieces)
+    for k in ("counts", "values", "shared", "scores"):
+        assert np.array_equal(piped[k], serial[k], equal_nan=True), (pieces, k)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok best", best)
