@@ -107,6 +107,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_TILE_MULTI")) {   // 1: graphs beyond one workgroup on the tile path; 2 (tests): tiles for every graph, no hand-back
         const int v = std::atoi(b);
         ctx->tile_multi = v ? 1 : 0;
@@ -902,6 +903,14 @@ int pgx_expansion_stats(pgx_ctx* ctx, int64_t stats[8])
 {
     if (!ctx || !stats) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_stats: NULL argument");
     for (int k = 0; k < 8; ++k) stats[k] = ctx->stats[k];
+    return PGX_OK;
+}
+
+int pgx_expansion_paths(pgx_ctx* ctx, int64_t paths[6])
+{
+    if (!ctx || !paths) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_paths: NULL argument");
+    for (int k = 0; k < 6; ++k) paths[k] = ctx->paths[k];
+    paths[5] = ctx->tile_fallbacks;
     return PGX_OK;
 }
 

@@ -1138,11 +1138,26 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     tune.debug = ctx->tile_debug;
     tune.bfs_hint = st->bfs_hint;
     tune.source_reach = source_reach ? 1 : 0;
+    // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
+    // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
+    if (ctx->mf_region && !source_reach && wq == nullptr && pair && ctx->max_degree >= 1 && ctx->max_degree <= 32 && L <= 64 &&
+        n < ((int64_t)1 << 30)) {   // (the conditions under which expand_alpha_region runs its first kernel = the per-site initialisation)
+        be.count_and_setup(v);
+        if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
+        const int rr = expand_alpha_region(ctx, v, changed);   // (its first kernel is init_sites fused with the search for open sites)
+        if (rr != PGX_TILE_FALLBACK) {
+            if (rr == PGX_OK) { ctx->stats[0] += 1; ctx->paths[2] += 1; }
+            return rr;
+        }
+        ctx->paths[4] += 1;
+        tune.preinit = 1;
+    }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);
     if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
     if (r != 0)
         return fail(ctx, PGX_ERR_NOCONVERGE, "push-relabel did not converge within %d global relabels (alpha=%d)",
                     tune.max_relabels, alpha);
+    ctx->paths[3] += 1;
     return PGX_OK;
 }
 

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include "maxflow_body.cuh"
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -42,6 +43,7 @@ namespace {
 
 constexpr int kInf = 0x3fffffff;
 constexpr int kMaxL = 64;
+constexpr int kRegionCapTotal = 8192;   // open sites a region move takes (expand_alpha_region)
 
 
 #define SC_WG __HIP_MEMORY_SCOPE_WORKGROUP
@@ -52,6 +54,17 @@ template <int SC> __device__ __forceinline__ int ld32(const int* p) { return __h
 template <int SC> __device__ __forceinline__ void st32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SC); }
 template <int SC> __device__ __forceinline__ void add64(long long* p, long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, SC); }
 template <int SC> __device__ __forceinline__ long long xadd64(long long* p, long long v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, SC); }
+
+// what the region kernels leave for the solver (device memory)
+struct RegionInfo {
+    int count;        // open sites found (may exceed the capacity: then nothing was built)
+    int bad;          // a neighbouring sink could be saturated by the region's arcs: not handled here
+    int cnt_alpha;    // sites that already carry alpha
+    int pad;
+    long long pool[kMaxL];      // per label: sink capacity of the sites OUTSIDE the region
+    long long needsum[kMaxL];   // per label: capacity of the region's arcs into such sites
+    int hub[kMaxL];             // the label has a hub in this move
+};
 
 // state of one move in sorted ("tile") space
 struct TView {
@@ -80,6 +93,8 @@ struct TView {
     int T;             // sites per tile
     int lazy;          // relax accepts only substantial improvements of finite heights (several tiles)
     unsigned long long* dbg;   // [16] PGX_MF_DEBUG: time per phase of tile 0 (100 MHz ticks), or nullptr
+    const struct RegionInfo* rg;   // region mode (expand_alpha_region): the problem is PREPARED in the arrays above, n = rg->count
+    int alpha_apply;   // the label apply writes (= alpha; region mode: the move's label, alpha itself is the dummy 1)
 };
 
 // ---- per-move setup ----------------------------------------------------------------------------------------------------
@@ -692,7 +707,7 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
             // sweep - the next exact search settles that at once
             stall = mv ? 0 : stall + 1;
         }
-        if (stall >= (single ? 12 : 32)) break;
+        if (stall >= (single ? 6 : 32)) break;
         const int w = __syncthreads_or((worked || lds.nfar > 0) ? 1 : 0);
         if (!w) {
             if (single) break;
@@ -762,27 +777,47 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     const int tiles = (int)gridDim.x, tile = (int)blockIdx.x;
     const bool single = tiles == 1;
     const int base = tile * T;
+    const bool region = v.rg != nullptr;   // (one workgroup) the arrays hold a prepared problem of rg->count sites, no hubs
+    if (region) {
+        // two launches per region move: a 256-thread workgroup for regions of <= 1024 sites (nearly all of them; barriers over 4
+        // waves instead of 16), then this kernel with 1024 threads, which returns at once when the small one took the move
+        const int c = v.rg->count;
+        if (v.flags[6] != 0) return;        // (plain read: written by the previous kernel)
+        if (c > kRegionCapTotal || v.rg->bad) {   // not built / not valid: the caller runs the general path
+            if (tid == 0) st32<SC_AG>(&v.flags[5], 4);
+            return;
+        }
+        if (c > T) return;                  // too large for this workgroup: the next launch takes it
+        if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
+        v.n = c;
+    }
     const int tile_n = (int)((v.n - base) < T ? (v.n - base) : T);
-    // labels in tile space + histogram
-    if (tid < kMaxL) lds.hubmin[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < tile_n; i += NT) {
-        const int l = v.labels[v.perm[base + i]];
-        v.lab[base + i] = l;
-        atomicAdd(&lds.hubmin[l], 1);
+    int cnt_alpha = 0;
+    if (region) {
+        cnt_alpha = v.rg->cnt_alpha;
+        __syncthreads();
+    } else {
+        // labels in tile space + histogram
+        if (tid < kMaxL) lds.hubmin[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < tile_n; i += NT) {
+            const int l = v.labels[v.perm[base + i]];
+            v.lab[base + i] = l;
+            atomicAdd(&lds.hubmin[l], 1);
+        }
+        __syncthreads();
+        if (tid < v.L && lds.hubmin[tid] > 0) add32_ag(&v.cnt[tid], lds.hubmin[tid]);
+        grid_barrier(v, tiles);
+        if (tile == 0 && tid < v.L) {
+            const bool ex = v.h_q > 0 && tid != v.alpha && ld32<SC_AG>(&v.cnt[tid]) > 0;
+            st32<SC_AG>(&v.hub_exists[tid], ex ? 1 : 0);
+            __hip_atomic_store(&v.hub_e[tid], ex ? v.h_q : 0ll, __ATOMIC_RELAXED, SC_AG);
+            st32<SC_AG>(&v.hub_d[tid], kInf);
+        }
+        cnt_alpha = ld32<SC_AG>(&v.cnt[v.alpha]);
+        for (int i = tid; i < tile_n; i += NT) init_site(v, (int64_t)base + i, base, tile_n);
+        grid_barrier(v, tiles);
     }
-    __syncthreads();
-    if (tid < v.L && lds.hubmin[tid] > 0) add32_ag(&v.cnt[tid], lds.hubmin[tid]);
-    grid_barrier(v, tiles);
-    if (tile == 0 && tid < v.L) {
-        const bool ex = v.h_q > 0 && tid != v.alpha && ld32<SC_AG>(&v.cnt[tid]) > 0;
-        st32<SC_AG>(&v.hub_exists[tid], ex ? 1 : 0);
-        __hip_atomic_store(&v.hub_e[tid], ex ? v.h_q : 0ll, __ATOMIC_RELAXED, SC_AG);
-        st32<SC_AG>(&v.hub_d[tid], kInf);
-    }
-    const int cnt_alpha = ld32<SC_AG>(&v.cnt[v.alpha]);
-    for (int i = tid; i < tile_n; i += NT) init_site(v, (int64_t)base + i, base, tile_n);
-    grid_barrier(v, tiles);
     int rounds = 0, gave_up = 0, it = 0;
     long long hub_left_prev = -1;
     unsigned long long tprev = wall_clock64();
@@ -895,6 +930,12 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     }
     lap(7);
     int changed = 0;
+    if (!gave_up && region) {
+        // the hubs were left out: a label's hub drains into members outside the region as long as their sink capacity exceeds what
+        // the region's arcs can claim of it by h; otherwise the hub interacts with this cut and the general path has to solve it
+        for (int l = 0; l < kMaxL; ++l)
+            if (v.rg->hub[l] && v.rg->pool[l] - v.rg->needsum[l] < v.h_q) gave_up = 4;
+    }
     if (!gave_up) {
         bool apply = true;
         if (cnt_alpha == 0 && v.h_q > 0) {   // alpha is not in use: taking it costs h once (maxflow_body.cuh, gate)
@@ -907,7 +948,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
             int mine = 0;
             for (int i = tid; i < tile_n; i += NT) {
                 const int64_t s = (int64_t)base + i;
-                if (v.lab[s] != v.alpha && ld32<SC_AG>(&v.d[s]) == kInf) { v.labels[v.perm[s]] = v.alpha; ++mine; }   // cannot reach t => takes alpha
+                if (v.lab[s] != v.alpha && ld32<SC_AG>(&v.d[s]) == kInf) { v.labels[v.perm[s]] = v.alpha_apply; ++mine; }   // cannot reach t => takes alpha
             }
             __syncthreads();
             if (tid == 0) s_cnt = 0;
@@ -925,6 +966,150 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
             st32<SC_AG>(&v.flags[5], gave_up);
         }
     }
+}
+
+// ---- region moves: the few sites without a t-link, compacted, solved by one workgroup ------------------------------------------
+// In a steady-state move almost every active site has residual capacity to t (it prefers its label): such a site is level 1 of
+// every search and a sink for its neighbours.  What a search and the pushes actually work on are the OPEN sites - no t-link:
+// they hold excess or are relays - a few hundred to a few thousand of 10^5..10^6.  expand_alpha_region (after maxflow.hip has set
+// up t-links and arcs as always) numbers the open sites, builds their sub-graph in compact arrays (uniform row stride, reverse
+// arcs by position) and folds every arc into a site WITH a t-link into the open site's own t-link.  That is exact as long as such
+// a neighbour cannot be saturated by the region - sum of the region's arc capacities into it <= its sink capacity (checked on the
+// device for every neighbour) - and as long as every label's hub can drain outside the region (pool - needsum >= h, checked by the
+// solver): then all of them stay on the sink side whatever the region does.  The compact problem goes through t_move_kernel's
+// rounds in ONE workgroup, which also applies the cut; the host makes a single read-back per move.  Anything else - more than
+// 8192 open sites (a new instance taking its points), a saturable neighbour, a hub in play - is handed to the general path.
+constexpr int kRegionCap = 8192;
+
+// maxflow.hip's per-site initialisation (t-links, arcs) and, in the same pass, the search for the open sites: they are numbered
+// (slot / site), need[] is cleared, and the sink capacity outside the region is summed per label (pool)
+__global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo* __restrict__ rg, int* __restrict__ slot, int* __restrict__ site,
+                                                          long long* __restrict__ need)
+{
+    __shared__ unsigned long long s_pool[kMaxL];
+    if (threadIdx.x < kMaxL) s_pool[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = mv.n;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n + 255 - (n + 255) % 256; u += (int64_t)gridDim.x * 256) {
+        bool open = false;
+        if (u < n) {
+            mf_body_init_site(mv, u);
+            need[u] = 0;
+            const int lu = mv.labels[u];
+            const long long r = mv.rt[u];
+            open = lu != mv.alpha && r <= 0;
+            if (!open) slot[u] = -1;
+            if (lu != mv.alpha && r > 0) atomicAdd(&s_pool[lu], (unsigned long long)r);
+        }
+        const unsigned long long m = __ballot(open);
+        if (m) {
+            const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+            int b = 0;
+            if (lane == leader) b = atomicAdd(&rg->count, __popcll(m));
+            b = __shfl(b, leader, 64);
+            if (open) {
+                const int i = b + __popcll(m & ((1ull << lane) - 1ull));
+                slot[u] = i < kRegionCap ? i : -1;
+                if (i < kRegionCap) site[i] = (int)u;
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < mv.L && s_pool[threadIdx.x] > 0) atomicAdd((unsigned long long*)&rg->pool[threadIdx.x], s_pool[threadIdx.x]);
+    if (blockIdx.x == 0 && (int)threadIdx.x < kMaxL) {
+        rg->hub[threadIdx.x] = (int)threadIdx.x < mv.L ? mv.hub_exists[threadIdx.x] : 0;
+        if (threadIdx.x == 0) rg->cnt_alpha = mv.cnt[mv.alpha];
+    }
+}
+
+// Weak sinks join the region.  A neighbour q with a t-link stays outside only if the region's arcs cannot saturate it:
+// need[q] = sum of the capacities of the region's arcs into q <= rt[q].  One workgroup walks the region in rounds: the members
+// of the round add their arcs' capacities to need[]; the add that crosses rt[q] makes q a member (it is appended and walked in
+// the next round), until a round promotes nobody.  (A member that is promoted while a neighbour still adds to its need is harmless:
+// need[] of a member is never read.)  Whatever still violates need <= rt after kPromoteRounds is caught by r_build_kernel.
+constexpr int kPromoteRounds = 16;
+
+__global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict__ rg, int alpha, const int* __restrict__ labels,
+                                                         const int* __restrict__ off, const int* __restrict__ idx, const long long* __restrict__ cap,
+                                                         const long long* __restrict__ rt, int* __restrict__ slot, int* __restrict__ site,
+                                                         long long* __restrict__ need)
+{
+    __shared__ int s_hi;
+    int lo = 0;
+    if (threadIdx.x == 0) s_hi = ld32<SC_AG>(&rg->count);
+    __syncthreads();
+    int hi = s_hi;
+    if (hi > kRegionCap) return;
+    for (int round = 0; round < kPromoteRounds && lo < hi; ++round) {
+        for (int i = lo + (int)threadIdx.x; i < hi; i += 1024) {
+            const int u = ld32<SC_AG>(&site[i]);
+            for (int a = off[u]; a < off[u + 1]; ++a) {
+                const long long c = cap[a];
+                const int q = idx[a];
+                if (c <= 0 || labels[q] == alpha || ld32<SC_AG>(&slot[q]) >= 0) continue;
+                const long long old = xadd64<SC_AG>(&need[q], c), r = rt[q];
+                if (old <= r && old + c > r) {   // this add crossed the neighbour's sink capacity: exactly one add does
+                    const int j = __hip_atomic_fetch_add(&rg->count, 1, __ATOMIC_RELAXED, SC_AG);
+                    if (j < kRegionCap) { st32<SC_AG>(&site[j], q); st32<SC_AG>(&slot[q], j); }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) s_hi = ld32<SC_AG>(&rg->count);
+        __syncthreads();
+        lo = hi;
+        hi = s_hi;
+        if (hi > kRegionCap) return;
+        __syncthreads();
+    }
+}
+
+// one thread per region site: its row in the compact graph; arcs into sites outside the region (all of them keep a t-link) are
+// folded into the site's own t-link, and every such neighbour is checked: need <= rt, else the region is not valid (bad)
+__global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ rg, int alpha, int stride, const int* __restrict__ labels,
+                                                      const int* __restrict__ off, const int* __restrict__ idx, const int* __restrict__ rev,
+                                                      const long long* __restrict__ cap, const long long* __restrict__ ex, const long long* __restrict__ rt,
+                                                      const int* __restrict__ slot, const int* __restrict__ site, const long long* __restrict__ need, TView c)
+{
+    const int count = rg->count;
+    if (count > kRegionCap) return;
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= count) return;
+    const int u = site[i];
+    const int a0 = off[u], deg = off[u + 1] - a0, base = i * stride;
+    const long long own = rt[u];
+    long long rtc = own;
+    bool bad = false;
+    for (int j = 0; j < stride; ++j) {
+        int head = i, r = base + j;
+        long long cc = 0;
+        if (j < deg) {
+            const int a = a0 + j, q = idx[a];
+            const long long ca = cap[a];
+            const int sq = slot[q];
+            if (sq >= 0) { head = sq; cc = ca; r = sq * stride + (rev[a] - off[q]); }
+            else if (ca > 0 && labels[q] != alpha) {   // a neighbour that keeps its t-link whatever the region does: as good as t
+                rtc += ca;
+                bad |= need[q] > rt[q];
+                atomicAdd((unsigned long long*)&rg->needsum[labels[q]], (unsigned long long)ca);
+            }
+        }
+        const_cast<int*>(c.idx)[base + j] = head;
+        const_cast<int*>(c.rev)[base + j] = r;
+        c.cap[base + j] = cc;
+    }
+    if (bad) rg->bad = 1;
+    if (own > 0) atomicAdd((unsigned long long*)&rg->pool[labels[u]], (unsigned long long)(-own));   // a promoted sink is not part of the pool
+    const_cast<int*>(c.off)[i] = base;
+    const_cast<int*>(c.off)[i + 1] = base + stride;
+    const long long e = ex[u];
+    if (e >= rtc) { c.ex[i] = e - rtc; c.rt[i] = 0; }   // (only an open site has e > 0, and then own = 0)
+    else { c.ex[i] = 0; c.rt[i] = rtc - e; }
+    c.f[i] = 0;
+    c.inbox[i] = 0;
+    c.d[i] = kInf;
+    c.lab[i] = 0;
 }
 
 // ---- the graph in tile space ---------------------------------------------------------------------------------------------
@@ -969,6 +1154,8 @@ struct TileState {
     int64_t version = -1;     // graph_version this copy was built from
     DevBuf perm, inv, off, idx, rev, mult, tmp;
     DevBuf cap, ex, inbox, rt, f, d, lab, small, epoch, dbg;
+    DevBuf rg_slot, rg_need, rg_site, rg_off, rg_idx, rg_rev, rg_cap, rg_site_state;   // region moves (expand_alpha_region)
+    long long region_moves = 0, region_rejects = 0;
     unsigned long long dbg_acc[16] = {0};
     long long dbg_moves = 0;
     void* h_small = nullptr;  // pinned mirror of the small block
@@ -979,7 +1166,8 @@ void tile_free(pgx_ctx* ctx)
     TileState* ts = ctx->tile;
     if (!ts) return;
     DevBuf* all[] = {&ts->perm, &ts->inv, &ts->off, &ts->idx, &ts->rev, &ts->mult, &ts->tmp, &ts->cap, &ts->ex, &ts->inbox,
-                     &ts->rt, &ts->f, &ts->d, &ts->lab, &ts->small, &ts->epoch, &ts->dbg};
+                     &ts->rt, &ts->f, &ts->d, &ts->lab, &ts->small, &ts->epoch, &ts->dbg,
+                     &ts->rg_slot, &ts->rg_need, &ts->rg_site, &ts->rg_off, &ts->rg_idx, &ts->rg_rev, &ts->rg_cap, &ts->rg_site_state};
     for (DevBuf* b : all) release(*b);
     if (ts->h_small) (void)hipHostFree(ts->h_small);
     delete ts;
@@ -1068,9 +1256,9 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     PGX_TRY(ensure(ctx, ts->f, (size_t)n * 8));
     PGX_TRY(ensure(ctx, ts->d, (size_t)n * 4));
     PGX_TRY(ensure(ctx, ts->lab, (size_t)n * 4));
-    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes));
+    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes + sizeof(RegionInfo)));
     PGX_TRY(ensure(ctx, ts->epoch, (size_t)(2 * tiles + 2) * 4));   // tile epochs | hub epoch | global epoch | acknowledgements
-    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes, hipHostMallocDefault));
+    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes + sizeof(RegionInfo), hipHostMallocDefault));
     char* sp = (char*)ts->small.p;
     TView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
@@ -1094,6 +1282,8 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     v.hub_epoch = ts->epoch.as<int>() + tiles;
     v.T = one ? (int)n : T;
     v.lazy = one ? 0 : ctx->tile_lazy;
+    v.rg = nullptr;
+    v.alpha_apply = alpha;
     *changed = 0;
     v.dbg = nullptr;
     if (ctx->tile_debug) {
@@ -1134,6 +1324,85 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     }
     if (h_flags[5] != 0 || h_flags[7] != 0) return PGX_TILE_FALLBACK;
     ctx->stats[0] += 1;
+    ctx->paths[one ? 0 : 1] += 1;
+    ctx->stats[2] += h_flags[4];
+    *changed = h_flags[1];
+    ctx->stats[4] += *changed;
+    return PGX_OK;
+}
+
+// One expansion move through the region path.  `mv` = the move as maxflow.hip has set it up (count_and_setup has run on the
+// context's stream; the per-site initialisation - t-links, arcs, hubs - is this function's first kernel, fused with the search
+// for open sites).  PGX_OK: done, *changed set.  PGX_TILE_FALLBACK: declined - the labels are untouched and mv's state is
+// initialised and intact, the general path continues from it.  The caller checks the applicability conditions of the first
+// line (maxflow.hip): when they fail nothing has been initialised.
+int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
+{
+    const int64_t n = mv.n;
+    const int stride = ctx->max_degree;
+    if (stride < 1 || stride > 32 || mv.L > kMaxL || n >= ((int64_t)1 << 30)) return PGX_TILE_FALLBACK;
+    if (!ctx->tile) ctx->tile = new TileState();
+    TileState* ts = ctx->tile;
+    const size_t C = kRegionCap, A = C * (size_t)stride;
+    PGX_TRY(ensure(ctx, ts->rg_slot, (size_t)n * 4));
+    PGX_TRY(ensure(ctx, ts->rg_need, (size_t)n * 8));
+    PGX_TRY(ensure(ctx, ts->rg_site, C * 4));
+    PGX_TRY(ensure(ctx, ts->rg_off, (C + 1) * 4));
+    PGX_TRY(ensure(ctx, ts->rg_idx, A * 4));
+    PGX_TRY(ensure(ctx, ts->rg_rev, A * 4));
+    PGX_TRY(ensure(ctx, ts->rg_cap, A * 8));
+    PGX_TRY(ensure(ctx, ts->rg_site_state, C * (8 * 4 + 4 * 2)));   // ex | rt | f | inbox (i64) | d | lab (i32)
+    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes + sizeof(RegionInfo)));   // the small block and the region info: one fill, one copy back
+    PGX_TRY(ensure(ctx, ts->epoch, 64));
+    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes + sizeof(RegionInfo), hipHostMallocDefault));
+    char* sp = (char*)ts->small.p;
+    TView v;
+    v.n = 0; v.L = 2; v.alpha = 1; v.alpha_apply = mv.alpha; v.lambda_q = mv.lambda_q; v.h_q = mv.h_q;
+    v.dq = nullptr; v.labels = mv.labels;
+    v.perm = ts->rg_site.as<int>();
+    v.off = ts->rg_off.as<int>(); v.idx = ts->rg_idx.as<int>(); v.rev = ts->rg_rev.as<int>(); v.mult = nullptr;
+    v.cap = ts->rg_cap.as<long long>();
+    long long* st8 = ts->rg_site_state.as<long long>();
+    v.ex = st8; v.rt = st8 + C; v.f = st8 + 2 * C; v.inbox = st8 + 3 * C;
+    v.d = (int*)(st8 + 4 * C); v.lab = v.d + C;
+    v.hub_e = (long long*)(sp + SmallLayout::hub_e);
+    v.stuck = (unsigned long long*)(sp + SmallLayout::stuck);
+    v.hub_d = (int*)(sp + SmallLayout::hub_d);
+    v.hub_exists = (int*)(sp + SmallLayout::hub_exists);
+    v.cnt = (int*)(sp + SmallLayout::cnt);
+    v.rchg = (int*)(sp + SmallLayout::rchg);
+    v.act = (int*)(sp + SmallLayout::act);
+    v.bar = (int*)(sp + SmallLayout::bar);
+    v.busy = (int*)(sp + SmallLayout::busy);
+    v.flags = (int*)(sp + SmallLayout::flags);
+    v.epoch = ts->epoch.as<int>();
+    v.hub_epoch = ts->epoch.as<int>() + 1;
+    v.T = kRegionCap;
+    v.lazy = 0;
+    v.dbg = nullptr;
+    RegionInfo* rg = (RegionInfo*)(sp + SmallLayout::bytes);
+    v.rg = rg;
+    *changed = 0;
+    PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes + sizeof(RegionInfo), ctx->stream));
+    const unsigned nb = (unsigned)((n + 255) / 256), agg = nb < 1024u ? nb : 1024u;
+    hipLaunchKernelGGL(r_init_mark_kernel, dim3(agg), dim3(256), 0, ctx->stream, mv, rg, ts->rg_slot.as<int>(), ts->rg_site.as<int>(),
+                       ts->rg_need.as<long long>());
+    hipLaunchKernelGGL(r_promote_kernel, dim3(1), dim3(1024), 0, ctx->stream, rg, mv.alpha, mv.labels, mv.off, mv.idx, mv.cap, mv.rt,
+                       ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>());
+    hipLaunchKernelGGL(r_build_kernel, dim3(kRegionCap / 256), dim3(256), 0, ctx->stream, rg, mv.alpha, stride, mv.labels, mv.off, mv.idx, mv.rev,
+                       mv.cap, mv.ex, mv.rt, ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), v);
+    hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
+    hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
+    PGX_HIP(ctx, hipGetLastError());
+    char* hs = (char*)ts->h_small;
+    PGX_HIP(ctx, hipMemcpyAsync(hs, sp, SmallLayout::bytes + 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int* h_flags = (const int*)(hs + SmallLayout::flags);
+    const int* h_rg = (const int*)(hs + SmallLayout::bytes);
+    if (ctx->tile_debug >= 2)
+        std::fprintf(stderr, "[region] alpha=%d open=%d bad=%d rounds=%d gave_up=%d changed=%d\n", mv.alpha, h_rg[0], h_rg[1], h_flags[4], h_flags[5], h_flags[1]);
+    if (h_flags[5] != 0 || h_flags[7] != 0) { ts->region_rejects += 1; return PGX_TILE_FALLBACK; }
+    ts->region_moves += 1;
     ctx->stats[2] += h_flags[4];
     *changed = h_flags[1];
     ctx->stats[4] += *changed;

@@ -108,10 +108,12 @@ struct pgx_ctx {
     int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
     int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
+    int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
     int tile_multi = 0;          // PGX_TILE_MULTI=1: graphs beyond one workgroup on the tile path too (measured slower: opt-in)
     int tile_hard_div = 64;      // a move with more than n / this sites holding excess that reaches t goes to maxflow.hip (0 = never)
     int tile_lazy = 1;           // multi-tile searches accept only substantial improvements of finite heights (maxflow_tile.hip)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
+    int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
     int64_t tile_fallbacks = 0;  // moves the tile path handed back to maxflow.hip
     int tile_debug = 0;          // PGX_MF_DEBUG: one stderr line per global relabel
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -202,6 +204,8 @@ constexpr int PGX_TILE_FALLBACK = 1000;   // expand_alpha_tile: not handled, run
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha,
                       int64_t* changed);
 void tile_free(pgx_ctx* ctx);
+struct MfView;
+int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed);   // maxflow_tile.hip: a move with few open sites, one workgroup
 void comm_free(pgx_ctx* ctx);
 
 }  // namespace pgx

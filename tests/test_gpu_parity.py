@@ -8,7 +8,7 @@ compound max) are required to be bit-identical: the kernels use the oracle's ope
 import numpy as np
 import pytest
 
-from helpers import (MODEL_CASES, make_case, random_sym_graph, realistic_labeling_problem)
+from helpers import (MODEL_CASES, csr_from_pairs, make_case, random_sym_graph, realistic_labeling_problem)
 from pyprogressivex import _lib, datasets
 
 pytestmark = pytest.mark.gpu
@@ -571,6 +571,7 @@ def mincut_ctx(request, monkeypatch):
     for key, val in MINCUT_PATHS[request.param].items():
         monkeypatch.setenv(key, val)
     ctx = _lib.Context(0)
+    ctx.path_name = request.param
     yield ctx
     ctx.close()
 
@@ -625,6 +626,75 @@ def test_full_expansion_matches_oracle(mincut_ctx, oracle, n, lam, h):
     assert eq2 == eq and cycles2 == 1 and np.array_equal(gpu_ctx.get_labels(), ref_labels)
     st = gpu_ctx.expansion_stats()
     assert st["relabelled_sites"] == 0
+
+
+@pytest.mark.parametrize("mincut_ctx", list(MINCUT_PATHS), indirect=True)
+def test_each_mincut_path_is_the_one_that_ran(mincut_ctx, oracle):
+    # pgx_expansion_paths: the schedule a fixture asks for must be the one that solved the moves
+    Dq, graph = realistic_labeling_problem(3000, L=4, lam=0.2, seed=5)
+    mincut_ctx.set_unary_q(Dq)
+    mincut_ctx.set_graph(*graph)
+    mincut_ctx.set_labels(np.zeros(3000, np.int32))
+    mincut_ctx.expansion(0.2, 3.0)
+    paths = mincut_ctx.expansion_paths()
+    assert paths[mincut_ctx.path_name] > 0
+    if mincut_ctx.path_name == "one_workgroup":
+        assert paths["level_synchronous"] == 0 and paths["tiles"] == 0 and paths["tile_handed_back"] == 0
+
+
+@pytest.mark.parametrize("n,lam,h,L", [(30000, 0.15, 4.0, 6), (60000, 0.3, 0.0, 5), (60000, 0.05, 12.0, 9)])
+def test_region_moves_match_oracle(oracle, monkeypatch, n, lam, h, L):
+    """Graphs beyond the one-workgroup limit: a move whose OPEN sites (no t-link left after the source / sink saturation)
+    number <= 8192 is solved by one workgroup on their compacted sub-graph (maxflow_tile.hip expand_alpha_region), the rest by
+    maxflow.hip - the labels, energy and cycle count are the oracle's either way, and with the region path switched off."""
+    Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=n + L)
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
+    seen = {}
+    for region in ("1", "0"):
+        monkeypatch.setenv("PGX_MF_REGION", region)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(np.zeros(n, np.int32))
+            eq, _, cycles = ctx.expansion(lam, h)
+            assert np.array_equal(ctx.get_labels(), ref_labels) and eq == ref_e and cycles == ref_cycles
+            seen[region] = ctx.expansion_paths()
+        finally:
+            ctx.close()
+    assert seen["1"]["region"] > 0 and seen["1"]["one_workgroup"] == 0
+    assert seen["0"]["region"] == 0 and seen["0"]["level_synchronous"] > 0
+
+
+def test_region_moves_decline_wide_graphs(oracle):
+    """A graph with a site of more than 32 neighbours: the region path's arc rows do not fit, every move goes to maxflow.hip
+    (which must then initialise the move itself - the regression of the fused initialisation)."""
+    rng = np.random.default_rng(9)
+    n, L, lam, h = 12000, 4, 0.2, 2.0
+    Dq, (off, idx, mult) = realistic_labeling_problem(n, L=L, lam=lam, seed=99)
+    src = np.repeat(np.arange(n), np.diff(off))
+    iu, ju, mu = src[src < idx], idx[src < idx], mult[src < idx]
+    for hub in (17, 5000):   # two stars of ~60 arcs each
+        spokes = np.setdiff1d(rng.choice(n, 60, replace=False), np.concatenate([[hub], idx[off[hub]:off[hub + 1]]]))
+        iu = np.concatenate([iu, np.minimum(hub, spokes)])
+        ju = np.concatenate([ju, np.maximum(hub, spokes)])
+        mu = np.concatenate([mu, np.ones(spokes.size, mu.dtype)])
+    graph = csr_from_pairs(n, iu, ju, mu)
+    assert np.diff(graph[0]).max() > 32
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_unary_q(Dq)
+        ctx.set_graph(*graph)
+        ctx.set_labels(np.zeros(n, np.int32))
+        eq, _, cycles = ctx.expansion(lam, h)
+        assert np.array_equal(ctx.get_labels(), ref_labels) and eq == ref_e and cycles == ref_cycles
+        paths = ctx.expansion_paths()
+        assert paths["region"] == 0 and paths["region_declined"] == 0 and paths["level_synchronous"] > 0
+    finally:
+        ctx.close()
 
 
 def test_expansion_energy_never_increases(gpu_ctx, oracle):
