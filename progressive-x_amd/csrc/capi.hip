@@ -865,6 +865,58 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
             std::vector<int> ev((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
             PGX_TRY(expand_cycle_l0(ctx, hq, ch.data(), ev.data()));
             for (int alpha = 0; alpha < ctx->L; ++alpha) changed_total += ch[(size_t)alpha];
+        } else if (region_moves_apply(ctx) && !(ctx->mf_tile && (ctx->dq_n <= ctx->tile_single_max || ctx->tile_multi))) {
+            // Region moves (maxflow_tile.hip): the moves of the cycle are enqueued back to back and resolved together - one
+            // host round trip per batch instead of one per move.  A move that declines poisons the rest of its batch on the device
+            // (they return untouched); it is solved by the general path and the cycle resumes behind it.  The skip rule below is
+            // applied on the device for moves behind others of the same batch (their outcome is not known when they are enqueued).
+            int alpha = 0;
+            std::vector<int> batch;
+            while (alpha < ctx->L) {
+                batch.clear();
+                PGX_TRY(region_batch_begin(ctx));
+                const int64_t version0 = version;
+                int rc = PGX_OK;
+                for (int a = alpha; a < ctx->L && rc == PGX_OK; ++a) {
+                    if (batch.empty() && noop_at[a] == version) { ctx->stats[7]++; alpha = a + 1; continue; }   // (known now: nothing is in flight)
+                    ctx->region_defer = 1;
+                    ctx->region_slot = (int)batch.size();
+                    ctx->region_skip_rel = noop_at[a] >= version0 ? (int)(noop_at[a] - version0) : -1;
+                    int64_t ch = 0;
+                    rc = expand_alpha_launch(ctx, lq, hq, a, &ch);
+                    ctx->region_defer = 0;
+                    if (rc == PGX_REGION_PENDING) { batch.push_back(a); rc = PGX_OK; }
+                    else if (rc == PGX_OK) rc = fail(ctx, PGX_ERR_INVALID, "pgx_expansion: a batched move was not enqueued");
+                }
+                if (rc != PGX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+                if (batch.empty()) break;
+                PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                int next = ctx->L;
+                for (size_t k = 0; k < batch.size(); ++k) {
+                    const int a = batch[k];
+                    int status = 0;
+                    int64_t ch = 0;
+                    PGX_TRY(region_result(ctx, (int)k, a, &status, &ch));
+                    if (status == 2) {   // the device applied the skip rule
+                        if (noop_at[a] != version) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: move %d of a batch did not run", a);
+                        ctx->stats[7]++;
+                        continue;
+                    }
+                    if (status == 1) {   // declined: the general path, then a new batch behind it
+                        const int keep = ctx->mf_region;
+                        ctx->mf_region = 0;
+                        const int r1 = expand_alpha_launch(ctx, lq, hq, a, &ch);
+                        ctx->mf_region = keep;
+                        PGX_TRY(r1);
+                        next = a + 1;
+                    }
+                    changed_total += ch;
+                    if (ch > 0) { ++version; noop_at[a] = -1; }
+                    else noop_at[a] = version;
+                    if (status == 1) break;
+                }
+                alpha = next;
+            }
         } else
         for (int alpha = 0; alpha < ctx->L; ++alpha) {
             // a move is a deterministic function of (labelling, alpha): one that relabelled nothing and has seen no

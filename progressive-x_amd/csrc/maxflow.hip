@@ -1056,6 +1056,13 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     return expand_alpha_on(ctx, n, L, ctx->dq.as<long long>(), ctx->labels.as<int>(), nullptr, lambda_q, h_q, alpha, changed);
 }
 
+// Region moves (maxflow_tile.hip expand_alpha_region) apply to the resident problem: a graph whose rows fit the compact arrays,
+// beyond the one-workgroup size (smaller graphs are solved whole), at most 64 labels.
+bool region_moves_apply(const pgx_ctx* ctx)
+{
+    return ctx->mf_region && ctx->max_degree >= 1 && ctx->max_degree <= 32 && ctx->L <= 64 && ctx->gn < ((int64_t)1 << 30);
+}
+
 // One expansion move on caller-chosen tables: dq [L][n] label-major, labels [n], and optionally per-arc weights wq [E]
 // (used by the binary inlier/outlier cut of gclo.hip, whose pairwise weights depend on both end points).
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq,
@@ -1140,16 +1147,11 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     tune.source_reach = source_reach ? 1 : 0;
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
-    if (ctx->mf_region && !source_reach && wq == nullptr && pair && ctx->max_degree >= 1 && ctx->max_degree <= 32 && L <= 64 &&
-        n < ((int64_t)1 << 30)) {   // (the conditions under which expand_alpha_region runs its first kernel = the per-site initialisation)
+    if (!source_reach && wq == nullptr && pair && L <= 64 && region_moves_apply(ctx)) {   // (then expand_alpha_region runs its first kernel = the per-site initialisation)
         be.count_and_setup(v);
         if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
         const int rr = expand_alpha_region(ctx, v, changed);   // (its first kernel is init_sites fused with the search for open sites)
-        if (rr != PGX_TILE_FALLBACK) {
-            if (rr == PGX_OK) { ctx->stats[0] += 1; ctx->paths[2] += 1; }
-            return rr;
-        }
-        ctx->paths[4] += 1;
+        if (rr != PGX_TILE_FALLBACK) return rr;   // solved, enqueued (PGX_REGION_PENDING) or an error
         tune.preinit = 1;
     }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);

@@ -66,6 +66,19 @@ struct RegionInfo {
     int hub[kMaxL];             // the label has a hub in this move
 };
 
+// Region moves of one expansion cycle are enqueued back to back, the host reads all results at the end (pgx_expansion).  Two
+// words in device memory keep that exact:  ctl[0] "poison" - a move declined (the general path has to solve it): every later move
+// of the batch returns at once, untouched, and is enqueued again after the host has solved the declined one;  ctl[1] - the moves
+// of the batch that relabelled sites so far: a move that relabelled nothing last time and has seen no relabelling since would
+// relabel nothing again (it is a function of the labelling and alpha) and returns at once (the host's skip rule, capi.hip).
+// Both words are only written by the LAST kernel of a move, so all kernels of a move decide alike.
+__device__ __forceinline__ bool batch_skips(const int* ctl, int skip_rel)
+{
+    if (ctl == nullptr) return false;
+    if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    return skip_rel >= 0 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == skip_rel;
+}
+
 // state of one move in sorted ("tile") space
 struct TView {
     int64_t n;
@@ -94,6 +107,8 @@ struct TView {
     int lazy;          // relax accepts only substantial improvements of finite heights (several tiles)
     unsigned long long* dbg;   // [16] PGX_MF_DEBUG: time per phase of tile 0 (100 MHz ticks), or nullptr
     const struct RegionInfo* rg;   // region mode (expand_alpha_region): the problem is PREPARED in the arrays above, n = rg->count
+    int* ctl;          // region moves enqueued without a host round trip (BatchCtl below), or nullptr
+    int skip_rel;      // ... this move relabels nothing if exactly this many moves of the batch have relabelled sites so far (-1: unknown)
     int alpha_apply;   // the label apply writes (= alpha; region mode: the move's label, alpha itself is the dummy 1)
 };
 
@@ -781,10 +796,14 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     if (region) {
         // two launches per region move: a 256-thread workgroup for regions of <= 1024 sites (nearly all of them; barriers over 4
         // waves instead of 16), then this kernel with 1024 threads, which returns at once when the small one took the move
-        const int c = v.rg->count;
         if (v.flags[6] != 0) return;        // (plain read: written by the previous kernel)
+        if (batch_skips(v.ctl, v.skip_rel)) return;
+        const int c = v.rg->count;
         if (c > kRegionCapTotal || v.rg->bad) {   // not built / not valid: the caller runs the general path
-            if (tid == 0) st32<SC_AG>(&v.flags[5], 4);
+            if (tid == 0) {
+                st32<SC_AG>(&v.flags[5], 4);
+                if (v.ctl) st32<SC_AG>(&v.ctl[0], 1);
+            }
             return;
         }
         if (c > T) return;                  // too large for this workgroup: the next launch takes it
@@ -965,6 +984,10 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
             st32<SC_AG>(&v.flags[4], rounds + 1);
             st32<SC_AG>(&v.flags[5], gave_up);
         }
+        if (region && v.ctl) {   // (one workgroup)
+            if (gave_up) st32<SC_AG>(&v.ctl[0], 1);
+            else if (changed) add32_ag(&v.ctl[1], 1);
+        }
     }
 }
 
@@ -984,9 +1007,10 @@ constexpr int kRegionCap = 8192;
 // maxflow.hip's per-site initialisation (t-links, arcs) and, in the same pass, the search for the open sites: they are numbered
 // (slot / site), need[] is cleared, and the sink capacity outside the region is summed per label (pool)
 __global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo* __restrict__ rg, int* __restrict__ slot, int* __restrict__ site,
-                                                          long long* __restrict__ need)
+                                                          long long* __restrict__ need, const int* __restrict__ ctl, int skip_rel)
 {
     __shared__ unsigned long long s_pool[kMaxL];
+    if (batch_skips(ctl, skip_rel)) return;
     if (threadIdx.x < kMaxL) s_pool[threadIdx.x] = 0;
     __syncthreads();
     const int64_t n = mv.n;
@@ -1032,9 +1056,10 @@ constexpr int kPromoteRounds = 16;
 __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict__ rg, int alpha, const int* __restrict__ labels,
                                                          const int* __restrict__ off, const int* __restrict__ idx, const long long* __restrict__ cap,
                                                          const long long* __restrict__ rt, int* __restrict__ slot, int* __restrict__ site,
-                                                         long long* __restrict__ need)
+                                                         long long* __restrict__ need, const int* __restrict__ ctl, int skip_rel)
 {
     __shared__ int s_hi;
+    if (batch_skips(ctl, skip_rel)) return;
     int lo = 0;
     if (threadIdx.x == 0) s_hi = ld32<SC_AG>(&rg->count);
     __syncthreads();
@@ -1072,6 +1097,7 @@ __global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ r
                                                       const long long* __restrict__ cap, const long long* __restrict__ ex, const long long* __restrict__ rt,
                                                       const int* __restrict__ slot, const int* __restrict__ site, const long long* __restrict__ need, TView c)
 {
+    if (batch_skips(c.ctl, c.skip_rel)) return;
     const int count = rg->count;
     if (count > kRegionCap) return;
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -1155,6 +1181,8 @@ struct TileState {
     DevBuf perm, inv, off, idx, rev, mult, tmp;
     DevBuf cap, ex, inbox, rt, f, d, lab, small, epoch, dbg;
     DevBuf rg_slot, rg_need, rg_site, rg_off, rg_idx, rg_rev, rg_cap, rg_site_state;   // region moves (expand_alpha_region)
+    DevBuf rg_small, rg_ctl;  // kRegionSlots small blocks (one per move in flight) and the batch's control words
+    void* h_rg = nullptr;     // pinned: what the host reads of each slot
     long long region_moves = 0, region_rejects = 0;
     unsigned long long dbg_acc[16] = {0};
     long long dbg_moves = 0;
@@ -1167,9 +1195,11 @@ void tile_free(pgx_ctx* ctx)
     if (!ts) return;
     DevBuf* all[] = {&ts->perm, &ts->inv, &ts->off, &ts->idx, &ts->rev, &ts->mult, &ts->tmp, &ts->cap, &ts->ex, &ts->inbox,
                      &ts->rt, &ts->f, &ts->d, &ts->lab, &ts->small, &ts->epoch, &ts->dbg,
-                     &ts->rg_slot, &ts->rg_need, &ts->rg_site, &ts->rg_off, &ts->rg_idx, &ts->rg_rev, &ts->rg_cap, &ts->rg_site_state};
+                     &ts->rg_slot, &ts->rg_need, &ts->rg_site, &ts->rg_off, &ts->rg_idx, &ts->rg_rev, &ts->rg_cap, &ts->rg_site_state,
+                     &ts->rg_small, &ts->rg_ctl};
     for (DevBuf* b : all) release(*b);
     if (ts->h_small) (void)hipHostFree(ts->h_small);
+    if (ts->h_rg) (void)hipHostFree(ts->h_rg);
     delete ts;
     ctx->tile = nullptr;
 }
@@ -1282,7 +1312,7 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     v.hub_epoch = ts->epoch.as<int>() + tiles;
     v.T = one ? (int)n : T;
     v.lazy = one ? 0 : ctx->tile_lazy;
-    v.rg = nullptr;
+    v.rg = nullptr; v.ctl = nullptr; v.skip_rel = -1;
     v.alpha_apply = alpha;
     *changed = 0;
     v.dbg = nullptr;
@@ -1336,6 +1366,10 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
 // for open sites).  PGX_OK: done, *changed set.  PGX_TILE_FALLBACK: declined - the labels are untouched and mv's state is
 // initialised and intact, the general path continues from it.  The caller checks the applicability conditions of the first
 // line (maxflow.hip): when they fail nothing has been initialised.
+constexpr int kRegionSlots = 64;   // moves in flight per batch (one per label: kMaxL)
+constexpr size_t kRegionBlock = (SmallLayout::bytes + sizeof(RegionInfo) + 255) / 256 * 256;   // a move's small block + region info
+constexpr size_t kRegionHost = 64;  // per slot on the host: flags[8] | count, bad, cnt_alpha, pad
+
 int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
 {
     const int64_t n = mv.n;
@@ -1343,6 +1377,9 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     if (stride < 1 || stride > 32 || mv.L > kMaxL || n >= ((int64_t)1 << 30)) return PGX_TILE_FALLBACK;
     if (!ctx->tile) ctx->tile = new TileState();
     TileState* ts = ctx->tile;
+    const bool defer = ctx->region_defer != 0;
+    const int slot = defer ? ctx->region_slot : 0;
+    if (slot < 0 || slot >= kRegionSlots) return fail(ctx, PGX_ERR_INVALID, "region move: slot %d out of range", slot);
     const size_t C = kRegionCap, A = C * (size_t)stride;
     PGX_TRY(ensure(ctx, ts->rg_slot, (size_t)n * 4));
     PGX_TRY(ensure(ctx, ts->rg_need, (size_t)n * 8));
@@ -1352,10 +1389,14 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     PGX_TRY(ensure(ctx, ts->rg_rev, A * 4));
     PGX_TRY(ensure(ctx, ts->rg_cap, A * 8));
     PGX_TRY(ensure(ctx, ts->rg_site_state, C * (8 * 4 + 4 * 2)));   // ex | rt | f | inbox (i64) | d | lab (i32)
-    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes + sizeof(RegionInfo)));   // the small block and the region info: one fill, one copy back
+    PGX_TRY(ensure(ctx, ts->rg_small, kRegionSlots * kRegionBlock));
     PGX_TRY(ensure(ctx, ts->epoch, 64));
-    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes + sizeof(RegionInfo), hipHostMallocDefault));
-    char* sp = (char*)ts->small.p;
+    if (!ts->rg_ctl.p) {
+        PGX_TRY(ensure(ctx, ts->rg_ctl, 64));
+        PGX_HIP(ctx, hipMemsetAsync(ts->rg_ctl.p, 0, 64, ctx->stream));
+    }
+    if (!ts->h_rg) PGX_HIP(ctx, hipHostMalloc(&ts->h_rg, kRegionSlots * kRegionHost, hipHostMallocDefault));
+    char* sp = (char*)ts->rg_small.p + (size_t)slot * kRegionBlock;
     TView v;
     v.n = 0; v.L = 2; v.alpha = 1; v.alpha_apply = mv.alpha; v.lambda_q = mv.lambda_q; v.h_q = mv.h_q;
     v.dq = nullptr; v.labels = mv.labels;
@@ -1380,32 +1421,75 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     v.T = kRegionCap;
     v.lazy = 0;
     v.dbg = nullptr;
+    if (ctx->tile_debug) {   // phase timers accumulate on the device over the moves (region_result prints them)
+        if (!ts->dbg.p) {
+            PGX_TRY(ensure(ctx, ts->dbg, 16 * 8));
+            PGX_HIP(ctx, hipMemsetAsync(ts->dbg.p, 0, 16 * 8, ctx->stream));
+        }
+        v.dbg = ts->dbg.as<unsigned long long>();
+    }
     RegionInfo* rg = (RegionInfo*)(sp + SmallLayout::bytes);
     v.rg = rg;
+    v.ctl = defer ? ts->rg_ctl.as<int>() : nullptr;
+    v.skip_rel = defer ? ctx->region_skip_rel : -1;
     *changed = 0;
     PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes + sizeof(RegionInfo), ctx->stream));
     const unsigned nb = (unsigned)((n + 255) / 256), agg = nb < 1024u ? nb : 1024u;
     hipLaunchKernelGGL(r_init_mark_kernel, dim3(agg), dim3(256), 0, ctx->stream, mv, rg, ts->rg_slot.as<int>(), ts->rg_site.as<int>(),
-                       ts->rg_need.as<long long>());
+                       ts->rg_need.as<long long>(), (const int*)v.ctl, v.skip_rel);
     hipLaunchKernelGGL(r_promote_kernel, dim3(1), dim3(1024), 0, ctx->stream, rg, mv.alpha, mv.labels, mv.off, mv.idx, mv.cap, mv.rt,
-                       ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>());
+                       ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), (const int*)v.ctl, v.skip_rel);
     hipLaunchKernelGGL(r_build_kernel, dim3(kRegionCap / 256), dim3(256), 0, ctx->stream, rg, mv.alpha, stride, mv.labels, mv.off, mv.idx, mv.rev,
                        mv.cap, mv.ex, mv.rt, ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), v);
     hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
     hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
     PGX_HIP(ctx, hipGetLastError());
-    char* hs = (char*)ts->h_small;
-    PGX_HIP(ctx, hipMemcpyAsync(hs, sp, SmallLayout::bytes + 16, hipMemcpyDeviceToHost, ctx->stream));
+    char* hs = (char*)ts->h_rg + (size_t)slot * kRegionHost;
+    static_assert(SmallLayout::flags + 8 * 4 == SmallLayout::bytes, "the flags end the small block: flags | region info head is one copy");
+    PGX_HIP(ctx, hipMemcpyAsync(hs, sp + SmallLayout::flags, 8 * 4 + 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (defer) return PGX_REGION_PENDING;
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int* h_flags = (const int*)(hs + SmallLayout::flags);
-    const int* h_rg = (const int*)(hs + SmallLayout::bytes);
+    int status = 0;
+    PGX_TRY(region_result(ctx, 0, mv.alpha, &status, changed));
+    return status == 0 ? PGX_OK : PGX_TILE_FALLBACK;
+}
+
+// the batch's control words back to zero (enqueued: the moves that follow on the stream see them cleared)
+int region_batch_begin(pgx_ctx* ctx)
+{
+    if (!ctx->tile) ctx->tile = new TileState();
+    TileState* ts = ctx->tile;
+    PGX_TRY(ensure(ctx, ts->rg_ctl, 64));
+    PGX_HIP(ctx, hipMemsetAsync(ts->rg_ctl.p, 0, 64, ctx->stream));
+    return PGX_OK;
+}
+
+// What the move in `slot` did, once the stream has been synchronised.  status 0: solved (*changed = sites relabelled),
+// 1: declined (the general path has to solve it; later moves of the batch did not run), 2: did not run (skipped by the
+// no-change rule, or behind a declined move)
+int region_result(pgx_ctx* ctx, int slot, int alpha, int* status, int64_t* changed)
+{
+    TileState* ts = ctx->tile;
+    const int* h = (const int*)((const char*)ts->h_rg + (size_t)slot * kRegionHost);   // flags[8] | count, bad, cnt_alpha
     if (ctx->tile_debug >= 2)
-        std::fprintf(stderr, "[region] alpha=%d open=%d bad=%d rounds=%d gave_up=%d changed=%d\n", mv.alpha, h_rg[0], h_rg[1], h_flags[4], h_flags[5], h_flags[1]);
-    if (h_flags[5] != 0 || h_flags[7] != 0) { ts->region_rejects += 1; return PGX_TILE_FALLBACK; }
+        std::fprintf(stderr, "[region] alpha=%d open=%d bad=%d rounds=%d gave_up=%d taken=%d changed=%d\n", alpha, h[8], h[9], h[4], h[5], h[6], h[1]);
+    *changed = 0;
+    if (h[5] != 0 || h[7] != 0) { ts->region_rejects += 1; ctx->paths[4] += 1; *status = 1; return PGX_OK; }
+    if (h[6] == 0) { *status = 2; return PGX_OK; }
     ts->region_moves += 1;
-    ctx->stats[2] += h_flags[4];
-    *changed = h_flags[1];
+    if (ctx->tile_debug && ts->region_moves % 1000 == 0 && ts->dbg.p) {
+        unsigned long long t[16];
+        (void)hipMemcpy(t, ts->dbg.p, sizeof(t), hipMemcpyDeviceToHost);
+        const double m = 100.0 * (double)ts->region_moves;
+        std::fprintf(stderr, "[region] %lld moves, us per move: setup %.1f | reset %.1f phase0 %.1f gb %.1f | count %.1f gb %.1f | decide %.1f discharge %.1f gb %.1f | apply %.1f\n",
+                     ts->region_moves, t[0] / m, t[1] / m, t[2] / m, t[3] / m, t[5] / m, t[6] / m, t[7] / m, t[8] / m, t[9] / m, t[10] / m);
+    }
+    ctx->stats[0] += 1;
+    ctx->paths[2] += 1;
+    ctx->stats[2] += h[4];
+    *changed = h[1];
     ctx->stats[4] += *changed;
+    *status = 0;
     return PGX_OK;
 }
 

@@ -114,6 +114,9 @@ struct pgx_ctx {
     int tile_lazy = 1;           // multi-tile searches accept only substantial improvements of finite heights (maxflow_tile.hip)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
     int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
+    int region_defer = 0;        // region moves are enqueued without a host round trip (pgx_expansion's batches): slot / skip rule below
+    int region_slot = 0;
+    int region_skip_rel = -1;
     int64_t tile_fallbacks = 0;  // moves the tile path handed back to maxflow.hip
     int tile_debug = 0;          // PGX_MF_DEBUG: one stderr line per global relabel
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -205,6 +208,10 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
                       int64_t* changed);
 void tile_free(pgx_ctx* ctx);
 struct MfView;
+constexpr int PGX_REGION_PENDING = 1001;  // expand_alpha_region with ctx->region_defer: enqueued, result by region_result after a synchronisation
+int region_batch_begin(pgx_ctx* ctx);
+int region_result(pgx_ctx* ctx, int slot, int alpha, int* status, int64_t* changed);
+bool region_moves_apply(const pgx_ctx* ctx);   // maxflow.hip: pgx_expansion's moves on the resident problem go through expand_alpha_region
 int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed);   // maxflow_tile.hip: a move with few open sites, one workgroup
 void comm_free(pgx_ctx* ctx);
 
