@@ -216,6 +216,16 @@ int pgx_residual_sums(pgx_ctx *ctx, const double *models, int K, double *sums);
 int pgx_gram_batch(pgx_ctx *ctx, int kind, const double *params, int nparams, const int32_t *index, int B, int m,
                    const double *weights_sel, int weight_power, double *out, int32_t *bad);
 
+/* The whole Gauss-Newton refit of B pose hypotheses in one launch (one wave per selection): from inits[B][12] (row-major
+ * [R | t]), `iterations` steps of  normal equations over the selection (the PGX_GRAM_PNP_GN rows) -> delta = pinv(J^T J)
+ * (-J^T r) with numpy.linalg.pinv's cut-off 6 eps -> R <- exp([delta_omega]_x) R, t += delta_t, stopping at |delta| < 1e-12.
+ * This is the non-minimal solver the local optimisation and PEARL call through estimator.estimateModelNonminimal
+ * (PEARL.h:374-380; GC-RANSAC's inner RANSAC [UPSTREAM-MEMORY U-12]); the reference's own solver for this model is OpenCV's
+ * iterative PnP, restated as plain Gauss-Newton on the reprojection error.  out[B][12]; status[b] = 1 if
+ * selection b produced a finite pose (0: a point behind / on the camera plane, non-finite sums, fewer than 4 points). */
+int pgx_pnp_refine_batch(pgx_ctx *ctx, const double *inits, const int32_t *index, int B, int m, const double *weights_sel,
+                         int weight_power, int iterations, double *out, int32_t *status);
+
 /* ---- the inlier/outlier graph cut of GC-RANSAC's local optimisation.
  * Replaces gcransac::GCRANSAC::labeling as reached from proposal_engine->run (progressive_x.h:294-299; settings
  * spatial_coherence_weight / threshold at :541-545).  The graph-cut-ransac sources are absent from the snapshot, so the

@@ -1001,6 +1001,13 @@ int pgx_gram_batch(pgx_ctx* ctx, int kind, const double* params, int nparams, co
     return gram_batch_launch(ctx, kind, params, nparams, index, B, m, weights_sel, weight_power, out, bad);
 }
 
+int pgx_pnp_refine_batch(pgx_ctx* ctx, const double* inits, const int32_t* index, int B, int m, const double* weights_sel,
+                         int weight_power, int iterations, double* out, int32_t* status)
+{
+    CTX_GUARD(ctx);
+    return pnp_refine_batch_launch(ctx, inits, index, B, m, weights_sel, weight_power, iterations, out, status);
+}
+
 int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
 {
     CTX_GUARD(ctx);

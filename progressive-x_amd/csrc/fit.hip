@@ -320,7 +320,214 @@ void launch_batch(pgx_ctx* ctx, int B, const double* prm, const int* index, int 
                        wsel, wpow, out, bad);
 }
 
+// ---- Gauss-Newton pose refits of a whole batch in ONE launch --------------------------------------------------------------
+// The local optimisation refits ~50 selections of 21 points per graph-cut round; each Gauss-Newton step used to be one
+// gram_batch launch, a copy back, a stacked 6x6 pseudo-inverse on the host and a copy up (10 steps per round: a third of
+// find6DPoses' proposal time at C4).  Here one wave owns one selection for all its steps: the normal equations by the same
+// rows and the same shuffle tree as gram_batch_kernel (bitwise the same sums), broadcast to every lane, and each lane
+// redundantly runs the small dense part - pseudo-inverse of the symmetric 6x6 through a cyclic Jacobi eigen-decomposition with
+// numpy.linalg.pinv's cut-off (|lambda| <= rcond max|lambda| dropped), Rodrigues update of R, t += dt - exactly the iteration
+// of pyprogressivex/_estimators.py PnPEstimator._fit_many, whose iterates it reproduces up to rounding (tests: 1e-9).
+
+// x = pinv(A) b for symmetric A (6x6).  Cyclic Jacobi, fixed rotation order, at most 12 sweeps (it converges quadratically:
+// 5-7 sweeps reach the rounding floor).
+__device__ __forceinline__ void sym6_pinv_apply(const double (&A0)[6][6], const double (&b)[6], double rcond, double (&x)[6])
+{
+    double A[6][6], V[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { A[r][c] = A0[r][c]; V[r][c] = r == c ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            dia += A[r][r] * A[r][r];
+#pragma unroll
+            for (int c = r + 1; c < 6; ++c) off += A[r][c] * A[r][c];
+        }
+        if (!(off > 1e-36 * dia)) break;   // (also leaves on NaN)
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {   // columns p, q
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {   // rows p, q
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    double smax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) smax = fmax(smax, fabs(A[i][i]));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double lam = A[i][i];
+        if (!(fabs(lam) > rcond * smax)) continue;
+        double vb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vb += V[k][i] * b[k];
+        const double f = vb / lam;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] += f * V[k][i];
+    }
+}
+
+__global__ __launch_bounds__(64) void pnp_refine_batch_kernel(const double* __restrict__ pts, const double* __restrict__ inits,
+                                                              const int* __restrict__ index, int m, const double* __restrict__ wsel, int wpow,
+                                                              int iterations, double* __restrict__ out, int* __restrict__ status)
+{
+    using G = GenPnpGn;
+    constexpr int Q = 7, NV = 28;
+    const int b = blockIdx.x;
+    FitParams p;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) p.v[k] = inits[(int64_t)b * 12 + k];
+    bool failed = m < 4;
+    for (int it = 0; it < iterations && !failed; ++it) {
+        Acc<Q> acc;
+        acc.zero();
+        int nbad = 0;
+        for (int t = threadIdx.x; t < m; t += 64) {
+            const int64_t i = index[(int64_t)b * m + t];
+            double pt[G::D];
+#pragma unroll
+            for (int k = 0; k < G::D; ++k) pt[k] = pts[i * G::D + k];
+            double w = 1.0;
+            if (wsel != nullptr) { w = wsel[(int64_t)b * m + t]; if (wpow == 2) w = w * w; }
+            int bd = 0;
+            emit<G>(pt, p, acc, w, bd);
+            nbad += bd;
+        }
+        double g[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double x = acc.s[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            g[k] = __shfl(x, 0, 64);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nbad += __shfl_down(nbad, off, 64);
+        nbad = __shfl(nbad, 0, 64);
+        if (nbad > 0) { failed = true; break; }
+        // upper triangle, row-major: (r, c) at r * 7 - r (r - 1) / 2 + (c - r)
+        double A[6][6], rhs[6];
+        bool fin = true;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                const double v = g[r * 7 - r * (r - 1) / 2 + (c - r)];
+                A[r][c] = v; A[c][r] = v;
+                fin = fin && isfinite(v);
+            }
+            rhs[r] = -g[r * 7 - r * (r - 1) / 2 + (6 - r)];
+            fin = fin && isfinite(rhs[r]);
+        }
+        if (!fin) { failed = true; break; }
+        double d[6];
+        sym6_pinv_apply(A, rhs, 6.0 * 2.220446049250313e-16, d);
+        const double ang = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (ang > 0.0) {   // R <- exp([omega]_x) R
+            const double kx = d[0] / ang, ky = d[1] / ang, kz = d[2] / ang;
+            const double K[3][3] = {{0.0, -kz, ky}, {kz, 0.0, -kx}, {-ky, kx, 0.0}};
+            const double sn = sin(ang), cs = 1.0 - cos(ang);
+            double rot[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double kk = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) kk += K[r][j] * K[j][c];
+                    rot[r][c] = (r == c ? 1.0 : 0.0) + sn * K[r][c] + cs * kk;
+                }
+            double Rn[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) v += rot[r][j] * p.v[j * 4 + c];
+                    Rn[r][c] = v;
+                }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p.v[r * 4 + c] = Rn[r][c];
+        }
+        p.v[3] += d[3]; p.v[7] += d[4]; p.v[11] += d[5];
+        double nd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nd += d[k] * d[k];
+        if (sqrt(nd) < 1e-12) break;
+    }
+    if (threadIdx.x == 0) {
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { out[(int64_t)b * 12 + k] = p.v[k]; fin = fin && isfinite(p.v[k]); }
+        status[b] = (!failed && fin) ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+int pnp_refine_batch_launch(pgx_ctx* ctx, const double* inits, const int32_t* index, int B, int m, const double* wsel, int wpow,
+                            int iterations, double* out, int32_t* status)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_pnp_refine_batch: points not set");
+    if (ctx->D != 5) return fail(ctx, PGX_ERR_INVALID, "pgx_pnp_refine_batch: needs 5-D 2D-3D rows");
+    if (wpow != 1 && wpow != 2) return fail(ctx, PGX_ERR_INVALID, "pgx_pnp_refine_batch: weight power must be 1 or 2");
+    if (!inits || !out || !status || B < 0 || m < 0 || iterations < 0 || ((int64_t)B * m > 0 && !index))
+        return fail(ctx, PGX_ERR_INVALID, "pgx_pnp_refine_batch: bad argument");
+    if (B == 0) return PGX_OK;
+    const int64_t tot = (int64_t)B * m;
+    for (int64_t t = 0; t < tot; ++t)
+        if (index[t] < 0 || index[t] >= ctx->n) return fail(ctx, PGX_ERR_INVALID, "pgx_pnp_refine_batch: index %d out of range", index[t]);
+    // scratch: inits[B][12] | out[B][12] | wsel[B][m] | index[B][m] | status[B]
+    const size_t prm_bytes = (size_t)B * 12 * 8, w_bytes = wsel ? (size_t)tot * 8 : 0;
+    const size_t idx_bytes = ((size_t)tot * 4 + 7) & ~(size_t)7, st_bytes = (size_t)B * 4;
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, 2 * prm_bytes + w_bytes + idx_bytes + st_bytes + 64));
+    char* base = (char*)ctx->fit_scratch.p;
+    double* d_in = (double*)base;
+    double* d_out = (double*)(base + prm_bytes);
+    double* d_w = (double*)(base + 2 * prm_bytes);
+    int* d_idx = (int*)(base + 2 * prm_bytes + w_bytes);
+    int* d_st = (int*)(base + 2 * prm_bytes + w_bytes + idx_bytes);
+    PGX_HIP(ctx, hipMemcpyAsync(d_in, inits, prm_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (tot > 0) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, (size_t)tot * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (w_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_w, wsel, w_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pnp_refine_batch_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), d_in, d_idx, m,
+                       wsel ? d_w : nullptr, wpow, iterations, d_out, d_st);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, prm_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(status, d_st, st_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
 
 static int gram_row_length(pgx_ctx* ctx, const char* who, int kind, int nparams, int* q)
 {

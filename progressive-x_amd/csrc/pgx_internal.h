@@ -198,6 +198,8 @@ int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams
 int residual_sums_launch(pgx_ctx* ctx, const double* models, int K, double* sums);
 int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, const int32_t* index, int B, int m,
                       const double* wsel, int wpow, double* out, int32_t* bad);
+int pnp_refine_batch_launch(pgx_ctx* ctx, const double* inits, const int32_t* index, int B, int m, const double* wsel, int wpow,
+                            int iterations, double* out, int32_t* status);
 int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed);
 int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated);  // lambda = 0: all labels, one read-back
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq, int64_t lambda_q,

@@ -781,6 +781,19 @@ class PnPEstimator(Estimator):
         return [out.reshape(-1)] if np.isfinite(out).all() else []
 
 
+    def nonminimal_batch(self, ctx, index, weights=None, init=None):
+        """The local optimisation's B refits from one start: ONE pgx_pnp_refine_batch launch that runs all Gauss-Newton steps
+        on the device when the context offers it (the GPU context); otherwise - the CPU oracle context of the tests - the
+        lockstep iteration of `_fit_many`, whose iterates the kernel reproduces up to rounding."""
+        refine = getattr(ctx, "pnp_refine_batch", None)
+        if refine is None or init is None:
+            return super().nonminimal_batch(ctx, index, weights, init)
+        index = np.asarray(index)
+        B = index.shape[0]
+        start = np.tile(np.asarray(init, dtype=np.float64).reshape(1, 12), (B, 1))
+        P, ok = refine(start, index, weights=weights, wpow=2, iterations=10)
+        return [[P[b]] if ok[b] else [] for b in range(B)]
+
     def _fit_many(self, gram, B, inits):
         """`_fit` for B items at once: the same Gauss-Newton iteration with the 6x6 solves, the rotation updates and the
         convergence tests done on [B, ...] arrays - 50 refits x 10 iterations per graph-cut round were 13 us of lstsq + 15 us

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths",
-    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
 ]
@@ -463,6 +463,26 @@ class Context:
         G[:, iu[0], iu[1]] = out
         G[:, iu[1], iu[0]] = out
         return G, bad
+
+    def pnp_refine_batch(self, inits, index, weights=None, wpow=2, iterations=10):
+        """pgx_pnp_refine_batch: the Gauss-Newton pose refit of B selections (index [B, m]) from inits [B, 12] in one launch.
+        weights = the full per-point weight vector (gathered here).  Returns (poses [B, 12], ok [B] bool)."""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        B, m = idx.shape
+        ini = np.ascontiguousarray(inits, dtype=np.float64).reshape(B, 12)
+        out = np.zeros((B, 12), dtype=np.float64)
+        status = np.zeros(B, dtype=np.int32)
+        w = None
+        if weights is not None and len(weights) > 0:
+            wf = np.asarray(weights, dtype=np.float64).reshape(-1)
+            if wf.shape[0] != self.n:
+                raise ValueError(f"weights must have one entry per point ({self.n}), got {wf.shape[0]}")
+            w = np.ascontiguousarray(wf[idx])
+        self._ck(self._lib.pgx_pnp_refine_batch(self._h, _ptr(ini, C.c_double), _ptr(idx, C.c_int32) if idx.size else None,
+                                                C.c_int(B), C.c_int(m), _ptr(w, C.c_double), C.c_int(int(wpow)),
+                                                C.c_int(int(iterations)), _ptr(out, C.c_double), _ptr(status, C.c_int32)),
+                 "pgx_pnp_refine_batch")
+        return out, status != 0
 
     def set_labels(self, labels):
         lab = _i32(labels)

@@ -977,6 +977,49 @@ def test_batched_refits_equal_single_refits(gpu_ctx):
             assert np.abs(a - c).max() <= 1e-6 * max(1.0, np.abs(a).max()), name
 
 
+def test_device_pose_refits_reproduce_the_host_iteration(gpu_ctx):
+    """pgx_pnp_refine_batch (all Gauss-Newton steps of a batch in one launch, 6x6 pseudo-inverse by Jacobi on the device)
+    against PnPEstimator._fit_many driven step by step through pgx_gram_batch with numpy's pinv on the host: the same
+    iterates up to rounding (1e-9), with and without weights, from perturbed starts; selections that fail (a point on the
+    camera plane, fewer than 4 points) fail in both."""
+    from pyprogressivex import _estimators
+    rng = np.random.default_rng(12)
+    mt, pts, models, thr = make_case("pnp", 6000, 3, seed=21)
+    est = _estimators.ESTIMATORS["pnp"]()
+    gpu_ctx.set_points(mt, pts)
+    weights = rng.random(len(pts)) + 0.5
+    for k in range(3):
+        one = gpu_ctx.score(models[k:k + 1], 2.25 * thr * thr, want_masks=True)
+        inl = np.nonzero(np.unpackbits(one["masks"][0].view(np.uint8), bitorder="little")[:len(pts)])[0]
+        for m in (21, 64, 150):
+            if len(inl) <= m:
+                continue
+            picks = np.array([np.sort(rng.choice(inl, m, replace=False)) for _ in range(33)])
+            init = models[k].reshape(3, 4).copy()
+            init[:, 3] += rng.normal(0, 0.01, 3)             # a start slightly off: several steps to converge
+            init = init.reshape(-1)
+            for w in (None, weights):
+                dev = est.nonminimal_batch(gpu_ctx, picks, w, init=init)
+
+                def gram(kind, prm, use_w, wpow, rows):
+                    G, bad = gpu_ctx.gram_batch(kind, picks[rows], params=prm, weights=w if use_w else None, wpow=wpow)
+                    return G, np.full(len(rows), m, dtype=np.int64), bad
+                host = est._fit_many(gram, len(picks), [init] * len(picks))
+                for b in range(len(picks)):
+                    assert len(dev[b]) == len(host[b]) == 1
+                    assert np.abs(dev[b][0] - host[b][0]).max() <= 1e-9 * max(1.0, np.abs(host[b][0]).max())
+    # failures: fewer than 4 points; a point exactly on the camera plane of the start
+    P, ok = gpu_ctx.pnp_refine_batch(np.tile(models[0], (2, 1)), inl[:6].reshape(2, 3).astype(np.int32))
+    assert not ok.any()
+    X = pts[inl[0], 2:5]
+    flat = models[0].reshape(3, 4).copy()
+    flat[2, 3] = -float(flat[2, :3] @ X)                     # z_c = 0 for that point
+    P, ok = gpu_ctx.pnp_refine_batch(np.stack([flat.reshape(-1), models[0]]), np.stack([inl[:8], inl[:8]]).astype(np.int32))
+    assert not ok[0] and ok[1]
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.pnp_refine_batch(models[:1], np.full((1, 5), len(pts), np.int32))
+
+
 @pytest.mark.parametrize("name", list(MODEL_CASES))
 def test_label_batched_gram_and_residual_sums_are_bitwise_the_single_label_calls(gpu_ctx, name):
     # pgx_gram_labels / pgx_residual_sums: all instances of a PEARL iteration in one launch, same trees as the single calls
