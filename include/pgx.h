@@ -235,6 +235,9 @@ int pgx_pnp_refine_batch(pgx_ctx *ctx, const double *inits, const int32_t *index
  *   lambda, both inliers 0.  One exact s-t cut on the device (terms in 2^-32 fixed point); inliers = sink segment.
  * flags[n] (host): 1 = inlier, 0 = outlier; count = number of inliers.  Needs pgx_set_points + a graph over the points. */
 int pgx_gc_labeling(pgx_ctx *ctx, const double *model, double T2, double lambda, int32_t *flags, int64_t *count);
+/* The same cut, returning the inliers' indices in ascending order (index: capacity n; *count of them are written) instead of
+ * n flags: what GCRANSAC::labeling hands to the inner sampler.  Same cut bit for bit; compaction on the device. */
+int pgx_gc_inliers(pgx_ctx *ctx, const double *model, double T2, double lambda, int32_t *index, int64_t *count);
 
 /* ---- a9: PEARL::parameterEstimation bookkeeping (PEARL.h:342-352, 369-371, 388-390) */
 int pgx_bucket(pgx_ctx *ctx, int L, int64_t *counts, int32_t *order);     /* order optional: stable, ascending index */

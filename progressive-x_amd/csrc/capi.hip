@@ -131,7 +131,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->masks, &ctx->g_counts, &ctx->g_values, &ctx->g_shared,
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
-                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc,
+                      &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc, &ctx->gc_sel,
                       &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->weights_scratch};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
@@ -1013,6 +1013,13 @@ int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda,
     CTX_GUARD(ctx);
     if (!model || !flags) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: NULL argument");
     return gc_labeling_launch(ctx, model, T2, lambda, flags, count);
+}
+
+int pgx_gc_inliers(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* index, int64_t* count)
+{
+    CTX_GUARD(ctx);
+    if (!model || !index || !count) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_inliers: NULL argument");
+    return gc_labeling_launch(ctx, model, T2, lambda, index, count, true);
 }
 
 }  // extern "C"

@@ -69,6 +69,7 @@ struct pgx_ctx {
     int score_split = 0;         // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT); 0 = 8 with the spread mapping, 5 co-located (score.hip)
     pgx::DevBuf cull_lists, cull_counts;
     pgx::DevBuf gc;          // inlier/outlier graph cut: e[n] | dq[2][n] | wq[E] | labels[n]
+    pgx::DevBuf gc_sel;      // ... the inliers' indices (pgx_gc_inliers): index[n] | count | select scratch
     int score_xcd_map = 1;       // XCD-aware block mapping of the score kernel (PGX_SCORE_NO_XCD=1 disables)
     int score_blocks_per_cu = 64;  // grid over-decomposition of the score kernel (PGX_SCORE_BLOCKS_PER_CU)
 
@@ -186,7 +187,7 @@ int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* su
 int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
 int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
 int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* opened);
-int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count);
+int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count, bool want_index = false);
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);

@@ -12,6 +12,10 @@
 // Model parameters are wave-uniform (kernel arguments or scalar loads); points are read once, coalesced per wave.
 // All floating-point reductions use a fixed tree (wave shuffle -> LDS -> per-block partial -> one-block final pass), so
 // results are bit-reproducible run to run.  Paths are relative to /root/reference/src/pyprogressivex/.
+#include <cstring>
+#include <cstdlib>
+#include <hipcub/hipcub.hpp>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(kPwBlock) void gc_terms_kernel(const double* __rest
     labels[i] = start_label;
 }
 
-int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
+int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count, bool want_index)
 {
     const int64_t n = ctx->n;
     if (n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_labeling: points not set");
@@ -322,9 +326,24 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
     PGX_HIP(ctx, hipGetLastError());
     int64_t changed = 0;
     PGX_TRY(expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, flip ? 1 : 0, &changed, flip));
-    PGX_HIP(ctx, hipMemcpyAsync(flags, labels, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const int64_t inliers = flip ? changed : n - changed;
+    if (want_index) {
+        // the inliers' indices in ascending order instead of n flags: the caller (the local optimisation's sampler) used to copy
+        // 4 n bytes back and scan them with numpy.flatnonzero - 1.9 ms per cut at n = 10^6, as long as the cut itself
+        size_t temp_bytes = 0;
+        hipcub::CountingInputIterator<int> ids(0);
+        PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, ids, labels, (int*)nullptr, (int*)nullptr, (int)n, ctx->stream));
+        PGX_TRY(ensure(ctx, ctx->gc_sel, (size_t)n * 4 + 64 + temp_bytes));
+        int* d_sel = ctx->gc_sel.as<int>();
+        int* d_num = d_sel + n;
+        void* d_temp = (void*)(d_num + 16);
+        PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, ids, labels, d_sel, d_num, (int)n, ctx->stream));
+        if (inliers > 0) PGX_HIP(ctx, hipMemcpyAsync(flags, d_sel, (size_t)inliers * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        PGX_HIP(ctx, hipMemcpyAsync(flags, labels, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (count) *count = flip ? changed : n - changed;
+    if (count) *count = inliers;
     return PGX_OK;
 }
 

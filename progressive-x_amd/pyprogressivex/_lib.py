@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths",
-    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
 ]
@@ -549,6 +549,16 @@ class Context:
         self._ck(self._lib.pgx_residual_sum(self._h, _ptr(m, C.c_double), C.c_int(int(label)), C.byref(s)),
                  "pgx_residual_sum")
         return s.value
+
+    def gc_inliers(self, model, T2, lam):
+        """pgx_gc_inliers: the inliers' indices (ascending, int64) of the inlier/outlier graph cut of `model`."""
+        m = _f64(model).reshape(-1)
+        if not hasattr(self, "_gc_index") or self._gc_index.shape[0] != self.n:
+            self._gc_index = np.empty(self.n, dtype=np.int32)
+        cnt = C.c_int64()
+        self._ck(self._lib.pgx_gc_inliers(self._h, _ptr(m, C.c_double), C.c_double(float(T2)), C.c_double(float(lam)),
+                                          _ptr(self._gc_index, C.c_int32), C.byref(cnt)), "pgx_gc_inliers")
+        return self._gc_index[:cnt.value].astype(np.int64)
 
     def gc_labeling(self, model, T2, lam):
         """GC-RANSAC's inlier/outlier graph cut of `model` on the resident graph (include/pgx.h pgx_gc_labeling):

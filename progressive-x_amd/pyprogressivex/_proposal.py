@@ -454,6 +454,8 @@ class ProposalEngine:
         when 0 < lambda < 1; without a pairwise term the cut decouples into r^2 < T^2, i.e. the scorer's inlier mask."""
         lam = float(self.s.spatial_coherence_weight)
         if 0.0 < lam < 1.0:
+            if hasattr(self.ctx, "gc_inliers"):      # the GPU context compacts the indices on the device
+                return self.ctx.gc_inliers(model, T2, lam)
             return np.flatnonzero(self.ctx.gc_labeling(model, T2, lam) != 0).astype(np.int64)   # (bool scan: half the time of nonzero on int32)
         one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
         return mask_to_indices(one["masks"][0], self.n)

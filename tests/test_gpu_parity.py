@@ -1125,12 +1125,15 @@ def test_gc_labeling_matches_oracle(gpu_ctx, oracle, name, n, lam):
         ref = oracle.gc_labeling(mt, pts, m, T2, lam, graph)
         got = gpu_ctx.gc_labeling(m, T2, lam)
         assert got.dtype == np.int32 and np.array_equal(got, ref), f"{name} n={n} lam={lam}: {int((got != ref).sum())} flags differ"
+        idx = gpu_ctx.gc_inliers(m, T2, lam)      # the same cut as ascending indices (device compaction)
+        assert idx.dtype == np.int64 and np.array_equal(idx, np.flatnonzero(ref))
         seen.add(int(ref.sum()))
     if n >= 3000:
         assert max(seen) > n // 20          # the ground-truth hypotheses keep a real inlier set
     # a degenerate (NaN) model: every residual counts as beyond the threshold (e = 1), on both sides
     bad = np.full(models.shape[1], np.nan)
     assert np.array_equal(gpu_ctx.gc_labeling(bad, T2, lam), oracle.gc_labeling(mt, pts, bad, T2, lam, graph))
+    assert np.array_equal(gpu_ctx.gc_inliers(bad, T2, lam), np.flatnonzero(oracle.gc_labeling(mt, pts, bad, T2, lam, graph)))
 
 
 def test_gc_labeling_orientations_agree_including_ties(oracle, monkeypatch):
