@@ -41,4 +41,6 @@ for sp in splits:
     crc = zlib.crc32(res["counts"].tobytes() + res["scores"].tobytes())
     if ref is None:
         ref = crc
-    print(f"split={sp} step={ms:.4f} ms  cull={kt[0]*1e3:.1f} group={kt[1]*1e3:.1f} finish={kt[2]*1e3:.1f} us  crc={crc:08x} {'same' if crc == ref else 'DIFFERENT'}", flush=True)
+    st = ctx.score_stats(T2, True)
+    print(f"  steps={st['surviving_group_steps']} exact={st['exact_evaluations']}", end="")
+    print(f" split={sp} step={ms:.4f} ms  cull={kt[0]*1e3:.1f} group={kt[1]*1e3:.1f} finish={kt[2]*1e3:.1f} us  crc={crc:08x} {'same' if crc == ref else 'DIFFERENT'}", flush=True)
