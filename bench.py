@@ -45,7 +45,7 @@ if os.path.exists(PMC_FILE):
 PMC_TRAFFIC_DEFAULT = int((2 * PMC["fetch_kib"] + PMC["write_kib"]) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
-FLOPS_PER_PAIR = {"pnp": 25, "fundamental": 33, "vanishing_point": 24}   # exact residual + score update, DESIGN.md 5.1
+FLOPS_PER_PAIR = {"pnp": 25, "fundamental": 33, "vanishing_point": 24}   # exact residual + score update, docs/lab-notebook.md 5.1
 
 
 def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
@@ -317,7 +317,7 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
                 "pearl_labelling_iterations_per_sec": 1.0 / (t_unary + best),
                 "ms_per_mincut": 1e3 * best / max(1, st["mincuts"]), **st,
                 "note": "best of 3; labels are those of the CPU oracle's Dinic solver (tests). <= 8192 sites: one workgroup, one launch per "
-                        "move (maxflow_tile.hip); larger: level-synchronous push-relabel, latency bound (DESIGN.md 5.4)"}
+                        "move (maxflow_tile.hip); larger: level-synchronous push-relabel, latency bound (DESIGN.md 4.3)"}
     finally:
         c.close()
 
