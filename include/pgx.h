@@ -216,6 +216,12 @@ int pgx_residual_sums(pgx_ctx *ctx, const double *models, int K, double *sums);
 int pgx_gram_batch(pgx_ctx *ctx, int kind, const double *params, int nparams, const int32_t *index, int B, int m,
                    const double *weights_sel, int weight_power, double *out, int32_t *bad);
 
+/* U-14 (DefaultFundamentalMatrixEstimator's model validity, progressivex_python.cpp:616; sources absent, restated from the
+ * literature): support of a fundamental matrix over all resident correspondences.  counts[0] = points whose squared
+ * Sampson distance is < T2 (the scorer's inliers), counts[1] = those of them whose symmetric epipolar distance
+ * r^2 (1 / |F x1|^2 + 1 / |F^T x2|^2) is < S2.  The points must be those of a fundamental-matrix problem. */
+int pgx_epipolar_support(pgx_ctx *ctx, const double *F, double T2, double S2, int64_t counts[2]);
+
 /* The whole Gauss-Newton refit of B pose hypotheses in one launch (one wave per selection): from inits[B][12] (row-major
  * [R | t]), `iterations` steps of  normal equations over the selection (the PGX_GRAM_PNP_GN rows) -> delta = pinv(J^T J)
  * (-J^T r) with numpy.linalg.pinv's cut-off 6 eps -> R <- exp([delta_omega]_x) R, t += delta_t, stopping at |delta| < 1e-12.

@@ -113,6 +113,30 @@ static double vp_residual(const double *p, const double *d)
     return fabs(lx * xs + ly * ys + lz) / sqrt(lx * lx + ly * ly);
 }
 
+/* U-14: the F estimator's symmetric-epipolar support (restated from the literature; see include/pgx.h pgx_epipolar_support).
+ * out[0] = Sampson inliers (fundamental_sq < T2, strict as the scorer), out[1] = those with r^2 (1/|F x1|^2 + 1/|F^T x2|^2) < S2. */
+void pgxo_epipolar_support(const double *pts, int64_t n, const double *f, double T2, double S2, int64_t *out)
+{
+    int64_t inl = 0, sup = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = pts + i * 4;
+        const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+        const double rxc = f[0] * x2 + f[3] * y2 + f[6];
+        const double ryc = f[1] * x2 + f[4] * y2 + f[7];
+        const double rwc = f[2] * x2 + f[5] * y2 + f[8];
+        const double r = x1 * rxc + y1 * ryc + rwc;
+        const double rx = f[0] * x1 + f[1] * y1 + f[2];
+        const double ry = f[3] * x1 + f[4] * y1 + f[5];
+        const double sym = (r * r) * (1.0 / (rx * rx + ry * ry) + 1.0 / (rxc * rxc + ryc * ryc));
+        if (fundamental_sq(p, f) < T2) {
+            ++inl;
+            if (sym < S2) ++sup;
+        }
+    }
+    out[0] = inl;
+    out[1] = sup;
+}
+
 double pgxo_squared_residual(int model_type, const double *pt, const double *model)
 {
     double r;

@@ -96,6 +96,7 @@ int64_t pgxo_maxflow(int nnodes, int64_t narcs, const int32_t *from, const int32
 
 /* a9: label bucketing + residual sums */
 void pgxo_bucket(const int32_t *labels, int64_t n, int L, int64_t *counts, int32_t *order);
+void pgxo_epipolar_support(const double *pts, int64_t n, const double *f, double T2, double S2, int64_t *out);
 double pgxo_residual_sum(int model_type, const double *pts, int64_t n, const double *model,
                          const int32_t *labels, int label);
 

@@ -37,6 +37,7 @@ def lib():
         _lib.pgxo_squared_residual.restype = C.c_double
         _lib.pgxo_residual.restype = C.c_double
         _lib.pgxo_residual_sum.restype = C.c_double
+        _lib.pgxo_epipolar_support.restype = None
         _lib.pgxo_quantize.restype = C.c_int64
         _lib.pgxo_quantize.argtypes = [C.c_double]
         _lib.pgxo_energy.restype = C.c_int64
@@ -230,6 +231,15 @@ def bucket(labels, L):
     lib().pgxo_bucket(_p(labels, C.c_int32), C.c_int64(labels.shape[0]), C.c_int(L),
                       _p(counts, C.c_int64), _p(order, C.c_int32))
     return counts, order
+
+
+def epipolar_support(pts, F, T2, S2):
+    """(Sampson inliers, those also within S2 of the symmetric epipolar distance) of F over the correspondences [n, 4]"""
+    pts = _f64(pts); F = _f64(F).reshape(-1)
+    out = np.zeros(2, dtype=np.int64)
+    lib().pgxo_epipolar_support(_p(pts, C.c_double), C.c_int64(pts.shape[0]), _p(F, C.c_double), C.c_double(T2), C.c_double(S2),
+                                _p(out, C.c_int64))
+    return int(out[0]), int(out[1])
 
 
 def residual_sum(model_type, pts, model, labels, label):

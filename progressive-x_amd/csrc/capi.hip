@@ -1015,6 +1015,13 @@ int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda,
     return gc_labeling_launch(ctx, model, T2, lambda, flags, count);
 }
 
+int pgx_epipolar_support(pgx_ctx* ctx, const double* F, double T2, double S2, int64_t counts[2])
+{
+    CTX_GUARD(ctx);
+    if (!F || !counts) return fail(ctx, PGX_ERR_INVALID, "pgx_epipolar_support: NULL argument");
+    return epipolar_support_launch(ctx, F, T2, S2, counts);
+}
+
 int pgx_gc_inliers(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* index, int64_t* count)
 {
     CTX_GUARD(ctx);

@@ -187,6 +187,7 @@ int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* su
 int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order);
 int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q);
 int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* opened);
+int epipolar_support_launch(pgx_ctx* ctx, const double* F, double T2, double S2, int64_t counts[2]);
 int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count, bool want_index = false);
 int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);

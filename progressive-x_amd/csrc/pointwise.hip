@@ -464,6 +464,61 @@ int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* su
     return PGX_OK;
 }
 
+// ---- U-14: support of a fundamental matrix under the symmetric epipolar distance --------------------------------------------
+// The validity stage of the F estimator (pyprogressivex/_estimators.py FundamentalEstimator.valid_best: a so-far-best F must keep
+// at least half of its Sampson inliers under the symmetric epipolar distance, thresholds T2 and S2) counted over all points in one
+// pass.  The Sampson value is the scorer's own (Residual<kFundamental>::squared: the same inlier set, strict <); the symmetric
+// distance r^2 (1 / |F x1|_12^2 + 1 / |F^T x2|_12^2) with the Sampson functor's intermediate values, left to right.
+__global__ __launch_bounds__(kPwBlock) void epipolar_support_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl, double T2,
+                                                                     double S2, unsigned long long* __restrict__ out /*[2]*/)
+{
+    using R = Residual<kFundamental>;
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    bool inl = false, sup = false;
+    if (i < n) {
+        double pt[R::D];
+        load_point<kFundamental>(pts, i, pt);
+        const double* f = mdl.v;
+        const double x1 = pt[0], y1 = pt[1], x2 = pt[2], y2 = pt[3];
+        const double rxc = f[0] * x2 + f[3] * y2 + f[6];
+        const double ryc = f[1] * x2 + f[4] * y2 + f[7];
+        const double rwc = f[2] * x2 + f[5] * y2 + f[8];
+        const double r = x1 * rxc + y1 * ryc + rwc;
+        const double rx = f[0] * x1 + f[1] * y1 + f[2];
+        const double ry = f[3] * x1 + f[4] * y1 + f[5];
+        const double sym = (r * r) * (1.0 / (rx * rx + ry * ry) + 1.0 / (rxc * rxc + ryc * ryc));
+        inl = R::squared(pt, mdl.v) < T2;       // false on NaN
+        sup = inl && sym < S2;
+    }
+    const unsigned long long mi = __ballot(inl), ms = __ballot(sup);
+    if ((threadIdx.x & 63) == 0) {
+        if (mi) atomicAdd(&s_cnt[0], (unsigned)__popcll(mi));
+        if (ms) atomicAdd(&s_cnt[1], (unsigned)__popcll(ms));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+int epipolar_support_launch(pgx_ctx* ctx, const double* F, double T2, double S2, int64_t counts[2])
+{
+    if (ctx->n <= 0 || ctx->model_type != kFundamental)
+        return fail(ctx, PGX_ERR_INVALID, "pgx_epipolar_support: needs the points of a fundamental-matrix problem");
+    ModelArg mdl;
+    for (int k = 0; k < 18; ++k) mdl.v[k] = k < 9 ? F[k] : 0.0;
+    PGX_TRY(ensure(ctx, ctx->red_out, 8 * sizeof(double)));
+    unsigned long long* out = (unsigned long long*)ctx->red_out.p;
+    PGX_HIP(ctx, hipMemsetAsync(out, 0, 16, ctx->stream));
+    const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
+    hipLaunchKernelGGL(epipolar_support_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n, mdl, T2, S2, out);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(counts, out, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
 // ---- a9: bucket by label (PEARL.h:342-352) -----------------------------------------------------------------------
 // Labels >= L-1 fall into the last (outlier) bucket, as `label < instance_number` does at PEARL.h:348.
 constexpr int kMaxBucketLabels = 64;

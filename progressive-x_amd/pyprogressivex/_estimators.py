@@ -553,10 +553,9 @@ class FundamentalEstimator(Estimator):
             return True, model
         F = np.asarray(model, dtype=np.float64).reshape(3, 3)
         T2 = 2.25 * threshold * threshold
-        samp, sym = self._sampson_and_symmetric(F, pts)
-        inl = samp < T2
-        need = max(self.sample_size, int(inl.sum() * self.minimum_inlier_ratio_in_validity_check))
-        if int((inl & (sym < 4.0 * T2)).sum()) < need:
+        inliers, supported = ctx.epipolar_support(F, T2, 4.0 * T2)           # one pass over all points on the device
+        need = max(self.sample_size, int(inliers * self.minimum_inlier_ratio_in_validity_check))
+        if supported < need:
             return False, model
         if self.validity != "full" or sample is None:
             return True, model

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
     "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths",
-    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
+    "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
 ]
@@ -549,6 +549,14 @@ class Context:
         self._ck(self._lib.pgx_residual_sum(self._h, _ptr(m, C.c_double), C.c_int(int(label)), C.byref(s)),
                  "pgx_residual_sum")
         return s.value
+
+    def epipolar_support(self, F, T2, S2):
+        """pgx_epipolar_support: (Sampson inliers of F, those also within S2 of the symmetric epipolar distance)."""
+        f = _f64(F).reshape(-1)
+        out = np.zeros(2, dtype=np.int64)
+        self._ck(self._lib.pgx_epipolar_support(self._h, _ptr(f, C.c_double), C.c_double(float(T2)), C.c_double(float(S2)),
+                                                _ptr(out, C.c_int64)), "pgx_epipolar_support")
+        return int(out[0]), int(out[1])
 
     def gc_inliers(self, model, T2, lam):
         """pgx_gc_inliers: the inliers' indices (ascending, int64) of the inlier/outlier graph cut of `model`."""

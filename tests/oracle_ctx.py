@@ -100,6 +100,9 @@ class OracleContext:
         return (np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.int64),
                 np.array([r[2] for r in res], dtype=np.int64))
 
+    def epipolar_support(self, F, T2, S2):
+        return O.epipolar_support(self.pts, F, T2, S2)
+
     def residual_sums(self, models):
         return np.array([self.residual_sum(m, k) for k, m in enumerate(np.asarray(models))])
 

@@ -977,6 +977,30 @@ def test_batched_refits_equal_single_refits(gpu_ctx):
             assert np.abs(a - c).max() <= 1e-6 * max(1.0, np.abs(a).max()), name
 
 
+def test_epipolar_support_matches_oracle(gpu_ctx, oracle):
+    """pgx_epipolar_support (U-14, the F estimator's symmetric-epipolar support): both counts equal to the oracle's over random and
+    near-true fundamental matrices, degenerate ones included (rank one, NaN)."""
+    mt, pts, models, thr = make_case("fundamental", 30011, 6, seed=5)
+    gpu_ctx.set_points(mt, pts)
+    rng = np.random.default_rng(3)
+    T2 = 2.25 * thr * thr
+    cands = list(models) + [rng.normal(0, 1, 9) for _ in range(4)]
+    cands.append(np.outer([0.0, 1.0, -500.0], [0.0, 1.0, -480.0]).reshape(-1))
+    cands.append(np.full(9, np.nan))
+    seen = 0
+    for F in cands:
+        for S2 in (T2, 4.0 * T2, 1e-9):
+            got = gpu_ctx.epipolar_support(F, T2, S2)
+            ref = oracle.epipolar_support(pts, F, T2, S2)
+            assert got == ref
+            seen = max(seen, got[0])
+    assert seen > 1000
+    mt2, pts2, _, _ = make_case("homography", 500, 1, seed=1)
+    gpu_ctx.set_points(mt2, pts2)
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.epipolar_support(cands[0], T2, T2)
+
+
 def test_device_pose_refits_reproduce_the_host_iteration(gpu_ctx):
     """pgx_pnp_refine_batch (all Gauss-Newton steps of a batch in one launch, 6x6 pseudo-inverse by Jacobi on the device)
     against PnPEstimator._fit_many driven step by step through pgx_gram_batch with numpy's pinv on the host: the same

@@ -350,7 +350,10 @@ def test_fundamental_validity_stages():
     assert (sg > 0).all() or (sg < 0).all()
     # the truth keeps its support under the symmetric distance; a rank-one matrix a b^T does not
     never = lambda c: np.full(len(c), -np.inf)                                   # (plane-and-parallax candidates never win here)
-    valid, _ = est.valid_best(None, pts, F0, smp[0], 0.75, never)
+    from pyprogressivex import _lib as L
+    octx = OracleContext()
+    octx.set_points(L.FUNDAMENTAL, pts)
+    valid, _ = est.valid_best(octx, pts, F0, smp[0], 0.75, never)
     assert valid
     a, b = np.array([0.0, 1.0, -500.0]), np.array([0.0, 1.0, -480.0])            # "x' on the line y = 500" times "x on y = 480"
     band = pts.copy()
@@ -359,7 +362,10 @@ def test_fundamental_validity_stages():
     R1 = np.outer(a, b).reshape(-1) / np.linalg.norm(np.outer(a, b))
     samp, sym = est._sampson_and_symmetric(R1.reshape(3, 3), band)
     assert (samp < 2.25 * 0.75 ** 2).sum() >= 250 and ((samp < 2.25 * 0.75 ** 2) & (sym < 9 * 0.75 ** 2)).sum() < 100
-    valid, _ = est.valid_best(None, band, R1, None, 0.75, never)
+    octx.set_points(L.FUNDAMENTAL, band)
+    inl_n, sup_n = octx.epipolar_support(R1, 2.25 * 0.75 ** 2, 9 * 0.75 ** 2)   # the counts the stage uses = the numpy formula's
+    assert inl_n == int((samp < 2.25 * 0.75 ** 2).sum()) and sup_n == int(((samp < 2.25 * 0.75 ** 2) & (sym < 9 * 0.75 ** 2)).sum())
+    valid, _ = est.valid_best(octx, band, R1, None, 0.75, never)
     assert not valid
     est_off = _estimators.FundamentalEstimator()
     est_off.validity = "off"
