@@ -524,7 +524,8 @@ int epipolar_support_launch(pgx_ctx* ctx, const double* F, double T2, double S2,
 constexpr int kMaxBucketLabels = 64;
 
 __global__ __launch_bounds__(kPwBlock) void bucket_count_kernel(const int* __restrict__ labels, int64_t n, int L,
-                                                                unsigned* __restrict__ block_counts /*[blocks][L]*/)
+                                                                unsigned* __restrict__ block_counts /*[blocks][L]*/,
+                                                                unsigned long long* __restrict__ totals /*[L] or nullptr*/)
 {
     __shared__ unsigned hist[kMaxBucketLabels];
     if (threadIdx.x < kMaxBucketLabels) hist[threadIdx.x] = 0;
@@ -539,7 +540,11 @@ __global__ __launch_bounds__(kPwBlock) void bucket_count_kernel(const int* __res
             atomicAdd(&hist[k], (unsigned)__popcll(b));
     }
     __syncthreads();
-    if ((int)threadIdx.x < L) block_counts[(int64_t)blockIdx.x * L + threadIdx.x] = hist[threadIdx.x];
+    if ((int)threadIdx.x < L) {
+        // bucket SIZES only (PEARL's refits select the members on the device by label): integer atomics, no scan over the blocks
+        if (totals != nullptr) { if (hist[threadIdx.x]) atomicAdd(&totals[threadIdx.x], (unsigned long long)hist[threadIdx.x]); }
+        else block_counts[(int64_t)blockIdx.x * L + threadIdx.x] = hist[threadIdx.x];
+    }
 }
 
 // exclusive scan over blocks for every label (one thread per label; blocks <= a few thousand) + label starts
@@ -604,9 +609,15 @@ int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)
     long long* d_starts = (long long*)(base + o); o += (size_t)L * sizeof(long long);
     o = (o + 15) & ~(size_t)15;
     int* d_order = (int*)(base + o);
-    hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
-                       ctx->labels.as<int>(), n, L, bc);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, bc, blocks, L, d_counts, d_starts);
+    if (!order) {   // (the one-thread-per-label scan over the blocks was 100 us per PEARL iteration at 2e5 points)
+        PGX_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)L * sizeof(long long), ctx->stream));
+        hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
+                           ctx->labels.as<int>(), n, L, bc, (unsigned long long*)d_counts);
+    } else {
+        hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
+                           ctx->labels.as<int>(), n, L, bc, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, bc, blocks, L, d_counts, d_starts);
+    }
     if (order)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
                            ctx->labels.as<int>(), n, L, bc, d_starts, d_order);

@@ -541,6 +541,8 @@ def test_bucket_matches_oracle(gpu_ctx, oracle, n, L):
     rc, ro = oracle.bucket(labels, L)
     assert np.array_equal(counts, rc)
     assert np.array_equal(order, ro)  # stable: ascending point index inside every bucket (PEARL.h:342-352)
+    sizes, none = gpu_ctx.bucket(L, want_order=False)   # the sizes-only form PEARL uses (integer atomics, no scan)
+    assert none is None and np.array_equal(sizes, rc)
 
 
 @pytest.mark.parametrize("name", list(MODEL_CASES))
