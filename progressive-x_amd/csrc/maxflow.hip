@@ -1148,11 +1148,9 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
     if (!source_reach && wq == nullptr && pair && L <= 64 && region_moves_apply(ctx)) {   // (then expand_alpha_region runs its first kernel = the per-site initialisation)
-        be.count_and_setup(v);
-        if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));
-        const int rr = expand_alpha_region(ctx, v, changed);   // (its first kernel is init_sites fused with the search for open sites)
+        const int rr = expand_alpha_region(ctx, v, changed);   // (its first kernel is init_sites + the label count fused with the search for open sites)
         if (rr != PGX_TILE_FALLBACK) return rr;   // solved, enqueued (PGX_REGION_PENDING) or an error
-        tune.preinit = 1;
+        tune.preinit = 1;   // the sites are initialised; the hub set-up (which does not touch them) is still to run
     }
     const int r = mf_expand_alpha(be, v, tune, changed, ctx->stats);
     if (be.err != hipSuccess) return fail(ctx, PGX_ERR_HIP, "expansion move failed: %s", hipGetErrorString(be.err));

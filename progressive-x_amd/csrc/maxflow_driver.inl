@@ -23,7 +23,7 @@ struct MfTuning {
     int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
     int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
     int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
-    int preinit = 0;          // count_and_setup + init_sites have already run for this move (the region path declined it)
+    int preinit = 0;          // init_sites has already run for this move (the region path declined it); count_and_setup has not
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
@@ -32,7 +32,7 @@ template <class Backend>
 int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t* changed, int64_t stats[8])
 {
     *changed = 0;
-    if (!tune.preinit) be.count_and_setup(v);
+    be.count_and_setup(v);   // (labels -> counts -> hub flags, small state: independent of the per-site initialisation)
     // The number of sites that already carry alpha travels back with the first flag read-back of the move (a read-back of
     // its own was a synchronisation per move: 5 % of a findVanishingPoints call).  If EVERY site carries alpha the move's
     // graph is empty: the first search finds nothing and the move ends there, as the early return used to.

@@ -63,7 +63,7 @@ struct RegionInfo {
     int pad;
     long long pool[kMaxL];      // per label: sink capacity of the sites OUTSIDE the region
     long long needsum[kMaxL];   // per label: capacity of the region's arcs into such sites
-    int hub[kMaxL];             // the label has a hub in this move
+    int cnt[kMaxL];             // sites per label (counted by the region's first kernel: a label in use other than alpha has a hub when h > 0)
 };
 
 // Region moves of one expansion cycle are enqueued back to back, the host reads all results at the end (pgx_expansion).  Two
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     const int tile_n = (int)((v.n - base) < T ? (v.n - base) : T);
     int cnt_alpha = 0;
     if (region) {
-        cnt_alpha = v.rg->cnt_alpha;
+        cnt_alpha = v.rg->cnt[v.alpha_apply];
         __syncthreads();
     } else {
         // labels in tile space + histogram
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         // the hubs were left out: a label's hub drains into members outside the region as long as their sink capacity exceeds what
         // the region's arcs can claim of it by h; otherwise the hub interacts with this cut and the general path has to solve it
         for (int l = 0; l < kMaxL; ++l)
-            if (v.rg->hub[l] && v.rg->pool[l] - v.rg->needsum[l] < v.h_q) gave_up = 4;
+            if (v.h_q > 0 && l != v.alpha_apply && v.rg->cnt[l] > 0 && v.rg->pool[l] - v.rg->needsum[l] < v.h_q) gave_up = 4;
     }
     if (!gave_up) {
         bool apply = true;
@@ -1010,20 +1010,30 @@ __global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo*
                                                           long long* __restrict__ need, const int* __restrict__ ctl, int skip_rel)
 {
     __shared__ unsigned long long s_pool[kMaxL];
+    __shared__ int s_lab[kMaxL];   // sites per label in this workgroup (maxflow.hip's count pass, folded in: the labels are read here anyway)
     if (batch_skips(ctl, skip_rel)) return;
-    if (threadIdx.x < kMaxL) s_pool[threadIdx.x] = 0;
+    if (threadIdx.x < kMaxL) { s_pool[threadIdx.x] = 0; s_lab[threadIdx.x] = 0; }
     __syncthreads();
     const int64_t n = mv.n;
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n + 255 - (n + 255) % 256; u += (int64_t)gridDim.x * 256) {
         bool open = false;
+        int lab_here = -1;
         if (u < n) {
             mf_body_init_site(mv, u);
             need[u] = 0;
             const int lu = mv.labels[u];
+            lab_here = lu;
             const long long r = mv.rt[u];
             open = lu != mv.alpha && r <= 0;
             if (!open) slot[u] = -1;
             if (lu != mv.alpha && r > 0) atomicAdd(&s_pool[lu], (unsigned long long)r);
+        }
+        // label histogram: one LDS atomic per (wave, label present)
+        for (unsigned long long todo = __ballot(lab_here >= 0); todo != 0;) {
+            const int l0 = __shfl(lab_here, __ffsll((long long)todo) - 1, 64);
+            const unsigned long long same = __ballot(lab_here == l0);
+            if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)same) - 1) && l0 < kMaxL) atomicAdd(&s_lab[l0], __popcll(same));
+            todo &= ~same;
         }
         const unsigned long long m = __ballot(open);
         if (m) {
@@ -1040,10 +1050,7 @@ __global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo*
     }
     __syncthreads();
     if ((int)threadIdx.x < mv.L && s_pool[threadIdx.x] > 0) atomicAdd((unsigned long long*)&rg->pool[threadIdx.x], s_pool[threadIdx.x]);
-    if (blockIdx.x == 0 && (int)threadIdx.x < kMaxL) {
-        rg->hub[threadIdx.x] = (int)threadIdx.x < mv.L ? mv.hub_exists[threadIdx.x] : 0;
-        if (threadIdx.x == 0) rg->cnt_alpha = mv.cnt[mv.alpha];
-    }
+    if ((int)threadIdx.x < kMaxL && s_lab[threadIdx.x] > 0) atomicAdd(&rg->cnt[threadIdx.x], s_lab[threadIdx.x]);
 }
 
 // Weak sinks join the region.  A neighbour q with a t-link stays outside only if the region's arcs cannot saturate it:
@@ -1361,9 +1368,8 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     return PGX_OK;
 }
 
-// One expansion move through the region path.  `mv` = the move as maxflow.hip has set it up (count_and_setup has run on the
-// context's stream; the per-site initialisation - t-links, arcs, hubs - is this function's first kernel, fused with the search
-// for open sites).  PGX_OK: done, *changed set.  PGX_TILE_FALLBACK: declined - the labels are untouched and mv's state is
+// One expansion move through the region path.  `mv` = the move's view of maxflow.hip; nothing has run for it yet: the per-site
+// initialisation (t-links, arcs) and the label count are this function's first kernel, fused with the search for open sites.  PGX_OK: done, *changed set.  PGX_TILE_FALLBACK: declined - the labels are untouched and mv's state is
 // initialised and intact, the general path continues from it.  The caller checks the applicability conditions of the first
 // line (maxflow.hip): when they fail nothing has been initialised.
 constexpr int kRegionSlots = 64;   // moves in flight per batch (one per label: kMaxL)
