@@ -789,8 +789,8 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     __shared__ int s_cnt;
     __shared__ unsigned long long s_stuck;
     const int tid = (int)threadIdx.x;
-    const int tiles = (int)gridDim.x, tile = (int)blockIdx.x;
-    const bool single = tiles == 1;
+    constexpr int tiles = 1, tile = 0;
+    constexpr bool single = true;
     const int base = tile * T;
     const bool region = v.rg != nullptr;   // (one workgroup) the arrays hold a prepared problem of rg->count sites, no hubs
     if (region) {
