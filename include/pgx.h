@@ -177,8 +177,8 @@ int pgx_greedy_labeling(pgx_ctx *ctx, double label_cost, int64_t *energy_q, doub
  * [6]=work-list sweeps, [7]=moves skipped because the labelling had not changed since that label's last move, which relabelled nothing */
 int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 /* which min-cut solver finished the moves since pgx_create (the cut is the same under all of them; tests use this to make
- * sure the solver under test is the one that ran): [0]=one workgroup on the whole graph (<= 8192 sites), [1]=co-operative
- * multi-tile launch (PGX_TILE_MULTI), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
+ * sure the solver under test is the one that ran): [0]=one workgroup on the whole graph (<= 8192 sites), [1]=0 (was: the
+ * multi-tile launch, removed), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
  * (maxflow.hip), [4]=region moves declined (too many open sites / a sink that could not be promoted), [5]=tile moves handed back */
 int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
 

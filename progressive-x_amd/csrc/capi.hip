@@ -108,11 +108,6 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_TILE_MULTI")) {   // 1: graphs beyond one workgroup on the tile path; 2 (tests): tiles for every graph, no hand-back
-        const int v = std::atoi(b);
-        ctx->tile_multi = v ? 1 : 0;
-        if (v == 2) { ctx->tile_single_max = 0; ctx->tile_hard_div = 0; }
-    }
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -865,7 +860,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
             std::vector<int> ev((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
             PGX_TRY(expand_cycle_l0(ctx, hq, ch.data(), ev.data()));
             for (int alpha = 0; alpha < ctx->L; ++alpha) changed_total += ch[(size_t)alpha];
-        } else if (region_moves_apply(ctx) && !(ctx->mf_tile && (ctx->dq_n <= ctx->tile_single_max || ctx->tile_multi))) {
+        } else if (region_moves_apply(ctx) && !(ctx->mf_tile && ctx->dq_n <= ctx->tile_single_max)) {
             // Region moves (maxflow_tile.hip): the moves of the cycle are enqueued back to back and resolved together - one
             // host round trip per batch instead of one per move.  A move that declines poisons the rest of its batch on the device
             // (they return untouched); it is solved by the general path and the cycle resumes behind it.  The skip rule below is

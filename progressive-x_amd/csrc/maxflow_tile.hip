@@ -1,4 +1,4 @@
-// maxflow_tile.hip — tile-resident push-relabel for one alpha-expansion move (the default min-cut path).
+// maxflow_tile.hip — LDS-resident push-relabel for one alpha-expansion move: one workgroup, one launch per move.
 //
 // Replaces: GCoptimizationGeneralGraph::alpha_expansion + BK max-flow behind pearl::PEARL::labeling
 //           (/root/reference/src/pyprogressivex/include/PEARL.h:499-551); upstream source absent [U-5].  Same binary
@@ -6,24 +6,22 @@
 //           maxflow_body.cuh, whose header states the construction; this file is a different SCHEDULE of it.
 //
 // Why: the level-synchronous schedule of maxflow.hip costs one launch per BFS level and two per sweep (~12 us each of
-// dependent device-scope round trips): ~820 launches per min-cut at N = 1e6.  Here the sites are permuted into a
-// locality order once per graph (Morton order of the graph's own coordinates, or the points' order) and cut into tiles
-// of consecutive sites; one workgroup owns a tile, keeps the tile's heights and excesses in LDS, and per launch runs
-//   * relax:     label-correcting reverse search from t to a LOCAL fixpoint (dozens of levels per launch; arcs that
-//                leave the tile read the neighbour's height from global memory and are re-polled), and
-//   * discharge: dozens of push-relabel sweeps (pushes inside the tile are LDS atomics; pushes that leave it go to the
-//                target's inbox word with device-scope atomics).
-// Heights are only a heuristic here: any sequence of capacity-respecting pushes is a preflow, and the move ends when a
-// relax pass started from scratch (heights reset, run to a global fixpoint = exact distances) shows that no site with
-// excess reaches t.  The sites that do not reach t then are the source side = take alpha, exactly as before.
-// A graph that fits ONE tile (<= 8192 sites) is solved by one launch of one workgroup per move (mf2_k_single).
+// dependent device-scope round trips): ~820 launches per min-cut at N = 1e6.  A problem of <= 8192 sites fits one workgroup:
+// the sites are permuted into a locality order once per graph (Morton order of the graph's own coordinates, or the points'
+// order), heights and excesses live in LDS, arc tables in registers, and ONE launch runs the whole move:
+//   * relax:     label-correcting reverse search from t to its fixpoint (exact distances; no launch per level),
+//   * discharge: push-relabel sweeps over the active sites (pushes are LDS / workgroup-scope atomics), 16 per outer step,
+//   * apply:     the sites that do not reach t are the source side = take alpha.
+// Heights are only a heuristic in between: any sequence of capacity-respecting pushes is a preflow, and the move ends when a
+// search started from scratch shows that no site with excess reaches t.
+// Two kinds of problems arrive here: a whole graph of <= 8192 sites (expand_alpha_tile), and the compacted sub-graph of the
+// OPEN sites of a move on a larger graph (expand_alpha_region, "region moves", below).
 //
-// Memory-scope rule (gfx950, 8 XCDs with one L2 each): an address is touched with ONE scope inside a kernel.  State
-// of arcs with both ends in the tile and the tile's own words: workgroup scope (served by the XCD's L2); arcs that
-// cross tiles, inbox words, published heights, hub words: agent scope.  Mixed scopes on one word are never used.
+// Memory-scope rule (gfx950, 8 XCDs with one L2 each): an address is touched with ONE scope inside a kernel.  Arc capacities:
+// workgroup scope; heights in global memory, hub words, flags: agent scope.
 //
 // Label costs: beta hubs (s -> y_beta (h), y_beta -> members (inf)) are global words; members with a t-link pull the
-// hub's excess through one aggregated reservation per (tile, hub); a member pushes back through its own counter f.
+// hub's excess through one aggregated reservation per hub; a member pushes back through its own counter f.
 // An unused alpha is handled by the stranded-excess test (maxflow_body.cuh, "gate").  Anything else (materialised alpha
 // hub, per-arc weights, the source-side variant of the local optimisation's cut, a hub that only reaches t through
 // members without t-links) falls back to maxflow.hip: the function returns PGX_TILE_FALLBACK before touching the labels.
@@ -88,23 +86,13 @@ struct TView {
     int* labels;          // [n]    original space
     const int* perm;      // sorted -> original
     const int *off, *idx, *rev, *mult;  // sorted-space CSR
-    long long *cap, *ex, *inbox, *rt, *f;
+    long long *cap, *ex, *rt, *f;
     int *d, *lab;
     // small block
     long long* hub_e;  // [L]
     int* hub_d;        // [L]
     int* hub_exists;   // [L]
-    int* cnt;          // [L]
-    int* rchg;         // [2] a verifying pass lowered something (by parity of the pass)
-    int* act;          // [2] sites with excess that reach t
-    int* bar;          // [2] grid barrier: arrivals, generation
-    int* busy;         // [2] tiles still working in the co-operative search / discharge
-    int* epoch;        // [tiles] bumped by a tile that published heights / by whoever pushed into the tile's inbox
-    int* hub_epoch;    // [1] bumped when a hub distance fell
     int* flags;        // 0 active sites that reach t, 1 sites relabelled by apply, 2 flow reached t (discharge), 3 work left after discharge
-    unsigned long long* stuck;  // [2] stranded excess of the sites
-    int T;             // sites per tile
-    int lazy;          // relax accepts only substantial improvements of finite heights (several tiles)
     unsigned long long* dbg;   // [16] PGX_MF_DEBUG: time per phase of tile 0 (100 MHz ticks), or nullptr
     const struct RegionInfo* rg;   // region mode (expand_alpha_region): the problem is PREPARED in the arrays above, n = rg->count
     int* ctl;          // region moves enqueued without a host round trip (BatchCtl below), or nullptr
@@ -113,35 +101,28 @@ struct TView {
 };
 
 // ---- per-move setup ----------------------------------------------------------------------------------------------------
-// t-links and arc capacities of site s (maxflow_body.cuh mf_body_init_site, in tile space).  Words that other tiles touch
-// during the move - heights, inbox, capacities of arcs that leave the tile - are written with device scope: the whole move
-// is one kernel, so there is no kernel boundary that would write this XCD's L2 back before they do.
-__device__ __forceinline__ void init_site(const TView& v, const int64_t s, const int base, const int tile_n)
+// t-links and arc capacities of site s (maxflow_body.cuh mf_body_init_site, in tile space)
+__device__ __forceinline__ void init_site(const TView& v, const int64_t s)
 {
     const int lu = v.lab[s];
     v.f[s] = 0;
-    __hip_atomic_store(&v.inbox[s], 0ll, __ATOMIC_RELAXED, SC_AG);
     st32<SC_AG>(&v.d[s], kInf);
     const int a0 = v.off[s], a1 = v.off[s + 1];
-    auto put = [&](int a, long long c) {
-        if ((unsigned)(v.idx[a] - base) < (unsigned)tile_n) v.cap[a] = c;
-        else __hip_atomic_store(&v.cap[a], c, __ATOMIC_RELAXED, SC_AG);
-    };
     if (lu == v.alpha) {
         v.ex[s] = 0;
         v.rt[s] = 0;
-        for (int a = a0; a < a1; ++a) put(a, 0);
+        for (int a = a0; a < a1; ++a) v.cap[a] = 0;
         return;
     }
     const int64_t o = v.perm[s];
     long long keep = v.dq[(int64_t)lu * v.n + o];
     const long long take = v.dq[(int64_t)v.alpha * v.n + o];
     for (int a = a0; a < a1; ++a) {
-        const int lq = v.labels[v.perm[v.idx[a]]];   // (the caller's labels: other tiles fill lab[] concurrently)
+        const int lq = v.lab[v.idx[a]];
         const long long w = v.lambda_q * (long long)v.mult[a];
-        if (lq == v.alpha) { keep += w; put(a, 0); }
-        else if (lq == lu) put(a, w);
-        else { keep += w / 2; put(a, w / 2); }
+        if (lq == v.alpha) { keep += w; v.cap[a] = 0; }
+        else if (lq == lu) v.cap[a] = w;
+        else { keep += w / 2; v.cap[a] = w / 2; }
     }
     if (keep > take) { v.ex[s] = keep - take; v.rt[s] = 0; }
     else { v.ex[s] = 0; v.rt[s] = take - keep; }
@@ -151,7 +132,7 @@ __device__ __forceinline__ void init_site(const TView& v, const int64_t s, const
 template <int T>
 struct TileLds {
     int d[T];
-    long long ex[T];              // discharge: excess.  relax: heads of the arcs that leave the tile (int[2T])
+    long long ex[T];              // discharge: excess
     unsigned short act[T];        // discharge: sites of the current inner sweep
     unsigned short farl[T];       // discharge: sites that wait for the next outer (device-scope) step
     unsigned char wf[T];          // discharge: site is on farl
@@ -160,138 +141,41 @@ struct TileLds {
     long long hube[kMaxL];
     unsigned long long want[kMaxL];
     long long got[kMaxL];
-    unsigned long long nbmask[64];   // tiles this tile's arcs lead to
     int nact, nfar;
-    int misc[4];
 };
 
 
-// ---- tiles of one launch keep working while ANY tile is still working --------------------------------------------------------
-// A tile that is idle cannot know whether a neighbour will still lower a height it reads or push into its inbox.  Every launch
-// has a counter that starts at the number of tiles; a tile takes itself off when a pass found nothing to do and back on when a
-// later one did, and leaves the kernel once it has seen the counter at zero twice in a row (or its budget is spent).  While
-// idle it does not re-scan its arcs: every tile bumps its own EPOCH word after publishing heights (relax) / a pusher bumps the
-// target tile's epoch (discharge), and an idle tile only watches the epochs of the tiles its arcs lead to (a bit mask over
-// <= 4096 tiles in LDS).  Tiles that are not resident yet count as busy, every loop is bounded, and a missed hand-over only
-// costs a launch: the host's stopping rules (a relax phase that changes nothing; no site with excess that reaches t) do not
-// depend on it.
 __device__ __forceinline__ void add32_ag(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, SC_AG); }
 
-struct TileSync {
-    int* ctr = nullptr;     // the launch's busy counter
-    int* epoch = nullptr;   // [tiles]
-    int* hub_epoch = nullptr;
-    int* gepoch = nullptr;  // bumped once per publish of ANY tile
-    int* ack = nullptr;     // [tiles] the value of gepoch up to which a tile has scanned and found nothing to do
-    int tile = 0, tiles = 0;
-    bool on = true, confirmed = false;
-    bool strict = false;    // relax: one look at the counter is enough (the acknowledgements decide); discharge: two looks
-    __device__ __forceinline__ void working()
-    {
-        if (!on) { if (threadIdx.x == 0) add32_ag(ctr, 1); on = true; }
-        confirmed = false;
-    }
-    __device__ __forceinline__ void idle()
-    {
-        if (on) { if (threadIdx.x == 0) { __threadfence(); add32_ag(ctr, -1); } on = false; }
-    }
-    __device__ __forceinline__ void leave() { idle(); }
-    // (uniform) true when every tile has been idle on two consecutive looks
-    template <class Lds> __device__ __forceinline__ bool all_idle(Lds& lds)
-    {
-        if (threadIdx.x == 0) lds.misc[0] = ld32<SC_AG>(ctr);
-        __syncthreads();
-        const int g = lds.misc[0];
-        __syncthreads();
-        if (g > 0) { confirmed = false; return false; }
-        if (confirmed || strict) return true;
-        confirmed = true;
-        return false;
-    }
-    // (uniform) every tile has acknowledged global epoch g, and g is still current
-    template <class Lds> __device__ __forceinline__ bool all_acked(Lds& lds, const int g)
-    {
-        bool bad = false;
-        for (int t = (int)threadIdx.x; t < tiles; t += (int)blockDim.x) bad |= ld32<SC_AG>(&ack[t]) != g;
-        if (threadIdx.x == 0) bad |= ld32<SC_AG>(gepoch) != g;
-        return __syncthreads_or(bad ? 1 : 0) == 0;
-    }
-    template <class Lds> __device__ __forceinline__ int global_epoch(Lds& lds)
-    {
-        if (threadIdx.x == 0) lds.misc[2] = ld32<SC_AG>(gepoch);
-        __syncthreads();
-        const int g = lds.misc[2];
-        __syncthreads();
-        return g;
-    }
-    // (uniform) sum of the epochs of the tiles this one reads from, plus the hub epoch
-    template <class Lds> __device__ __forceinline__ int epoch_sum(Lds& lds)
-    {
-        const int tid = (int)threadIdx.x;
-        if (tid < 64) {
-            int sum = 0;
-            if (tiles <= 4096) {
-                unsigned long long m = lds.nbmask[tid];
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    sum += ld32<SC_AG>(&epoch[tid * 64 + b]);
-                }
-            } else {
-                for (int t = tid; t < tiles; t += 64) sum += ld32<SC_AG>(&epoch[t]);
-            }
-            if (tid == 0) sum += ld32<SC_AG>(hub_epoch);
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            if (tid == 0) lds.misc[1] = sum;
-        }
-        __syncthreads();
-        const int r = lds.misc[1];
-        __syncthreads();
-        return r;
-    }
-};
-
-// ---- relax: reverse label-correcting search from t, to the tile's fixpoint -------------------------------------------------
-// phase 0: heights are reset (1 for sites with a t-link, "unreachable" otherwise) and only arcs inside the tile are used -
-// other tiles may not have reset yet; phases >= 1 also read the heights other tiles have published.  Values only fall, every
-// value is witnessed by a path, and the host repeats phases until one changes nothing: that state is the exact distance
-// labelling.  Returns (workgroup-uniform) whether this tile lowered anything.
+// ---- relax: reverse label-correcting search from t, to the fixpoint -------------------------------------------------------
+// phase 0: heights are reset (1 for sites with a t-link, "unreachable" otherwise) and the arcs of the register tables are used;
+// phase 2 (only when some row is longer than the register table): continues from the stored heights and also walks the rest of
+// those rows in memory.  Values only fall, every value is witnessed by a path, and the caller repeats phase 2 until it changes
+// nothing: that state is the exact distance labelling.  Returns (workgroup-uniform) whether anything was lowered.
 template <int NT, int SPT, int MAXD>
-__device__ __forceinline__ bool tile_relax(const TView& v, const int base, const int tile_n, const int phase, TileLds<NT * SPT>& lds, const int max_polls,
-                                           TileSync& ts, const bool coop, const bool lazy, int& any_far, bool& exhausted)
+__device__ __forceinline__ bool tile_relax(const TView& v, const int tile_n, const int phase, TileLds<NT * SPT>& lds, int& any_far)
 {
-    exhausted = false;
-    // coop: several tiles in this launch (phases >= 1); `ts` is always a valid object (it is only used when coop).
-    // lazy (launches with several tiles): a height that is already finite is only replaced by one that is at least a quarter
-    // (+2) lower.  Label-correcting across tiles otherwise spends most of its time improving heights a few percent at a time
-    // as better values trickle in from neighbours, and every improvement makes the neighbours re-scan; REACHABILITY - all the
-    // stopping rule needs - is unaffected (an unlabelled site takes whatever it is offered), heights stay witnessed by a path.
-    constexpr int T = NT * SPT;
     const int tid = (int)threadIdx.x;
-    TileSync* const sync = &ts;
-    int* const farhead = reinterpret_cast<int*>(lds.ex);   // [2T]
     bool open[SPT], fpos[SPT], slow[SPT];
-    int myd[SPT], d0[SPT], mylab[SPT], rmin[SPT], fstart[SPT], fcnt[SPT];
+    int myd[SPT], d0[SPT], mylab[SPT], rmin[SPT];
     unsigned resm[SPT];
     unsigned pk[SPT][MAXD / 2];
-    if (tid < kMaxL) { lds.hubmin[tid] = kInf; lds.hubd[tid] = kInf; lds.nbmask[tid] = 0; }
-    if (tid == 0) lds.nfar = 0;
+    if (tid < kMaxL) { lds.hubmin[tid] = kInf; lds.hubd[tid] = kInf; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
         const int slot = tid + j * NT;
         const bool valid = slot < tile_n;
-        const int64_t s = (int64_t)base + slot;
+        const int64_t s = slot;
         const int lab = valid ? v.lab[s] : v.alpha;
         mylab[j] = lab;
         open[j] = false; fpos[j] = false; slow[j] = false;
         resm[j] = 0;
         rmin[j] = kInf;
-        fstart[j] = 0; fcnt[j] = 0;
         int dl = kInf;
         if (valid && lab != v.alpha) {
             const long long r = v.rt[s];
-            dl = phase == 0 ? (r > 0 ? 1 : kInf) : ld32<SC_AG>(&v.d[s]);
+            dl = phase == 0 ? (r > 0 ? 1 : kInf) : ld32<SC_AG>(&v.d[s]);   // (one scope per address and kernel: v.d is read and written at device scope throughout)
             open[j] = r <= 0;
         }
         myd[j] = dl;
@@ -302,8 +186,6 @@ __device__ __forceinline__ bool tile_relax(const TView& v, const int base, const
         if (open[j]) {
             fpos[j] = v.hub_exists[lab] != 0 && v.f[s] > 0;
             const int a0 = v.off[s], a1 = v.off[s + 1];
-            int nf = 0;
-            unsigned farm = 0;   // arcs of the register table that leave the tile and are residual
             if (a1 > a0) {
                 // all loads of the row are issued before the first one is used (clamped addresses instead of branches): one
                 // round trip per row instead of one per arc
@@ -311,79 +193,37 @@ __device__ __forceinline__ bool tile_relax(const TView& v, const int base, const
                 long long c[MAXD];
 #pragma unroll
                 for (int k = 0; k < MAXD; ++k) q[k] = v.idx[a0 + k < a1 ? a0 + k : a1 - 1];
-                bool anyfar = false;
 #pragma unroll
-                for (int k = 0; k < MAXD; ++k) {
-                    c[k] = ld64<SC_WG>(&v.cap[a0 + k < a1 ? a0 + k : a1 - 1]);   // (meaningless for arcs that leave the tile: re-read below)
-                    anyfar |= a0 + k < a1 && (unsigned)(q[k] - base) >= (unsigned)tile_n;
-                }
-                if (anyfar) {
-#pragma unroll
-                    for (int k = 0; k < MAXD; ++k)
-                        if (a0 + k < a1 && (unsigned)(q[k] - base) >= (unsigned)tile_n) c[k] = ld64<SC_AG>(&v.cap[a0 + k]);
-                }
+                for (int k = 0; k < MAXD; ++k) c[k] = ld64<SC_WG>(&v.cap[a0 + k < a1 ? a0 + k : a1 - 1]);
 #pragma unroll
                 for (int k = 0; k < MAXD; ++k) {
                     if (a0 + k >= a1 || c[k] <= 0) continue;
-                    const unsigned w = (unsigned)(q[k] - base);
-                    if (w < (unsigned)tile_n) { resm[j] |= 1u << k; pk[j][k >> 1] |= (w & 0xffffu) << ((k & 1) * 16); }
-                    else { farm |= 1u << k; ++nf; }
+                    resm[j] |= 1u << k;
+                    pk[j][k >> 1] |= ((unsigned)q[k] & 0xffffu) << ((k & 1) * 16);
                 }
             }
             if (a1 - a0 > MAXD) slow[j] = true;   // rows longer than the register table: the rest is walked in memory at every poll
-            if (nf > 0 && phase > 0) {
-                const int st = atomicAdd(&lds.nfar, nf);
-                if (st + nf <= 2 * T) {
-                    fstart[j] = st;
-                    fcnt[j] = nf;
-                    int o = st;
-#pragma unroll
-                    for (int k = 0; k < MAXD; ++k)
-                        if (farm & (1u << k)) {
-                            const int q = v.idx[a0 + k];
-                            farhead[o++] = q;
-                            const int tq = q / T;
-                            if (coop && tq < 4096) atomicOr(&lds.nbmask[tq >> 6], 1ull << (tq & 63));
-                        }
-                } else slow[j] = true;
-            }
-            if (slow[j] && coop)
-                for (int a = a0; a < a1; ++a) {
-                    const int tq = v.idx[a] / T;
-                    if (tq < 4096) atomicOr(&lds.nbmask[tq >> 6], 1ull << (tq & 63));
-                }
         }
     }
     bool farany = false;
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) farany |= slow[j] || fcnt[j] > 0;
+    for (int j = 0; j < SPT; ++j) farany |= slow[j];
     const int far_wg = __syncthreads_or(farany ? 1 : 0);
     any_far = far_wg;
-    bool tile_changed = false;
-    for (int poll = 0; poll < max_polls; ++poll) {
-        const int seen = coop ? sync->epoch_sum(lds) : 0;   // sampled BEFORE the remote heights are read
-        // heights of the heads outside the tile (and of the arcs beyond the register table)
+    bool changed = false;
+    for (;;) {
+        // the arcs beyond the register table
         if (phase > 0 && far_wg) {
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
+                if (!slow[j]) continue;
                 int m = kInf;
-                for (int i = 0; i < fcnt[j]; ++i) {
-                    const int h = ld32<SC_AG>(&v.d[farhead[fstart[j] + i]]);
+                const int64_t s = tid + j * NT;
+                const int a0 = v.off[s], a1 = v.off[s + 1];
+                for (int a = a0 + MAXD; a < a1; ++a) {
+                    if (ld64<SC_WG>(&v.cap[a]) <= 0) continue;
+                    const int h = lds.d[v.idx[a]];
                     m = h < m ? h : m;
-                }
-                if (slow[j]) {
-                    const int64_t s = (int64_t)base + tid + j * NT;
-                    const int a0 = v.off[s], a1 = v.off[s + 1];
-                    for (int a = a0; a < a1; ++a) {
-                        const int k = a - a0;
-                        const int q = v.idx[a];
-                        const unsigned w = (unsigned)(q - base);
-                        const bool local = w < (unsigned)tile_n;
-                        if (k < MAXD && (local || fcnt[j] > 0)) continue;   // in the register table / on the far list
-                        if ((local ? ld64<SC_WG>(&v.cap[a]) : ld64<SC_AG>(&v.cap[a])) <= 0) continue;
-                        const int h = local ? lds.d[w] : ld32<SC_AG>(&v.d[q]);
-                        m = h < m ? h : m;
-                    }
                 }
                 rmin[j] = m;
             }
@@ -405,20 +245,20 @@ __device__ __forceinline__ bool tile_relax(const TView& v, const int base, const
                     }
                 if (fpos[j]) { const int h = lds.hubd[mylab[j]]; m = h < m ? h : m; }
                 const int nd = m >= kInf ? kInf : m + 1;
-                if (nd < myd[j] && (!lazy || myd[j] == kInf || nd + (myd[j] >> 2) + 2 <= myd[j])) { myd[j] = nd; lds.d[tid + j * NT] = nd; ch = true; }
+                if (nd < myd[j]) { myd[j] = nd; lds.d[tid + j * NT] = nd; ch = true; }
             }
             mine |= ch;
             if (!__syncthreads_or(ch ? 1 : 0)) break;
         }
-        // what the tile's members say about their hubs
+        // what the members say about their hubs
 #pragma unroll
         for (int j = 0; j < SPT; ++j)
             if (mylab[j] != v.alpha && myd[j] < kInf && v.hub_exists[mylab[j]] && myd[j] + 1 < lds.hubd[mylab[j]])
                 atomicMin(&lds.hubmin[mylab[j]], myd[j] + 1);
-        // publish lowered heights
+        // store lowered heights
 #pragma unroll
         for (int j = 0; j < SPT; ++j)
-            if (myd[j] != d0[j] && tid + j * NT < tile_n) { st32<SC_AG>(&v.d[(int64_t)base + tid + j * NT], myd[j]); d0[j] = myd[j]; }
+            if (myd[j] != d0[j] && tid + j * NT < tile_n) { st32<SC_AG>(&v.d[tid + j * NT], myd[j]); d0[j] = myd[j]; }
         __syncthreads();
         bool hub_ch = false;
         if (tid < v.L && lds.hubmin[tid] < lds.hubd[tid]) {
@@ -427,40 +267,10 @@ __device__ __forceinline__ bool tile_relax(const TView& v, const int base, const
         }
         const int any_hub = __syncthreads_or(hub_ch ? 1 : 0);
         const int any = __syncthreads_or(mine ? 1 : 0) | any_hub;
-        if (any) tile_changed = true;
-        if (!coop) {
-            if (!any) break;
-            continue;
-        }
-        if (any) {
-            if (tid == 0) {   // tell the tiles that read from this one
-                __threadfence();
-                add32_ag(&sync->epoch[sync->tile], 1);
-                if (any_hub) add32_ag(sync->hub_epoch, 1);
-                __builtin_amdgcn_s_waitcnt(0);
-                add32_ag(sync->gepoch, 1);   // after the tile's own epoch: who sees this also sees that
-            }
-            sync->working();
-            continue;
-        }
-        // Nothing to do as of `seen`.  Termination (exactness of the search rests on it): every publish bumps the global epoch G
-        // after the publisher's own epoch; an idle tile samples G, then its neighbours' epochs - a change means work - and
-        // otherwise acknowledges that value of G; it leaves when no tile is working and EVERY tile has acknowledged the current G:
-        // then each tile has scanned after the last publish anywhere, and nobody is about to publish.
-        sync->idle();
-        bool leave = false, rescan = false;
-        for (int w = 0; w < 1 << 12; ++w) {
-            const int g = sync->global_epoch(lds);
-            if (sync->epoch_sum(lds) != seen) { rescan = true; break; }
-            if (tid == 0) st32<SC_AG>(&sync->ack[sync->tile], g);
-            if (sync->all_idle(lds) && sync->all_acked(lds, g)) { leave = true; break; }
-            __builtin_amdgcn_s_sleep(16);
-        }
-        if (leave) break;
-        if (!rescan || poll + 1 == max_polls) { exhausted = true; break; }   // out of budget: the caller has the search repeated
+        if (!any) break;
+        changed = true;
     }
-    if (coop) sync->leave();
-    return tile_changed;
+    return changed;
 }
 
 // ---- discharge: push-relabel sweeps of one tile ---------------------------------------------------------------------------
@@ -475,15 +285,14 @@ __device__ __forceinline__ long long reserve_ag(long long* budget, long long wan
     return got;
 }
 
-// One push-relabel step of the site in `slot`.  FAR = false (inner sweeps): only the t-link and the arcs inside the tile are used -
-// LDS heights, LDS excesses, workgroup-scope capacities: no device-scope round trip - and a site that still holds excess and has
-// arcs leaving the tile (or a residual into its hub) is deferred to the next outer step (returns true) instead of being relabelled.
-// FAR = true (outer step): every arc, device scope for those that leave the tile; the site is relabelled if nothing is admissible.
-template <int T, bool FAR, class Lds>
-__device__ __forceinline__ bool site_step(const TView& v, const int base, const int tile_n, Lds& lds, const int slot, TileSync* const sync,
-                                          const bool single, bool& moved_now)
+// One push-relabel step of the site in `slot`.  FAR = false (inner sweeps): the t-link and the arcs - LDS heights, LDS excesses,
+// workgroup-scope capacities: no device-scope round trip - and a site that still holds excess and has a residual into its hub is
+// deferred to the next outer step (returns true) instead of being relabelled.  FAR = true (outer step): the hub residual as well
+// (device scope); the site is relabelled if nothing is admissible.
+template <bool FAR, class Lds>
+__device__ __forceinline__ bool site_step(const TView& v, Lds& lds, const int slot, bool& moved_now)
 {
-    const int64_t s = (int64_t)base + slot;
+    const int64_t s = slot;
     const int du = lds.d[slot];
     long long e = lds.ex[slot], pushed = 0;
     bool defer = false;
@@ -502,34 +311,23 @@ __device__ __forceinline__ bool site_step(const TView& v, const int base, const 
         for (int ab = a0; ab < a1 && e > 0; ab += 8) {
             long long c[8];
             int w[8], h[8];
-            bool loc[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const bool in = ab + q < a1;
-                w[q] = in ? v.idx[ab + q] : base;
-                loc[q] = (unsigned)(w[q] - base) < (unsigned)tile_n;
-                if (FAR) c[q] = !in ? 0 : (loc[q] ? ld64<SC_WG>(&v.cap[ab + q]) : ld64<SC_AG>(&v.cap[ab + q]));
-                else { c[q] = (in && loc[q]) ? ld64<SC_WG>(&v.cap[ab + q]) : 0; has_far |= in && !loc[q]; }
+                w[q] = in ? v.idx[ab + q] : 0;
+                c[q] = in ? ld64<SC_WG>(&v.cap[ab + q]) : 0;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) h[q] = c[q] <= 0 ? kInf : (loc[q] ? lds.d[w[q] - base] : ld32<SC_AG>(&v.d[w[q]]));
+            for (int q = 0; q < 8; ++q) h[q] = c[q] <= 0 ? kInf : lds.d[w[q]];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (c[q] <= 0) continue;
                 if (h[q] < du && e > 0) {
                     const long long dl = e < c[q] ? e : c[q];
                     const int a = ab + q, ra = v.rev[a];
-                    if (loc[q]) {
-                        add64<SC_WG>(&v.cap[a], -dl);
-                        add64<SC_WG>(&v.cap[ra], dl);
-                        atomicAdd((unsigned long long*)&lds.ex[w[q] - base], (unsigned long long)dl);
-                    } else {
-                        add64<SC_AG>(&v.cap[a], -dl);
-                        add64<SC_AG>(&v.cap[ra], dl);
-                        add64<SC_AG>(&v.inbox[w[q]], dl);
-                        add32_ag(&sync->epoch[w[q] / T], 1);
-                        moved_now = true;   // progress: the flow left the tile
-                    }
+                    add64<SC_WG>(&v.cap[a], -dl);
+                    add64<SC_WG>(&v.cap[ra], dl);
+                    atomicAdd((unsigned long long*)&lds.ex[w[q]], (unsigned long long)dl);
                     e -= dl;
                     pushed += dl;
                     c[q] -= dl;
@@ -563,10 +361,7 @@ __device__ __forceinline__ bool site_step(const TView& v, const int base, const 
             if (!FAR && has_far) defer = true;
             else {   // no admissible arc left: relabel (heights only rise here; a relax pass resets them)
                 const int nd = minh >= kInf ? kInf : minh + 1;
-                if (nd > du) {
-                    lds.d[slot] = nd;
-                    if (!single) st32<SC_AG>(&v.d[s], nd);
-                }
+                if (nd > du) lds.d[slot] = nd;
             }
         }
     }
@@ -586,13 +381,11 @@ __device__ __forceinline__ void lds_append(int* counter, unsigned short* list, i
     if (want) list[b + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)value;
 }
 
-// `sweeps` = budget of inner sweeps; an outer step (hubs, inbox, arcs that leave the tile, the all-idle protocol) every kInner
+// `sweeps` = budget of inner sweeps; an outer step (everything that needs a device-scope round trip: the hubs) every kInner
 template <int NT, int SPT>
-__device__ __forceinline__ void tile_discharge(const TView& v, const int base, const int tile_n, TileLds<NT * SPT>& lds, const int sweeps, const bool single,
-                                               int& out_left, int& out_moved, TileSync& ts)
+__device__ __forceinline__ void tile_discharge(const TView& v, const int tile_n, TileLds<NT * SPT>& lds, const int sweeps, int& out_left, int& out_moved)
 {
-    TileSync* const sync = &ts;
-    constexpr int T = NT * SPT;
+    constexpr int base = 0;
     constexpr int kInner = 16;
     const int tid = (int)threadIdx.x;
     int mylab[SPT];
@@ -612,10 +405,9 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
     if (tid < kMaxL) { lds.hube[tid] = 0; lds.hubd[tid] = kInf; }
     __syncthreads();
     bool moved = false;
-    int seen_in = -1;   // (per thread) epoch of this tile's inbox at the last drain
-    int stall = 0;      // inner sweeps in a row in which this tile delivered nothing to t or to another tile
+    int stall = 0;      // inner sweeps in a row in which nothing was delivered to t
     int done = 0;
-    for (int outer = 0; done < sweeps; ++outer) {
+    while (done < sweeps) {
         // ---- outer step: everything that needs a device-scope round trip
         bool worked = false, moved_now = false;
         if (any_hub && tid < kMaxL) {
@@ -624,24 +416,6 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
             const bool ex = tid < v.L && v.hub_exists[tid];
             lds.hube[tid] = ex ? ld64<SC_AG>(&v.hub_e[tid]) : 0;
             lds.hubd[tid] = ex ? ld32<SC_AG>(&v.hub_d[tid]) : kInf;
-        }
-        // what other tiles pushed into this one (every pusher bumps the tile's epoch; every 4th outer step unconditionally: the
-        // epoch can overtake the push it announces)
-        if (!single) {
-            const int in_now = ld32<SC_AG>(&sync->epoch[sync->tile]);
-            if (in_now != seen_in || (outer & 3) == 0) {
-                seen_in = in_now;
-#pragma unroll
-                for (int j = 0; j < SPT; ++j) {
-                    const int slot = tid + j * NT;
-                    if (slot >= tile_n || mylab[j] == v.alpha) continue;
-                    long long* ib = &v.inbox[(int64_t)base + slot];
-                    if (ld64<SC_AG>(ib) > 0) {
-                        const long long got = __hip_atomic_exchange(ib, 0ll, __ATOMIC_RELAXED, SC_AG);
-                        if (got > 0) { atomicAdd((unsigned long long*)&lds.ex[slot], (unsigned long long)got); worked = true; }
-                    }
-                }
-            }
         }
         __syncthreads();
         // hubs holding excess: members with a t-link pull it (one reservation per tile and hub)
@@ -681,7 +455,7 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
         const int nfar = lds.nfar;
         for (int i = tid; i < nfar; i += NT) {
             const int slot = lds.farl[i];
-            site_step<T, true>(v, base, tile_n, lds, slot, sync, single, moved_now);
+            site_step<true>(v, lds, slot, moved_now);
             lds.wf[slot] = 0;
         }
         if (nfar > 0) worked = true;
@@ -709,7 +483,7 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
             worked = true;
             for (int i = tid; i < nact; i += NT) {
                 const int slot = lds.act[i];
-                const bool defer = site_step<T, false>(v, base, tile_n, lds, slot, sync, single, moved_now);
+                const bool defer = site_step<false>(v, lds, slot, moved_now);
                 if (defer) lds.wf[slot] = 1;
                 lds_append(&lds.nfar, lds.farl, slot, defer);
             }
@@ -722,17 +496,9 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
             // sweep - the next exact search settles that at once
             stall = mv ? 0 : stall + 1;
         }
-        if (stall >= (single ? 6 : 32)) break;
-        const int w = __syncthreads_or((worked || lds.nfar > 0) ? 1 : 0);
-        if (!w) {
-            if (single) break;
-            sync->idle();
-            if (sync->all_idle(lds)) break;
-            __builtin_amdgcn_s_sleep(16);
-            ++done;   // (an idle outer step counts against the budget: every loop is bounded)
-        } else if (!single) sync->working();
+        if (stall >= 6) break;
+        if (!__syncthreads_or((worked || lds.nfar > 0) ? 1 : 0)) break;
     }
-    if (!single) sync->leave();
     __syncthreads();
     // write the tile back
     bool left = false;
@@ -751,48 +517,20 @@ __device__ __forceinline__ void tile_discharge(const TView& v, const int base, c
     out_moved = __syncthreads_or(moved ? 1 : 0);
 }
 
-// ---- the whole move in ONE launch ----------------------------------------------------------------------------------------
-// One workgroup per tile, all resident (cooperative launch; a graph of <= 8192 sites is one workgroup), grid barriers between
-// the phases: labels + histogram | t-links | per round { reset | local search | co-operative search | verifying pass + count |
-// co-operative discharge } | gate + apply.  Everything tiles exchange is read and written with device scope, so the barrier
-// needs no L2-wide fence (which costs ~60 us on this part: 8 XCDs, one L2 each): a wave waits for its own memory
-// operations, then one thread per workgroup arrives on a counter and spins on a generation word.
-__device__ __forceinline__ void grid_barrier(const TView& v, const int nblocks)
-{
-    if (nblocks == 1) { __syncthreads(); return; }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0 && ld32<SC_AG>(&v.flags[7]) == 0) {
-        int* bar = v.bar;
-        const int gen = ld32<SC_AG>(&bar[1]);
-        if (__hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_RELAXED, SC_AG) == nblocks - 1) {
-            st32<SC_AG>(&bar[0], 0);
-            __builtin_amdgcn_s_waitcnt(0);
-            add32_ag(&bar[1], 1);
-        } else {
-            int spins = 0;
-            while (ld32<SC_AG>(&bar[1]) == gen) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 21)) { st32<SC_AG>(&v.flags[7], 1); break; }   // a workgroup is missing: give up (the host falls back)
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// flags out: [1] sites relabelled, [4] rounds, [5] 1 = gave up (round cap / hub stall), 2 = hard move (hand it to maxflow.hip), [7] barrier broke
+// ---- the whole move in ONE launch of ONE workgroup ------------------------------------------------------------------------
+// labels + histogram | t-links | per round { search from t to its fixpoint | count | discharge } | gate + apply, separated by
+// workgroup barriers.  (A variant with one workgroup per 4096-site tile and device-scope hand-overs between them was exact and
+// slower than maxflow.hip's schedule on every configuration measured - docs/lab-notebook.md, round 3 - and has been removed.)
+// flags out: [1] sites relabelled, [4] rounds, [5] != 0 gave up: 1 round cap / hub stall, 4 region not valid or a hub in play, [6] a region solver took the move
 template <int NT, int SPT, int MAXD>
-__global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max_rounds, int hard_div)
+__global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max_rounds)
 {
     constexpr int T = NT * SPT;
     __shared__ TileLds<T> lds;
     __shared__ int s_cnt;
     __shared__ unsigned long long s_stuck;
     const int tid = (int)threadIdx.x;
-    constexpr int tiles = 1, tile = 0;
-    constexpr bool single = true;
-    const int base = tile * T;
-    const bool region = v.rg != nullptr;   // (one workgroup) the arrays hold a prepared problem of rg->count sites, no hubs
+    const bool region = v.rg != nullptr;   // the arrays hold a prepared problem of rg->count sites, no hubs
     if (region) {
         // two launches per region move: a 256-thread workgroup for regions of <= 1024 sites (nearly all of them; barriers over 4
         // waves instead of 16), then this kernel with 1024 threads, which returns at once when the small one took the move
@@ -810,7 +548,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
         v.n = c;
     }
-    const int tile_n = (int)((v.n - base) < T ? (v.n - base) : T);
+    const int tile_n = (int)v.n;
     int cnt_alpha = 0;
     if (region) {
         cnt_alpha = v.rg->cnt[v.alpha_apply];
@@ -820,105 +558,56 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         if (tid < kMaxL) lds.hubmin[tid] = 0;
         __syncthreads();
         for (int i = tid; i < tile_n; i += NT) {
-            const int l = v.labels[v.perm[base + i]];
-            v.lab[base + i] = l;
+            const int l = v.labels[v.perm[i]];
+            v.lab[i] = l;
             atomicAdd(&lds.hubmin[l], 1);
         }
         __syncthreads();
-        if (tid < v.L && lds.hubmin[tid] > 0) add32_ag(&v.cnt[tid], lds.hubmin[tid]);
-        grid_barrier(v, tiles);
-        if (tile == 0 && tid < v.L) {
-            const bool ex = v.h_q > 0 && tid != v.alpha && ld32<SC_AG>(&v.cnt[tid]) > 0;
+        if (tid < v.L) {
+            const bool ex = v.h_q > 0 && tid != v.alpha && lds.hubmin[tid] > 0;
             st32<SC_AG>(&v.hub_exists[tid], ex ? 1 : 0);
             __hip_atomic_store(&v.hub_e[tid], ex ? v.h_q : 0ll, __ATOMIC_RELAXED, SC_AG);
             st32<SC_AG>(&v.hub_d[tid], kInf);
         }
-        cnt_alpha = ld32<SC_AG>(&v.cnt[v.alpha]);
-        for (int i = tid; i < tile_n; i += NT) init_site(v, (int64_t)base + i, base, tile_n);
-        grid_barrier(v, tiles);
+        cnt_alpha = lds.hubmin[v.alpha];
+        for (int i = tid; i < tile_n; i += NT) init_site(v, i);
+        __syncthreads();
     }
-    int rounds = 0, gave_up = 0, it = 0;
+    int rounds = 0, gave_up = 0;
     long long hub_left_prev = -1;
     unsigned long long tprev = wall_clock64();
     auto lap = [&](int k) {   // (debug) time since the last lap goes to slot k
-        if (v.dbg && tile == 0 && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
+        if (v.dbg && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
     };
     lap(0);
     unsigned long long stuck_final = 0;
-    TileSync rs, ds;
-    rs.ctr = &v.busy[0];
-    ds.ctr = &v.busy[1];
-    rs.epoch = ds.epoch = v.epoch;
-    rs.hub_epoch = ds.hub_epoch = v.hub_epoch;
-    rs.gepoch = ds.gepoch = v.hub_epoch + 1;
-    rs.ack = ds.ack = v.hub_epoch + 2;
-    rs.strict = true;
-    rs.tile = ds.tile = tile;
-    rs.tiles = ds.tiles = tiles;
     for (;; ++rounds) {
-        if (tile == 0) {
-            if (tid < v.L) st32<SC_AG>(&v.hub_d[tid], kInf);
-            if (tid == 0) { st32<SC_AG>(&v.busy[0], tiles); st32<SC_AG>(&v.busy[1], tiles); }
-        }
-        grid_barrier(v, tiles);
+        if (tid < v.L) st32<SC_AG>(&v.hub_d[tid], kInf);
+        __syncthreads();
         lap(1);
         int any_far = 0;
-        bool ex0 = false;
-        tile_relax<NT, SPT, MAXD>(v, base, tile_n, 0, lds, 1 << 20, rs, false, !single && v.lazy, any_far, ex0);
+        tile_relax<NT, SPT, MAXD>(v, tile_n, 0, lds, any_far);
+        // arcs of rows longer than the register table read the stored heights, which phase 0 ignores
+        if (any_far) while (tile_relax<NT, SPT, MAXD>(v, tile_n, 2, lds, any_far)) {}
         lap(2);
-        grid_barrier(v, tiles);
-        lap(3);
-        for (;; ++it) {
-            const int par = it & 1;
-            bool exhausted = false;
-            int ch = 0;
-            if (!single) {
-                rs.on = true; rs.confirmed = false;
-                tile_relax<NT, SPT, MAXD>(v, base, tile_n, 1, lds, 1 << 12, rs, true, v.lazy != 0, any_far, exhausted);
-                ch = exhausted ? 1 : 0;   // a tile that ran out of budget may have missed a hand-over: everybody searches again
-                lap(4);
-            } else if (any_far) {
-                // arcs of rows longer than the register table read published heights, which phase 0 ignores
-                ch = 0;
-                while (tile_relax<NT, SPT, MAXD>(v, base, tile_n, 2, lds, 1 << 20, rs, false, false, any_far, exhausted)) {}
-            }
-            // sites with excess that reach t / excess that does not (lds.d holds the tile's heights)
-            if (tid == 0) { s_cnt = 0; s_stuck = 0; }
-            __syncthreads();
-            int mine = 0;
-            unsigned long long st = 0;
-            for (int i = tid; i < tile_n; i += NT) {
-                const int64_t s = (int64_t)base + i;
-                if (v.lab[s] == v.alpha) continue;
-                const long long e = v.ex[s] + (single ? 0 : ld64<SC_AG>(&v.inbox[s]));
-                if (e <= 0) continue;
-                if (lds.d[i] < kInf) ++mine;
-                else st += (unsigned long long)e;
-            }
-            if (mine) atomicAdd(&s_cnt, mine);
-            if (st) atomicAdd(&s_stuck, st);
-            __syncthreads();
-            if (tid == 0) {
-                if (ch && !single) st32<SC_AG>(&v.rchg[par], 1);
-                if (s_cnt) add32_ag(&v.act[par], s_cnt);
-                if (s_stuck) __hip_atomic_fetch_add(&v.stuck[par], s_stuck, __ATOMIC_RELAXED, SC_AG);
-                if (tile == 0) {   // the other parity's words are free until the next pass
-                    st32<SC_AG>(&v.rchg[par ^ 1], 0);
-                    st32<SC_AG>(&v.act[par ^ 1], 0);
-                    __hip_atomic_store(&v.stuck[par ^ 1], 0ull, __ATOMIC_RELAXED, SC_AG);
-                }
-            }
-            lap(5);
-            grid_barrier(v, tiles);
-            lap(6);
-            if (single || ld32<SC_AG>(&v.rchg[par]) == 0) break;
-            if (tile == 0 && tid == 0) st32<SC_AG>(&v.busy[0], tiles);
-            grid_barrier(v, tiles);
+        // sites with excess that reach t / excess that does not (lds.d holds the heights)
+        if (tid == 0) { s_cnt = 0; s_stuck = 0; }
+        __syncthreads();
+        int mine = 0;
+        unsigned long long st = 0;
+        for (int i = tid; i < tile_n; i += NT) {
+            if (v.lab[i] == v.alpha) continue;
+            const long long e = v.ex[i];
+            if (e <= 0) continue;
+            if (lds.d[i] < kInf) ++mine;
+            else st += (unsigned long long)e;
         }
-        const int par = it & 1;
-        ++it;
-        const int active = ld32<SC_AG>(&v.act[par]);
-        stuck_final = __hip_atomic_load(&v.stuck[par], __ATOMIC_RELAXED, SC_AG);
+        if (mine) atomicAdd(&s_cnt, mine);
+        if (st) atomicAdd(&s_stuck, st);
+        __syncthreads();
+        const int active = s_cnt;
+        stuck_final = s_stuck;
+        lap(5);
         bool hub_act = false;
         long long hub_left = 0;
         for (int l = 0; l < v.L; ++l)
@@ -927,12 +616,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
                 hub_left += he > 0 ? he : 0;
                 hub_act |= he > 0 && ld32<SC_AG>(&v.hub_d[l]) < kInf;
             }
-        if (ld32<SC_AG>(&v.flags[7]) != 0) { gave_up = 3; break; }
         if (active == 0 && !hub_act) break;
-        // A move in which a sizeable part of the sites holds excess (a new instance being handed its points) is a deep, global
-        // max-flow: many rounds of long searches, which the level-synchronous schedule of maxflow.hip handles better (measured,
-        // DESIGN.md 5.4b).  Nothing has been pushed yet; the labels are untouched.
-        if (rounds == 0 && hard_div > 0 && (long long)active * hard_div > v.n) { gave_up = 2; break; }
         if (active == 0) {   // only hubs hold excess that reaches t: members with a t-link pull it.  Nothing pulled since the last
                              // round => the hub reaches t through members WITHOUT a t-link only: not handled here
             if (hub_left == hub_left_prev) { gave_up = 1; break; }
@@ -940,20 +624,18 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         }
         if (rounds >= max_rounds) { gave_up = 1; break; }
         int left = 0, moved = 0;
-        ds.on = true; ds.confirmed = false;
         lap(7);
-        tile_discharge<NT, SPT>(v, base, tile_n, lds, sweeps, single, left, moved, ds);
+        tile_discharge<NT, SPT>(v, tile_n, lds, sweeps, left, moved);
         lap(8);
-        grid_barrier(v, tiles);
-        lap(9);
     }
     lap(7);
     int changed = 0;
     if (!gave_up && region) {
         // the hubs were left out: a label's hub drains into members outside the region as long as their sink capacity exceeds what
-        // the region's arcs can claim of it by h; otherwise the hub interacts with this cut and the general path has to solve it
+        // the region's arcs can claim of it by MORE than h (then some member keeps a residual t-link whatever happens, and every
+        // member the hub pushed into reaches t through the hub); otherwise the hub interacts with this cut: the general path solves it
         for (int l = 0; l < kMaxL; ++l)
-            if (v.h_q > 0 && l != v.alpha_apply && v.rg->cnt[l] > 0 && v.rg->pool[l] - v.rg->needsum[l] < v.h_q) gave_up = 4;
+            if (v.h_q > 0 && l != v.alpha_apply && v.rg->cnt[l] > 0 && v.rg->pool[l] - v.rg->needsum[l] <= v.h_q) gave_up = 4;
     }
     if (!gave_up) {
         bool apply = true;
@@ -965,10 +647,8 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         }
         if (apply) {
             int mine = 0;
-            for (int i = tid; i < tile_n; i += NT) {
-                const int64_t s = (int64_t)base + i;
-                if (v.lab[s] != v.alpha && ld32<SC_AG>(&v.d[s]) == kInf) { v.labels[v.perm[s]] = v.alpha_apply; ++mine; }   // cannot reach t => takes alpha
-            }
+            for (int i = tid; i < tile_n; i += NT)
+                if (v.lab[i] != v.alpha && ld32<SC_AG>(&v.d[i]) == kInf) { v.labels[v.perm[i]] = v.alpha_apply; ++mine; }   // cannot reach t => takes alpha
             __syncthreads();
             if (tid == 0) s_cnt = 0;
             __syncthreads();
@@ -980,11 +660,9 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     lap(10);
     if (tid == 0) {
         if (changed) add32_ag(&v.flags[1], changed);
-        if (tile == 0) {
-            st32<SC_AG>(&v.flags[4], rounds + 1);
-            st32<SC_AG>(&v.flags[5], gave_up);
-        }
-        if (region && v.ctl) {   // (one workgroup)
+        st32<SC_AG>(&v.flags[4], rounds + 1);
+        st32<SC_AG>(&v.flags[5], gave_up);
+        if (region && v.ctl) {
             if (gave_up) st32<SC_AG>(&v.ctl[0], 1);
             else if (changed) add32_ag(&v.ctl[1], 1);
         }
@@ -997,8 +675,8 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
 // they hold excess or are relays - a few hundred to a few thousand of 10^5..10^6.  expand_alpha_region (after maxflow.hip has set
 // up t-links and arcs as always) numbers the open sites, builds their sub-graph in compact arrays (uniform row stride, reverse
 // arcs by position) and folds every arc into a site WITH a t-link into the open site's own t-link.  That is exact as long as such
-// a neighbour cannot be saturated by the region - sum of the region's arc capacities into it <= its sink capacity (checked on the
-// device for every neighbour) - and as long as every label's hub can drain outside the region (pool - needsum >= h, checked by the
+// a neighbour cannot be saturated by the region - sum of the region's arc capacities into it < its sink capacity, strictly (checked on the
+// device for every neighbour) - and as long as every label's hub can drain outside the region (pool - needsum > h, checked by the
 // solver): then all of them stay on the sink side whatever the region does.  The compact problem goes through t_move_kernel's
 // rounds in ONE workgroup, which also applies the cut; the host makes a single read-back per move.  Anything else - more than
 // 8192 open sites (a new instance taking its points), a saturable neighbour, a hub in play - is handed to the general path.
@@ -1054,10 +732,12 @@ __global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo*
 }
 
 // Weak sinks join the region.  A neighbour q with a t-link stays outside only if the region's arcs cannot saturate it:
-// need[q] = sum of the capacities of the region's arcs into q <= rt[q].  One workgroup walks the region in rounds: the members
+// need[q] = sum of the capacities of the region's arcs into q < rt[q], STRICTLY - a neighbour whose t-link the region can use up
+// exactly may end with no residual to t, and whether it then still reaches t (it takes alpha if not: ties go to alpha, the minimal
+// sink side) depends on the rest of the graph.  (The soak found the non-strict form on a unary table full of ties.)  One workgroup walks the region in rounds: the members
 // of the round add their arcs' capacities to need[]; the add that crosses rt[q] makes q a member (it is appended and walked in
 // the next round), until a round promotes nobody.  (A member that is promoted while a neighbour still adds to its need is harmless:
-// need[] of a member is never read.)  Whatever still violates need <= rt after kPromoteRounds is caught by r_build_kernel.
+// need[] of a member is never read.)  Whatever still violates need < rt after kPromoteRounds is caught by r_build_kernel.
 constexpr int kPromoteRounds = 16;
 
 __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict__ rg, int alpha, const int* __restrict__ labels,
@@ -1080,7 +760,7 @@ __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict_
                 const int q = idx[a];
                 if (c <= 0 || labels[q] == alpha || ld32<SC_AG>(&slot[q]) >= 0) continue;
                 const long long old = xadd64<SC_AG>(&need[q], c), r = rt[q];
-                if (old <= r && old + c > r) {   // this add crossed the neighbour's sink capacity: exactly one add does
+                if (old < r && old + c >= r) {   // this add reached the neighbour's sink capacity: exactly one add does
                     const int j = __hip_atomic_fetch_add(&rg->count, 1, __ATOMIC_RELAXED, SC_AG);
                     if (j < kRegionCap) { st32<SC_AG>(&site[j], q); st32<SC_AG>(&slot[q], j); }
                 }
@@ -1098,7 +778,7 @@ __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict_
 }
 
 // one thread per region site: its row in the compact graph; arcs into sites outside the region (all of them keep a t-link) are
-// folded into the site's own t-link, and every such neighbour is checked: need <= rt, else the region is not valid (bad)
+// folded into the site's own t-link, and every such neighbour is checked: need < rt, else the region is not valid (bad)
 __global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ rg, int alpha, int stride, const int* __restrict__ labels,
                                                       const int* __restrict__ off, const int* __restrict__ idx, const int* __restrict__ rev,
                                                       const long long* __restrict__ cap, const long long* __restrict__ ex, const long long* __restrict__ rt,
@@ -1124,7 +804,7 @@ __global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ r
             if (sq >= 0) { head = sq; cc = ca; r = sq * stride + (rev[a] - off[q]); }
             else if (ca > 0 && labels[q] != alpha) {   // a neighbour that keeps its t-link whatever the region does: as good as t
                 rtc += ca;
-                bad |= need[q] > rt[q];
+                bad |= need[q] >= rt[q];
                 atomicAdd((unsigned long long*)&rg->needsum[labels[q]], (unsigned long long)ca);
             }
         }
@@ -1140,7 +820,6 @@ __global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ r
     if (e >= rtc) { c.ex[i] = e - rtc; c.rt[i] = 0; }   // (only an open site has e > 0, and then own = 0)
     else { c.ex[i] = 0; c.rt[i] = rtc - e; }
     c.f[i] = 0;
-    c.inbox[i] = 0;
     c.d[i] = kInf;
     c.lab[i] = 0;
 }
@@ -1186,7 +865,7 @@ struct TileState {
     int64_t n = 0, E = 0;
     int64_t version = -1;     // graph_version this copy was built from
     DevBuf perm, inv, off, idx, rev, mult, tmp;
-    DevBuf cap, ex, inbox, rt, f, d, lab, small, epoch, dbg;
+    DevBuf cap, ex, rt, f, d, lab, small, dbg;
     DevBuf rg_slot, rg_need, rg_site, rg_off, rg_idx, rg_rev, rg_cap, rg_site_state;   // region moves (expand_alpha_region)
     DevBuf rg_small, rg_ctl;  // kRegionSlots small blocks (one per move in flight) and the batch's control words
     void* h_rg = nullptr;     // pinned: what the host reads of each slot
@@ -1200,8 +879,8 @@ void tile_free(pgx_ctx* ctx)
 {
     TileState* ts = ctx->tile;
     if (!ts) return;
-    DevBuf* all[] = {&ts->perm, &ts->inv, &ts->off, &ts->idx, &ts->rev, &ts->mult, &ts->tmp, &ts->cap, &ts->ex, &ts->inbox,
-                     &ts->rt, &ts->f, &ts->d, &ts->lab, &ts->small, &ts->epoch, &ts->dbg,
+    DevBuf* all[] = {&ts->perm, &ts->inv, &ts->off, &ts->idx, &ts->rev, &ts->mult, &ts->tmp, &ts->cap, &ts->ex,
+                     &ts->rt, &ts->f, &ts->d, &ts->lab, &ts->small, &ts->dbg,
                      &ts->rg_slot, &ts->rg_need, &ts->rg_site, &ts->rg_off, &ts->rg_idx, &ts->rg_rev, &ts->rg_cap, &ts->rg_site_state,
                      &ts->rg_small, &ts->rg_ctl};
     for (DevBuf* b : all) release(*b);
@@ -1256,69 +935,43 @@ namespace {
 
 struct SmallLayout {   // byte offsets inside the small block
     static constexpr size_t hub_e = 0;                       // [64] i64
-    static constexpr size_t stuck = 64 * 8;                  // [2] u64
-    static constexpr size_t hub_d = stuck + 16;              // [64] i32
+    static constexpr size_t hub_d = 64 * 8;                  // [64] i32
     static constexpr size_t hub_exists = hub_d + 64 * 4;     // [64]
-    static constexpr size_t cnt = hub_exists + 64 * 4;       // [64]
-    static constexpr size_t rchg = cnt + 64 * 4;             // [2]
-    static constexpr size_t act = rchg + 8;                  // [2]
-    static constexpr size_t bar = act + 8;                   // [2]
-    static constexpr size_t busy = bar + 8;                  // [2]
-    static constexpr size_t flags = busy + 8;                // [8]
+    static constexpr size_t flags = hub_exists + 64 * 4;     // [8]
     static constexpr size_t bytes = flags + 8 * 4;
 };
 
 }  // namespace
 
-// One expansion move on the tile path.  Returns PGX_OK (done, *changed set), PGX_TILE_FALLBACK (not handled: the caller
-// runs maxflow.hip; labels untouched) or an error.
+// One expansion move on a graph that fits one workgroup (<= 8192 sites): one launch.  Returns PGX_OK (done, *changed set),
+// PGX_TILE_FALLBACK (not handled: the caller runs maxflow.hip; labels untouched) or an error.
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
 {
-    if (n >= ((int64_t)1 << 30) || L > kMaxL) return PGX_TILE_FALLBACK;
-    constexpr int T = 4096;
-    const bool one = n <= ctx->tile_single_max;
-    // Several tiles (one co-operative launch per move, tiles hand heights and flow over through device-scope words) are exact but
-    // were measured SLOWER than maxflow.hip's schedule on the BASELINE configs (DESIGN.md 5.4b has the phase timings): opt-in.
-    if (!one && !ctx->tile_multi) return PGX_TILE_FALLBACK;
-    const unsigned tiles = one ? 1u : (unsigned)((n + T - 1) / T);
-    // the tiles of a move wait for each other: all of them must be resident, one workgroup of 1024 per CU
-    if ((int)tiles > (ctx->cu_count > 0 ? ctx->cu_count : 64)) return PGX_TILE_FALLBACK;
+    if (n > ctx->tile_single_max || n > 8192 || L > kMaxL) return PGX_TILE_FALLBACK;
     PGX_TRY(tile_graph_prepare(ctx));
     TileState* ts = ctx->tile;
     const int64_t E = ts->E;
     PGX_TRY(ensure(ctx, ts->cap, (size_t)(E > 0 ? E : 1) * 8));
     PGX_TRY(ensure(ctx, ts->ex, (size_t)n * 8));
-    PGX_TRY(ensure(ctx, ts->inbox, (size_t)n * 8));
     PGX_TRY(ensure(ctx, ts->rt, (size_t)n * 8));
     PGX_TRY(ensure(ctx, ts->f, (size_t)n * 8));
     PGX_TRY(ensure(ctx, ts->d, (size_t)n * 4));
     PGX_TRY(ensure(ctx, ts->lab, (size_t)n * 4));
-    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes + sizeof(RegionInfo)));
-    PGX_TRY(ensure(ctx, ts->epoch, (size_t)(2 * tiles + 2) * 4));   // tile epochs | hub epoch | global epoch | acknowledgements
-    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes + sizeof(RegionInfo), hipHostMallocDefault));
+    PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes));
+    if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes, hipHostMallocDefault));
     char* sp = (char*)ts->small.p;
     TView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
     v.dq = dq; v.labels = labels;
     v.perm = ts->perm.as<int>();
     v.off = ts->off.as<int>(); v.idx = ts->idx.as<int>(); v.rev = ts->rev.as<int>(); v.mult = ts->mult.as<int>();
-    v.cap = ts->cap.as<long long>(); v.ex = ts->ex.as<long long>(); v.inbox = ts->inbox.as<long long>();
+    v.cap = ts->cap.as<long long>(); v.ex = ts->ex.as<long long>();
     v.rt = ts->rt.as<long long>(); v.f = ts->f.as<long long>();
     v.d = ts->d.as<int>(); v.lab = ts->lab.as<int>();
     v.hub_e = (long long*)(sp + SmallLayout::hub_e);
-    v.stuck = (unsigned long long*)(sp + SmallLayout::stuck);
     v.hub_d = (int*)(sp + SmallLayout::hub_d);
     v.hub_exists = (int*)(sp + SmallLayout::hub_exists);
-    v.cnt = (int*)(sp + SmallLayout::cnt);
-    v.rchg = (int*)(sp + SmallLayout::rchg);
-    v.act = (int*)(sp + SmallLayout::act);
-    v.bar = (int*)(sp + SmallLayout::bar);
-    v.busy = (int*)(sp + SmallLayout::busy);
     v.flags = (int*)(sp + SmallLayout::flags);
-    v.epoch = ts->epoch.as<int>();
-    v.hub_epoch = ts->epoch.as<int>() + tiles;
-    v.T = one ? (int)n : T;
-    v.lazy = one ? 0 : ctx->tile_lazy;
     v.rg = nullptr; v.ctl = nullptr; v.skip_rel = -1;
     v.alpha_apply = alpha;
     *changed = 0;
@@ -1329,17 +982,10 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
         v.dbg = ts->dbg.as<unsigned long long>();
     }
     PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes, ctx->stream));
-    PGX_HIP(ctx, hipMemsetAsync(ts->epoch.p, 0, (size_t)(2 * tiles + 2) * 4, ctx->stream));
-    int sweeps = ctx->tile_sweeps, max_rounds = 4096, hard = one ? 0 : ctx->tile_hard_div;
-    if (one) {
-        if (n <= 4096) hipLaunchKernelGGL((t_move_kernel<1024, 4, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds, hard);
-        else hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds, hard);
-        PGX_HIP(ctx, hipGetLastError());
-    } else {
-        void* args[] = {&v, &sweeps, &max_rounds, &hard};
-        const hipError_t e = hipLaunchCooperativeKernel((const void*)t_move_kernel<1024, 4, 16>, dim3(tiles), dim3(1024), args, 0, ctx->stream);
-        if (e != hipSuccess) { (void)hipGetLastError(); return PGX_TILE_FALLBACK; }   // (not all tiles can be resident on this device)
-    }
+    const int sweeps = ctx->tile_sweeps, max_rounds = 4096;
+    if (n <= 4096) hipLaunchKernelGGL((t_move_kernel<1024, 4, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
+    else hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
+    PGX_HIP(ctx, hipGetLastError());
     char* hs = (char*)ts->h_small;
     PGX_HIP(ctx, hipMemcpyAsync(hs, sp, SmallLayout::bytes, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1350,18 +996,17 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
         for (int k = 0; k < 16; ++k) ts->dbg_acc[k] += t[k];
         ts->dbg_moves += 1;
         if (ctx->tile_debug >= 2)
-            std::fprintf(stderr, "[tile] alpha=%d tiles=%u rounds=%d gave_up=%d changed=%d\n", alpha, tiles, h_flags[4], h_flags[5], h_flags[1]);
+            std::fprintf(stderr, "[tile] alpha=%d rounds=%d gave_up=%d changed=%d\n", alpha, h_flags[4], h_flags[5], h_flags[1]);
         if (ts->dbg_moves % 500 == 0 || ctx->tile_debug >= 2) {
-            std::fprintf(stderr, "[tile] %lld moves, us per move: setup %.1f | gb-reset %.1f phase0 %.1f gb %.1f | coop %.1f count %.1f gb %.1f | decide %.1f discharge %.1f gb %.1f | apply %.1f\n",
-                         ts->dbg_moves, ts->dbg_acc[0] / 100.0 / ts->dbg_moves, ts->dbg_acc[1] / 100.0 / ts->dbg_moves, ts->dbg_acc[2] / 100.0 / ts->dbg_moves,
-                         ts->dbg_acc[3] / 100.0 / ts->dbg_moves, ts->dbg_acc[4] / 100.0 / ts->dbg_moves, ts->dbg_acc[5] / 100.0 / ts->dbg_moves,
-                         ts->dbg_acc[6] / 100.0 / ts->dbg_moves, ts->dbg_acc[7] / 100.0 / ts->dbg_moves, ts->dbg_acc[8] / 100.0 / ts->dbg_moves,
-                         ts->dbg_acc[9] / 100.0 / ts->dbg_moves, ts->dbg_acc[10] / 100.0 / ts->dbg_moves);
+            const double m = 100.0 * (double)ts->dbg_moves;
+            std::fprintf(stderr, "[tile] %lld moves, us per move: setup %.1f | reset %.1f search %.1f | count %.1f | decide %.1f discharge %.1f | apply %.1f\n",
+                         ts->dbg_moves, ts->dbg_acc[0] / m, ts->dbg_acc[1] / m, ts->dbg_acc[2] / m, ts->dbg_acc[5] / m, ts->dbg_acc[7] / m,
+                         ts->dbg_acc[8] / m, ts->dbg_acc[10] / m);
         }
     }
-    if (h_flags[5] != 0 || h_flags[7] != 0) return PGX_TILE_FALLBACK;
+    if (h_flags[5] != 0) return PGX_TILE_FALLBACK;
     ctx->stats[0] += 1;
-    ctx->paths[one ? 0 : 1] += 1;
+    ctx->paths[0] += 1;
     ctx->stats[2] += h_flags[4];
     *changed = h_flags[1];
     ctx->stats[4] += *changed;
@@ -1394,9 +1039,8 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     PGX_TRY(ensure(ctx, ts->rg_idx, A * 4));
     PGX_TRY(ensure(ctx, ts->rg_rev, A * 4));
     PGX_TRY(ensure(ctx, ts->rg_cap, A * 8));
-    PGX_TRY(ensure(ctx, ts->rg_site_state, C * (8 * 4 + 4 * 2)));   // ex | rt | f | inbox (i64) | d | lab (i32)
+    PGX_TRY(ensure(ctx, ts->rg_site_state, C * (8 * 3 + 4 * 2)));   // ex | rt | f (i64) | d | lab (i32)
     PGX_TRY(ensure(ctx, ts->rg_small, kRegionSlots * kRegionBlock));
-    PGX_TRY(ensure(ctx, ts->epoch, 64));
     if (!ts->rg_ctl.p) {
         PGX_TRY(ensure(ctx, ts->rg_ctl, 64));
         PGX_HIP(ctx, hipMemsetAsync(ts->rg_ctl.p, 0, 64, ctx->stream));
@@ -1410,22 +1054,12 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     v.off = ts->rg_off.as<int>(); v.idx = ts->rg_idx.as<int>(); v.rev = ts->rg_rev.as<int>(); v.mult = nullptr;
     v.cap = ts->rg_cap.as<long long>();
     long long* st8 = ts->rg_site_state.as<long long>();
-    v.ex = st8; v.rt = st8 + C; v.f = st8 + 2 * C; v.inbox = st8 + 3 * C;
-    v.d = (int*)(st8 + 4 * C); v.lab = v.d + C;
+    v.ex = st8; v.rt = st8 + C; v.f = st8 + 2 * C;
+    v.d = (int*)(st8 + 3 * C); v.lab = v.d + C;
     v.hub_e = (long long*)(sp + SmallLayout::hub_e);
-    v.stuck = (unsigned long long*)(sp + SmallLayout::stuck);
     v.hub_d = (int*)(sp + SmallLayout::hub_d);
     v.hub_exists = (int*)(sp + SmallLayout::hub_exists);
-    v.cnt = (int*)(sp + SmallLayout::cnt);
-    v.rchg = (int*)(sp + SmallLayout::rchg);
-    v.act = (int*)(sp + SmallLayout::act);
-    v.bar = (int*)(sp + SmallLayout::bar);
-    v.busy = (int*)(sp + SmallLayout::busy);
     v.flags = (int*)(sp + SmallLayout::flags);
-    v.epoch = ts->epoch.as<int>();
-    v.hub_epoch = ts->epoch.as<int>() + 1;
-    v.T = kRegionCap;
-    v.lazy = 0;
     v.dbg = nullptr;
     if (ctx->tile_debug) {   // phase timers accumulate on the device over the moves (region_result prints them)
         if (!ts->dbg.p) {
@@ -1447,8 +1081,8 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
                        ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), (const int*)v.ctl, v.skip_rel);
     hipLaunchKernelGGL(r_build_kernel, dim3(kRegionCap / 256), dim3(256), 0, ctx->stream, rg, mv.alpha, stride, mv.labels, mv.off, mv.idx, mv.rev,
                        mv.cap, mv.ex, mv.rt, ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), v);
-    hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
-    hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_sweeps, 4096, 0);
+    hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096);
+    hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_sweeps, 4096);
     PGX_HIP(ctx, hipGetLastError());
     char* hs = (char*)ts->h_rg + (size_t)slot * kRegionHost;
     static_assert(SmallLayout::flags + 8 * 4 == SmallLayout::bytes, "the flags end the small block: flags | region info head is one copy");

@@ -110,9 +110,6 @@ struct pgx_ctx {
     int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
     int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
-    int tile_multi = 0;          // PGX_TILE_MULTI=1: graphs beyond one workgroup on the tile path too (measured slower: opt-in)
-    int tile_hard_div = 64;      // a move with more than n / this sites holding excess that reaches t goes to maxflow.hip (0 = never)
-    int tile_lazy = 1;           // multi-tile searches accept only substantial improvements of finite heights (maxflow_tile.hip)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
     int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
     int region_defer = 0;        // region moves are enqueued without a host round trip (pgx_expansion's batches): slot / skip rule below

@@ -333,10 +333,11 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
         size_t temp_bytes = 0;
         hipcub::CountingInputIterator<int> ids(0);
         PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, ids, labels, (int*)nullptr, (int*)nullptr, (int)n, ctx->stream));
-        PGX_TRY(ensure(ctx, ctx->gc_sel, (size_t)n * 4 + 64 + temp_bytes));
+        const size_t sel_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;   // (the select's scratch holds 64-bit words it updates atomically: keep it aligned)
+        PGX_TRY(ensure(ctx, ctx->gc_sel, sel_bytes + 256 + temp_bytes));
         int* d_sel = ctx->gc_sel.as<int>();
-        int* d_num = d_sel + n;
-        void* d_temp = (void*)(d_num + 16);
+        int* d_num = (int*)((char*)ctx->gc_sel.p + sel_bytes);
+        void* d_temp = (void*)((char*)ctx->gc_sel.p + sel_bytes + 256);
         PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, ids, labels, d_sel, d_num, (int)n, ctx->stream));
         if (inliers > 0) PGX_HIP(ctx, hipMemcpyAsync(flags, d_sel, (size_t)inliers * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     } else {

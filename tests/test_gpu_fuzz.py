@@ -29,11 +29,12 @@ def test_expansion_fuzz_against_the_oracle(gpu_ctx, oracle, seed):
         assert np.array_equal(got, ref) and eq == re and cyc == rc, (seed, trial, n, L, lam, h, int((got != ref).sum()))
 
 
-def test_expansion_fuzz_on_forced_tiles(oracle, monkeypatch):
-    """The same loop with every graph cut into 4096-site tiles and solved by the co-operative multi-workgroup launch
-    (PGX_TILE_MULTI=2: tiles even for small graphs, hard moves not handed back) - the path that is opt-in for large graphs."""
+def test_expansion_fuzz_on_region_moves(oracle, monkeypatch):
+    """The same loop with the one-workgroup whole-graph path switched off (PGX_MF_TILE=0): every move goes through the region
+    path - compaction of the open sites, weak-sink promotion, one-workgroup solve, a cycle's moves enqueued back to back - and
+    the ones it declines through maxflow.hip's level-synchronous launches."""
     from pyprogressivex import _lib
-    monkeypatch.setenv("PGX_TILE_MULTI", "2")
+    monkeypatch.setenv("PGX_MF_TILE", "0")
     ctx = _lib.Context(0)
     try:
         rng = np.random.default_rng(77)
@@ -52,6 +53,8 @@ def test_expansion_fuzz_on_forced_tiles(oracle, monkeypatch):
             eq, e, cyc = ctx.expansion(lam, h)
             got = ctx.get_labels()
             assert np.array_equal(got, ref) and eq == re and cyc == rc, (trial, n, L, lam, h, int((got != ref).sum()))
+        paths = ctx.expansion_paths()
+        assert paths["region"] > 0 and paths["one_workgroup"] == 0
     finally:
         ctx.close()
 
@@ -91,3 +94,14 @@ def test_expansion_soak_slice(oracle, seed):
     energy and cycle count identical to the oracle's Dinic solver (4 200 such problems on record: no mismatch)."""
     from soak_expansion import soak
     assert soak(seed, 120, verbose=False, max_n=2500) == 0   # (the oracle's Dinic solver needs a minute for some 9000-site cases)
+
+
+@pytest.mark.parametrize("seed", [32, 403])
+def test_expansion_soak_slice_through_region_moves(oracle, seed, monkeypatch):
+    """The same soak with the one-workgroup whole-graph solver switched off, so that every move of these small odd problems goes
+    through the region path (open sites compacted, weak sinks promoted, hubs checked) or is declined by it.  Seed 32 holds the
+    problem - a long path, ten labels, a unary table full of ties, lambda = 1 - on which the non-strict forms of the region's
+    validity conditions (need <= rt, pool - needsum >= h) returned a different minimum cut than the minimal sink side."""
+    from soak_expansion import soak
+    monkeypatch.setenv("PGX_MF_TILE", "0")
+    assert soak(seed, 120, verbose=False, max_n=2500) == 0

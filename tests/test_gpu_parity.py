@@ -560,15 +560,16 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0"}, "tiles": {"PGX_TILE_MULTI": "2"}}
+MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0"},
+                "region": {"PGX_MF_TILE": "0"}}
 
 
 @pytest.fixture
 def mincut_ctx(request, monkeypatch):
     """A context per min-cut schedule (the switches are read when the context is created): the default (a graph of <= 8192
-    sites is one workgroup, one launch per move), maxflow.hip's level-synchronous launches for everything, and 4096-site tiles
-    with a co-operative launch even for small graphs."""
-    for key in ("PGX_MF_TILE", "PGX_TILE_MULTI"):
+    sites is one workgroup, one launch per move), maxflow.hip's level-synchronous launches for everything, and region moves
+    (the open sites of a move compacted and solved by one workgroup, enqueued a cycle at a time) even for small graphs."""
+    for key in ("PGX_MF_TILE", "PGX_MF_REGION"):
         monkeypatch.delenv(key, raising=False)
     for key, val in MINCUT_PATHS[request.param].items():
         monkeypatch.setenv(key, val)
@@ -641,7 +642,7 @@ def test_each_mincut_path_is_the_one_that_ran(mincut_ctx, oracle):
     paths = mincut_ctx.expansion_paths()
     assert paths[mincut_ctx.path_name] > 0
     if mincut_ctx.path_name == "one_workgroup":
-        assert paths["level_synchronous"] == 0 and paths["tiles"] == 0 and paths["tile_handed_back"] == 0
+        assert paths["level_synchronous"] == 0 and paths["region"] == 0 and paths["tile_handed_back"] == 0
 
 
 @pytest.mark.parametrize("n,lam,h,L", [(30000, 0.15, 4.0, 6), (60000, 0.3, 0.0, 5), (60000, 0.05, 12.0, 9)])
@@ -1399,8 +1400,8 @@ def test_expansion_at_c4_size_is_schedule_invariant(gpu_ctx, monkeypatch):
     eq, e, cycles = gpu_ctx.expansion(lam, h)
     results.append((eq, cycles, gpu_ctx.get_labels()))
     assert gpu_ctx.energy(lam, h)[0] == eq
-    for env in ({"PGX_MF_TILE": "0"}, {"PGX_TILE_MULTI": "1"}):     # level-synchronous only / 4096-site tiles, co-operative launch
-        for key in ("PGX_MF_TILE", "PGX_TILE_MULTI"):
+    for env in ({"PGX_MF_REGION": "0"},):     # level-synchronous launches only (the default context mixes in region moves)
+        for key in ("PGX_MF_TILE", "PGX_MF_REGION"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
