@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void r_init_mark_kernel(MfView mv, RegionInfo*
 // sink side) depends on the rest of the graph.  (The soak found the non-strict form on a unary table full of ties.)  One workgroup walks the region in rounds: the members
 // of the round add their arcs' capacities to need[]; the add that crosses rt[q] makes q a member (it is appended and walked in
 // the next round), until a round promotes nobody.  (A member that is promoted while a neighbour still adds to its need is harmless:
-// need[] of a member is never read.)  Whatever still violates need < rt after kPromoteRounds is caught by r_build_kernel.
+// need[] of a member is never read.)  A region that is still growing after kPromoteRounds is declined (bad).
 constexpr int kPromoteRounds = 16;
 
 __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict__ rg, int alpha, const int* __restrict__ labels,
@@ -775,6 +775,9 @@ __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict_
         if (hi > kRegionCap) return;
         __syncthreads();
     }
+    // members promoted in the last round have not added their own arcs to need[] yet: the checks of r_build_kernel would be made
+    // on incomplete sums - the region is not valid
+    if (lo < hi && threadIdx.x == 0) rg->bad = 1;
 }
 
 // one thread per region site: its row in the compact graph; arcs into sites outside the region (all of them keep a t-link) are

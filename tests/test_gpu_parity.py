@@ -670,6 +670,36 @@ def test_region_moves_match_oracle(oracle, monkeypatch, n, lam, h, L):
     assert seen["0"]["region"] == 0 and seen["0"]["level_synchronous"] > 0
 
 
+def test_region_moves_decline_a_domino_of_weak_sinks(oracle, monkeypatch):
+    """A path on which every site but the first barely prefers its label (sink capacity of one unit) while the arcs are strong: the
+    first site's excess saturates its neighbour's t-link, which makes that neighbour a member of the region, whose arc saturates
+    the next ... the region grows by one site per promotion round.  After its round limit the region must be DECLINED - the last
+    members have not charged their arcs to their neighbours yet, so "this neighbour keeps its t-link" cannot be checked - and the
+    general path solves the move (regression test: the limit used to fall through to the build with incomplete sums)."""
+    monkeypatch.setenv("PGX_MF_TILE", "0")          # small graph through the region path
+    n, lam = 3000, 0.5
+    a = np.arange(n - 1)
+    graph = csr_from_pairs(n, a, a + 1, np.full(n - 1, 2))
+    Dq = np.zeros((n, 2), np.int64)
+    Dq[:, 1] = 1                                      # every site: label 1 costs one unit (2^-32) more than label 0 ...
+    Dq[0] = (1 << 40, 0)                              # ... except the first, which wants label 1 badly
+    lq, hq = oracle.quantize_lambda(lam), 0
+    start = np.zeros(n, np.int32)
+    ref, re, rc = oracle.expansion(Dq, graph, lq, hq, start.copy())
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_unary_q(Dq)
+        ctx.set_graph(*graph)
+        ctx.set_labels(start.copy())
+        eq, _, cyc = ctx.expansion(lam, 0.0)
+        assert np.array_equal(ctx.get_labels(), ref) and eq == re and cyc == rc
+        assert ref.sum() == n                         # the domino: everybody follows the first site
+        paths = ctx.expansion_paths()
+        assert paths["region_declined"] > 0 and paths["level_synchronous"] > 0
+    finally:
+        ctx.close()
+
+
 def test_region_moves_decline_wide_graphs(oracle):
     """A graph with a site of more than 32 neighbours: the region path's arc rows do not fit, every move goes to maxflow.hip
     (which must then initialise the move itself - the regression of the fused initialisation)."""
