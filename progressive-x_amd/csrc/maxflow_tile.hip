@@ -634,8 +634,8 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         // the hubs were left out: a label's hub drains into members outside the region as long as their sink capacity exceeds what
         // the region's arcs can claim of it by MORE than h (then some member keeps a residual t-link whatever happens, and every
         // member the hub pushed into reaches t through the hub); otherwise the hub interacts with this cut: the general path solves it
-        for (int l = 0; l < kMaxL; ++l)
-            if (v.h_q > 0 && l != v.alpha_apply && v.rg->cnt[l] > 0 && v.rg->pool[l] - v.rg->needsum[l] <= v.h_q) gave_up = 4;
+        const bool in_play = tid < kMaxL && v.h_q > 0 && tid != v.alpha_apply && v.rg->cnt[tid] > 0 && v.rg->pool[tid] - v.rg->needsum[tid] <= v.h_q;
+        if (__syncthreads_or(in_play ? 1 : 0)) gave_up = 4;   // (one label per thread: the serial loop over 64 labels was 4 us of every move)
     }
     if (!gave_up) {
         bool apply = true;
