@@ -155,5 +155,25 @@ class OracleContext:
     def gc_labeling(self, model, T2, lam):
         return O.gc_labeling(self.model_type, self.pts, model, T2, lam, self.graph)
 
+    def gc_inliers(self, model, T2, lam):
+        """the GPU context's pgx_gc_inliers: the same cut as ascending indices"""
+        return np.flatnonzero(self.gc_labeling(model, T2, lam) != 0).astype(np.int64)
+
+    def pnp_refine_batch(self, inits, index, weights=None, wpow=2, iterations=10):
+        """the GPU context's pgx_pnp_refine_batch: the Gauss-Newton iteration of PnPEstimator._fit_many (the host statement of the
+        same mathematics: numpy pinv instead of the kernel's Jacobi pseudo-inverse) on the oracle's Gram sums"""
+        from pyprogressivex import _estimators
+        index = np.asarray(index, dtype=np.int64)
+        inits = np.asarray(inits, dtype=np.float64).reshape(index.shape[0], 12)
+        assert iterations == 10
+
+        def gram(kind, prm, use_w, wp, rows):
+            G, bad = self.gram_batch(kind, index[rows], params=prm, weights=weights if use_w else None, wpow=wp)
+            return G, np.full(len(rows), index.shape[1], dtype=np.int64), bad
+        fits = _estimators.PnPEstimator()._fit_many(gram, index.shape[0], [inits[b] for b in range(index.shape[0])])
+        ok = np.array([len(f) == 1 for f in fits], dtype=bool)
+        P = np.array([f[0] if len(f) == 1 else inits[b] for b, f in enumerate(fits)])
+        return P, ok
+
     def residual_sum(self, model, label):
         return O.residual_sum(self.model_type, self.pts, model, self.labels, label)
