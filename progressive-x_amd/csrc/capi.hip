@@ -108,7 +108,6 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_MF_SCHED")) ctx->mf_sched = std::atoi(b) & 3;
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;

@@ -610,161 +610,6 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
         mf_body_wave(v, v.order[i], k);
 }
 
-__device__ __forceinline__ int dv_ld32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void dv_st32(int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ---- global relabel by tile-resident label correcting (deep searches) ----------------------------------------------------
-// The level-synchronous search costs one launch (~13 us at N = 1e6) per BFS level whatever the frontier holds; the moves
-// that hand a new instance its points from the all-zero labelling of a fresh PEARL run (PEARL.h:541-551) search 65-200
-// levels deep, 10-17 times per move: the graph there is a chain of dense clusters (one per object) joined by narrow
-// funnels, the few units of flow the funnels admit must cross all of it, and 0.9 s of a find6DPoses call at C4 were level
-// launches.  Here a workgroup owns a TILE of 4096 sites that are consecutive in the Morton order of the graph's
-// coordinates (the tile path's site order: a tile is spatially compact, most arcs stay inside it), keeps their distances in
-// LDS and the heads of their residual arcs in registers, and relaxes  d[u] = 1 + min { d[w] : cap(u -> w) > 0 }  to a fixed
-// point at LDS speed; only distances of sites in OTHER tiles are read from global memory, once per round, and changed
-// distances are published once per round.  All values are upper bounds of the true distance that only decrease, so any
-// interleaving is valid; a search crosses a tile per round instead of a site per launch.  The fixed point is the exact BFS
-// distance (Bellman-Ford), unreached sites keep kMfInf - the same d[] the level-synchronous search produces, hence the same
-// labels.  Termination: a second launch of ONE round per tile that changes nothing proves the fixed point (every tile
-// re-read every neighbour after all writes of the first launch were complete).
-// Beta hubs (label costs): d[y_beta] = 1 + min over the members, a member with residual u -> y_beta (f[u] > 0) gets
-// d[y_beta] + 1: the hub distances are one more monotone word per label (atomicMin), read back once per round.
-constexpr int kLcThreads = 1024;
-constexpr int kLcSpt = 4;                        // sites per thread
-constexpr int kLcTile = kLcThreads * kLcSpt;     // sites per tile
-constexpr int kLcAdj = 12;                       // arc slots per site held in LDS (heads inside the tile); longer rows go through global memory
-constexpr int kLcExt = 3;                        // heads outside the tile held in registers per site; more: the row is re-read every round
-
-__global__ __launch_bounds__(kLcThreads) void mf_k_lc_search(MfView v, const int* __restrict__ perm, const int* __restrict__ toff,
-                                                             const int* __restrict__ tidx, int rounds, int* __restrict__ ctl /* [0] change counter of this launch */,
-                                                             int zero_word /* flags word cleared by this launch (-1: none) */,
-                                                             int report /* flags word that counts the tiles this launch changed (-1: none) */)
-{
-    __shared__ int s_d[kLcTile + 1];                          // distances of the tile's sites; [kLcTile] = kMfInf (unused arc slots point there)
-    __shared__ unsigned short s_nb[kLcAdj][kLcTile];          // slot-major: lanes read consecutive addresses
-    __shared__ int s_min[kMfMaxLabels];
-    __shared__ int s_seen;
-    const int tid = (int)threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kLcTile;
-    if (blockIdx.x == 0 && tid == 0 && zero_word >= 0) dv_st32(&v.flags[zero_word], 0);   // (the verifying launch, which counts into it, follows on the stream)
-    int u[kLcSpt], cur[kLcSpt], pub[kLcSpt], em[kLcSpt], hubf[kLcSpt], hubm[kLcSpt], a_lo[kLcSpt], a_hi[kLcSpt];
-    int ext[kLcSpt][kLcExt];
-#pragma unroll
-    for (int s = 0; s < kLcSpt; ++s) {
-        const int loc = s * kLcThreads + tid;
-        const int64_t p = base + loc;
-        u[s] = p < v.n ? perm[p] : -1;
-        cur[s] = u[s] >= 0 ? v.d[u[s]] : kMfDead;     // (written by earlier kernels)
-        pub[s] = cur[s];
-        s_d[loc] = cur[s];
-        hubf[s] = hubm[s] = -1;
-        a_lo[s] = a_hi[s] = 0;                        // non-empty: the site's row is walked in global memory every round
-#pragma unroll
-        for (int j = 0; j < kLcExt; ++j) ext[s][j] = -1;
-        int next = 0;
-        bool slow = false;
-        if (cur[s] >= 0) {
-            const int lu = v.labels[u[s]];
-            if (v.hub_exists[lu]) { hubm[s] = lu; if (v.f[u[s]] > 0) hubf[s] = lu; }
-            const int t0 = toff[p], deg = toff[p + 1] - t0, a0 = v.off[u[s]];
-#pragma unroll
-            for (int j = 0; j < kLcAdj; ++j) {
-                int x = kLcTile;
-                if (j < deg && v.cap[a0 + j] > 0) {
-                    const int64_t q = tidx[t0 + j];
-                    if (q >= base && q < base + kLcTile) x = (int)(q - base);
-                    else {
-                        const int w = perm[q];
-                        if (next == 0) ext[s][0] = w; else if (next == 1) ext[s][1] = w; else if (next == 2) ext[s][2] = w; else slow = true;
-                        ++next;
-                    }
-                }
-                s_nb[j][loc] = (unsigned short)x;
-            }
-            if (deg > kLcAdj || slow) { a_lo[s] = a0; a_hi[s] = a0 + deg; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kLcAdj; ++j) s_nb[j][loc] = (unsigned short)kLcTile;
-        }
-    }
-    if (tid == 0) { s_d[kLcTile] = kMfInf; s_seen = -1; }
-    if (tid < kMfMaxLabels) s_min[tid] = kMfInf;
-    __syncthreads();
-    bool launch_changed = false;
-    int idle = 0, quiet = 0, last_seen = -1;
-    for (int r = 0; r < rounds; ++r) {
-        // distances outside the tile (and of the hubs), as published so far
-#pragma unroll
-        for (int s = 0; s < kLcSpt; ++s) {
-            int m = kMfInf;
-            if (cur[s] > 1) {
-                if (a_hi[s] > a_lo[s]) {
-                    for (int a = a_lo[s]; a < a_hi[s]; ++a)
-                        if (v.cap[a] > 0) { const int dv = dv_ld32(&v.d[v.idx[a]]); m = dv < m ? dv : m; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kLcExt; ++j)
-                        if (ext[s][j] >= 0) { const int dv = dv_ld32(&v.d[ext[s][j]]); m = dv < m ? dv : m; }
-                }
-                if (hubf[s] >= 0) { const int hd = dv_ld32(&v.bfs_hub_d[hubf[s]]); m = hd < m ? hd : m; }
-            }
-            em[s] = m;
-        }
-        // fixed point inside the tile (racy LDS reads are fine: every value is a valid upper bound)
-        bool ch;
-        do {
-            ch = false;
-#pragma unroll
-            for (int s = 0; s < kLcSpt; ++s) {
-                if (cur[s] <= 1) continue;   // inactive (kMfDead) or already at distance 1
-                const int loc = s * kLcThreads + tid;
-                int m = em[s];
-#pragma unroll
-                for (int j = 0; j < kLcAdj; ++j) { const int dv = s_d[s_nb[j][loc]]; m = dv < m ? dv : m; }
-                int nd = m >= kMfInf ? kMfInf : m + 1;
-                if (nd >= v.hmax) nd = kMfInf;
-                if (nd < cur[s]) { cur[s] = nd; s_d[loc] = nd; ch = true; }
-            }
-        } while (__syncthreads_or(ch ? 1 : 0));
-        // publish what changed
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < kLcSpt; ++s)
-            if (cur[s] < pub[s]) {
-                dv_st32(&v.d[u[s]], cur[s]);
-                pub[s] = cur[s];
-                any = true;
-                if (hubm[s] >= 0) atomicMin(&s_min[hubm[s]], cur[s] + 1);
-            }
-        const int wg_any = __syncthreads_or(any ? 1 : 0);
-        if (wg_any) {
-            launch_changed = true;
-            if (tid < v.L && s_min[tid] != kMfInf) { mf_report_min(&v.bfs_hub_d[tid], s_min[tid]); s_min[tid] = kMfInf; }
-            if (tid == 0) atomicAdd(&ctl[0], 1);
-        }
-        if (r + 1 >= rounds) break;
-        // leave when this tile and everybody else have been quiet for a while (a heuristic: the verifying launch decides)
-        if (tid == 0) s_seen = dv_ld32(&ctl[0]);
-        __syncthreads();
-        const int seen = s_seen;
-        idle = wg_any ? 0 : idle + 1;
-        quiet = seen == last_seen ? quiet + 1 : 0;
-        last_seen = seen;
-        if (idle >= 2 && quiet >= 2) break;
-    }
-    // last labelled "level" (flags[0], a hint for the driver) and the verdict of a verifying launch
-    {
-        int m = 0;
-#pragma unroll
-        for (int s = 0; s < kLcSpt; ++s)
-            if (cur[s] > m && cur[s] != kMfInf) m = cur[s];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_down(m, off, 64); m = o > m ? o : m; }
-        if ((tid & 63) == 0 && m > dv_ld32(&v.flags[0])) atomicMax(&v.flags[0], m);
-    }
-    if (launch_changed && tid == 0 && report >= 0) atomicAdd(&v.flags[report], 1);
-}
-
 // The sweep epilogue (maxflow_body.cuh mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
 // labels through a chain of dependent loads (~5.3 us; at C5 a call ran 80 k of them, 19 % of its GPU time).  Same result.
 __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed)
@@ -806,50 +651,6 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
         v.flags[8] = 0;
         if (consumed >= 0) v.acnt[consumed] = 0;
     }
-}
-
-// ---- a round of work-list sweeps in ONE launch of one workgroup -----------------------------------------------------------
-// After the first round of a hard move a few hundred to a few thousand sites hold the excess that still looks for a way
-// through the funnels; a round was up to 96 x (mf_k_sweep_list + its epilogue) = 192 launches of ~9 us for a few passes of
-// work each.  One workgroup of 1024 threads runs the same steps - sweep over the list, build the next list, epilogue, the
-// driver's stop conditions - with workgroup barriers in place of kernel boundaries.
-constexpr int kLoopThreads = 1024;
-
-__global__ __launch_bounds__(kLoopThreads) void mf_k_list_loop(MfView v, int sweep_id, int parity, int stamp, int budget, int stall_limit,
-                                                               int* pub, int seq)   // flags[10] = sweeps run
-{
-    __shared__ SweepLds s;
-    int ran = 0;
-    for (; ran < budget; ++ran, ++sweep_id, parity ^= 1) {
-        const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
-        sweep_lds_init(s);
-        const int cnt = dv_ld32(&v.acnt[parity]);
-        const int* in = v.act[parity];
-        bool any = false;
-        const int rounded = (cnt + kLoopThreads - 1) / kLoopThreads * kLoopThreads;
-        for (int i = (int)threadIdx.x; i < rounded; i += kLoopThreads) {
-            const int u = i < cnt ? dv_ld32(&in[i]) : -1;
-            int pushed = -1;
-            bool listed = false;
-            any |= mf_sweep_step(v, u, prev, cur, true, s, &pushed, &listed);
-            const bool again = u >= 0 && listed && mf_list_claim(v, u, stamp + 1 + ran);
-            const bool fresh = pushed >= 0 && mf_list_claim(v, pushed, stamp + 1 + ran);
-            mf_append2(&v.acnt[1 - parity], v.act[1 - parity], u, again, pushed, fresh);
-        }
-        mf_sweep_flush(v, cur, true, s, any);
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x < 64) mf_sweep_epilogue_wave(v, cur, next, parity);
-        __threadfence();
-        __syncthreads();
-        // the driver's conditions for leaving a round (maxflow_driver.inl)
-        if (dv_ld32(&v.flags[4]) == 0 || dv_ld32(&v.flags[6]) != 0) { ++ran; break; }
-        if (stall_limit > 0 && dv_ld32(&v.flags[11]) >= stall_limit) { ++ran; break; }
-    }
-    if (threadIdx.x == 0) dv_st32(&v.flags[10], ran < budget ? ran : budget);
-    __threadfence();
-    __syncthreads();
-    if (pub != nullptr && threadIdx.x < 64) mf_publish(v, pub, seq);
 }
 
 __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub, int seq)
@@ -1101,31 +902,6 @@ struct HipBackend {
         hipLaunchKernelGGL(mf_k_sweep_list, dim3(list_blocks), dim3(kMfBlock), 0, ctx->stream, v, prev, cur, parity, stamp);
         check();
     }
-    // global relabel by tile-resident label correcting (mf_k_lc_search): the search launch, then the one-round launch whose
-    // count of tiles that still changed (flags[9]) travels with the next flag read-back
-    static constexpr bool kHasLc = true;
-    const int* lc_perm = nullptr; const int* lc_toff = nullptr; const int* lc_tidx = nullptr;
-    int lc_rounds = 48;
-    void lc_search(const MfView& v)
-    {
-        int* ctl = st->bar.as<int>() + 12;   // [12] change counter of the search launch, [13] of the verifying launch
-        hipError_t e = hipMemsetAsync(ctl, 0, 8, ctx->stream);
-        if (e != hipSuccess && err == hipSuccess) err = e;
-        const unsigned tiles = (unsigned)((v.n + kLcTile - 1) / kLcTile);
-        hipLaunchKernelGGL(mf_k_lc_search, dim3(tiles), dim3(kLcThreads), 0, ctx->stream, v, lc_perm, lc_toff, lc_tidx, lc_rounds, ctl, 9, -1);
-        hipLaunchKernelGGL(mf_k_lc_search, dim3(tiles), dim3(kLcThreads), 0, ctx->stream, v, lc_perm, lc_toff, lc_tidx, 1, ctl + 1, -1, 9);
-        check();
-    }
-    // a round of work-list sweeps in one launch (mf_k_list_loop); the flags (flags[10] = sweeps run) are published by it
-    static constexpr bool kHasLoop = true;
-    void list_loop(const MfView& v, int sweep_id, int parity, int stamp, int budget, int stall_limit)
-    {
-        int* pub = (publish && st->h_pub) ? st->h_pub : nullptr;
-        hipLaunchKernelGGL(mf_k_list_loop, dim3(1), dim3(kLoopThreads), 0, ctx->stream, v, sweep_id, parity, stamp, budget, stall_limit, pub,
-                           pub ? ++st->pub_seq : 0);
-        check();
-        if (pub) pub_pending = true;
-    }
     long long stuck_excess(const MfView& v)
     {
         // sites: device reduction into the first word of the (free after the BFS) histogram-sized scratch in `lists`
@@ -1369,11 +1145,6 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     tune.debug = ctx->tile_debug;
     tune.bfs_hint = st->bfs_hint;
     tune.source_reach = source_reach ? 1 : 0;
-    if ((ctx->mf_sched & 1) && pair && n > 4 * (int64_t)kLcTile) {   // (small graphs: a level costs a few us, the tile search does not pay)
-        PGX_TRY(tile_order_prepare(ctx, &be.lc_perm, &be.lc_toff, &be.lc_tidx));
-        tune.lc_min_depth = 32;
-    }
-    if (ctx->mf_sched & 2) tune.loop_max_active = 8192;
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
     if (!source_reach && wq == nullptr && pair && L <= 64 && region_moves_apply(ctx)) {   // (then expand_alpha_region runs its first kernel = the per-site initialisation)

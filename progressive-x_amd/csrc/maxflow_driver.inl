@@ -25,8 +25,6 @@ struct MfTuning {
     int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
     int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
     int preinit = 0;          // init_sites has already run for this move (the region path declined it); count_and_setup has not
-    int lc_min_depth = 0;     // searches expected to be at least this deep (bfs_hint) run as tile-resident label correcting (Backend::lc_search); 0 = never
-    int loop_max_active = 0;  // work-list rounds that start with at most this many active sites run in one launch (Backend::list_loop); 0 = never
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
@@ -46,36 +44,13 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
     bool converged = false;
     for (int it = 0; it < tune.max_relabels && !converged; ++it) {
         // ---- global relabel
-        const auto t_search = std::chrono::steady_clock::now();
-        int lc_pairs = 0;
+        const auto t_search = std::chrono::steady_clock::now();   // (PGX_MF_DEBUG: wall time of the search, read-backs included)
         be.bfs_reset(v);
         be.bfs_init(v);
         int level = 1, last = 1;
         const int slot = (sweep_id + 2) % 3;
         int fl[kMfFlags];
-        bool used_lc = false;
-        if constexpr (Backend::kHasLc) {
-            // Deep searches (the previous search of the same kind labelled lc_min_depth levels or more): distances by label
-            // correcting inside tiles instead of one launch per level.  The launch pair ends with a one-round pass over every
-            // tile; flags[9] = tiles it still changed travels with the read-back, and the pair is repeated until it is 0.
-            int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
-            if (tune.lc_min_depth > 0 && v.gate && v.off != nullptr && hint && *hint >= tune.lc_min_depth) {
-                used_lc = true;
-                for (;;) {
-                    be.lc_search(v);
-                    be.bfs_finish(v, slot, 1);
-                    be.count_active(v);
-                    if (cnt_alpha < 0) be.read_flags_and_count(v, fl, &cnt_alpha);
-                    else be.read_flags(v, fl);
-                    ++lc_pairs;
-                    if (fl[9] == 0) break;
-                }
-                last = fl[0];
-                level = last + 1;
-                *hint = last > 1 ? last : 1;
-            }
-        }
-        if (!used_lc) {
+        {
             // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
             // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
             // The first batch is sized by the depth of the previous search of the same kind - the first search of a move (from
@@ -117,15 +92,14 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         stats[3] += level;
         if (fl[1] == 0) { converged = true; break; }
         if (tune.debug)
-            std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d lc_pairs=%d search_us=%.0f\n", v.alpha, it, level, fl[3], fl[7], lc_pairs,
+            std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d search_us=%.0f\n", v.alpha, it, level, fl[3], fl[7],
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_search).count());
-        const auto t_sweeps = std::chrono::steady_clock::now();
         if (tune.debug > 1) be.debug_dump(v, tune.debug == 4 ? level : fl[3]);
         // ---- wave pass over the BFS levels, farthest first
         // One launch per level: after a deep search (86 levels at C4) the pass costs more than the list sweeps it saves
         // (find6DPoses PEARL 2.96 -> 2.70 s without it), after a shallow one (7 levels at C5) it pays (2.7 vs 3.2 s).  A move
         // that still needs many relabels gets it back: it is what moved excess along 100-arc paths in round 1.
-        if (tune.wave && !used_lc && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {
+        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {
             const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
             for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
@@ -138,21 +112,6 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         if (list_mode) be.build_list(v, stamp);
         int parity = 0, s = 0;
         bool round_done = false;
-        if constexpr (Backend::kHasLoop) {
-            if (list_mode && tune.loop_max_active > 0 && fl[3] <= tune.loop_max_active) {
-                // the whole round in one launch of one workgroup, with the stop conditions of the loop below evaluated on the device
-                const int stall = tune.stall_sweeps > 0 ? (tune.stall_sweeps > last + 2 ? tune.stall_sweeps : last + 2) : 0;
-                be.list_loop(v, sweep_id, parity, stamp, budget, stall);
-                be.read_flags(v, fl);
-                if (tune.debug)
-                    std::fprintf(stderr, "[mf]   list loop: %d sweeps, %.0f us\n", fl[10],
-                                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sweeps).count());
-                sweep_id += fl[10];
-                stats[1] += fl[10];
-                stats[6] += fl[10];
-                round_done = true;
-            }
-        }
         for (; s < budget && !round_done; ++s) {
             const int cur = sweep_id % 3, prev = (sweep_id + 2) % 3, next = (sweep_id + 1) % 3;
             const bool read_follows = (s + 1) % tune.sweep_check == 0;   // the epilogue then hands the flags to the host itself

@@ -934,17 +934,6 @@ static int tile_graph_prepare(pgx_ctx* ctx)
     return PGX_OK;
 }
 
-// The tile path's site order for other solvers (maxflow.hip mf_k_lc_search): perm[position] = site, and the graph rows in
-// position order (toff / tidx: heads as positions, entry j of a row = entry j of the site's own row).
-int tile_order_prepare(pgx_ctx* ctx, const int** perm, const int** toff, const int** tidx)
-{
-    PGX_TRY(tile_graph_prepare(ctx));
-    *perm = ctx->tile->perm.as<int>();
-    *toff = ctx->tile->off.as<int>();
-    *tidx = ctx->tile->idx.as<int>();
-    return PGX_OK;
-}
-
 namespace {
 
 struct SmallLayout {   // byte offsets inside the small block

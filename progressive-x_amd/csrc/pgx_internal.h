@@ -111,8 +111,6 @@ struct pgx_ctx {
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
     int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
-    int mf_sched = 3;            // PGX_MF_SCHED bit 0: deep global relabels by tile-resident label correcting (maxflow.hip mf_k_lc_search),
-                                 // bit 1: work-list rounds in one launch (mf_k_list_loop); 0 = the level-synchronous schedule of round 3 (A/B)
     int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
     int region_defer = 0;        // region moves are enqueued without a host round trip (pgx_expansion's batches): slot / skip rule below
     int region_slot = 0;
@@ -215,7 +213,6 @@ constexpr int PGX_REGION_PENDING = 1001;  // expand_alpha_region with ctx->regio
 int region_batch_begin(pgx_ctx* ctx);
 int region_result(pgx_ctx* ctx, int slot, int alpha, int* status, int64_t* changed);
 bool region_moves_apply(const pgx_ctx* ctx);   // maxflow.hip: pgx_expansion's moves on the resident problem go through expand_alpha_region
-int tile_order_prepare(pgx_ctx* ctx, const int** perm, const int** toff, const int** tidx);   // maxflow_tile.hip: the tile path's site order and the graph rows in it
 int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed);   // maxflow_tile.hip: a move with few open sites, one workgroup
 void comm_free(pgx_ctx* ctx);
 

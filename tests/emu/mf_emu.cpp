@@ -20,7 +20,6 @@ using namespace pgx;
 namespace {
 
 struct EmuBackend {
-    static constexpr bool kHasLc = false, kHasLoop = false;   // device-only schedules (maxflow.hip)
     std::mt19937_64 rng;
     bool shuffle;
     std::vector<int64_t> order;
