@@ -244,6 +244,30 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
             legs["rccl_single_rank"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s,
                                         "step": "two batches in flight: launch(i) + pgx_score_allgather_begin(i) [copy aside, ncclAllGather and copy to pinned memory "
                                                 "on the exchange stream] + pgx_score_allgather_end(i - 1) + select"}
+            # the point-sharded exchange (bench.py --gpus N's default): integer accumulators exported, all-reduced (sum, uint64) and
+            # converted on the exchange stream while the next batch is scored
+            state["i"] = 0
+            cc.score_launch(T2, has_compound=True)
+            cc.score_allreduce_begin(0)
+
+            def step_red():
+                i = state["i"] = state["i"] + 1
+                cc.score_launch(T2, has_compound=True)
+                cc.score_allreduce_begin(i & 1)
+                res = cc.score_allreduce_end((i - 1) & 1, exponent=2)
+                return parallel.select_best(res["scores"], res["counts"])
+            for _ in range(warmup):
+                step_red()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_red()
+            cc.sync()
+            s = (time.perf_counter() - t0) / steps
+            cc.score_allreduce_end(state["i"] & 1, exponent=2)
+            legs["rccl_single_rank_allreduce"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s,
+                                                  "step": "two batches in flight: launch(i) + pgx_score_allreduce_begin(i) [export of the integer accumulators, "
+                                                          "ncclAllReduce(sum, uint64), conversion and copy to pinned memory on the exchange stream] + "
+                                                          "pgx_score_allreduce_end(i - 1) + select"}
             cc.comm_destroy()
         finally:
             cc.close()
@@ -369,6 +393,44 @@ def strong_scaling_legs(ctx, parallel, hyps, T2, steps, warmup):
     return out
 
 
+def strong_points_legs(_lib, ctx, parallel, pts, hyps, gt0, T2, steps, warmup):
+    """The same question for the POINT-sharded split (pgx_score_allreduce: every GPU scores all 2048 hypotheses against N / G of
+    the points, integer accumulators all-reduced): the step at N = 1e6 / 5e5 / 2.5e5 / 1.25e5 points x 2048 hypotheses on this
+    one GPU.  Cull, dispatch, group work and row loads all divide by G; what does not is the finish and the launch gaps."""
+    out = {}
+    base = None
+    n = pts.shape[0]
+    try:
+        for div in (1, 2, 4, 8):
+            lo, hi = parallel.point_slice(n, div, 0)
+            ctx.set_points(_lib.PNP, pts[lo:hi])
+            ctx.score_set_global_n(n)
+            ctx.preference(gt0, T2, slot=0)
+            ctx.compound_update([0])
+            ctx.score_upload(hyps)
+            buf = ctx.score_buffers()
+
+            def step():
+                ctx.score_launch(T2, has_compound=True)
+                res = ctx.score_fetch(exponent=2, out=buf)
+                return parallel.select_best(res["scores"], res["counts"])
+            s, kt = timed_steps(ctx, step, max(20, min(steps, 50)), max(10, min(warmup, 50)))
+            base = s if base is None else base
+            out[f"gpus_{div}"] = {"points_per_gpu": int(hi - lo), "hypotheses_per_gpu": int(len(hyps)), "ms_per_step": 1e3 * s,
+                                  "kernel_ms": {"cull": float(kt[0]), "group_major": float(kt[1]), "finish": float(kt[2])},
+                                  "projected_models_per_sec": len(hyps) / s,
+                                  "projected_efficiency": base / (div * s),
+                                  "note": "projection: every GPU does this step concurrently on its slice; the all-reduce of 48 KB "
+                                          "(overlapped with the next launch in bench.py --gpus N) is not included"}
+    finally:
+        ctx.score_set_global_n(0)
+        ctx.set_points(_lib.PNP, pts)
+        ctx.preference(gt0, T2, slot=0)
+        ctx.compound_update([0])
+        ctx.score_upload(hyps)
+    return out
+
+
 gt_pose0 = None
 
 
@@ -380,8 +442,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)   # the first ~30 steps (10 ms) run 6 % slower: the clocks are still ramping
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--hyps", type=int, default=2048)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --hyps hypotheses per GPU; strong: --hyps hypotheses in total, split over the GPUs")
+    ap.add_argument("--scaling", choices=("strong-points", "strong", "weak"), default="strong-points",
+                    help="strong-points (default; the BASELINE metric '1e6 pts x 2048 hyps, 1/2/4/8 GPU': fixed total work): every GPU "
+                         "scores all --hyps hypotheses against its 1/N slice of the points, the integer accumulators are summed by an "
+                         "RCCL all-reduce (bitwise the 1-GPU table); strong: --hyps hypotheses in total, split over the GPUs, every "
+                         "GPU holds all points (all-gather); weak: --hyps hypotheses per GPU, all points on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
@@ -400,8 +465,12 @@ def main():
     pts, f = datasets.normalize_pnp(x1, x2, K)
     thr = 4.0 / f                       # find6DPoses default threshold 4 px (bindings.cpp:467), normalised (:96-98)
     T2 = 9.0 / 4.0 * thr * thr          # progressive_x.h:523
+    by_points = args.scaling == "strong-points"
+    n_total = pts.shape[0]
     if args.scaling == "weak":      # every rank scores its own batch of --hyps hypotheses
         hyps = datasets.make_pose_hypotheses(gt, M=args.hyps, seed=1 + rank)
+    elif by_points:                 # ONE batch of --hyps hypotheses on every rank, rank r holds slice r of the POINTS
+        hyps = datasets.make_pose_hypotheses(gt, M=args.hyps, seed=1)
     else:                           # strong: ONE batch of --hyps hypotheses, rank r scores slice r (BASELINE: 2048 in total)
         hyps = np.ascontiguousarray(np.array_split(datasets.make_pose_hypotheses(gt, M=args.hyps, seed=1), world)[rank])
     gt_pose0 = gt[0]
@@ -409,8 +478,11 @@ def main():
     ctx = _lib.Context(local)
     info = ctx.device_info()
     ctx.score_profile(1)                # HIP events around the dominant scoring kernel, on the stream the kernels run on
-    ctx.set_points(_lib.PNP, pts)
-    # a non-empty compound instance: the preference vector of the first accepted model (GT pose 0)
+    p_lo, p_hi = parallel.point_slice(n_total, world, rank) if by_points else (0, n_total)
+    ctx.set_points(_lib.PNP, pts[p_lo:p_hi] if by_points and world > 1 else pts)
+    if by_points:
+        ctx.score_set_global_n(n_total)     # one fixed-point scale for the whole job: the all-reduced sums are bitwise the 1-GPU sums
+    # a non-empty compound instance: the preference vector of the first accepted model (GT pose 0) - per point, so per slice
     ctx.preference(gt[0], T2, slot=0)
     ctx.compound_update([0])
     comp = ctx.get_compound() if rank == 0 else None
@@ -425,22 +497,33 @@ def main():
     # ~9 us of a 0.25 ms step, so timing every launch would put 3.5 % of measurement into the number being measured
     EVENT_EVERY = 5
 
-    pipe = {"i": 0}
-    if use_comm:                      # two batches in flight: the exchange of step i - 1 overlaps the scoring of step i
-        ctx.score_launch(T2, has_compound=True)
-        ctx.score_allgather_begin(0)
+    # with a communicator: two batches in flight - the exchange of step i - 1 overlaps the scoring of step i.  A pipelined exchange
+    # runs on the exchange stream; every other collective (the barriers below) needs the slots collected first (comm.hip refuses
+    # it otherwise: one communicator, two streams), so the pipeline is drained before a barrier and refilled by the next step.
+    pipe = {"i": 0, "open": False, "res": None}
+    begin = ctx.score_allreduce_begin if by_points else ctx.score_allgather_begin
+    end = ctx.score_allreduce_end if by_points else ctx.score_allgather_end
+
+    def drain():
+        if pipe["open"]:
+            pipe["res"] = end(pipe["i"] & 1, exponent=2)
+            pipe["open"] = False
+        return pipe["res"]
 
     def step(sample=True):
         ctx.score_profile(1 if sample else 0)
         ctx.score_launch(T2, has_compound=True)
         if use_comm:
             i = pipe["i"] = pipe["i"] + 1
-            ctx.score_allgather_begin(i & 1)
-            res = ctx.score_allgather_end((i - 1) & 1, exponent=2)
+            begin(i & 1)
+            if pipe["open"]:
+                pipe["res"] = end((i - 1) & 1, exponent=2)
+            pipe["open"] = True
+            res = pipe["res"]
         else:
             res = ctx.score_fetch(exponent=2, out=fetch_buf)
         kt = ctx.score_kernel_times() if sample else None    # (waits for the launch's last event)
-        best = parallel.select_best(res["scores"], res["counts"])
+        best = parallel.select_best(res["scores"], res["counts"]) if res is not None else -1
         return kt, best, res
 
     for i in range(args.warmup):
@@ -455,6 +538,7 @@ def main():
             step(False)
             extra_warmup += 1
     if use_comm:
+        drain()
         ctx.comm_barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -464,7 +548,8 @@ def main():
         if kms is not None:
             kernel_ms.append(kms)
     if use_comm:
-        ctx.score_allgather_end(pipe["i"] & 1, exponent=2)    # drain the pipeline inside the timed region: K launches, K exchanges
+        res = drain()                 # inside the timed region: K launches, K exchanges
+        best = parallel.select_best(res["scores"], res["counts"])
         ctx.comm_barrier()
     ctx.sync()
     elapsed = time.perf_counter() - t0
@@ -472,7 +557,7 @@ def main():
         elapsed = ctx.comm_allreduce_max(elapsed)
 
     if rank == 0:
-        n, M = pts.shape[0], hyps.shape[0]
+        n, M = n_total, hyps.shape[0]
         total_hyps = M * world if args.scaling == "weak" else args.hyps
         pairs_per_step = n * total_hyps
         ms_per_step = 1e3 * elapsed / args.steps
@@ -502,13 +587,16 @@ def main():
             "executed_pairs_note": "f32 filter evaluations + exact FP64 evaluations actually run per second (rank 0's batch x ranks)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_extra_steps_by_time": extra_warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.scaling == "weak" else "strong", "scaling_mode": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4 multi-6D-pose points (1e6 2D-3D correspondences, 16 objects, 20% outliers) x "
-                                   "metric batch of 2048 pose hypotheses per GPU (16 GT + perturbed), PnP reprojection "
+                                   "metric batch of 2048 pose hypotheses (16 GT + perturbed; weak mode: per GPU), PnP reprojection "
                                    "residual, MSAC + compound-model score, compound instance = 1 model",
-                       "points": n, "hypotheses_per_gpu": M, "hypotheses_total": total_hyps, "parallelism": f"hypothesis-sharded x{world}",
-                       "exchange": "rccl all-gather of (count,value,shared), overlapped with the next batch's scoring (two in flight)" if use_comm else "none",
+                       "points": n, "points_per_gpu": int(p_hi - p_lo), "hypotheses_per_gpu": M, "hypotheses_total": total_hyps,
+                       "parallelism": (f"point-sharded x{world}" if by_points else f"hypothesis-sharded x{world}") if world > 1 else "1 GPU",
+                       "exchange": ("none" if not use_comm else
+                                    "rccl all-reduce (sum, uint64) of the integer accumulators (count, 2^-q fixed-point value and shared), overlapped with the next launch (two in flight)"
+                                    if by_points else "rccl all-gather of (count,value,shared), overlapped with the next batch's scoring (two in flight)"),
                        "device": info["name"], "cu_count": info["cu_count"]},
             "winner": {"index": best, "inliers": int(res["counts"][best]) if best >= 0 else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -546,6 +634,10 @@ def main():
                 out["legs"]["strong_scaling_projection"] = strong_scaling_legs(ctx, parallel, hyps, T2, args.steps, args.warmup)
             except Exception as e:       # never fail the bench over a secondary leg
                 out["legs"]["strong_scaling_projection"] = {"error": str(e)}
+            try:
+                out["legs"]["strong_points_projection"] = strong_points_legs(_lib, ctx, parallel, pts, hyps, gt[0], T2, args.steps, args.warmup)
+            except Exception as e:
+                out["legs"]["strong_points_projection"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(pts, hyps, T2, comp)
             out["cpu_baseline"] = cb

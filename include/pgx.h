@@ -111,7 +111,9 @@ int pgx_score_stats(pgx_ctx *ctx, double T2, int has_compound, int64_t stats[8])
 int pgx_score_profile(pgx_ctx *ctx, int on);
 /* Diagnostic read-back of what pgx_set_points derived for the score path (tests compare the device preprocessing with the
  * host version bit for bit): what = 0 sorted order (n int32), 1 group + super-group rows ((groups + supers) x 12 f32),
- * 2 / 3 the group-blocked f64 / f32 row copies, 4 the sorted f32 rows.  bytes must match exactly. */
+ * 2 / 3 the group-blocked f64 / f32 row copies, 4 the sorted f32 rows; 5 the integer accumulators of the last launch, replicas
+ * summed, in the caller's hypothesis order (3 x Mpad u64: count | value | shared in 2^-q fixed point - what pgx_score_allreduce
+ * adds across ranks).  bytes must match exactly. */
 int pgx_score_debug_fetch(pgx_ctx *ctx, int what, void *out, int64_t bytes);
 /* Test hook: launch geometry of the group-major score path (results must not depend on it - integer accumulation of per-pair
  * fixed point; tests/test_gpu_parity.py).  what = 0 waves per 64-point group (0 = automatic), 1 a group's waves on one XCD
@@ -249,8 +251,9 @@ int pgx_gc_inliers(pgx_ctx *ctx, const double *model, double T2, double lambda, 
 int pgx_bucket(pgx_ctx *ctx, int L, int64_t *counts, int32_t *order);     /* order optional: stable, ascending index */
 int pgx_residual_sum(pgx_ctx *ctx, const double *model, int label, double *sum);
 
-/* ---- multi-GPU (no reference counterpart): hypotheses are sharded over ranks, every rank holds all
- * points; RCCL all-gather of the per-hypothesis (count, value, shared) triples; all-reduce(max) of the compound vector */
+/* ---- multi-GPU (no reference counterpart): either the hypotheses are sharded over ranks and every rank holds all
+ * points (RCCL all-gather of the per-hypothesis (count, value, shared) triples), or the points are sharded and every rank scores all
+ * hypotheses (RCCL all-reduce of the integer accumulators); all-reduce(max) of the compound vector */
 int pgx_comm_unique_id(uint8_t id[PGX_UNIQUE_ID_BYTES]);
 int pgx_comm_init(pgx_ctx *ctx, int nranks, int rank, const uint8_t id[PGX_UNIQUE_ID_BYTES]);
 int pgx_comm_destroy(pgx_ctx *ctx);
@@ -258,12 +261,24 @@ int pgx_comm_barrier(pgx_ctx *ctx);
 int pgx_comm_allreduce_max_f64(pgx_ctx *ctx, double *value);                /* host scalar in/out, via device */
 int pgx_score_allgather(pgx_ctx *ctx);                                      /* after pgx_score_launch, asynchronous */
 int pgx_score_fetch_all(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
-                        double *scores);                                    /* The same exchange, overlapped with the scoring of the NEXT batch (two batches in flight, slot = 0 / 1): _begin right behind
+                        double *scores);                                    /* nranks*M entries, rank-major */
+/* The same exchange, overlapped with the scoring of the NEXT batch (two batches in flight, slot = 0 / 1): _begin right behind
  * pgx_score_launch copies the launch's result block aside and runs all-gather + copy to pinned memory on a second stream; _end
- * waits for that slot and unpacks it like pgx_score_fetch_all (M = the launch's batch size).  Bitwise the serial results. */
+ * waits for that slot and unpacks it like pgx_score_fetch_all (M = the launch's batch size).  Bitwise the serial results.
+ * While a slot is in flight every other collective of the context is refused (one communicator, two streams). */
 int pgx_score_allgather_begin(pgx_ctx *ctx, int slot);
 int pgx_score_allgather_end(pgx_ctx *ctx, int slot, int exponent, int64_t *counts, double *values, double *shared, double *scores);
-/* nranks*M entries, rank-major */
+/* Point-sharded scoring (north_star: "RCCL all-reduce of per-model inlier counts"; the batched form of getScore,
+ * scoring_function_with_compound_model.h:78-121, with the loop over the points split across ranks): every rank holds a SLICE
+ * of the points and scores all M hypotheses against it; the integer accumulators of the launch (count, 2^-q fixed-point value
+ * and shared support) are summed over the ranks with ncclAllReduce(sum, uint64) - exact in any order, so the reduced table is
+ * bitwise the table of one GPU holding all the points.  pgx_score_set_global_n(total points of the job; 0 = this context's own)
+ * makes the ranks agree on q.  pgx_score_allreduce: after pgx_score_launch, asynchronous; pgx_score_fetch then returns the
+ * reduced table.  _begin / _end: the overlapped form (M rows, one table). */
+int pgx_score_set_global_n(pgx_ctx *ctx, int64_t n_total);
+int pgx_score_allreduce(pgx_ctx *ctx);
+int pgx_score_allreduce_begin(pgx_ctx *ctx, int slot);
+int pgx_score_allreduce_end(pgx_ctx *ctx, int slot, int exponent, int64_t *counts, double *values, double *shared, double *scores);
 int pgx_compound_allreduce_max(pgx_ctx *ctx);
 
 #ifdef __cplusplus

@@ -417,6 +417,14 @@ int pgx_solve_minimal(pgx_ctx* ctx, const int32_t* samples, int S, double* model
     return solve_minimal_launch(ctx, samples, S, models_out);
 }
 
+int pgx_score_set_global_n(pgx_ctx* ctx, int64_t n_total)
+{
+    CTX_GUARD(ctx);
+    if (n_total < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_set_global_n: negative point count");
+    ctx->score_global_n = n_total;
+    return PGX_OK;
+}
+
 int pgx_score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks)
 {
     CTX_GUARD(ctx);
@@ -528,6 +536,15 @@ int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)
     if (!out || bytes <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: empty destination");
     if (!ctx->point_sort) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: no sorted copies for the resident points");
     const int64_t groups = (ctx->n + 63) / 64, supers = (groups + kSuper - 1) / kSuper;
+    if (what == 5) {   // the last launch's integer accumulators, replicas summed, caller's order: [3][Mpad] u64 (score.hip score_acc_export)
+        const int64_t want = (int64_t)3 * ctx->Mpad * 8;
+        if (bytes != want) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: buffer 5 holds %lld bytes, asked for %lld", (long long)want, (long long)bytes);
+        PGX_TRY(ensure(ctx, ctx->g_counts, (size_t)want));
+        PGX_TRY(score_acc_export(ctx, (unsigned long long*)ctx->g_counts.p, ctx->stream));
+        PGX_HIP(ctx, hipMemcpyAsync(out, ctx->g_counts.p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PGX_OK;
+    }
     const DevBuf* b = nullptr;
     int64_t have = 0;
     switch (what) {
@@ -712,6 +729,10 @@ int pgx_set_labels(pgx_ctx* ctx, const int32_t* labels, int64_t n)
 {
     CTX_GUARD(ctx);
     if (!labels || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_labels: empty labels");
+    int32_t lo = labels[0], hi = labels[0];
+    for (int64_t i = 1; i < n; ++i) { lo = labels[i] < lo ? labels[i] : lo; hi = labels[i] > hi ? labels[i] : hi; }
+    if (lo < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_labels: negative label %d", (int)lo);
+    ctx->labels_max = hi;
     PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, labels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));

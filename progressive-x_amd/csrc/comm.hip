@@ -67,6 +67,7 @@ struct ExchangeSlot {
     size_t host_cap = 0;
     hipEvent_t scored = nullptr, done = nullptr;
     int M = 0, Mpad = 0, has_compound = 0, busy = 0;
+    int reduced = 0;   // begun by pgx_score_allreduce_begin: `host` holds ONE block counts | values | shared, not one per rank
 };
 
 struct CommState {
@@ -76,6 +77,14 @@ struct CommState {
     hipStream_t xstream = nullptr;
     ExchangeSlot slot[2];
 };
+
+// Collectives on ONE communicator must be issued in the same order on every rank.  The pipelined exchanges run on the exchange
+// stream; a collective on the context's stream while one of them is in flight could overtake it on some ranks only and hang the
+// job, so those calls are refused until the slots have been collected.
+static bool exchange_in_flight(const CommState* cs) { return cs->slot[0].busy || cs->slot[1].busy; }
+#define PGX_NO_EXCHANGE(ctx, name)                                                                                        \
+    if (exchange_in_flight((ctx)->comm))                                                                                  \
+        return fail(ctx, PGX_ERR_INVALID, name ": a pipelined exchange is still in flight (collect it with pgx_score_all*_end first)")
 
 #define PGX_NCCL(ctx, call)                                                                              \
     do {                                                                                                 \
@@ -147,6 +156,7 @@ int pgx_comm_destroy(pgx_ctx* ctx)
 int pgx_comm_barrier(pgx_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_barrier: communicator not initialised");
+    PGX_NO_EXCHANGE(ctx, "pgx_comm_barrier");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     PGX_TRY(ensure(ctx, ctx->comm->tmp, 64));
     PGX_HIP(ctx, hipMemsetAsync(ctx->comm->tmp.p, 0, 8, ctx->stream));
@@ -158,6 +168,7 @@ int pgx_comm_barrier(pgx_ctx* ctx)
 int pgx_comm_allreduce_max_f64(pgx_ctx* ctx, double* value)
 {
     if (!ctx || !ctx->comm || !value) return fail(ctx, PGX_ERR_INVALID, "pgx_comm_allreduce_max_f64: communicator not initialised");
+    PGX_NO_EXCHANGE(ctx, "pgx_comm_allreduce_max_f64");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     PGX_TRY(ensure(ctx, ctx->comm->tmp, 64));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->comm->tmp.p, value, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -173,6 +184,7 @@ int pgx_comm_allreduce_max_f64(pgx_ctx* ctx, double* value)
 int pgx_score_allgather(pgx_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: communicator not initialised");
+    PGX_NO_EXCHANGE(ctx, "pgx_score_allgather");
     if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather: nothing launched");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     const size_t W = (size_t)3 * (size_t)ctx->Mpad, G = (size_t)ctx->comm->nranks;
@@ -245,14 +257,15 @@ int pgx_score_allgather_begin(pgx_ctx* ctx, int slot)
     PGX_NCCL(ctx, g_rccl.AllGather(e.stage.p, e.gathered.p, W, ncclInt64, cs->comm, cs->xstream));
     PGX_HIP(ctx, hipMemcpyAsync(e.host, e.gathered.p, need, hipMemcpyDeviceToHost, cs->xstream));
     PGX_HIP(ctx, hipEventRecord(e.done, cs->xstream));
-    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1;
+    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1; e.reduced = 0;
     return PGX_OK;
 }
 
 int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* counts, double* values, double* shared, double* scores)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_end: communicator not initialised");
-    if (slot < 0 || slot > 1 || !ctx->comm->slot[slot].busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_end: slot %d holds nothing", slot);
+    if (slot < 0 || slot > 1 || !ctx->comm->slot[slot].busy || ctx->comm->slot[slot].reduced)
+        return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_end: slot %d holds no gathered table", slot);
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     ExchangeSlot& e = ctx->comm->slot[slot];
     PGX_HIP(ctx, hipEventSynchronize(e.done));
@@ -273,9 +286,92 @@ int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
     return PGX_OK;
 }
 
+// ---- point-sharded scoring: every rank scores ALL hypotheses against ITS slice of the points ---------------------------------
+// north_star: "RCCL all-reduce of per-model inlier counts / compound-preference vectors".  The accumulators of a launch are
+// integers (count, 2^-q fixed-point value and shared support), so ncclAllReduce(sum, uint64) over 3 x Mpad words is exact in
+// any order and the reduced table is bitwise the table of ONE GPU scoring all the points (the ranks agree on q through
+// pgx_score_set_global_n).  Cull, dispatch and the group kernel's work all divide by the number of ranks, which sharding the
+// hypotheses does not do (the fixed ~60 us of a step).  After the call pgx_score_fetch returns the reduced table.
+int pgx_score_allreduce(pgx_ctx* ctx)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce: communicator not initialised");
+    PGX_NO_EXCHANGE(ctx, "pgx_score_allreduce");
+    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce: nothing launched");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t W = (size_t)3 * (size_t)ctx->Mpad;
+    PGX_TRY(ensure(ctx, ctx->g_counts, W * 8));
+    unsigned long long* blk = (unsigned long long*)ctx->g_counts.p;
+    PGX_TRY(score_acc_export(ctx, blk, ctx->stream));
+    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W, ncclUint64, ncclSum, ctx->comm->comm, ctx->stream));
+    PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, ctx->last_qscale, ctx->counts.as<long long>(), ctx->values.as<double>(),
+                             ctx->shared.as<double>(), ctx->stream));
+    ctx->mirror_valid = 0;   // the host mirror holds this rank's partial table
+    return PGX_OK;
+}
+
+// The same, overlapped with the next launch (two in flight, like pgx_score_allgather_begin / _end): the accumulators are exported
+// on the context's stream right behind the launch (the next launch's cull kernel zeroes them), reduced and converted on the
+// exchange stream.  _end returns M rows - one table, not one per rank.
+int pgx_score_allreduce_begin(pgx_ctx* ctx, int slot)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: communicator not initialised");
+    if (slot < 0 || slot > 1) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: slot %d (0 or 1)", slot);
+    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: nothing launched");
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    CommState* cs = ctx->comm;
+    ExchangeSlot& e = cs->slot[slot];
+    if (e.busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: slot %d is still in flight (call pgx_score_allreduce_end)", slot);
+    if (!cs->xstream) PGX_HIP(ctx, hipStreamCreateWithFlags(&cs->xstream, hipStreamNonBlocking));
+    if (!e.scored) PGX_HIP(ctx, hipEventCreateWithFlags(&e.scored, hipEventDisableTiming));
+    if (!e.done) PGX_HIP(ctx, hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+    const size_t W = (size_t)3 * (size_t)ctx->Mpad, need = W * 8;
+    PGX_TRY(ensure(ctx, e.stage, need));
+    PGX_TRY(ensure(ctx, e.gathered, need));
+    if (e.host_cap < need) {
+        if (e.host) (void)hipHostFree(e.host);
+        e.host = nullptr; e.host_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&e.host, need * 2, hipHostMallocDefault));
+        e.host_cap = need * 2;
+    }
+    unsigned long long* blk = (unsigned long long*)e.stage.p;
+    PGX_TRY(score_acc_export(ctx, blk, ctx->stream));
+    PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
+    PGX_HIP(ctx, hipStreamWaitEvent(cs->xstream, e.scored, 0));
+    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W, ncclUint64, ncclSum, cs->comm, cs->xstream));
+    long long* res = (long long*)e.gathered.p;
+    PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, ctx->last_qscale, res, (double*)res + ctx->Mpad, (double*)res + 2 * (size_t)ctx->Mpad, cs->xstream));
+    PGX_HIP(ctx, hipMemcpyAsync(e.host, e.gathered.p, need, hipMemcpyDeviceToHost, cs->xstream));
+    PGX_HIP(ctx, hipEventRecord(e.done, cs->xstream));
+    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1; e.reduced = 1;
+    return PGX_OK;
+}
+
+int pgx_score_allreduce_end(pgx_ctx* ctx, int slot, int exponent, int64_t* counts, double* values, double* shared, double* scores)
+{
+    if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_end: communicator not initialised");
+    if (slot < 0 || slot > 1 || !ctx->comm->slot[slot].busy || !ctx->comm->slot[slot].reduced)
+        return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_end: slot %d holds no reduced table", slot);
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    ExchangeSlot& e = ctx->comm->slot[slot];
+    PGX_HIP(ctx, hipEventSynchronize(e.done));
+    e.busy = 0; e.reduced = 0;
+    const size_t M = (size_t)e.M, Mp = (size_t)e.Mpad;
+    const int64_t* c = (const int64_t*)e.host;
+    const double* v = (const double*)e.host + Mp;
+    const double* sh = (const double*)e.host + 2 * Mp;
+    if (counts) memcpy(counts, c, M * 8);
+    if (values) memcpy(values, v, M * 8);
+    if (shared) memcpy(shared, sh, M * 8);
+    if (scores)
+        for (size_t m = 0; m < M; ++m)
+            scores[m] = e.has_compound && !(sh[m] == 0.0 && !std::signbit(sh[m]) && exponent > 0) ? v[m] - std::pow(sh[m], (double)exponent) : v[m];
+    return PGX_OK;
+}
+
 int pgx_compound_allreduce_max(pgx_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_allreduce_max: communicator not initialised");
+    PGX_NO_EXCHANGE(ctx, "pgx_compound_allreduce_max");
     if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_compound_allreduce_max: points not set");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     PGX_NCCL(ctx, g_rccl.AllReduce(ctx->comp.p, ctx->comp.p, (size_t)ctx->n, ncclFloat64, ncclMax, ctx->comm->comm, ctx->stream));

@@ -1006,6 +1006,7 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
     const int L = ctx->L;
     if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: unary table not set");
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
+    if (ctx->labels_max >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, L);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();
@@ -1050,6 +1051,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     const int L = ctx->L;
     if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: unary table not set");
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
+    if (ctx->labels_max >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, L);
     if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
     if (lambda_q <= 0) return expand_alpha_l0(ctx, h_q, alpha, changed);
@@ -1071,10 +1073,10 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
-    if (ctx->mf_tile && !source_reach && wq == nullptr) {
+    if (ctx->mf_tile && !source_reach && wq == nullptr && n <= ctx->tile_single_max && n <= 8192 && L <= 64) {   // (the sizes expand_alpha_tile takes)
         const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed);
         if (r != PGX_TILE_FALLBACK) return r;
-        ctx->tile_fallbacks += 1;
+        ctx->tile_fallbacks += 1;   // the one-workgroup solver ran and gave the move back
     }
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();

@@ -78,6 +78,11 @@ struct pgx_ctx {
     int64_t chunk = 0, words = 0;
     bool have_masks = false;
     int score_has_compound = 0;
+    int64_t score_global_n = 0;  // pgx_score_set_global_n: the fixed-point scale of the sums is taken from max(n, this) - the ranks of a
+                                 // point-sharded job (pgx_score_allreduce) then add integers of the SAME scale: bitwise the unsharded sums
+    unsigned long long* last_acc = nullptr;   // integer accumulators [nrep][3][Mpad] of the last group-major launch (device order), or nullptr
+    int last_nrep = 0;
+    double last_qscale = 0.0;
     pgx::DevBuf models, pcnt, pval, psh, counts, values, shared, masks;
     pgx::DevBuf perm;        // perm[sorted position] = caller's hypothesis index (locality ordering, capi.hip)
     int score_sort = 1;      // PGX_NO_SORT=1 keeps the caller's order (A/B)
@@ -95,6 +100,7 @@ struct pgx_ctx {
     pgx::DevBuf kmodels;
     pgx::DevBuf labels; // int32 [n]
     int64_t labels_n = 0;
+    int labels_max = 0;          // largest label pgx_set_labels uploaded (the moves index per-label tables with the labels: checked against L)
     // graph (symmetric CSR)
     int64_t gn = 0, gE = 0;
     int max_degree = 0;
@@ -176,6 +182,11 @@ constexpr int kSuper = 8;      // groups per super-group (512 points): first lev
 // launchers implemented in the .hip translation units
 int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n);  // setpoints.hip: upload + all preprocessing
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
+// point-sharded exchange (comm.hip): the last launch's integer accumulators, replicas summed, in the caller's hypothesis order
+// ([3][Mpad] words) / counts | values | shared from such a block
+int score_acc_export(pgx_ctx* ctx, unsigned long long* out, hipStream_t stream);
+int score_acc_import(pgx_ctx* ctx, const unsigned long long* in, int M, int Mpad, double qscale, long long* counts, double* values,
+                     double* shared, hipStream_t stream);
 int score_sort_points(pgx_ctx* ctx, const double* points, const float* p32, const double* pmax);  // builds the sorted copies
 int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pref, double out3[3]);
 int compound_launch(pgx_ctx* ctx, const int32_t* slots, int K);

@@ -664,6 +664,7 @@ int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q
     const int L = ctx->L;
     if (n <= 0 || L <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: unary table not set");
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: labels not set");
+    if (ctx->labels_max >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: label %d out of range (the unary table has %d labels)", ctx->labels_max, L);
     const bool pair = lambda_q > 0 && ctx->gn == n;
     if (lambda_q > 0 && ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_energy: lambda > 0 but no graph set");
     PGX_TRY(ensure(ctx, ctx->scratch, 16 + (size_t)L * sizeof(unsigned)));
@@ -790,6 +791,7 @@ int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* op
                     (long long)ctx->dq_max, (long long)n);
     PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
     ctx->labels_n = n;
+    ctx->labels_max = L - 1;
     const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
     const long long* dq = ctx->dq.as<long long>();
     int* labels = ctx->labels.as<int>();

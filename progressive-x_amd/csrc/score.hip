@@ -550,6 +550,62 @@ __global__ __launch_bounds__(256) void score_finish_kernel(const unsigned long l
     }
 }
 
+// ---- point-sharded jobs (comm.hip pgx_score_allreduce): the integer accumulators leave / enter here ---------------------------
+// Counts are integers and both sums are 2^-q fixed point, so the accumulators of ranks that scored DIFFERENT points against the
+// same hypotheses add exactly in any order: ncclAllReduce(sum, uint64) of 3 x Mpad words gives bitwise the accumulators of one
+// GPU scoring all the points (given one q: pgx_score_set_global_n).  Hypotheses are in locality order on the device and the
+// order may differ between ranks (it depends on nothing but the models today, but the exchange must not rely on that): the
+// block travels in the CALLER's order.
+__global__ __launch_bounds__(256) void score_acc_export_kernel(const unsigned long long* __restrict__ acc, int M, int Mpad, int nrep,
+                                                               const int* __restrict__ perm, unsigned long long* __restrict__ out)
+{
+    const int m = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (m >= Mpad) return;
+    if (m >= M) {   // the padding is nobody's target: zero
+        out[m] = 0; out[(size_t)Mpad + m] = 0; out[2 * (size_t)Mpad + m] = 0;
+        return;
+    }
+    unsigned long long c = 0, v = 0, sh = 0;
+    for (int r = 0; r < nrep; ++r) {
+        const unsigned long long* a = acc + (size_t)r * 3 * (size_t)Mpad;
+        c += a[m];
+        v += a[(size_t)Mpad + m];
+        sh += a[2 * (size_t)Mpad + m];
+    }
+    const int o = perm[m];
+    out[o] = c; out[(size_t)Mpad + o] = v; out[2 * (size_t)Mpad + o] = sh;
+}
+
+__global__ __launch_bounds__(256) void score_acc_import_kernel(const unsigned long long* __restrict__ in, int M, int Mpad, double qscale,
+                                                               long long* __restrict__ counts, double* __restrict__ values,
+                                                               double* __restrict__ shared)
+{
+    const int m = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (m >= M) return;
+    counts[m] = (long long)in[m];                                                // as score_finish_kernel
+    values[m] = (double)(long long)in[(size_t)Mpad + m] / qscale;
+    shared[m] = (double)(long long)in[2 * (size_t)Mpad + m] / qscale;
+}
+
+int score_acc_export(pgx_ctx* ctx, unsigned long long* out, hipStream_t stream)
+{
+    if (ctx->last_acc == nullptr || ctx->last_score_path != 2)
+        return fail(ctx, PGX_ERR_INVALID, "point-sharded exchange: the last launch did not run the group-major path (integer accumulators); "
+                                          "it needs sorted points, the f32 filter and the cull (the defaults)");
+    hipLaunchKernelGGL(score_acc_export_kernel, dim3((unsigned)((ctx->Mpad + 255) / 256)), dim3(256), 0, stream, ctx->last_acc, ctx->M, ctx->Mpad,
+                       ctx->last_nrep, ctx->perm.as<int>(), out);
+    PGX_HIP(ctx, hipGetLastError());
+    return PGX_OK;
+}
+
+int score_acc_import(pgx_ctx* ctx, const unsigned long long* in, int M, int Mpad, double qscale, long long* counts, double* values,
+                     double* shared, hipStream_t stream)
+{
+    hipLaunchKernelGGL(score_acc_import_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, in, M, Mpad, qscale, counts, values, shared);
+    PGX_HIP(ctx, hipGetLastError());
+    return PGX_OK;
+}
+
 // Adds the chunk partials of each hypothesis in a FIXED order (bit-reproducible): 64 hypotheses per block, 16 waves
 // each summing the chunks k = wave, wave+16, ... sequentially, then the 16 wave sums are added in wave order.
 constexpr int kReduceWaves = 16;
@@ -657,7 +713,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             const double* pts_g = ctx->pts_g.p ? ctx->pts_g.as<double>() : (const double*)nullptr;   // group-blocked SoA copies of the rows
             const float* p32_g = ctx->pts_g.p ? ctx->p32_g.as<float>() : (const float*)nullptr;
             int lg = 0;
-            while (((int64_t)1 << lg) < ctx->n + 1) ++lg;
+            const int64_t n_scale = ctx->score_global_n > ctx->n ? ctx->score_global_n : ctx->n;   // pgx_score_set_global_n
+            while (((int64_t)1 << lg) < n_scale + 1) ++lg;
             const double qscale = std::ldexp(1.0, 62 - lg < 50 ? 62 - lg : 50);  // every sum is <= n < 2^lg; terms < 2^51 (to_fixed)
             // the accumulators are zeroed by the cull kernel, which runs before their first use
             const int64_t zero_words = (int64_t)nrep * ctx->Mpad * 3;
@@ -722,12 +779,14 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                ctx->shared.as<double>(), nrep, mirror);
             PGX_HIP(ctx, hipGetLastError());
             ctx->mirror_valid = mirror != nullptr;
+            ctx->last_acc = acc; ctx->last_nrep = nrep; ctx->last_qscale = qscale;
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
             ctx->last_score_path = 2;
             return PGX_OK;
         }
     }
     ctx->last_score_path = 1;
+    ctx->last_acc = nullptr;
     if (ctx->score_profile) PGX_HIP(ctx, hipEventRecord(ctx->kev[0], ctx->stream));
     if constexpr (Filter<MT>::enabled) {
         if (want_masks) {

@@ -88,7 +88,11 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     from . import parallel
     exchange = parallel.default_exchange(ctx, distributed)
     if exchange is not None:
-        parallel.check_same_problem(exchange, pts)
+        parallel.check_same_problem(exchange, pts, params=(
+            type(estimator).__name__, float(radius), getattr(sampler_factory, "sampler_id", None), float(threshold), float(conf),
+            float(spatial_coherence_weight), float(maximum_tanimoto_similarity), int(max_iters), int(minimum_point_number),
+            int(maximum_model_number), int(scoring_exponent), seed, int(max_outer_iterations), str(neighborhood),
+            str(local_optimization), str(labeling_l0)))
         if seed is None:
             seed = parallel.shared_seed()
     rng = np.random.default_rng(seed)
@@ -178,8 +182,14 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None):
-    """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n])."""
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="full"):
+    """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n]).
+    validity [U-14, keyword-only, not in the reference's signature]: which of the estimator's model-validity stages run -
+    "off" (strict restatement of what is in the snapshot: none), "oriented", "symmetric" (oriented + symmetric-epipolar
+    support) or "full" (+ DEGENSAC, the default: the recollection of gcransac's FundamentalMatrixEstimator::isValidModel;
+    its source is absent from the snapshot - INTEGRATION.md lists the one threshold that deviates from that recollection)."""
+    if validity not in ("off", "oriented", "symmetric", "full"):
+        raise ValueError("validity should be 'off', 'oriented', 'symmetric' or 'full'")
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
     if dim != 4 or n < 7:
@@ -189,6 +199,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
     if do_logging and sampler_id == 2:
         print("Note: Progressive NAPSAC sampler requires the correspondences to be order by quality, e.g., SNN ratio.")
     est = _estimators.FundamentalEstimator()
+    est.validity = validity
     # the driver ignores scoring_exponent (never calls setScoringExponent: :621-638) => ProgressiveX's default 2
     models, labels, _ = _run(est, corrs, corrs, neighborhood_ball_radius,
                              _sampler_factory(sampler_id, {0: "uniform", 1: "prosac", 2: "pnapsac", 3: "napsac"}, corrs,

@@ -121,15 +121,14 @@ class Pearl:
             # [U-8, UNVERIFIED recollection of GCO-v3] no setSmoothCost / setNeighbors call was made (:523-536), so expansion()
             # (:550-551) leaves through solveSpecialCases(): per-site argmin without label costs, greedy facility location with
             # them - not alpha-expansion.  labeling_l0="expansion" runs the closed-form alpha-expansion moves instead; so does a
-            # run with more than 63 instances (max_outer_iterations extension) or a greedy call that fails.
-            try:
-                eq, e, opened = self.ctx.greedy_labeling(h)
-                cycles = 1
-            except Exception as ex:                                   # PgxError / oracle error: fall back, do not abort the run
-                if self.do_logging:
-                    print(f"[Optimization] greedy labelling unavailable ({ex}); alpha-expansion instead.")
-                greedy = False
-        if not greedy:
+            # run with more than 63 instances (max_outer_iterations extension: the greedy solver keeps label sets as 64-bit
+            # masks - decided above, never by catching an error: a device fault must not silently change the semantics).
+            eq, e, opened = self.ctx.greedy_labeling(h)
+            cycles = 1
+        else:
+            if lam == 0.0 and self.labeling_l0 == "greedy":
+                import warnings
+                warnings.warn(f"pyprogressivex: {K + 1} labels exceed the greedy lambda = 0 labelling's 64; alpha-expansion moves instead")
             eq, e, cycles = self.ctx.expansion(lam, h, 1000)          # :550-551
         self.has_engine = True
         self.cycles += cycles

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
+    "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
 ]
 
 
@@ -626,6 +627,39 @@ class Context:
                                                    _ptr(values, C.c_double), _ptr(shared, C.c_double), _ptr(scores, C.c_double)),
                  "pgx_score_allgather_end")
         return dict(counts=counts, values=values, shared=shared, scores=scores)
+
+    # -- point-sharded scoring: this context holds a slice of the job's points (include/pgx.h pgx_score_allreduce)
+    def score_set_global_n(self, n_total):
+        """the point count of the whole job: the ranks then accumulate in one fixed-point scale (0 = this context's own n)"""
+        self._ck(self._lib.pgx_score_set_global_n(self._h, C.c_int64(int(n_total))), "pgx_score_set_global_n")
+
+    def score_allreduce(self):
+        """after score_launch: sums the launch's integer accumulators over the ranks; score_fetch then returns the job's table"""
+        self._ck(self._lib.pgx_score_allreduce(self._h), "pgx_score_allreduce")
+
+    def score_allreduce_begin(self, slot):
+        self._ck(self._lib.pgx_score_allreduce_begin(self._h, C.c_int(int(slot))), "pgx_score_allreduce_begin")
+        self._slot_M = getattr(self, "_slot_M", {})
+        self._slot_M[int(slot)] = self.M
+
+    def score_allreduce_end(self, slot, exponent=2):
+        M = self._slot_M[int(slot)]
+        counts = np.empty(M, dtype=np.int64)
+        values = np.empty(M, dtype=np.float64)
+        shared = np.empty(M, dtype=np.float64)
+        scores = np.empty(M, dtype=np.float64)
+        self._ck(self._lib.pgx_score_allreduce_end(self._h, C.c_int(int(slot)), C.c_int(int(exponent)), _ptr(counts, C.c_int64),
+                                                   _ptr(values, C.c_double), _ptr(shared, C.c_double), _ptr(scores, C.c_double)),
+                 "pgx_score_allreduce_end")
+        return dict(counts=counts, values=values, shared=shared, scores=scores)
+
+    def score_accumulators(self):
+        """pgx_score_debug_fetch(5): the last launch's integer accumulators in the caller's order, dict of uint64 [M] arrays"""
+        Mpad = (self.M + 255) // 256 * 256
+        out = np.empty((3, Mpad), dtype=np.uint64)
+        self._ck(self._lib.pgx_score_debug_fetch(self._h, C.c_int(5), out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)),
+                 "pgx_score_debug_fetch")
+        return dict(counts=out[0, :self.M].copy(), values_q=out[1, :self.M].copy(), shared_q=out[2, :self.M].copy())
 
     def compound_allreduce_max(self):
         self._ck(self._lib.pgx_compound_allreduce_max(self._h), "pgx_compound_allreduce_max")

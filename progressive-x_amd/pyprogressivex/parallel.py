@@ -6,6 +6,11 @@ per-hypothesis (count, value, shared) triples (24 B each) makes the full score t
 then runs the same deterministic selection (ties -> lowest hypothesis index, i.e. the sequential "first best wins").
 The reference has no counterpart (single-threaded CPU: progressive_x.h:251-489, no collectives anywhere).
 
+The other split (`score_point_sharded`, north_star's "all-reduce of per-model inlier counts"): every rank holds a SLICE of the
+points and scores the whole batch against it; the launch's integer accumulators (count, 2^-q fixed-point sums) are added over
+the ranks by an RCCL all-reduce - exact in any order, so the table is bitwise the single-GPU one, and cull / dispatch / group
+work all divide by the number of ranks (the BASELINE metric's strong-scaling mode, bench.py --scaling strong-points).
+
 Data plane: RCCL all-gather inside libpgx.so (pgx_score_allgather), bootstrapped here with a file rendezvous for the
 ncclUniqueId (single node, which is what the launch contract covers).  For CPU tests of this host logic the exchange
 runs over torch.distributed/gloo (tests/gloo_exchange.py, a test double outside this package).
@@ -214,6 +219,23 @@ class RcclExchange:
         """the rank-major table of the batch that was begun in `slot`"""
         return self.ctx.score_allgather_end(slot, exponent)
 
+    # -- point-sharded: the context holds this rank's slice of the points (score_point_sharded) -------------------------------
+    def reduce_scores(self, models, T2, has_compound, exponent):
+        """all hypotheses against this rank's points, accumulators summed over the ranks: the job's table, on every rank"""
+        self.ctx.score_upload(models)
+        self.ctx.score_launch(T2, has_compound=has_compound)
+        if self.world > 1 or getattr(self.ctx, "force_comm", False):
+            self.ctx.score_allreduce()
+        return self.ctx.score_fetch(exponent)
+
+    def begin_reduce(self, slot, models, T2, has_compound):
+        self.ctx.score_upload(models)
+        self.ctx.score_launch(T2, has_compound=has_compound)
+        self.ctx.score_allreduce_begin(slot)
+
+    def end_reduce(self, slot, exponent):
+        return self.ctx.score_allreduce_end(slot, exponent)
+
 
 def score_shard_pipelined(exchange, shard, T2, has_compound, exponent, pieces=2):
     """`exchange.score_shard(shard, ...)` with the shard cut into `pieces` consecutive parts whose exchanges overlap the scoring
@@ -225,11 +247,22 @@ def score_shard_pipelined(exchange, shard, T2, has_compound, exponent, pieces=2)
         return exchange.score_shard(shard, T2, has_compound, exponent)
     cuts = [(per * k) // pieces for k in range(pieces + 1)]
     tables = []
-    for k in range(pieces):
-        exchange.begin(k & 1, np.ascontiguousarray(shard[cuts[k]:cuts[k + 1]]), T2, has_compound)
-        if k >= 1:
-            tables.append(exchange.end((k - 1) & 1, exponent))
-    tables.append(exchange.end((pieces - 1) & 1, exponent))
+    open_slots = []          # begun, not yet collected: drained on the way out of an exception, or every later call would find them busy
+    try:
+        for k in range(pieces):
+            exchange.begin(k & 1, np.ascontiguousarray(shard[cuts[k]:cuts[k + 1]]), T2, has_compound)
+            open_slots.append(k & 1)
+            if k >= 1:
+                open_slots.remove((k - 1) & 1)
+                tables.append(exchange.end((k - 1) & 1, exponent))
+        open_slots.remove((pieces - 1) & 1)
+        tables.append(exchange.end((pieces - 1) & 1, exponent))
+    finally:
+        for slot in open_slots:
+            try:
+                exchange.end(slot, exponent)
+            except Exception:
+                pass
     out = {}
     for key in ("counts", "values", "shared", "scores"):      # [rank][piece rows] per piece -> [rank][all rows of the rank]
         parts = [np.asarray(t[key]).reshape(exchange.world, cuts[k + 1] - cuts[k]) for k, t in enumerate(tables)]
@@ -268,19 +301,21 @@ def default_exchange(ctx, distributed=None):
     return _process_exchange
 
 
-def check_same_problem(exchange, pts):
-    """Every rank of a sharded call must hold the same points: max and min over the ranks of a 52-bit digest of (shape, bytes)
-    must agree.  Raises on every rank alike (the reduction is collective), before any proposal is exchanged."""
+def check_same_problem(exchange, pts, params=None):
+    """Every rank of a sharded call must hold the same points AND make the same call: max and min over the ranks of a 52-bit
+    digest of (shape, bytes, repr of the call's scalar parameters - thresholds, iteration limits, sampler, seed ...) must agree
+    (ranks that differ in any of them run different numbers of collectives).  Raises on every rank alike (the reduction is
+    collective), before any proposal is exchanged."""
     import hashlib
     if exchange is None or exchange.world == 1 or not hasattr(exchange.ctx, "comm_allreduce_max"):
         return
     a = np.ascontiguousarray(pts)
-    h = hashlib.sha256(repr(a.shape).encode() + a.tobytes()).digest()
+    h = hashlib.sha256(repr(a.shape).encode() + a.tobytes() + repr(params).encode()).digest()
     v = float(int.from_bytes(h[:8], "little") >> 12)            # exact in a double
     hi = exchange.ctx.comm_allreduce_max(v)
     lo = -exchange.ctx.comm_allreduce_max(-v)
     if hi != lo:
-        raise RuntimeError("pyprogressivex: the ranks of this sharded call hold different point sets (or shapes); sharding needs every "
+        raise RuntimeError("pyprogressivex: the ranks of this sharded call hold different point sets (or shapes) or passed different parameters; sharding needs every "
                            "rank to make the same call on the same data - unset PGX_MULTI_GPU / distributed= for independent calls")
 
 
@@ -322,3 +357,60 @@ def score_sharded(exchange, models, T2, has_compound=False, exponent=2):
     gathered = score_shard_pipelined(exchange, shard, T2, has_compound, exponent, pieces)
     keys = {k: gathered[k] for k in ("counts", "values", "shared", "scores")}
     return merge_gathered(keys, M, exchange.world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# point-sharded scoring
+# ---------------------------------------------------------------------------------------------------------------------
+def point_slice(n, world, rank):
+    """Contiguous slice [lo, hi) of the job's n points for this rank (the last ranks may hold one point less)."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def fixed_point_scale(n_total):
+    """The 2^q the score path accumulates its sums in for a job of n_total points (score.hip: q = min(62 - ceil(log2(n + 1)), 50))."""
+    lg = 0
+    while (1 << lg) < int(n_total) + 1:
+        lg += 1
+    return float(2 ** min(62 - lg, 50))
+
+
+def table_from_accumulators(counts, values_q, shared_q, n_total, has_compound, exponent):
+    """counts / values / shared / scores from summed integer accumulators - what score_finish_kernel and pgx_score_fetch do."""
+    q = fixed_point_scale(n_total)
+    values = np.asarray(values_q).astype(np.int64).astype(np.float64) / q
+    shared = np.asarray(shared_q).astype(np.int64).astype(np.float64) / q
+    scores = values - np.power(shared, float(exponent)) if has_compound else values.copy()
+    return dict(counts=np.asarray(counts).astype(np.int64), values=values, shared=shared, scores=scores)
+
+
+def score_point_sharded(exchange, models, T2, has_compound=False, exponent=2, pieces=1):
+    """Scores `models` (the same full batch on every rank) against the points of ALL ranks: exchange.ctx holds this rank's
+    slice (`ctx.set_points(slice)`, `ctx.score_set_global_n(n_total)`, compound slice likewise).  Every rank returns the job's
+    table, bitwise the one a single GPU holding all the points returns.  pieces > 1: the batch in consecutive parts, the
+    reduction of one overlapping the scoring of the next (begin_reduce / end_reduce)."""
+    models = np.ascontiguousarray(models, dtype=np.float64)
+    M = models.shape[0]
+    pieces = max(1, min(int(pieces), M))
+    if pieces == 1 or not hasattr(exchange, "begin_reduce"):
+        return exchange.reduce_scores(models, T2, has_compound, exponent)
+    cuts = [(M * k) // pieces for k in range(pieces + 1)]
+    tables, open_slots = [], []
+    try:
+        for k in range(pieces):
+            exchange.begin_reduce(k & 1, np.ascontiguousarray(models[cuts[k]:cuts[k + 1]]), T2, has_compound)
+            open_slots.append(k & 1)
+            if k >= 1:
+                open_slots.remove((k - 1) & 1)
+                tables.append(exchange.end_reduce((k - 1) & 1, exponent))
+        open_slots.remove((pieces - 1) & 1)
+        tables.append(exchange.end_reduce((pieces - 1) & 1, exponent))
+    finally:
+        for slot in open_slots:
+            try:
+                exchange.end_reduce(slot, exponent)
+            except Exception:
+                pass
+    return {key: np.concatenate([t[key] for t in tables]) for key in ("counts", "values", "shared", "scores")}

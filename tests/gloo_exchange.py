@@ -55,3 +55,21 @@ class GlooExchange:
         return out
 
     _exponent = 2
+
+    # -- point-sharded jobs (parallel.score_point_sharded): acc_scorer(models, T2, has_compound) -> integer accumulators of THIS
+    #    rank's slice (helpers.fixed_point_accumulators: the oracle's residuals in the score path's fixed point); all_reduce(sum)
+    acc_scorer = None
+    n_total = 0
+
+    def reduce_scores(self, models, T2, has_compound, exponent):
+        import torch
+        import torch.distributed as dist
+        from pyprogressivex import parallel
+        acc = self.acc_scorer(models, T2, has_compound)
+        red = {}
+        for key in ("counts", "values_q", "shared_q"):
+            t = torch.from_numpy(np.ascontiguousarray(acc[key]).astype(np.int64))
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            red[key] = t.numpy()
+        return parallel.table_from_accumulators(red["counts"], red["values_q"], red["shared_q"], self.n_total, has_compound, exponent)

@@ -92,3 +92,27 @@ def realistic_labeling_problem(n, L, lam, seed=0):
     D[np.arange(n), cl] *= 0.1
     Dq = np.rint(D * 2.0 ** 32).astype(np.int64)
     return Dq, graph
+
+
+def fixed_point_accumulators(O, mt, pts, models, T2, comp=None, n_total=None):
+    """The integer accumulators the group-major score path builds (score.hip: count, and value / shared support as sums of
+    round-to-nearest-even(term * 2^q) per inlier), restated from the ORACLE's residuals: getScore's terms
+    (scoring_function_with_compound_model.h:85-97, 115-117) in the fixed point of a job of n_total points."""
+    from pyprogressivex import parallel
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    models = np.ascontiguousarray(models, dtype=np.float64)
+    q = parallel.fixed_point_scale(pts.shape[0] if n_total is None else n_total)
+    M = models.shape[0]
+    counts = np.zeros(M, np.int64)
+    values_q = np.zeros(M, np.int64)
+    shared_q = np.zeros(M, np.int64)
+    for m in range(M):
+        sq = O.squared_residuals(mt, pts, models[m])
+        with np.errstate(invalid="ignore"):
+            inl = sq < T2
+        sc = np.maximum(0.0, 1.0 - sq[inl] / T2)
+        counts[m] = int(inl.sum())
+        values_q[m] = int(np.rint(sc * q).astype(np.int64).sum())
+        if comp is not None:
+            shared_q[m] = int(np.rint(np.minimum(np.asarray(comp)[inl], sc) * q).astype(np.int64).sum())
+    return dict(counts=counts, values_q=values_q, shared_q=shared_q)

@@ -1340,6 +1340,76 @@ def test_rccl_single_rank_allgather(gpu_ctx):
         gpu_ctx.comm_destroy()
 
 
+def test_point_sharded_accumulators_are_exact(gpu_ctx, oracle):
+    """pgx_score_allreduce adds the integer accumulators of ranks that hold different points.  On one GPU: the accumulators of
+    the whole point set (a) ARE the oracle's per-inlier terms in the path's fixed point, integer for integer, and (b) equal
+    the sum of the accumulators of three slices scored with the job's scale (pgx_score_set_global_n): what the ranks of a
+    point-sharded job all-reduce is bitwise the single-GPU table."""
+    from helpers import fixed_point_accumulators
+    from pyprogressivex import parallel
+    for name in ("pnp", "fundamental", "vanishing_point"):
+        mt, pts, models, thr = make_case(name, 20011, 96, seed=9)
+        T2 = 2.25 * thr * thr
+        n = pts.shape[0]
+        comp = np.random.default_rng(3).uniform(0, 1, n)
+        gpu_ctx.score_set_global_n(0)
+        gpu_ctx.set_points(mt, pts)
+        gpu_ctx.set_compound(comp)
+        full = gpu_ctx.score(models, T2, has_compound=True, exponent=2)
+        acc = gpu_ctx.score_accumulators()
+        ref = fixed_point_accumulators(oracle, mt, pts, models, T2, comp)
+        for k in ("counts", "values_q", "shared_q"):
+            assert np.array_equal(acc[k].astype(np.int64), ref[k]), (name, k)
+        total = {k: np.zeros(len(models), np.uint64) for k in acc}
+        try:
+            for r in range(3):
+                lo, hi = parallel.point_slice(n, 3, r)
+                gpu_ctx.set_points(mt, pts[lo:hi])
+                gpu_ctx.score_set_global_n(n)
+                gpu_ctx.set_compound(comp[lo:hi])
+                gpu_ctx.score(models, T2, has_compound=True, exponent=2)
+                part = gpu_ctx.score_accumulators()
+                for k in total:
+                    total[k] += part[k]
+        finally:
+            gpu_ctx.score_set_global_n(0)
+        for k in total:
+            assert np.array_equal(total[k], acc[k]), (name, k)
+        table = parallel.table_from_accumulators(total["counts"], total["values_q"], total["shared_q"], n, True, 2)
+        for k in ("counts", "values", "shared"):
+            assert np.array_equal(table[k], full[k]), (name, k)
+
+
+def test_rccl_single_rank_allreduce(gpu_ctx):
+    """the point-sharded exchange with RCCL on the path (one rank: the all-reduce is the identity): serial and pipelined forms"""
+    from pyprogressivex import _lib, parallel
+    mt, pts, models, thr = make_case("pnp", 20011, 300, seed=2)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.set_compound(np.linspace(0, 1, pts.shape[0]))
+    direct = gpu_ctx.score(models, T2, has_compound=True, exponent=2)
+    gpu_ctx.comm_init(1, 0, _lib.comm_unique_id())
+    try:
+        gpu_ctx.force_comm = True
+        ex = parallel.RcclExchange(gpu_ctx)
+        for pieces in (1, 2, 5):
+            table = parallel.score_point_sharded(ex, models, T2, has_compound=True, exponent=2, pieces=pieces)
+            for k in ("counts", "values", "shared", "scores"):
+                assert np.array_equal(table[k], direct[k]), (pieces, k)
+        # a collective on the context's stream while a pipelined exchange is in flight is refused, not reordered
+        gpu_ctx.score_upload(models)
+        gpu_ctx.score_launch(T2, has_compound=True)
+        gpu_ctx.score_allreduce_begin(0)
+        with pytest.raises(_lib.PgxError, match="in flight"):
+            gpu_ctx.comm_barrier()
+        got = gpu_ctx.score_allreduce_end(0, 2)
+        assert np.array_equal(got["scores"], direct["scores"])
+        gpu_ctx.comm_barrier()
+    finally:
+        gpu_ctx.force_comm = False
+        gpu_ctx.comm_destroy()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # error paths of the C ABI (status codes + messages, never a crash) and a BASELINE-size labelling move
 # ----------------------------------------------------------------------------------------------------------------------

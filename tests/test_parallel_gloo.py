@@ -135,3 +135,60 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     assert parallel.exchange_unique_id(1, 2, lambda: b"", timeout=5) == uid
     parallel.cleanup_unique_id(0)
     assert not list(tmp_path.iterdir())
+
+
+WORKER_POINTS = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(r"{root}", "progressive-x_amd"), os.path.join(r"{root}", "oracle"), r"{here}"]
+import torch.distributed as dist
+import pgx_oracle as O
+from pyprogressivex import parallel
+from helpers import make_case, fixed_point_accumulators
+from gloo_exchange import GlooExchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mt, pts, models, thr = make_case("pnp", 3001, 37, seed=4)      # 3001 points: ragged slices (1501 + 1500)
+T2 = 2.25 * thr * thr
+n = pts.shape[0]
+comp = np.linspace(0, 1, n)
+lo, hi = parallel.point_slice(n, world, rank)
+assert (lo, hi) == ((0, 1501) if rank == 0 else (1501, 3001))
+ex = GlooExchange(world, rank)
+ex.n_total = n
+ex.acc_scorer = lambda mdl, T2, hc: fixed_point_accumulators(O, mt, pts[lo:hi], mdl, T2, comp[lo:hi] if hc else None, n_total=n)
+table = parallel.score_point_sharded(ex, models, T2, has_compound=True, exponent=2)
+# the sum over the slices IS the unsharded accumulation (integers): bitwise
+one = fixed_point_accumulators(O, mt, pts, models, T2, comp, n_total=n)
+ref = parallel.table_from_accumulators(one["counts"], one["values_q"], one["shared_q"], n, True, 2)
+for k in ("counts", "values", "shared", "scores"):
+    assert np.array_equal(table[k], ref[k]), k
+# ... and it is the oracle's table: counts exactly, sums to the quantisation of the fixed point
+full = O.score(mt, pts, models, T2, compound=comp, has_compound=True, exponent=2)
+assert np.array_equal(table["counts"], full["counts"])
+for k in ("values", "shared"):
+    assert np.max(np.abs(table[k] - full[k]) / np.maximum(np.abs(full[k]), 1e-300)) <= 1e-9, k
+assert parallel.select_best(table["scores"], table["counts"]) == parallel.select_best(full["scores"], full["counts"])
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok points")
+'''
+
+
+def test_point_sharded_scoring_world2_gloo(tmp_path):
+    """parallel.score_point_sharded: every rank scores all hypotheses against its slice of the points, integer accumulators
+    all-reduced (sum): bitwise the unsharded table."""
+    script = tmp_path / "worker_points.py"
+    script.write_text(WORKER_POINTS.format(root=ROOT, here=HERE))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok points" in o for o in outs)
