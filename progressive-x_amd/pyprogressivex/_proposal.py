@@ -280,6 +280,16 @@ def replay_sequential(counts, scores, iteration_of, n, sample_size, confidence, 
 # ---------------------------------------------------------------------------------------------------------------------
 # the proposal engine
 # ---------------------------------------------------------------------------------------------------------------------
+# [U-15] experiment switches for the three hypotheses of docs/experiments-cubetoy.md §3 about what keeps upstream's proposal
+# stage from accepting the "mixed" fundamental matrix first (all inside the absent graph-cut-ransac).
+# Defaults = the shipped behaviour; scripts/exp_cubetoy.py flips them.  Not read from the environment, not part of the API.
+U15 = {
+    "rank": "value",          # "count": a so-far-best is ranked by inlier count first, MSAC value second
+    "stop_at_first": False,   # True: the main loop ends at the first valid so-far-best found after min_iteration_number_before_lo
+                              # iterations (the most aggressive early termination any confidence rule could produce)
+}
+
+
 class ProposalEngine:
     """gcransac::GCRANSAC::run, restated [UPSTREAM-MEMORY, U-9] around ONE scoring launch per proposal:
 
@@ -347,6 +357,8 @@ class ProposalEngine:
         counts = np.asarray(table["counts"], dtype=np.int64)
         scores = np.where(counts > 0, np.asarray(table["scores"], dtype=np.float64), -np.inf)
         scores = np.where(np.isnan(scores), -np.inf, scores)
+        if U15["rank"] == "count":     # [U-15 i] count first, value second (a value never exceeds its count)
+            scores = np.where(np.isfinite(scores), counts * float(self.n + 2) + scores, -np.inf)
         check = getattr(est, "validity", "off") != "off"                       # [U-14] model validity, both overloads
         smp_arr = np.asarray(samples)
         if check and models is not None:
@@ -400,6 +412,8 @@ class ProposalEngine:
                                                                           exponent, weights)
             bound = min(max_iters, ransac_iteration_bound(best_count, self.n, est.sample_size, s.confidence))
             h += 1
+            if U15["stop_at_first"] and it > lo_after:     # [U-15 ii]
+                break
         iterations = int(max(it_best, min(max_iters, np.ceil(bound)), min(min_iters, len(samples)), 1))
         if model is None:
             return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iterations)

@@ -5,7 +5,9 @@ sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__f
 import numpy as np
 from pyprogressivex import _lib, datasets
 
-splits = [int(a) for a in sys.argv[1:]] or [0]
+# arguments: plain integers = waves per group of score_group_kernel; key=value sets any geometry knob of pgx_score_debug_geometry
+# for that run (e.g. "transposed=1,tsplit=3,dense_min=24")
+splits = [a for a in sys.argv[1:]] or ["0"]
 x1, x2, K, lab, gt = datasets.make_poses(n_per_object=50000, n_objects=16, n_outliers=200000, seed=0)
 pts, f = datasets.normalize_pnp(x1, x2, K)
 thr = 4.0 / f
@@ -19,7 +21,10 @@ ctx.score_upload(hyps)
 buf = ctx.score_buffers()
 ref = None
 for sp in splits:
-    ctx.score_debug_geometry(split=sp)
+    if "=" in sp:
+        ctx.score_debug_geometry(**{k: int(v) for k, v in (kv.split("=") for kv in sp.split(","))})
+    else:
+        ctx.score_debug_geometry(split=int(sp))
     ctx.score_profile(0)
     for _ in range(300):
         ctx.score_launch(T2, has_compound=True)
@@ -41,6 +46,4 @@ for sp in splits:
     crc = zlib.crc32(res["counts"].tobytes() + res["scores"].tobytes())
     if ref is None:
         ref = crc
-    st = ctx.score_stats(T2, True)
-    print(f"  steps={st['surviving_group_steps']} exact={st['exact_evaluations']}", end="")
     print(f" split={sp} step={ms:.4f} ms  cull={kt[0]*1e3:.1f} group={kt[1]*1e3:.1f} finish={kt[2]*1e3:.1f} us  crc={crc:08x} {'same' if crc == ref else 'DIFFERENT'}", flush=True)
