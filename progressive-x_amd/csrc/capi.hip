@@ -525,8 +525,6 @@ int pgx_score_debug_geometry(pgx_ctx* ctx, int what, int value)
     case 1: if (value < -1 || value > 1) break; ctx->score_group_xcd = value; return PGX_OK;
     case 2: if (value < 0 || value > 1024 || value % 8) break; ctx->score_nrep = value; return PGX_OK;
     case 3: if (value < 1 || value > 65) break; ctx->score_dense_min = value; return PGX_OK;
-    case 5: if (value < 0 || value > 1) break; ctx->score_transposed = value; return PGX_OK;
-    case 6: if (value < 0 || value > 64) break; ctx->score_tsplit = value; return PGX_OK;
     case 4: if (value < 1 || value > 65535) break; ctx->score_cull_segs = value; return PGX_OK;
     }
     return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_geometry: what = %d, value = %d out of range", what, value);
@@ -609,10 +607,9 @@ int pgx_score_stats(pgx_ctx* ctx, double T2, int has_compound, int64_t stats[8])
     stats[6] = ctx->last_score_path;
     stats[7] = ctx->last_score_filtered;
     if (ctx->last_score_path == 2) {
-        unsigned long long h[16];
+        unsigned long long h[8];
         PGX_HIP(ctx, hipMemcpyAsync(h, ctx->stats_buf.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (std::getenv("PGX_T_PROF")) std::fprintf(stderr, "[tprof] waves %llu | x10ns: entry %llu list %llu const %llu filter %llu direct %llu expand %llu drain %llu\n", h[3], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
         stats[1] = groups * (int64_t)ctx->M;  // (hypothesis, group) bound tests an un-hierarchical cull would run
         stats[2] = (int64_t)h[0];             // surviving (hypothesis, group) steps: 64 f32 filter evaluations each
         stats[3] = (int64_t)h[1];             // exact FP64 residual evaluations

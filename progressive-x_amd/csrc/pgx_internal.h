@@ -66,8 +66,6 @@ struct pgx_ctx {
     pgx::DevBuf weights_scratch; // scratch of the k-d build (64-bit keys, sort workspace, per-node extents)
     int score_group_xcd = -1;    // PGX_SCORE_GROUP_XCD: 1 = a group's workgroups on one XCD (8x less row fetch, per-XCD accumulator replicas), 0 = part p on XCD p;
                                  // -1 (default) = 1 for a locality-ordered batch (few hypothesis words per group have survivors), 0 otherwise (score.hip)
-    int score_transposed = 1;    // the transposed group kernel (score_transposed.hip.h) where it exists; 0: score_group_kernel (pgx_score_debug_geometry 5)
-    int score_tsplit = 0;        // its waves per group (0 = 2; pgx_score_debug_geometry 6)
     int score_split = 0;         // waves per 64-point group in the group-major kernel (PGX_SCORE_SPLIT); 0 = 8 with the spread mapping, 5 co-located (score.hip)
     pgx::DevBuf cull_lists, cull_counts;
     pgx::DevBuf gc;          // inlier/outlier graph cut: e[n] | dq[2][n] | wq[E] | labels[n]

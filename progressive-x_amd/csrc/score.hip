@@ -468,10 +468,6 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
     }
 }
 
-}  // namespace pgx
-#include "score_transposed.hip.h"
-namespace pgx {
-
 // ---- PGX_VERIFY=1: every decision of the bound / filter chain against the exact residual -----------------------------------
 // The correctness of counts and masks rests on inequalities with hand-derived error budgets (score_filters.cuh): a group bound
 // that removes (hypothesis, 64-point group) pairs and an f32 filter that removes single pairs may only ever remove outliers.
@@ -745,15 +741,8 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                    qscale, acc, ctx->Mpad, ctx->masks_s.as<unsigned long long>(), ctx->words, ctx->perm.as<int>(), split, xcd_local, models_t,
                                    (unsigned long long*)nullptr, pts_g, p32_g, nrep, 65);
             } else if (ctx->score_stats) {  // pgx_score_stats: the same launch with work counters (never timed)
-                PGX_TRY(ensure(ctx, ctx->stats_buf, 16 * sizeof(unsigned long long)));
-                PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
-                if (ctx->score_transposed && pts_g != nullptr && MT == kPnP) {
-                    const int tsplit = ctx->score_tsplit > 0 ? (ctx->score_tsplit < 64 ? ctx->score_tsplit : 64) : 1;
-                    const unsigned tblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * tsplit) : (unsigned)((int64_t)groups * tsplit);
-                    hipLaunchKernelGGL((score_groupT_kernel<MT, true>), dim3(tblocks), dim3(64), 0, ctx->stream, ctx->comp_s.as<double>(), ctx->n, groups,
-                                       ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32, qscale, acc, ctx->Mpad,
-                                       tsplit, xcd_local, models_t, ctx->stats_buf.as<unsigned long long>(), pts_g, p32_g, nrep, ctx->score_dense_min);
-                } else
+                PGX_TRY(ensure(ctx, ctx->stats_buf, 8 * sizeof(unsigned long long)));
+                PGX_HIP(ctx, hipMemsetAsync(ctx->stats_buf.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
                 hipLaunchKernelGGL((score_group_kernel<MT, false, true>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,
                                    ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32,
@@ -763,13 +752,6 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                     hipLaunchKernelGGL((score_verify_kernel<MT>), dim3((unsigned)groups, (unsigned)W), dim3(64), 0, ctx->stream,
                                        ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->n, ctx->models.as<double>(), ctx->M, W, T2,
                                        ctx->cull_lists.as<unsigned long long>(), hyp32, ctx->stats_buf.as<unsigned long long>() + 4);
-            } else if (ctx->score_transposed && pts_g != nullptr && MT == kPnP) {
-                // lanes = (surviving hypothesis, half group) tasks, points broadcast two at a time (score_transposed.hip.h)
-                const int tsplit = ctx->score_tsplit > 0 ? (ctx->score_tsplit < 64 ? ctx->score_tsplit : 64) : 1;
-                const unsigned tblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * tsplit) : (unsigned)((int64_t)groups * tsplit);
-                hipLaunchKernelGGL((score_groupT_kernel<MT, false>), dim3(tblocks), dim3(64), 0, ctx->stream, ctx->comp_s.as<double>(), ctx->n, groups,
-                                   ctx->models.as<double>(), W, T2, has_compound, ctx->cull_lists.as<unsigned long long>(), hyp32, qscale, acc, ctx->Mpad,
-                                   tsplit, xcd_local, models_t, (unsigned long long*)nullptr, pts_g, p32_g, nrep, ctx->score_dense_min);
             } else {
                 hipLaunchKernelGGL((score_group_kernel<MT, false>), dim3(gblocks), dim3(64 * kGroupWaves), 0, ctx->stream,
                                    ctx->pts_s.as<double>(), ctx->pts32_s.as<float>(), ctx->comp_s.as<double>(), ctx->n, groups,

@@ -286,8 +286,8 @@ class Context:
         return out
 
     def score_debug_geometry(self, **kw):
-        """pgx_score_debug_geometry (test hook): split=, group_xcd=, nrep=, dense_min=, cull_segs=, transposed=, tsplit="""
-        keys = {"split": 0, "group_xcd": 1, "nrep": 2, "dense_min": 3, "cull_segs": 4, "transposed": 5, "tsplit": 6}
+        """pgx_score_debug_geometry (test hook): split=, group_xcd=, nrep=, dense_min=, cull_segs="""
+        keys = {"split": 0, "group_xcd": 1, "nrep": 2, "dense_min": 3, "cull_segs": 4}
         for k, v in kw.items():
             self._ck(self._lib.pgx_score_debug_geometry(self._h, C.c_int(keys[k]), C.c_int(int(v))), "pgx_score_debug_geometry")
 
