@@ -42,6 +42,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_current.json")   # refreshed by s
 if os.path.exists(PMC_FILE):
     with open(PMC_FILE) as _f:
         PMC = json.load(_f)
+F32_FLOPS_PER_FILTER_TEST = 31   # Filter32<PnP>::reject: 13 FMA (2 flops) + 3 mul + 2 compares
 PMC_TRAFFIC_DEFAULT = int((2 * PMC["fetch_kib"] + PMC["write_kib"]) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
@@ -611,6 +612,15 @@ def main():
                                                "exact_queue": float(kt[3]), "sum": launch_ms,
                                                "note": "breakdown from 5 extra steps with events around every kernel (an event costs "
                                                        "~5 us on the stream); kernel_ms above is from the timed region"},
+                         # what actually bounds the kernel travels with `frac`: executed arithmetic per second of
+                         # the dominant kernel and the busy fractions of the two units its filter loop is co-bound by
+                         "compute": {"fp64_exact_tflops": work["exact_evaluations"] * FLOPS_PER_PAIR["pnp"] / (k_ms * 1e-3) / 1e12,
+                                     "f32_filter_tflops": work["surviving_group_steps"] * 64 * F32_FLOPS_PER_FILTER_TEST / (k_ms * 1e-3) / 1e12,
+                                     "valu_busy": PMC.get("valu_busy_frac") if default_workload else None,
+                                     "lds_busy": PMC.get("lds_busy_frac") if default_workload else None,
+                                     "fp64_vector_peak_tflops_no_fma": 39.3,
+                                     "source": f"work counters of an untimed launch (pgx_score_stats) over the timed kernel duration; busy fractions from the "
+                                               f"SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_LDS passes of {PMC['source']}"},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_formula": "N d 8 + M p 8 + M 16 + N 8 (compound), SURVEY 8(d); no derived copies",
                          "note": "arithmetic/latency bound by construction (~0.02 algorithmic B/pair): the fraction is small "

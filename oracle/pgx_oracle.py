@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpgx_oracle.so")
+_SO = os.environ.get("PGX_ORACLE_SO") or os.path.join(_HERE, "libpgx_oracle.so")   # (scripts/sanitize.sh points it at the ASAN/UBSAN build)
 
 LINE2D, HOMOGRAPHY, FUNDAMENTAL, PNP, VANISHING_POINT, HOMOGRAPHY_SYM = range(6)
 POINT_DIM = {0: 2, 1: 4, 2: 4, 3: 5, 4: 4, 5: 4}
@@ -21,6 +21,8 @@ FIXED_ONE = 1 << 32
 
 def build(force=False):
     src = os.path.join(_HERE, "pgx_oracle.c")
+    if os.environ.get("PGX_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO

@@ -1,4 +1,4 @@
-// maxflow.hip — HIP backend of the alpha-expansion move: kernels wrapping the per-site bodies of maxflow_body.cuh and
+// maxflow.hip — HIP backend of the alpha-expansion move: kernels wrapping the per-site bodies of maxflow_body.hip.h and
 // the launch plumbing for maxflow_driver.inl.
 //
 // Replaces: GCoptimizationGeneralGraph::alpha_expansion + BK max-flow behind pearl::PEARL::labeling
@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "maxflow_driver.inl"
-#include "maxflow_l0.cuh"
+#include "maxflow_l0.hip.h"
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_sweep_list(MfView v, int prev, 
     mf_sweep_flush(v, cur, true, s, any);
 }
 
-// ---- lambda = 0: closed-form move (maxflow_l0.cuh) -------------------------------------------------------------------
+// ---- lambda = 0: closed-form move (maxflow_l0.hip.h) -------------------------------------------------------------------
 __global__ __launch_bounds__(kMfBlock) void mf_k_l0_reduce(const long long* __restrict__ dq, const int* __restrict__ labels,
                                                            int64_t n, int L, int alpha, long long* __restrict__ sums)
 {
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_src_finish(MfView v, int stamp,
     if (v.d[u] == kMfInf && v.mark[u] != stamp) v.d[u] = kMfInf - 1;   // not reached from s: keeps its label
 }
 
-// stranded excess of the sites (maxflow_body.cuh mf_body_stuck_excess): per-workgroup sum, one atomic per workgroup
+// stranded excess of the sites (maxflow_body.hip.h mf_body_stuck_excess): per-workgroup sum, one atomic per workgroup
 __global__ __launch_bounds__(kMfBlock) void mf_k_stuck(MfView v, unsigned long long* __restrict__ out, int)
 {
     __shared__ unsigned long long s_sum;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_stuck(MfView v, unsigned long l
     if (threadIdx.x == 0 && s_sum > 0) atomicAdd(out, s_sum);
 }
 
-// ---- wave pass: the sites of BFS level k push into level k-1 (maxflow_body.cuh mf_body_wave) -------------------------
+// ---- wave pass: the sites of BFS level k push into level k-1 (maxflow_body.hip.h mf_body_wave) -------------------------
 constexpr int kWaveBlocks = 256;
 
 __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kMfBlock) void mf_k_wave(MfView v, int k)
         mf_body_wave(v, v.order[i], k);
 }
 
-// The sweep epilogue (maxflow_body.cuh mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
+// The sweep epilogue (maxflow_body.hip.h mf_body_sweep_epilogue) with one LANE per label: the one-thread version walks the
 // labels through a chain of dependent loads (~5.3 us; at C5 a call ran 80 k of them, 19 % of its GPU time).  Same result.
 __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur, int next, int consumed)
 {
@@ -949,7 +949,7 @@ void maxflow_free(pgx_ctx* ctx)
     ctx->mf = nullptr;
 }
 
-// lambda = 0: one reduction pass, a host decision over <= 64 labels, one apply pass (maxflow_l0.cuh)
+// lambda = 0: one reduction pass, a host decision over <= 64 labels, one apply pass (maxflow_l0.hip.h)
 static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* changed)
 {
     const int64_t n = ctx->dq_n;
@@ -1131,7 +1131,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
-    v.gate = 1;   // an unused alpha is handled by the stranded-excess test (maxflow_body.cuh); the materialised hub stays in the bodies for the CPU emulation
+    v.gate = 1;   // an unused alpha is handled by the stranded-excess test (maxflow_body.hip.h); the materialised hub stays in the bodies for the CPU emulation
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
     if (!st->bar.p) {

@@ -1,4 +1,4 @@
-// maxflow_body.cuh — per-site bodies of the alpha-expansion min-cut (lock-free push-relabel + BFS global relabel).
+// maxflow_body.hip.h — per-site bodies of the alpha-expansion min-cut (lock-free push-relabel + BFS global relabel).
 //
 // Replaces: GCoptimizationGeneralGraph::expansion -> alpha_expansion -> Energy::minimize (BK max-flow) as driven by
 //           pearl::PEARL::labeling, /root/reference/src/pyprogressivex/include/PEARL.h:507-551.  The GCoptimization

@@ -7,7 +7,7 @@
 #include <chrono>
 #include <cstdio>
 
-#include "maxflow_body.cuh"
+#include "maxflow_body.hip.h"
 
 namespace pgx {
 

@@ -1,6 +1,6 @@
-// maxflow_l0.cuh — closed-form expansion move for lambda = 0 (no pairwise term): unary + per-label costs only.
+// maxflow_l0.hip.h — closed-form expansion move for lambda = 0 (no pairwise term): unary + per-label costs only.
 //
-// Without n-links the binary problem of a move on alpha (maxflow_body.cuh header) decouples into the label groups
+// Without n-links the binary problem of a move on alpha (maxflow_body.hip.h header) decouples into the label groups
 // P_beta, coupled only by "does anybody switch" when alpha is unused:
 //   ex_p = max(0, keep_p - take_p)  gain of switching p,   rt_p = max(0, take_p - keep_p)  loss of switching p
 //   group beta (label cost h):  switch ALL members iff sum_{P_beta} rt <= h   (saves h; ties -> alpha)

@@ -3,7 +3,7 @@
 // Replaces: GCoptimizationGeneralGraph::alpha_expansion + BK max-flow behind pearl::PEARL::labeling
 //           (/root/reference/src/pyprogressivex/include/PEARL.h:499-551); upstream source absent [U-5].  Same binary
 //           problem, same fixed-point capacities and the same answer (the unique minimal sink side) as maxflow.hip /
-//           maxflow_body.cuh, whose header states the construction; this file is a different SCHEDULE of it.
+//           maxflow_body.hip.h, whose header states the construction; this file is a different SCHEDULE of it.
 //
 // Why: the level-synchronous schedule of maxflow.hip costs one launch per BFS level and two per sweep (~12 us each of
 // dependent device-scope round trips): ~820 launches per min-cut at N = 1e6.  A problem of <= 8192 sites fits one workgroup:
@@ -22,7 +22,7 @@
 //
 // Label costs: beta hubs (s -> y_beta (h), y_beta -> members (inf)) are global words; members with a t-link pull the
 // hub's excess through one aggregated reservation per hub; a member pushes back through its own counter f.
-// An unused alpha is handled by the stranded-excess test (maxflow_body.cuh, "gate").  Anything else (materialised alpha
+// An unused alpha is handled by the stranded-excess test (maxflow_body.hip.h, "gate").  Anything else (materialised alpha
 // hub, per-arc weights, the source-side variant of the local optimisation's cut, a hub that only reaches t through
 // members without t-links) falls back to maxflow.hip: the function returns PGX_TILE_FALLBACK before touching the labels.
 #include <cstdlib>
@@ -32,7 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
-#include "maxflow_body.cuh"
+#include "maxflow_body.hip.h"
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -101,7 +101,7 @@ struct TView {
 };
 
 // ---- per-move setup ----------------------------------------------------------------------------------------------------
-// t-links and arc capacities of site s (maxflow_body.cuh mf_body_init_site, in tile space)
+// t-links and arc capacities of site s (maxflow_body.hip.h mf_body_init_site, in tile space)
 __device__ __forceinline__ void init_site(const TView& v, const int64_t s)
 {
     const int lu = v.lab[s];
@@ -274,7 +274,7 @@ __device__ __forceinline__ bool tile_relax(const TView& v, const int tile_n, con
 }
 
 // ---- discharge: push-relabel sweeps of one tile ---------------------------------------------------------------------------
-// Take up to `want` out of a shared budget, wait-free (maxflow_body.cuh mf_reserve, device scope).
+// Take up to `want` out of a shared budget, wait-free (maxflow_body.hip.h mf_reserve, device scope).
 __device__ __forceinline__ long long reserve_ag(long long* budget, long long want)
 {
     if (want <= 0 || ld64<SC_AG>(budget) <= 0) return 0;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     }
     if (!gave_up) {
         bool apply = true;
-        if (cnt_alpha == 0 && v.h_q > 0) {   // alpha is not in use: taking it costs h once (maxflow_body.cuh, gate)
+        if (cnt_alpha == 0 && v.h_q > 0) {   // alpha is not in use: taking it costs h once (maxflow_body.hip.h, gate)
             long long total = (long long)stuck_final;
             for (int l = 0; l < v.L; ++l)
                 if (v.hub_exists[l]) { const long long he = ld64<SC_AG>(&v.hub_e[l]); total += he > 0 ? he : 0; }

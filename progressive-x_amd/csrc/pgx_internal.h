@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "../../include/pgx.h"
-#include "residuals.cuh"
+#include "residuals.hip.h"
 
 namespace pgx {
 

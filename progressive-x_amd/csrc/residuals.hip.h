@@ -1,4 +1,4 @@
-// residuals.cuh — per-(point, model) residuals for the five Progressive-X problem types, gfx950 device code.
+// residuals.hip.h — per-(point, model) residuals for the five Progressive-X problem types, gfx950 device code.
 //
 // FP64 throughout, compiled with -ffp-contract=off: the reference is built for baseline x86-64 (no FMA,
 // /root/reference/CMakeLists.txt:23) and parity of inlier masks is bit-exact, so every product and sum is

@@ -18,7 +18,7 @@
 #include <cstdlib>
 
 #include "pgx_internal.h"
-#include "score_filters.cuh"
+#include "score_filters.hip.h"
 
 namespace pgx {
 
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
 }
 
 // ---- PGX_VERIFY=1: every decision of the bound / filter chain against the exact residual -----------------------------------
-// The correctness of counts and masks rests on inequalities with hand-derived error budgets (score_filters.cuh): a group bound
+// The correctness of counts and masks rests on inequalities with hand-derived error budgets (score_filters.hip.h): a group bound
 // that removes (hypothesis, 64-point group) pairs and an f32 filter that removes single pairs may only ever remove outliers.
 // This kernel re-decides EVERY pair of the batch with the exact FP64 residual (the reference's operation order) and counts the
 // pairs the chain discarded although they are inliers: out[0] removed by the group bound, out[1] by the f32 filter; out[2] =

@@ -1,4 +1,4 @@
-// score_filters.cuh — the conservative rejection filters of the score path: Filter<MT> (FP64, division-free), Filter32<MT>
+// score_filters.hip.h — the conservative rejection filters of the score path: Filter<MT> (FP64, division-free), Filter32<MT>
 // (FP32 pre-filter per pair + the group bound of the cull kernel).  A filter may only say "certainly an outlier"; every pair it
 // does not reject goes through the exact FP64 residual in the reference's operation order, so counts, masks and scores are
 // those of evaluating every pair.  The error budgets are derived in docs/lab-notebook.md (5.2) and machine-checked by
@@ -83,7 +83,7 @@ template <> struct Filter<kHomography> {
 };
 
 // Symmetric transfer error, model [H | H^-1]: r^2 = fl(forward + backward) >= the forward term, which is computed in exactly
-// the operation order of Residual<kHomography> (residuals.cuh) - rounding is monotone and the backward term is >= 0 or NaN -
+// the operation order of Residual<kHomography> (residuals.hip.h) - rounding is monotone and the backward term is >= 0 or NaN -
 // so every pair the forward filters prove "not an inlier" is not an inlier of the symmetric residual either: the
 // homography filters are reused on the first nine entries.  (The backward term is not filtered.)
 template <> struct Filter<kHomographySym> : Filter<kHomography> {};
@@ -344,7 +344,7 @@ template <> struct Filter32<kVanishingPoint> {
     }
 };
 
-// ---- fundamental matrices: Sampson distance [U-2] (residuals.cuh Residual<kFundamental>) -----------------------------------
+// ---- fundamental matrices: Sampson distance [U-2] (residuals.hip.h Residual<kFundamental>) -----------------------------------
 // n(p) = x_b^T F x_a (x_a = (p0, p1, 1), x_b = (p2, p3, 1)) is BILINEAR in the four image coordinates and the Sampson
 // denominator is the squared norm of its gradient: (rxc, ryc, rx, ry) = (dn/dp0, dn/dp1, dn/dp2, dn/dp3).  So the squared
 // residual is n^2 / |grad n|^2 and the filter needs neither the division nor a root: 21 f32 operations per pair.

@@ -9,7 +9,7 @@ src, committed_as = sys.argv[1], sys.argv[2]
 vals = {}
 for line in open(src):
     name, parts = line[:50].strip(), line[50:].split()      # fixed-width columns: kernel names contain blanks
-    if len(parts) >= 8 and name.startswith("pgx::score_") and parts[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU"):
+    if len(parts) >= 8 and name.startswith("pgx::score_") and parts[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU"):
         if "group_kernel" in name and (", true, " in name or name.rstrip().endswith(", true>")):
             continue                                          # the counting variant of pgx_score_stats (never timed)
         vals[(name.split("<")[0], parts[0])] = (float(parts[1]), float(parts[-1]))
@@ -20,4 +20,11 @@ key = ("pgx::score_group_kernel", "SQ_ACTIVE_INST_VALU")
 if key in vals:
     quad_cycles, avg_ns = vals[key]
     busy = quad_cycles * 4.0 / (1024 * avg_ns * 2.4)
-print(json.dumps({"source": committed_as, "fetch_kib": fetch, "write_kib": write, "valu_busy_frac": busy}))
+lds_busy = None
+key = ("pgx::score_group_kernel", "SQ_ACTIVE_INST_LDS")    # quad-cycles of the CU's LDS pipe: x4 / (256 CUs x kernel cycles)
+if key in vals:
+    quad_cycles, avg_ns = vals[key]
+    lds_busy = quad_cycles * 4.0 / (256 * avg_ns * 2.4)
+insts = vals.get(("pgx::score_group_kernel", "SQ_INSTS_VALU"), (None, None))[0]
+print(json.dumps({"source": committed_as, "fetch_kib": fetch, "write_kib": write, "valu_busy_frac": busy, "lds_busy_frac": lds_busy,
+                  "valu_wave_instructions": insts}))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Machine check of the filter error budgets.
 
-score_filters.cuh removes (hypothesis, 64-point group) pairs with a bound and single pairs with an f32 test; both rest on
+score_filters.hip.h removes (hypothesis, 64-point group) pairs with a bound and single pairs with an f32 test; both rest on
 hand-derived inequalities.  Here every residual type gets batches of >= 1e7 (point, hypothesis) pairs CONSTRUCTED to sit at
 |r^2 / T^2 - 1| < 1e-4 - the only place where a too-optimistic error term can show - and the device re-decides every pair
 with the exact FP64 residual (PGX_VERIFY=1, score_verify_kernel): a pair the chain discarded although the exact residual calls

@@ -22,7 +22,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
-    """One libpgx context on cuda:0 for the whole session; fails loudly if the HIP library or the GPU is missing."""
+    """One libpgx context on device 0 for the whole session; fails loudly if the HIP library or the GPU is missing."""
     from pyprogressivex import _lib
     ctx = _lib.Context(0)
     yield ctx

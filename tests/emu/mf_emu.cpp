@@ -1,6 +1,6 @@
 // mf_emu.cpp — sequential CPU emulation of the HIP push-relabel expansion move (TEST INFRASTRUCTURE).
 //
-// Compiles progressive-x_amd/csrc/maxflow_body.cuh + maxflow_driver.inl with g++ and runs every "kernel" as a loop
+// Compiles progressive-x_amd/csrc/maxflow_body.hip.h + maxflow_driver.inl with g++ and runs every "kernel" as a loop
 // over sites in a (optionally shuffled) order.  It lets `pytest -m "not gpu"` check the algorithm that the GPU runs
 // (graph construction, hub handling, BFS/sweep orchestration, termination) against the oracle's Dinic solver on
 // thousands of random instances without a GPU.  It is never loaded by the product package.
@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "../../progressive-x_amd/csrc/maxflow_driver.inl"
-#include "../../progressive-x_amd/csrc/maxflow_l0.cuh"
+#include "../../progressive-x_amd/csrc/maxflow_l0.hip.h"
 
 using namespace pgx;
 

@@ -1,5 +1,5 @@
 """Host-logic check of the expansion move: the SAME per-site bodies and orchestration that the HIP kernels run
-(progressive-x_amd/csrc/maxflow_body.cuh + maxflow_driver.inl), executed sequentially on the CPU in natural and in
+(progressive-x_amd/csrc/maxflow_body.hip.h + maxflow_driver.inl), executed sequentially on the CPU in natural and in
 shuffled "thread" order, must reproduce the oracle's Dinic min-cut labels bit for bit."""
 import ctypes as C
 import os
@@ -11,14 +11,14 @@ import pytest
 from helpers import random_sym_graph, realistic_labeling_problem
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "emu", "libmf_emu.so")
+SO = os.environ.get("PGX_EMU_SO") or os.path.join(HERE, "emu", "libmf_emu.so")   # (scripts/sanitize.sh: the sanitizer build)
 
 
 @pytest.fixture(scope="module")
 def emu():
     src = os.path.join(HERE, "emu", "mf_emu.cpp")
     deps = [src] + [os.path.join(HERE, "..", "progressive-x_amd", "csrc", f)
-                    for f in ("maxflow_body.cuh", "maxflow_driver.inl")]
+                    for f in ("maxflow_body.hip.h", "maxflow_driver.inl")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, src])
     return C.CDLL(SO)
@@ -75,7 +75,7 @@ def test_emulated_cycle_on_radius_graph(emu, oracle):
 
 
 def test_closed_form_lambda0_move_matches_oracle_with_ties(emu, oracle):
-    """lambda = 0: the product solves a move in closed form (maxflow_l0.cuh).  Tiny integer costs make ties between
+    """lambda = 0: the product solves a move in closed form (maxflow_l0.hip.h).  Tiny integer costs make ties between
     'switch all', 'switch individually' and 'nobody switches' frequent; every case must equal the oracle's min-cut."""
     rng = np.random.default_rng(7)
     for trial in range(4000):
