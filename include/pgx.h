@@ -159,7 +159,13 @@ int pgx_graph_fetch(pgx_ctx *ctx, int32_t *off, int32_t *idx, int32_t *mult);
 /* ---- a8/a19: GCoptimizationGeneralGraph::{setLabel, expansion, whatLabel} as used by PEARL::labeling
  * (PEARL.h:507-551).  lambda = spatial coherence weight of ONE directed neighbour entry (PEARL.h:76-78),
  * label_cost = model_complexity_weight (PEARL.h:144,529).  Energies are returned both as the exact fixed-point
- * integer and as double (= energy_q / 2^32). */
+ * integer and as double (= energy_q / 2^32).
+ * PEARL builds a fresh GCO engine - i.e. starts from the all-zero labelling - for every labelling it cannot warm-start
+ * (PEARL.h:507-508, 541-547), mostly with the same instances plus one.  pgx_expansion therefore keeps the labels after each
+ * move of the FIRST cycle of an expansion that starts from the all-zero labelling uploaded by pgx_set_labels; when the next
+ * such expansion has the same leading unary columns (same model bytes, threshold, lambda, points, graph, label cost) it
+ * restores the state behind those moves instead of solving their min-cuts again.  A move is a deterministic function of
+ * (labelling, alpha, the columns of the labels present): results are bit-identical with and without the memo (PGX_MF_MEMO=0). */
 int pgx_set_labels(pgx_ctx *ctx, const int32_t *labels, int64_t n);
 int pgx_get_labels(pgx_ctx *ctx, int32_t *labels);
 int pgx_energy(pgx_ctx *ctx, double lambda, double label_cost, int64_t *energy_q, double *energy);
@@ -179,8 +185,8 @@ int pgx_greedy_labeling(pgx_ctx *ctx, double label_cost, int64_t *energy_q, doub
  * [6]=work-list sweeps, [7]=moves skipped because the labelling had not changed since that label's last move, which relabelled nothing */
 int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
 /* which min-cut solver finished the moves since pgx_create (the cut is the same under all of them; tests use this to make
- * sure the solver under test is the one that ran): [0]=one workgroup on the whole graph (<= 8192 sites), [1]=0 (was: the
- * multi-tile launch, removed), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
+ * sure the solver under test is the one that ran): [0]=one workgroup on the whole graph (<= 8192 sites), [1]=first-cycle
+ * moves restored from the memo of the previous expansion from the all-zero labelling (same unary columns: not solved again), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
  * (maxflow.hip), [4]=region moves declined (too many open sites / a sink that could not be promoted), [5]=tile moves handed back */
 int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
 

@@ -108,6 +108,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_MEMO")) ctx->mf_memo = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -263,6 +264,8 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     if (!points || n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: empty input");
     if (n >= ((int64_t)1 << 31)) return fail(ctx, PGX_ERR_INVALID, "pgx_set_points: n must be < 2^31");
     ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
+    ctx->points_version += 1;
+    ctx->labels_all_zero = 0;
     ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
     ctx->weights_n = 0;  // weights belong to a point set
     // upload + every derived copy on the device (setpoints.hip): filter scales, f32 rows, Morton order, group bounds
@@ -687,6 +690,14 @@ int pgx_pearl_unary(pgx_ctx* ctx, const double* models, int K, double threshold,
     if (K > 0)
         PGX_HIP(ctx, hipMemcpyAsync(ctx->kmodels.p, models, (size_t)K * ctx->P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PGX_TRY(unary_launch(ctx, K, threshold, lambda));
+    {   // what each column was computed from, byte for byte (the first-cycle memo of pgx_expansion compares these)
+        ctx->unary_ident.assign((size_t)L, std::string());
+        char head[64];
+        const int hl = std::snprintf(head, sizeof head, "%d|%lld|%a|%a|", ctx->model_type, (long long)ctx->points_version, threshold, lambda);
+        for (int l = 0; l < K; ++l)
+            ctx->unary_ident[(size_t)l] = std::string(head, (size_t)hl) + std::string((const char*)(models + (size_t)l * ctx->P), (size_t)ctx->P * sizeof(double));
+        ctx->unary_ident[(size_t)K] = std::string(head, (size_t)hl) + "outlier";
+    }
     ctx->L = L;
     ctx->dq_n = ctx->n;
     ctx->dq_max = (int64_t)1 << 33;  // 2 (1 - lambda) <= 2 in 2^-32 fixed point (PEARL.h:123)
@@ -717,6 +728,7 @@ int pgx_set_unary_q(pgx_ctx* ctx, const int64_t* Dq, int64_t n, int L)
             if (v > mx) mx = v;
         }
     ctx->dq_max = mx;
+    ctx->unary_ident.clear();   // an injected table has no identity: no first-cycle memo
     PGX_TRY(ensure(ctx, ctx->dq, tmp.size() * sizeof(int64_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->dq.p, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -733,6 +745,7 @@ int pgx_set_labels(pgx_ctx* ctx, const int32_t* labels, int64_t n)
     for (int64_t i = 1; i < n; ++i) { lo = labels[i] < lo ? labels[i] : lo; hi = labels[i] > hi ? labels[i] : hi; }
     if (lo < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_labels: negative label %d", (int)lo);
     ctx->labels_max = hi;
+    ctx->labels_all_zero = hi == 0 ? 1 : 0;
     PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, labels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -852,6 +865,7 @@ int pgx_expand_alpha(pgx_ctx* ctx, double lambda, double label_cost, int alpha, 
     int64_t lq, hq, ch = 0;
     PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
     for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
+    ctx->labels_all_zero = 0;
     PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
     if (changed) *changed = ch;
     return PGX_OK;
@@ -872,10 +886,57 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
     int done = 0;
     int64_t version = 0;
     std::vector<int64_t> noop_at((size_t)(ctx->L > 0 ? ctx->L : 1), -1);
+    // ---- first-cycle memo (pgx_internal.h ExpansionMemo): usable when this expansion starts from the all-zero labelling on columns
+    // of known identity; `keep` = first-cycle moves recorded by this call, `memo_p` = leading moves restored instead of solved
+    pgx_ctx::ExpansionMemo& memo = ctx->memo;
+    const int64_t n_sites = ctx->dq_n;
+    const bool memo_on = ctx->mf_memo && lq > 0 && ctx->labels_all_zero && ctx->L > 1 && (int)ctx->unary_ident.size() == ctx->L &&
+                         ctx->labels_n == n_sites && (size_t)ctx->L * (size_t)n_sites * 4 <= ((size_t)2 << 30);
+    ctx->labels_all_zero = 0;
+    int memo_p = 0;
+    if (memo_on) {
+        if (memo.n != n_sites || memo.lq != lq || memo.hq != hq || memo.graph_version != ctx->graph_version) memo.valid = 0;
+        while (memo_p < memo.valid && memo_p < ctx->L && memo.ident[(size_t)memo_p] == ctx->unary_ident[(size_t)memo_p]) ++memo_p;
+        if (memo.cap < ctx->L || memo.n != n_sites) {   // room for this call's snapshots (the kept prefix moves along)
+            pgx::DevBuf grown;
+            PGX_TRY(ensure(ctx, grown, (size_t)ctx->L * (size_t)n_sites * 4));
+            if (memo_p > 0)
+                PGX_HIP(ctx, hipMemcpyAsync(grown.p, memo.snaps.p, (size_t)memo_p * (size_t)n_sites * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            release(memo.snaps);
+            memo.snaps = grown;
+            memo.cap = ctx->L;
+        }
+        memo.ident.resize((size_t)ctx->L);
+        memo.changed.resize((size_t)ctx->L, 0);
+        memo.valid = memo_p;
+        memo.n = n_sites; memo.lq = lq; memo.hq = hq; memo.graph_version = ctx->graph_version;
+    }
+    auto memo_snapshot = [&](int a) -> int {     // enqueued right behind move a of the first cycle: the labels it left
+        PGX_HIP(ctx, hipMemcpyAsync((char*)memo.snaps.p + (size_t)a * (size_t)n_sites * 4, ctx->labels.p, (size_t)n_sites * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return PGX_OK;
+    };
+    auto memo_record = [&](int a, int64_t ch) {  // once move a's outcome is known (moves are recorded in order: valid stays a prefix)
+        if (memo.valid == a) { memo.ident[(size_t)a] = ctx->unary_ident[(size_t)a]; memo.changed[(size_t)a] = ch; memo.valid = a + 1; }
+    };
     for (int cycle = 1; cycle <= max_cycles; ++cycle) {
         if (new_e == old_e) break;
         old_e = new_e;
         int64_t changed_total = 0;
+        int alpha0 = 0;
+        const bool keep = memo_on && cycle == 1;
+        if (keep && memo_p > 0) {   // the leading moves as they went last time: their label changes, the skip rule's bookkeeping, the labels
+            for (int a = 0; a < memo_p; ++a) {
+                const int64_t ch = memo.changed[(size_t)a];
+                changed_total += ch;
+                if (ch > 0) { ++version; noop_at[(size_t)a] = -1; }
+                else noop_at[(size_t)a] = version;
+            }
+            PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, (char*)memo.snaps.p + (size_t)(memo_p - 1) * (size_t)n_sites * 4, (size_t)n_sites * 4,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->memo_hits += memo_p;
+            alpha0 = memo_p;
+        }
         if (lq <= 0) {  // no pairwise term: closed-form moves, the whole cycle enqueued at once (one host round trip)
             std::vector<int64_t> ch((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
             std::vector<int> ev((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
@@ -886,7 +947,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
             // host round trip per batch instead of one per move.  A move that declines poisons the rest of its batch on the device
             // (they return untouched); it is solved by the general path and the cycle resumes behind it.  The skip rule below is
             // applied on the device for moves behind others of the same batch (their outcome is not known when they are enqueued).
-            int alpha = 0;
+            int alpha = alpha0;
             std::vector<int> batch;
             while (alpha < ctx->L) {
                 batch.clear();
@@ -901,7 +962,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
                     int64_t ch = 0;
                     rc = expand_alpha_launch(ctx, lq, hq, a, &ch);
                     ctx->region_defer = 0;
-                    if (rc == PGX_REGION_PENDING) { batch.push_back(a); rc = PGX_OK; }
+                    if (rc == PGX_REGION_PENDING) { batch.push_back(a); rc = keep ? memo_snapshot(a) : PGX_OK; }
                     else if (rc == PGX_OK) rc = fail(ctx, PGX_ERR_INVALID, "pgx_expansion: a batched move was not enqueued");
                 }
                 if (rc != PGX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
@@ -919,13 +980,15 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
                         continue;
                     }
                     if (status == 1) {   // declined: the general path, then a new batch behind it
-                        const int keep = ctx->mf_region;
+                        const int region_on = ctx->mf_region;
                         ctx->mf_region = 0;
                         const int r1 = expand_alpha_launch(ctx, lq, hq, a, &ch);
-                        ctx->mf_region = keep;
+                        ctx->mf_region = region_on;
                         PGX_TRY(r1);
+                        if (cycle == 1 && memo_on) PGX_TRY(memo_snapshot(a));   // (the snapshot taken behind the declined move holds the untouched labels)
                         next = a + 1;
                     }
+                    if (cycle == 1 && memo_on) memo_record(a, ch);
                     changed_total += ch;
                     if (ch > 0) { ++version; noop_at[a] = -1; }
                     else noop_at[a] = version;
@@ -934,12 +997,13 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
                 alpha = next;
             }
         } else
-        for (int alpha = 0; alpha < ctx->L; ++alpha) {
+        for (int alpha = alpha0; alpha < ctx->L; ++alpha) {
             // a move is a deterministic function of (labelling, alpha): one that relabelled nothing and has seen no
             // label change since would relabel nothing again — skipped (typically the tail of the verifying cycle)
             if (noop_at[alpha] == version) { ctx->stats[7]++; continue; }
             int64_t ch = 0;
             PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
+            if (keep) { PGX_TRY(memo_snapshot(alpha)); memo_record(alpha, ch); }
             changed_total += ch;
             if (ch > 0) { ++version; noop_at[alpha] = -1; }
             else noop_at[alpha] = version;
@@ -978,6 +1042,7 @@ int pgx_expansion_paths(pgx_ctx* ctx, int64_t paths[6])
 {
     if (!ctx || !paths) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_paths: NULL argument");
     for (int k = 0; k < 6; ++k) paths[k] = ctx->paths[k];
+    paths[1] = ctx->memo_hits;
     paths[5] = ctx->tile_fallbacks;
     return PGX_OK;
 }

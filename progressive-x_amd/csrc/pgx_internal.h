@@ -100,6 +100,24 @@ struct pgx_ctx {
     pgx::DevBuf kmodels;
     pgx::DevBuf labels; // int32 [n]
     int64_t labels_n = 0;
+    // First-cycle memo of pgx_expansion (capi.hip): PEARL starts every labelling it cannot warm-start from the all-zero labelling
+    // (PEARL.h:507-508, 541-547), so the first cycle's move alpha sees labels < alpha only and is a deterministic function of the
+    // unary columns 0..alpha, lambda, h and the graph.  The labels after each first-cycle move are kept; a later expansion from
+    // zeros whose leading unary columns are THE SAME (exact identity of what pgx_pearl_unary computed them from) restores the
+    // state behind that prefix instead of solving its min-cuts again.
+    struct ExpansionMemo {
+        std::vector<std::string> ident;   // identity of the unary column each kept move was solved with
+        std::vector<int64_t> changed;     // sites the move relabelled
+        int valid = 0;                    // moves 0 .. valid-1 of the last from-zeros expansion are kept
+        pgx::DevBuf snaps;                // [cap][n] int32: labels after move alpha
+        int64_t n = 0, lq = 0, hq = 0, graph_version = -1;
+        int cap = 0;
+    } memo;
+    std::vector<std::string> unary_ident; // per label: what its unary column was computed from (pgx_pearl_unary); empty = unknown (injected table)
+    int64_t points_version = 0;           // bumped by pgx_set_points
+    int labels_all_zero = 0;              // the resident labelling is the all-zero one pgx_set_labels uploaded (no move has run since)
+    int mf_memo = 1;                      // PGX_MF_MEMO=0: no first-cycle memo (A/B)
+    int64_t memo_hits = 0;                // moves restored from the memo (pgx_expansion_paths[1])
     int labels_max = 0;          // largest label pgx_set_labels uploaded (the moves index per-label tables with the labels: checked against L)
     // graph (symmetric CSR)
     int64_t gn = 0, gE = 0;

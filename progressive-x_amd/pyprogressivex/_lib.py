@@ -534,7 +534,7 @@ class Context:
         """Which min-cut solver finished the moves of this context so far (include/pgx.h pgx_expansion_paths)."""
         st = np.zeros(6, dtype=np.int64)
         self._ck(self._lib.pgx_expansion_paths(self._h, _ptr(st, C.c_int64)), "pgx_expansion_paths")
-        return dict(one_workgroup=int(st[0]), region=int(st[2]), level_synchronous=int(st[3]),
+        return dict(one_workgroup=int(st[0]), memo=int(st[1]), region=int(st[2]), level_synchronous=int(st[3]),
                     region_declined=int(st[4]), tile_handed_back=int(st[5]))
 
     def bucket(self, L, want_order=True):

@@ -1340,6 +1340,53 @@ def test_rccl_single_rank_allgather(gpu_ctx):
         gpu_ctx.comm_destroy()
 
 
+def test_first_cycle_memo_is_transparent(monkeypatch):
+    """pgx_expansion keeps the labels after every first-cycle move of an expansion from the all-zero labelling and restores the
+    state behind the leading moves whose unary columns are unchanged (PEARL re-runs such expansions with mostly the same
+    models).  The memo must be invisible: energy, cycles and labels of a sequence of expansions with a growing / partly refitted
+    model list equal those of a context with the memo switched off - and the oracle's, on the last one."""
+    import pgx_oracle as O
+    from pyprogressivex import _lib
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=3000, n_objects=6, n_outliers=6000, seed=3)
+    pts, f = datasets.normalize_pnp(x1, x2, K)
+    n = pts.shape[0]
+    lam, h, thr = 0.1, 6.0, 4.0 / f
+    raw = np.column_stack([x1, x2])
+    rng = np.random.default_rng(5)
+    jig = lambda P: P + rng.normal(0, 1e-4, P.shape)          # a refit: the model moves a little
+    lists = [poses[:3], np.vstack([poses[:3], poses[3:4]]),                       # one model appended: 3 leading columns kept
+             np.vstack([poses[:2], jig(poses[2:3]), poses[3:4], poses[4:5]]),     # column 2 refitted: only 2 kept
+             np.vstack([poses[:2], jig(poses[2:3]), poses[3:4], poses[4:5]])[[0, 1, 2, 3, 4]],
+             poses[:6]]
+    lists[3] = lists[2].copy()                                                    # identical list: every first-cycle move restored
+
+    def run(memo):
+        monkeypatch.setenv("PGX_MF_MEMO", "1" if memo else "0")
+        ctx = _lib.Context(0)
+        out = []
+        try:
+            ctx.set_points(_lib.PNP, pts)
+            ctx.graph_build(raw, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+            for models in lists:
+                ctx.pearl_unary(models, thr, lam)
+                ctx.set_labels(np.zeros(n, np.int32))
+                eq, e, cycles = ctx.expansion(lam, h)
+                out.append((eq, cycles, ctx.get_labels()))
+            hits = ctx.expansion_paths()["memo"]
+        finally:
+            ctx.close()
+        return out, hits
+    with_memo, hits = run(True)
+    without, none = run(False)
+    assert none == 0 and hits >= 3 + 2 + 6, hits
+    for (eq, cycles, lab), (eq0, cycles0, lab0) in zip(with_memo, without):
+        assert eq == eq0 and cycles == cycles0 and np.array_equal(lab, lab0)
+    Dq = O.unary_q(O.PNP, pts, lists[-1], thr, lam)
+    graph = O.graph_build(raw, 0, radius=20.0, k=5)
+    ref, ref_e, ref_cyc = O.expansion(Dq, graph, O.quantize_lambda(lam), O.quantize(h), np.zeros(n, np.int32))
+    assert np.array_equal(with_memo[-1][2], ref) and with_memo[-1][0] == ref_e and with_memo[-1][1] == ref_cyc
+
+
 def test_point_sharded_accumulators_are_exact(gpu_ctx, oracle):
     """pgx_score_allreduce adds the integer accumulators of ranks that hold different points.  On one GPU: the accumulators of
     the whole point set (a) ARE the oracle's per-inlier terms in the path's fixed point, integer for integer, and (b) equal
