@@ -116,7 +116,9 @@ def test_c3_quality_with_the_full_iteration_budget():
     K = F.shape[0] // 3
     me = datasets.misclassification(np.where(lab == K, 0, lab + 1), gt)
     print(f"C3 findTwoViewMotions: {K} motions, misclassification {me:.4f}")
-    assert 5 <= K <= 10 and me < 0.7
+    # the measured band at this seed, not a sanity bound (a regression 0.47 -> 0.53 used to pass silently):
+    # 8 motions, ME 0.527 with the U-14 validity stages on (round 3 and round 4 runs; 0.466 with validity="off", round 2)
+    assert K == 8 and 0.50 <= me <= 0.55
 
 
 def test_c5_vanishing_point_scoring_all_segments_vs_oracle(gpu_ctx, oracle):
