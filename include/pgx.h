@@ -94,6 +94,10 @@ int pgx_solve_minimal(pgx_ctx *ctx, const int32_t *samples, int S, double *model
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
                     double *scores, uint64_t *masks);
+/* The inlier set of hypothesis `row` of the last launch that produced masks (pgx_score with masks / pgx_score_launch with
+ * want_masks), as ascending point indices - the `inliers` vector getScore fills (scoring_function_with_compound_model.h:88) -
+ * compacted on the device.  index: room for n entries. */
+int pgx_score_inliers(pgx_ctx *ctx, int row, int32_t *index, int64_t *count);
 /* what one pgx_score_launch reads+writes at minimum (points + models + compound + results), for rooflines */
 int pgx_score_algorithmic_bytes(pgx_ctx *ctx, int want_masks, int64_t *bytes, int64_t *pairs);
 /* Work counters of one scoring launch of the resident batch (a separate, untimed launch of the same kernels with counting

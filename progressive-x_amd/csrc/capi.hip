@@ -1103,6 +1103,13 @@ int pgx_epipolar_support(pgx_ctx* ctx, const double* F, double T2, double S2, in
     return epipolar_support_launch(ctx, F, T2, S2, counts);
 }
 
+int pgx_score_inliers(pgx_ctx* ctx, int row, int32_t* index, int64_t* count)
+{
+    CTX_GUARD(ctx);
+    if (!index || !count) return fail(ctx, PGX_ERR_INVALID, "pgx_score_inliers: NULL argument");
+    return score_inliers_launch(ctx, row, index, count);
+}
+
 int pgx_gc_inliers(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* index, int64_t* count)
 {
     CTX_GUARD(ctx);

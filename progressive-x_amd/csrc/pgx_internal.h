@@ -200,6 +200,7 @@ constexpr int kSuper = 8;      // groups per super-group (512 points): first lev
 // launchers implemented in the .hip translation units
 int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_t n);  // setpoints.hip: upload + all preprocessing
 int score_launch(pgx_ctx* ctx, double T2, int has_compound, int want_masks);
+int score_inliers_launch(pgx_ctx* ctx, int row, int32_t* index, int64_t* count);   // pointwise.hip
 // point-sharded exchange (comm.hip): the last launch's integer accumulators, replicas summed, in the caller's hypothesis order
 // ([3][Mpad] words) / counts | values | shared from such a block
 int score_acc_export(pgx_ctx* ctx, unsigned long long* out, hipStream_t stream);

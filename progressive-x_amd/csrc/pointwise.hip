@@ -348,6 +348,45 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
     return PGX_OK;
 }
 
+// ---- inlier indices of a scored hypothesis (the `inliers` vector getScore fills, scoring_function_with_compound_model.h:88) ----
+// pgx_score returns inlier sets as bit masks; the host's proposal loop needs index lists (refit selections, the final inlier
+// list of a proposal) and used to unpack a 10^6-bit row with numpy (unpackbits + nonzero: ~1.5 ms, 100+ times per find6DPoses
+// call).  Here the row is expanded to flags and compacted on the device (hipcub select): ascending indices, bit for bit the set.
+__global__ __launch_bounds__(kPwBlock) void mask_flags_kernel(const unsigned long long* __restrict__ row, int64_t n, int* __restrict__ flags)
+{
+    const int64_t i = (int64_t)blockIdx.x * kPwBlock + threadIdx.x;
+    if (i < n) flags[i] = (int)((row[i >> 6] >> (i & 63)) & 1ull);
+}
+
+int score_inliers_launch(pgx_ctx* ctx, int row, int32_t* index, int64_t* count)
+{
+    const int64_t n = ctx->n;
+    if (!ctx->have_masks || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_inliers: the last launch produced no masks");
+    if (row < 0 || row >= ctx->M) return fail(ctx, PGX_ERR_INVALID, "pgx_score_inliers: row %d of %d", row, ctx->M);
+    size_t temp_bytes = 0;
+    hipcub::CountingInputIterator<int> ids(0);
+    PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, ids, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int)n, ctx->stream));
+    const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
+    PGX_TRY(ensure(ctx, ctx->gc_sel, 2 * arr + 256 + temp_bytes));
+    int* d_flags = ctx->gc_sel.as<int>();
+    int* d_sel = (int*)((char*)ctx->gc_sel.p + arr);
+    int* d_num = (int*)((char*)ctx->gc_sel.p + 2 * arr);
+    void* d_temp = (void*)((char*)ctx->gc_sel.p + 2 * arr + 256);
+    hipLaunchKernelGGL(mask_flags_kernel, dim3((unsigned)((n + kPwBlock - 1) / kPwBlock)), dim3(kPwBlock), 0, ctx->stream,
+                       ctx->masks.as<unsigned long long>() + (size_t)row * (size_t)ctx->words, n, d_flags);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, ids, d_flags, d_sel, d_num, (int)n, ctx->stream));
+    int num = 0;
+    PGX_HIP(ctx, hipMemcpyAsync(&num, d_num, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (num > 0) {
+        PGX_HIP(ctx, hipMemcpyAsync(index, d_sel, (size_t)num * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *count = num;
+    return PGX_OK;
+}
+
 // ---- a9: residual sums ---------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(kPwBlock) void residual_sum_kernel(const double* __restrict__ pts, int64_t n, ModelArg mdl,

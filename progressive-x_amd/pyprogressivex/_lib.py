@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
-    "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
+    "pgx_score_inliers", "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
 ]
 
 
@@ -271,6 +271,14 @@ class Context:
         self._ck(self._lib.pgx_score_algorithmic_bytes(self._h, C.c_int(1 if want_masks else 0), C.byref(b),
                                                        C.byref(p)), "pgx_score_algorithmic_bytes")
         return b.value, p.value
+
+    def score_inliers(self, row=0):
+        """pgx_score_inliers: ascending indices (int64) of the inliers of hypothesis `row` of the last launch with masks"""
+        if not hasattr(self, "_inl_index") or self._inl_index.shape[0] != self.n:
+            self._inl_index = np.empty(self.n, dtype=np.int32)
+        cnt = C.c_int64()
+        self._ck(self._lib.pgx_score_inliers(self._h, C.c_int(int(row)), _ptr(self._inl_index, C.c_int32), C.byref(cnt)), "pgx_score_inliers")
+        return self._inl_index[:cnt.value].astype(np.int64)
 
     def score_debug_fetch(self, what):
         """pgx_score_debug_fetch: 'order' | 'bounds' | 'rows64' | 'rows32' | 'rows32_sorted' of the resident point set"""

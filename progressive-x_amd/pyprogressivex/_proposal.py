@@ -424,7 +424,7 @@ class ProposalEngine:
             model, best_score = self._lsq_lo(model, best_score, T2, has_compound, exponent, weights,
                                              budget=int(getattr(s, "max_least_squares_iterations", 10)))
         final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
-        return dict(model=model, inliers=mask_to_indices(final["masks"][0], self.n), iterations=iterations,
+        return dict(model=model, inliers=self._mask_inliers(final), iterations=iterations,
                     score=float(final["scores"][0]))
 
     # -- local optimisation ------------------------------------------------------------------------------------------
@@ -450,7 +450,7 @@ class ProposalEngine:
         while budget > 0:
             budget -= 1
             one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
-            inl = mask_to_indices(one["masks"][0], self.n)
+            inl = self._mask_inliers(one)
             if len(inl) < est.nonminimal_sample_size:
                 break
             fits = est.nonminimal(self.ctx, ("index", inl), weights, init=model)
@@ -472,7 +472,14 @@ class ProposalEngine:
                 return self.ctx.gc_inliers(model, T2, lam)
             return np.flatnonzero(self.ctx.gc_labeling(model, T2, lam) != 0).astype(np.int64)   # (bool scan: half the time of nonzero on int32)
         one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
-        return mask_to_indices(one["masks"][0], self.n)
+        return self._mask_inliers(one)
+
+    def _mask_inliers(self, table):
+        """ascending inlier indices of the single hypothesis just scored with masks: compacted on the device when the context
+        offers it (pgx_score_inliers), else unpacked from the mask row (the oracle-backed context of the tests) - the same set"""
+        if hasattr(self.ctx, "score_inliers"):
+            return self.ctx.score_inliers(0)
+        return mask_to_indices(table["masks"][0], self.n)
 
     def _graph_cut_lo(self, model, score, count, T2, has_compound, exponent, weights):
         """gcransac::GCRANSAC::graphCutLocalOptimization, restated [UPSTREAM-MEMORY, U-12] and batched:

@@ -80,3 +80,7 @@ if __name__ == "__main__":
         x1, x2, K, gt, poses = datasets.make_poses(seed=0)
         timed("C4 6D poses 1e6/16 (cap 10)", px.find6DPoses, gt, 3, x1, x2, K, seed=1, minimum_point_number=5000,
               max_iters=2048)
+    if "C4all" in which:   # the same scene with the reference's hard-wired cap of 10 proposals (progressive_x.h:272) lifted: all 16 objects
+        x1, x2, K, gt, poses = datasets.make_poses(seed=0)
+        timed("C4 6D poses 1e6/16 (max_outer_iterations=20)", px.find6DPoses, gt, 3, x1, x2, K, seed=1, minimum_point_number=5000,
+              max_iters=2048, max_outer_iterations=20)

@@ -1340,6 +1340,28 @@ def test_rccl_single_rank_allgather(gpu_ctx):
         gpu_ctx.comm_destroy()
 
 
+@pytest.mark.parametrize("name", ["pnp", "homography", "line"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 5000, 100003])
+def test_score_inliers_are_the_mask_row(gpu_ctx, oracle, name, n):
+    """pgx_score_inliers: the inlier vector of getScore (scoring_function_with_compound_model.h:88) as ascending indices,
+    compacted on the device = the mask row unpacked on the host = the oracle's strict r^2 < T^2 set."""
+    from pyprogressivex._proposal import mask_to_indices
+    mt, pts, models, thr = make_case(name, n, 3, seed=n + 1)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    got = gpu_ctx.score(models, T2, want_masks=True)
+    for row in range(len(models)):
+        idx = gpu_ctx.score_inliers(row)
+        assert np.array_equal(idx, mask_to_indices(got["masks"][row], n))
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(idx, np.flatnonzero(oracle.squared_residuals(mt, pts, models[row]) < T2))
+    with pytest.raises(_lib.PgxError, match="row"):
+        gpu_ctx.score_inliers(len(models))
+    gpu_ctx.score(models, T2)
+    with pytest.raises(_lib.PgxError, match="no masks"):
+        gpu_ctx.score_inliers(0)
+
+
 def test_first_cycle_memo_is_transparent(monkeypatch):
     """pgx_expansion keeps the labels after every first-cycle move of an expansion from the all-zero labelling and restores the
     state behind the leading moves whose unary columns are unchanged (PEARL re-runs such expansions with mostly the same
@@ -1497,6 +1519,18 @@ def test_abi_error_paths():
             ctx.expand_alpha(0.0, 0.0, 0)
         with pytest.raises(_lib.PgxError):
             ctx.comm_barrier()                                        # communicator not initialised
+        with pytest.raises(_lib.PgxError, match="communicator not initialised"):
+            ctx.score_allreduce()
+        with pytest.raises(_lib.PgxError, match="negative point count"):
+            ctx.score_set_global_n(-1)
+        with pytest.raises(_lib.PgxError, match="negative label"):
+            ctx.set_labels(np.array([0, -1, 0], np.int32))
+        ctx.set_unary_q(np.zeros((100, 2), np.int64))
+        ctx.set_labels(np.full(100, 2, np.int32))                     # label 2 of a 2-label table: indexes per-label tables out of range
+        with pytest.raises(_lib.PgxError, match="out of range"):
+            ctx.expansion(0.0, 1.0)
+        with pytest.raises(_lib.PgxError, match="out of range"):
+            ctx.energy(0.0, 1.0)
     finally:
         ctx.close()
 
