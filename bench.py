@@ -4,9 +4,11 @@ hypotheses per GPU (config C4 points + the metric batch of SURVEY.md §8d), thro
 
 One step = one pass of the proposal hot path over one batch: score every hypothesis of the batch against all points
 (MSAC + compound-model score, scoring_function_with_compound_model.h:61-125), exchange the per-hypothesis results
-(RCCL all-gather when N > 1), fetch them and select the winner on the host.  Inputs (points, compound preference
-vector, hypotheses) are resident in HBM before the timed region starts.  Weak scaling: every rank scores its own 2048
-hypotheses against all points, value = (points x hypotheses of all ranks) / time.
+when N > 1, fetch them and select the winner on the host.  Inputs (points, compound preference vector, hypotheses) are
+resident in HBM before the timed region starts.  --gpus N (default mode, --scaling strong-points = BASELINE's fixed total
+work "1e6 pts x 2048 hyps, 1/2/4/8 GPU"): rank r holds 1/N of the points and scores all 2048 hypotheses against them, the
+integer accumulators are summed by an RCCL all-reduce (bitwise the 1-GPU table), value = (points x hypotheses of the JOB) /
+time, "scaling": "strong".  --scaling strong / weak: the hypotheses split over the ranks (all-gather) / 2048 per rank.
 
 The JSON line carries, next to the headline:
   roofline       HBM roofline of the dominant kernel: ALGORITHMIC bytes of SURVEY 8(d) (N d 8 + M p 8 + M 16 + N 8 for the
@@ -315,7 +317,18 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
     alpha-expansion from the all-zero labelling (what the first iteration of every PEARL::run does), on the neighbourhood
     graph built on the device.  expansion cycles/s and min-cuts/s are of that expansion; a PEARL iteration's labelling part
     is unary + expansion (its refits are host-size solves, not measured here)."""
-    c = _lib.Context(0)
+    # The leg repeats ONE expansion from the all-zero labelling on the same models: pgx_expansion's first-cycle memo (DESIGN.md 4.3)
+    # would answer every repetition after the first from its kept labels - cached work inside a timed region.  The context of
+    # this leg is created with the memo off (PGX_MF_MEMO is read once, in pgx_create): every repetition solves every min-cut.
+    saved = os.environ.get("PGX_MF_MEMO")
+    os.environ["PGX_MF_MEMO"] = "0"
+    try:
+        c = _lib.Context(0)
+    finally:
+        if saved is None:
+            os.environ.pop("PGX_MF_MEMO", None)
+        else:
+            os.environ["PGX_MF_MEMO"] = saved
     try:
         c.set_points(mt, pts)
         t0 = time.perf_counter()
@@ -341,7 +354,8 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
                 "expansion_cycles_per_sec": cycles / best, "mincuts_per_sec": st["mincuts"] / best,
                 "pearl_labelling_iterations_per_sec": 1.0 / (t_unary + best),
                 "ms_per_mincut": 1e3 * best / max(1, st["mincuts"]), **st,
-                "note": "best of 3; labels are those of the CPU oracle's Dinic solver (tests). <= 8192 sites: one workgroup, one launch per "
+                "memo_hits": int(c.expansion_paths()["memo"]),
+                "note": "best of 3, first-cycle memo OFF (every repetition solves every min-cut); labels are those of the CPU oracle's Dinic solver (tests). <= 8192 sites: one workgroup, one launch per "
                         "move (maxflow_tile.hip); larger: level-synchronous push-relabel, latency bound (DESIGN.md 4.3)"}
     finally:
         c.close()
