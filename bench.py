@@ -166,6 +166,24 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
                                       "kernel_ms": [float(x) for x in kt], "work": st,
                                       "step": f"{S} minimal samples drawn on the host (half all-inlier, half random) -> "
                                               "pgx_solve_minimal (device P3P, 4 slots each) -> launch -> fetch -> select"}
+    # (2b) the same step with the samples drawn ON THE DEVICE by the in-repo counter-based generator (csrc/rng.hip.h): no host RNG,
+    #      no index upload.  Uniform samples (what gcransac's UniformSampler draws: a new batch number every step), so nearly all
+    #      hypotheses are outlier-contaminated - a different batch from (2), listed for the step's host share, not for its kernel time
+    state = {"b": 0}
+
+    def step_sampled():
+        state["b"] += 1
+        ctx.solve_minimal_sampled(0x5EEDC0DE, state["b"], S, fetch=False)
+        ctx.score_launch(T2, has_compound=True)
+        res = ctx.score_fetch(exponent=2, out=buf)
+        return parallel.select_best(res["scores"], res["counts"])
+    try:
+        s, kt = timed_steps(ctx, step_sampled, steps, warmup)
+        legs["device_sampled_end_to_end"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s, "kernel_ms": [float(x) for x in kt],
+                                             "step": f"pgx_solve_minimal_sampled: {S} uniform minimal samples drawn on the device (Philox4x32-10, key + batch "
+                                                     "number) -> device P3P (4 slots each) -> launch -> fetch -> select; no host RNG, no index upload"}
+    except Exception as e:
+        legs["device_sampled_end_to_end"] = {"error": str(e)}
     ctx.score_upload(hyps)    # leave the metric batch resident
 
     # (3) one pgx_set_points (the once-per-problem preprocessing of the group-major path)

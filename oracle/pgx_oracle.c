@@ -1049,3 +1049,40 @@ int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32
     }
     return 0;
 }
+
+
+/* ---- in-repo counter-based generator (see pgx_oracle.h) ------------------------------------------------------------------ */
+void pgxo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, k[2] = {key[0], key[1]};
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
+void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, int m, int32_t* samples)
+{
+    const uint32_t k[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+    for (int64_t t = 0; t < count; ++t) {
+        const uint64_t s = (uint64_t)(first + t);
+        int64_t taken[8];
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int j = 0; j < m; ++j) {
+            if (j % 4 == 0) {
+                const uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), batch, (uint32_t)(j / 4)};
+                pgxo_philox4x32(ctr, k, w);
+            }
+            int64_t r = (int64_t)(((uint64_t)w[j % 4] * (uint64_t)(n - j)) >> 32);
+            int pos = 0;
+            while (pos < j && taken[pos] <= r) { ++r; ++pos; }      /* the r-th index not taken yet */
+            for (int q = j; q > pos; --q) taken[q] = taken[q - 1];
+            taken[pos] = r;
+            samples[t * m + j] = (int32_t)r;
+        }
+    }
+}

@@ -103,6 +103,12 @@ double pgxo_residual_sum(int model_type, const double *pts, int64_t n, const dou
 /* minimal solvers: 2-point line, 2-segment vanishing point; NaN model for a degenerate sample */
 int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32_t *samples, int S, double *models_out);
 
+/* ---- the in-repo counter-based generator: Philox4x32-10 (Salmon et al., SC'11) and the uniform
+ * minimal-sample sampler on it - an independent C restatement of csrc/rng.hip.h / pyprogressivex/_rng.py for the tests.
+ * Replaces gcransac::sampler::UniformSampler (progressivex_python.cpp:121, 215-245; source absent). */
+void pgxo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, int m, int32_t* samples);
+
 #ifdef __cplusplus
 }
 #endif

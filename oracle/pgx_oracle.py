@@ -45,6 +45,8 @@ def lib():
         _lib.pgxo_energy.restype = C.c_int64
         _lib.pgxo_maxflow.restype = C.c_int64
         _lib.pgxo_predicted_unseen_inliers.restype = C.c_uint64
+        _lib.pgxo_philox4x32.restype = None
+        _lib.pgxo_sample_uniform.restype = None
         _lib.pgxo_predicted_unseen_inliers.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
     return _lib
 
@@ -242,6 +244,20 @@ def epipolar_support(pts, F, T2, S2):
     lib().pgxo_epipolar_support(_p(pts, C.c_double), C.c_int64(pts.shape[0]), _p(F, C.c_double), C.c_double(T2), C.c_double(S2),
                                 _p(out, C.c_int64))
     return int(out[0]), int(out[1])
+
+
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in ctr]); k = (C.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+    out = (C.c_uint32 * 4)()
+    lib().pgxo_philox4x32(c, k, out)
+    return [int(x) for x in out]
+
+
+def sample_uniform(key, batch, first, count, n, m):
+    out = np.empty((count, m), dtype=np.int32)
+    lib().pgxo_sample_uniform(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int64(first), C.c_int64(count),
+                              C.c_int64(n), C.c_int(m), _p(out, C.c_int32))
+    return out
 
 
 def residual_sum(model_type, pts, model, labels, label):

@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "pgx_internal.h"
+#include "rng.hip.h"
 
 namespace pgx {
 
@@ -416,10 +417,20 @@ static int upload_samples(pgx_ctx* ctx, const int32_t* samples, size_t bytes)
     return PGX_OK;
 }
 
-int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out)
+// ---- samples drawn on the device (rng.hip.h): one lane per sample, straight into the buffer the solvers read -----------------
+__global__ __launch_bounds__(256) void sample_uniform_kernel(unsigned long long key, unsigned batch, int S, int64_t n, int m, int* __restrict__ samples)
+{
+    const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (s >= S) return;
+    int32_t row[kMaxSampleSize];
+    sample_distinct(key, batch, (uint64_t)s, n, m, row);
+    for (int j = 0; j < m; ++j) samples[(int64_t)s * m + j] = row[j];
+}
+
+int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out, bool resident)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: points not set");
-    if (!samples || S <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: empty sample batch");
+    if ((!samples && !resident) || S <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: empty sample batch");
     if (ctx->model_type == kFundamental) {
         // three model slots per sample; isotropic pre-scaling by the largest coordinate magnitude (pmax of set_points is 1
         // for this model type, so it is recomputed here from the caller-visible data: umax is not kept either)
@@ -428,7 +439,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((Mtot + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)Mtot * 9 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 7 * sizeof(int32_t)));
+        if (!resident) PGX_TRY(upload_samples(ctx, samples, (size_t)S * 7 * sizeof(int32_t)));
         const unsigned blocks = (unsigned)((S + 63) / 64);
         hipLaunchKernelGGL(solve_f7_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
@@ -444,7 +455,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((Mtot + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)Mtot * 12 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 3 * sizeof(int32_t)));
+        if (!resident) PGX_TRY(upload_samples(ctx, samples, (size_t)S * 3 * sizeof(int32_t)));
         hipLaunchKernelGGL(solve_p3p_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
@@ -459,7 +470,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         ctx->Mpad = ((S + 255) / 256) * 256;
         PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 9 * sizeof(double)));
         PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-        PGX_TRY(upload_samples(ctx, samples, (size_t)S * 4 * sizeof(int32_t)));
+        if (!resident) PGX_TRY(upload_samples(ctx, samples, (size_t)S * 4 * sizeof(int32_t)));
         hipLaunchKernelGGL(solve_h4_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
@@ -474,7 +485,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     ctx->Mpad = ((S + 255) / 256) * 256;
     PGX_TRY(ensure(ctx, ctx->models, (size_t)S * 3 * sizeof(double)));
     PGX_TRY(ensure(ctx, ctx->perm, (size_t)ctx->Mpad * sizeof(int)));
-    PGX_TRY(upload_samples(ctx, samples, (size_t)S * 2 * sizeof(int32_t)));
+    if (!resident) PGX_TRY(upload_samples(ctx, samples, (size_t)S * 2 * sizeof(int32_t)));
     const unsigned blocks = (unsigned)((ctx->Mpad + kSolveBlock - 1) / kSolveBlock);
     if (ctx->model_type == kLine2D)
         hipLaunchKernelGGL((solve_kernel<kLine2D>), dim3(blocks), dim3(kSolveBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
@@ -488,6 +499,32 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->M = S;
     return PGX_OK;
+}
+
+// pgx_solve_minimal_sampled: S uniform minimal samples from the in-repo generator (key, batch), drawn by the device into the
+// solvers' sample buffer - no host RNG, no index upload - then the solver of the resident model type as in pgx_solve_minimal.
+int solve_minimal_sampled_launch(pgx_ctx* ctx, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
+{
+    if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: points not set");
+    if (S <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: empty sample batch");
+    int m = 0;
+    switch (ctx->model_type) {
+    case kLine2D: case kVanishingPoint: m = 2; break;
+    case kPnP: m = 3; break;
+    case kHomography: m = 4; break;
+    case kFundamental: m = 7; break;
+    default: return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: no device solver for model type %d", ctx->model_type);
+    }
+    if (ctx->n < m) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: %lld points, the minimal sample needs %d", (long long)ctx->n, m);
+    PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * m * sizeof(int32_t)));
+    hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n, m,
+                       ctx->scratch.as<int>());
+    PGX_HIP(ctx, hipGetLastError());
+    if (samples_out) {
+        PGX_HIP(ctx, hipMemcpyAsync(samples_out, ctx->scratch.p, (size_t)S * m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return solve_minimal_launch(ctx, nullptr, S, models_out, true);
 }
 
 }  // namespace pgx

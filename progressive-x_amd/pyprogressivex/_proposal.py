@@ -65,6 +65,27 @@ class UniformSampler:
         return _distinct_rows(self.rng, np.full(count, self.n, dtype=np.int64), m)
 
 
+class PhiloxUniformSampler(UniformSampler):
+    """gcransac::sampler::UniformSampler on the in-repo counter-based generator (_rng.py / csrc/rng.hip.h): draw number b of
+    this sampler is batch b under the sampler's 64-bit key, so a context that can (`solve_minimal_sampled`) draws the batch on
+    the device, inside the solver's launch, and every other consumer gets the same rows from `draw`.  Opt-in
+    (`sampler_rng="philox"` on the drop-in calls): the default uniform sampler keeps numpy's stream."""
+
+    def __init__(self, n, rng):
+        super().__init__(n, rng)
+        self.key = int(rng.integers(0, 1 << 63))     # one draw from the call's seeded generator: the key of every batch
+        self.batch = 0                               # draws made so far (NOT restarted by reset(): a new proposal, new samples)
+        self.last = None                             # (batch, count, m) of the latest draw: ProposalEngine hands it to the device
+
+    def draw(self, count, m):
+        from . import _rng
+        if self.n < m:
+            return np.zeros((0, m), dtype=np.int64)
+        self.last = (self.batch, int(count), int(m))
+        self.batch += 1
+        return _rng.uniform_samples(self.key, self.last[0], int(count), self.n, int(m))
+
+
 def prosac_growth_function(n, m, t_n):
     """Chum & Matas' PROSAC growth function T'_n as USAC / GC-RANSAC tabulate it [UPSTREAM-MEMORY]: g[i] = number of
     samples after which the hypothesis-generation set grows beyond its i + 1 best points (g[i] = 1 for i < m)."""
@@ -327,7 +348,12 @@ class ProposalEngine:
         if est.device_minimal and not sharded:
             # hypotheses generated on the GPU from the resident points and scored where they are (no model upload);
             # a degenerate sample is a NaN model: never an inlier, never the winner
-            models = self.ctx.solve_minimal(samples)
+            philox = getattr(self.sampler, "last", None) if hasattr(self.ctx, "solve_minimal_sampled") else None
+            if philox is not None and philox[1] == len(samples):
+                # the batch is drawn on the device from (key, batch): the same rows as `samples` (tests), no index upload
+                models, _ = self.ctx.solve_minimal_sampled(self.sampler.key, philox[0], len(samples))
+            else:
+                models = self.ctx.solve_minimal(samples)
             src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)
             self.ctx.score_launch(T2, has_compound=has_compound)
             table = self.ctx.score_fetch(exponent)

@@ -1,0 +1,51 @@
+"""The in-repo counter-based random number generator (Philox4x32-10) and the uniform minimal-sample sampler built on it -
+the numpy restatement of csrc/rng.hip.h, word for word ("a counter-based RNG identical in Python and
+C++"; §8(f1): "uniform sampler with the in-repo RNG").  Replaces gcransac::sampler::UniformSampler
+(progressivex_python.cpp:121, 215-245; source absent, seeded from std::random_device upstream).
+
+Sample s of batch b under a 64-bit key is a pure function of (key, b, s): the device generates a batch inside
+pgx_solve_minimal_sampled's launch, the host (and the oracle-backed context of the tests) the same rows here."""
+import numpy as np
+
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+_S32 = np.uint64(32)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Philox4x32-R on arrays of 32-bit words (broadcast together): four uint32 arrays."""
+    c0, c1, c2, c3 = np.broadcast_arrays(*(np.asarray(x, dtype=np.uint64) & _MASK for x in (c0, c1, c2, c3)))
+    k0, k1 = np.uint64(int(k0) & 0xFFFFFFFF), np.uint64(int(k1) & 0xFFFFFFFF)
+    for _ in range(rounds):
+        p0, p1 = _M0 * c0, _M1 * c2
+        c0, c1, c2, c3 = (p1 >> _S32) ^ c1 ^ k0, p1 & _MASK, (p0 >> _S32) ^ c3 ^ k1, p0 & _MASK
+        k0, k1 = (k0 + _W0) & _MASK, (k1 + _W1) & _MASK
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def uniform_samples(key, batch, count, n, m, first=0):
+    """[count, m] int64: samples first .. first + count - 1 of batch `batch` under `key` - m DISTINCT indices of range(n) each
+    (csrc/rng.hip.h sample_distinct: position j takes the r-th index not taken yet, r = (word * (n - j)) >> 32)."""
+    if not (1 <= m <= 8) or n < m:
+        raise ValueError("uniform_samples: need 1 <= m <= 8 <= ... and n >= m")
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    s = np.arange(first, first + count, dtype=np.uint64)
+    out = np.empty((count, m), dtype=np.int64)
+    taken = np.empty((count, m), dtype=np.int64)      # ascending per row
+    words = None
+    for j in range(m):
+        if j % 4 == 0:
+            words = philox4x32(s & _MASK, s >> _S32, int(batch) & 0xFFFFFFFF, j // 4, key & 0xFFFFFFFF, key >> 32)
+        r = ((words[j % 4].astype(np.uint64) * np.uint64(n - j)) >> _S32).astype(np.int64)
+        pos = np.zeros(count, dtype=np.int64)
+        for q in range(j):                            # step past every taken index <= r, in ascending order
+            hit = (pos == q) & (taken[:, q] <= r)
+            r = r + hit
+            pos = pos + hit
+        for q in range(j, 0, -1):                     # insert at pos, keeping the row ascending
+            shift = pos < q
+            taken[:, q] = np.where(shift, taken[:, q - 1], taken[:, q])
+        taken[np.arange(count), pos] = r
+        out[:, j] = r
+    return out

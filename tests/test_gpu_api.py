@@ -55,6 +55,22 @@ def test_poses_with_spatial_coherence_identical_to_cpu_restatement(monkeypatch):
     assert _me(lab, 3, gt) < 0.05
 
 
+def test_philox_sampler_device_drawn_batches_identical_to_cpu_restatement(monkeypatch):
+    """sampler_rng="philox": the GPU context draws every proposal's samples on the device (pgx_solve_minimal_sampled), the
+    oracle-backed host draws them with the numpy restatement of the same generator: the same hypotheses, the same result."""
+    pts, gt, _ = datasets.make_lines(seed=0)
+    (L, lab), (Lr, labr) = _both(monkeypatch, px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99,
+                                 sampler_id=0, seed=1, minimum_point_number=50, sampler_rng="philox")
+    assert L.shape == (3, 3) and np.array_equal(lab, labr) and np.allclose(L, Lr, rtol=1e-9, atol=1e-12)
+    assert _me(lab, 3, gt) < 0.03
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=600, n_objects=3, n_outliers=600, seed=0)
+    (P, lab), (Pr, labr) = _both(monkeypatch, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=30, sampler_rng="philox")
+    assert P.shape == (9, 4) and np.array_equal(lab, labr) and np.allclose(P, Pr, rtol=1e-8, atol=1e-8)
+    assert _me(lab, 3, gt) < 0.05
+    with pytest.raises(ValueError, match="sampler_rng"):
+        px.findLines(pts, np.array(0), 1000, 1000, sampler_id=0, sampler_rng="mt19937")
+
+
 def test_vanishing_points_identical_to_cpu_restatement(monkeypatch):
     pts, gt, _ = datasets.make_vanishing_points(n_inliers=3000, n_vps=6, n_outliers=3000, seed=0)
     (V, lab), (Vr, labr) = _both(monkeypatch, px.findVanishingPoints, pts, np.array(0), 1000, 1000, threshold=1.5,

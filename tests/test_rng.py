@@ -1,0 +1,66 @@
+"""The in-repo counter-based generator: Philox4x32-10 against the published known-answer vectors
+(Random123's kat_vectors: Salmon, Moraes, Dror, Shaw, SC'11), three restatements against each other - numpy
+(pyprogressivex/_rng.py), C (oracle/pgx_oracle.c) and, on the GPU, the device kernel (csrc/rng.hip.h) - and the uniform
+minimal-sample sampler built on it: distinct indices, in range, uniform, a pure function of (key, batch, sample)."""
+import numpy as np
+import pytest
+
+from pyprogressivex import _lib, _proposal, _rng
+
+KAT = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+       ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+       ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+
+
+def test_philox_known_answers(oracle):
+    for ctr, key, want in KAT:
+        assert tuple(int(x) for x in _rng.philox4x32(*ctr, *key)) == want
+        assert tuple(oracle.philox4x32(ctr, key)) == want
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        ctr, key = rng.integers(0, 1 << 32, 4), rng.integers(0, 1 << 32, 2)
+        assert [int(x) for x in _rng.philox4x32(*ctr, *key)] == oracle.philox4x32(ctr, key)
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (7, 7), (9, 7), (10, 3), (1000, 4), (1000003, 3), (2 ** 31 - 1, 8)])
+def test_uniform_samples_numpy_equals_c(oracle, n, m):
+    key, batch = 0x1234567890ABCDEF, 5
+    a = _rng.uniform_samples(key, batch, 3000, n, m, first=7)
+    assert np.array_equal(a, oracle.sample_uniform(key, batch, 7, 3000, n, m))
+    srt = np.sort(a, axis=1)
+    assert a.min() >= 0 and a.max() < n and (srt[:, 1:] != srt[:, :-1]).all()
+    assert np.array_equal(a[10:20], _rng.uniform_samples(key, batch, 10, n, m, first=17))          # a pure function of the sample number
+    assert not np.array_equal(a, _rng.uniform_samples(key, batch + 1, 3000, n, m, first=7))
+
+
+def test_uniform_samples_are_uniform():
+    s = _rng.uniform_samples(99, 0, 400000, 9, 7)
+    for j in (0, 3, 6):            # every position uniform over the 9 indices: 7 / 9 of the mass each way
+        f = np.bincount(s[:, j], minlength=9) / s.shape[0]
+        assert np.abs(f - 1.0 / 9.0).max() < 0.004
+    pairs = np.bincount(s[:, 0] * 9 + s[:, 1], minlength=81).reshape(9, 9) / s.shape[0]
+    assert np.abs(pairs[~np.eye(9, dtype=bool)] - 1.0 / 72.0).max() < 0.002 and np.all(np.diag(pairs) == 0)
+
+
+def test_philox_sampler_batches():
+    smp = _proposal.PhiloxUniformSampler(500, np.random.default_rng(3))
+    a, b = smp.draw(100, 4), smp.draw(100, 4)
+    assert a.shape == (100, 4) and not np.array_equal(a, b) and smp.last == (1, 100, 4)
+    again = _proposal.PhiloxUniformSampler(500, np.random.default_rng(3))
+    assert np.array_equal(again.draw(100, 4), a)
+    assert _proposal.PhiloxUniformSampler(3, np.random.default_rng(0)).draw(10, 4).shape == (0, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m", [("line", 2), ("vanishing_point", 2), ("pnp", 3), ("homography", 4), ("fundamental", 7)])
+@pytest.mark.parametrize("n", [8, 1000, 100003])
+def test_device_sampler_draws_the_same_rows_and_models(gpu_ctx, name, m, n):
+    from helpers import make_case
+    mt, pts, models, thr = make_case(name, n, 2, seed=n)
+    gpu_ctx.set_points(mt, pts)
+    key, batch, S = 0xFEEDFACE12345678, 11, 777
+    got, smp = gpu_ctx.solve_minimal_sampled(key, batch, S, fetch=True, fetch_samples=True)
+    want = _rng.uniform_samples(key, batch, S, n, m)
+    assert np.array_equal(smp, want)
+    ref = gpu_ctx.solve_minimal(want.astype(np.int32))
+    assert np.array_equal(got, ref, equal_nan=True)          # the same solver on the same samples: bit for bit
