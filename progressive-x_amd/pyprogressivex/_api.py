@@ -102,12 +102,17 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     # FlannNeighborhoodGraph(&points, radius) [U-7]: built on the GPU (pgx_graph_build) and left resident there; the
     # CSR comes back for the neighbourhood samplers.
     resident = True
+    # ... and it only comes BACK to the host for the sampler that walks it (NAPSAC): 74 MB of CSR at N = 1e6 otherwise cross PCIe
+    # for nothing (find6DPoses always samples uniformly)
+    fetch = bool(getattr(sampler_factory, "needs_graph", True))
     if neighborhood == "radius":
-        graph = ctx.graph_build(graph_points, _lib.GRAPH_BALL, radius=radius)
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_BALL, radius=radius, fetch=fetch)
     elif str(neighborhood).startswith("knn:"):
-        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN, k=int(str(neighborhood)[4:]))
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN, k=int(str(neighborhood)[4:]), fetch=fetch)
     else:
-        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN_IN_BALL, radius=radius, k=5)
+        graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN_IN_BALL, radius=radius, k=5, fetch=fetch)
+    if not fetch:
+        graph = None
     sampler = sampler_factory(n, rng, graph)
     if sampler_rng == "philox" and type(sampler) is _proposal.UniformSampler:   # the in-repo counter-based generator (device-drawable)
         sampler = _proposal.PhiloxUniformSampler(n, rng)
@@ -152,6 +157,7 @@ def _sampler_factory(sampler_id, valid, pts=None, sizes=None, sample_size=None, 
             return _proposal.ProgressiveNapsacSampler(n, rng, pts, sizes, sample_size)
         return _proposal.NapsacSampler(n, rng, graph)
     make.unknown = sampler_id not in valid
+    make.needs_graph = valid.get(sampler_id) == "napsac"
     make.sampler_id = sampler_id
     return make
 
@@ -303,6 +309,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
     def factory(n_, rng, graph):
         print("Neighborhood calculation time = %f secs." % (time.perf_counter() - t0))   # :109
         return _proposal.UniformSampler(n_, rng)                                          # :112 always uniform
+    factory.needs_graph = False
 
     models, labels, _ = _run(est, normalized, raw, neighborhood_ball_radius, factory,
                              threshold=threshold / f, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
