@@ -973,6 +973,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
                 }
                 if (rc != PGX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
                 if (batch.empty()) break;
+                PGX_TRY(region_batch_fetch(ctx, (int)batch.size()));
                 PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 int next = ctx->L;
                 for (size_t k = 0; k < batch.size(); ++k) {

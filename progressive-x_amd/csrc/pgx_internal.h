@@ -242,6 +242,7 @@ void tile_free(pgx_ctx* ctx);
 struct MfView;
 constexpr int PGX_REGION_PENDING = 1001;  // expand_alpha_region with ctx->region_defer: enqueued, result by region_result after a synchronisation
 int region_batch_begin(pgx_ctx* ctx);
+int region_batch_fetch(pgx_ctx* ctx, int slots);   // the batch's results to the host mirror (one copy), before the synchronisation
 int region_result(pgx_ctx* ctx, int slot, int alpha, int* status, int64_t* changed);
 bool region_moves_apply(const pgx_ctx* ctx);   // maxflow.hip: pgx_expansion's moves on the resident problem go through expand_alpha_region
 int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed);   // maxflow_tile.hip: a move with few open sites, one workgroup
