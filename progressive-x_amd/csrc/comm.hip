@@ -178,6 +178,50 @@ int pgx_comm_allreduce_max_f64(pgx_ctx* ctx, double* value)
     return PGX_OK;
 }
 
+} // extern "C"
+
+// common head of the two pipelined exchanges: the slot's stream, events and buffers (stage: what leaves this rank, gathered: what
+// comes back, host: its pinned copy)
+static int slot_prepare(pgx_ctx* ctx, const char* who, int slot, size_t stage_bytes, size_t result_bytes, ExchangeSlot** out)
+{
+    if (slot < 0 || slot > 1) return fail(ctx, PGX_ERR_INVALID, "%s: slot %d (0 or 1)", who, slot);
+    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "%s: nothing launched", who);
+    PGX_HIP(ctx, hipSetDevice(ctx->device));
+    CommState* cs = ctx->comm;
+    ExchangeSlot& e = cs->slot[slot];
+    if (e.busy) return fail(ctx, PGX_ERR_INVALID, "%s: slot %d is still in flight (collect it with the matching _end call)", who, slot);
+    if (!cs->xstream) PGX_HIP(ctx, hipStreamCreateWithFlags(&cs->xstream, hipStreamNonBlocking));
+    if (!e.scored) PGX_HIP(ctx, hipEventCreateWithFlags(&e.scored, hipEventDisableTiming));
+    if (!e.done) PGX_HIP(ctx, hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+    PGX_TRY(ensure(ctx, e.stage, stage_bytes));
+    PGX_TRY(ensure(ctx, e.gathered, result_bytes));
+    if (e.host_cap < result_bytes) {
+        if (e.host) (void)hipHostFree(e.host);
+        e.host = nullptr; e.host_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&e.host, result_bytes * 2, hipHostMallocDefault));
+        e.host_cap = result_bytes * 2;
+    }
+    *out = &e;
+    return PGX_OK;
+}
+
+// rows of M (count, value, shared) triples out of a [3][Mpad] block, with the score of scoring_function_with_compound_model.h:110,120
+static void unpack_block(const void* block, size_t M, size_t Mp, int has_compound, int exponent, int64_t* counts, double* values, double* shared, double* scores)
+{
+    const int64_t* c = (const int64_t*)block;
+    const double* v = (const double*)block + Mp;
+    const double* sh = (const double*)block + 2 * Mp;
+    if (counts) memcpy(counts, c, M * 8);
+    if (values) memcpy(values, v, M * 8);
+    if (shared) memcpy(shared, sh, M * 8);
+    if (scores)
+        for (size_t m = 0; m < M; ++m)
+            // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
+            scores[m] = has_compound && !(sh[m] == 0.0 && !std::signbit(sh[m]) && exponent > 0) ? v[m] - std::pow(sh[m], (double)exponent) : v[m];
+}
+
+extern "C" {
+
 // counts | values | shared of a launch are ONE allocation of 3 x Mpad words (score_launch): one all-gather of that block per
 // step (three grouped ones before) into [rank][3][Mpad], one copy back into pinned memory (three copies into pageable
 // vectors before: staged, ~15 us each).  Every rank scores a shard of the same padded length, so Mpad agrees across ranks.
@@ -208,19 +252,9 @@ int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* val
     }
     PGX_HIP(ctx, hipMemcpyAsync(ctx->h_res, ctx->g_counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t r = 0; r < G; ++r) {   // rank-major [M] rows out of [rank][3][Mpad]
-        const int64_t* c = (const int64_t*)ctx->h_res + r * 3 * Mp;
-        const double* v = (const double*)ctx->h_res + r * 3 * Mp + Mp;
-        const double* s = (const double*)ctx->h_res + r * 3 * Mp + 2 * Mp;
-        if (counts) memcpy(counts + r * M, c, M * 8);
-        if (values) memcpy(values + r * M, v, M * 8);
-        if (shared) memcpy(shared + r * M, s, M * 8);
-        if (scores)
-            for (size_t m = 0; m < M; ++m)
-                // (shared == +0: pow(+0, e) = +0 and v - (+0) = v bit for bit - capi.hip finish_scores)
-                scores[r * M + m] = ctx->score_has_compound && !(s[m] == 0.0 && !std::signbit(s[m]) && exponent > 0)
-                                        ? v[m] - std::pow(s[m], (double)exponent) : v[m];
-    }
+    for (size_t r = 0; r < G; ++r)   // rank-major [M] rows out of [rank][3][Mpad]
+        unpack_block((const int64_t*)ctx->h_res + r * 3 * Mp, M, Mp, ctx->score_has_compound, exponent, counts ? counts + r * M : nullptr,
+                     values ? values + r * M : nullptr, shared ? shared + r * M : nullptr, scores ? scores + r * M : nullptr);
     return PGX_OK;
 }
 
@@ -233,24 +267,11 @@ int pgx_score_fetch_all(pgx_ctx* ctx, int exponent, int64_t* counts, double* val
 int pgx_score_allgather_begin(pgx_ctx* ctx, int slot)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: communicator not initialised");
-    if (slot < 0 || slot > 1) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: slot %d (0 or 1)", slot);
-    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: nothing launched");
-    PGX_HIP(ctx, hipSetDevice(ctx->device));
     CommState* cs = ctx->comm;
-    ExchangeSlot& e = cs->slot[slot];
-    if (e.busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allgather_begin: slot %d is still in flight (call pgx_score_allgather_end)", slot);
-    if (!cs->xstream) PGX_HIP(ctx, hipStreamCreateWithFlags(&cs->xstream, hipStreamNonBlocking));
-    if (!e.scored) PGX_HIP(ctx, hipEventCreateWithFlags(&e.scored, hipEventDisableTiming));
-    if (!e.done) PGX_HIP(ctx, hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
-    const size_t W = (size_t)3 * (size_t)ctx->Mpad, G = (size_t)cs->nranks, need = G * W * 8;
-    PGX_TRY(ensure(ctx, e.stage, W * 8));
-    PGX_TRY(ensure(ctx, e.gathered, need));
-    if (e.host_cap < need) {
-        if (e.host) (void)hipHostFree(e.host);
-        e.host = nullptr; e.host_cap = 0;
-        PGX_HIP(ctx, hipHostMalloc(&e.host, need * 2, hipHostMallocDefault));
-        e.host_cap = need * 2;
-    }
+    const size_t W = (size_t)3 * (size_t)ctx->Mpad, need = (size_t)cs->nranks * W * 8;
+    ExchangeSlot* ep = nullptr;
+    PGX_TRY(slot_prepare(ctx, "pgx_score_allgather_begin", slot, W * 8, need, &ep));
+    ExchangeSlot& e = *ep;
     PGX_HIP(ctx, hipMemcpyAsync(e.stage.p, ctx->counts.p, W * 8, hipMemcpyDeviceToDevice, ctx->stream));
     PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
     PGX_HIP(ctx, hipStreamWaitEvent(cs->xstream, e.scored, 0));
@@ -271,18 +292,9 @@ int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
     PGX_HIP(ctx, hipEventSynchronize(e.done));
     e.busy = 0;
     const size_t M = (size_t)e.M, Mp = (size_t)e.Mpad, G = (size_t)ctx->comm->nranks;
-    for (size_t r = 0; r < G; ++r) {   // rank-major [M] rows out of [rank][3][Mpad]
-        const int64_t* c = (const int64_t*)e.host + r * 3 * Mp;
-        const double* v = (const double*)e.host + r * 3 * Mp + Mp;
-        const double* sh = (const double*)e.host + r * 3 * Mp + 2 * Mp;
-        if (counts) memcpy(counts + r * M, c, M * 8);
-        if (values) memcpy(values + r * M, v, M * 8);
-        if (shared) memcpy(shared + r * M, sh, M * 8);
-        if (scores)
-            for (size_t m = 0; m < M; ++m)
-                scores[r * M + m] = e.has_compound && !(sh[m] == 0.0 && !std::signbit(sh[m]) && exponent > 0)
-                                        ? v[m] - std::pow(sh[m], (double)exponent) : v[m];
-    }
+    for (size_t r = 0; r < G; ++r)   // rank-major [M] rows out of [rank][3][Mpad]
+        unpack_block((const int64_t*)e.host + r * 3 * Mp, M, Mp, e.has_compound, exponent, counts ? counts + r * M : nullptr,
+                     values ? values + r * M : nullptr, shared ? shared + r * M : nullptr, scores ? scores + r * M : nullptr);
     return PGX_OK;
 }
 
@@ -315,24 +327,11 @@ int pgx_score_allreduce(pgx_ctx* ctx)
 int pgx_score_allreduce_begin(pgx_ctx* ctx, int slot)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: communicator not initialised");
-    if (slot < 0 || slot > 1) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: slot %d (0 or 1)", slot);
-    if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: nothing launched");
-    PGX_HIP(ctx, hipSetDevice(ctx->device));
     CommState* cs = ctx->comm;
-    ExchangeSlot& e = cs->slot[slot];
-    if (e.busy) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce_begin: slot %d is still in flight (call pgx_score_allreduce_end)", slot);
-    if (!cs->xstream) PGX_HIP(ctx, hipStreamCreateWithFlags(&cs->xstream, hipStreamNonBlocking));
-    if (!e.scored) PGX_HIP(ctx, hipEventCreateWithFlags(&e.scored, hipEventDisableTiming));
-    if (!e.done) PGX_HIP(ctx, hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
     const size_t W = (size_t)3 * (size_t)ctx->Mpad, need = W * 8;
-    PGX_TRY(ensure(ctx, e.stage, need));
-    PGX_TRY(ensure(ctx, e.gathered, need));
-    if (e.host_cap < need) {
-        if (e.host) (void)hipHostFree(e.host);
-        e.host = nullptr; e.host_cap = 0;
-        PGX_HIP(ctx, hipHostMalloc(&e.host, need * 2, hipHostMallocDefault));
-        e.host_cap = need * 2;
-    }
+    ExchangeSlot* ep = nullptr;
+    PGX_TRY(slot_prepare(ctx, "pgx_score_allreduce_begin", slot, need, need, &ep));
+    ExchangeSlot& e = *ep;
     unsigned long long* blk = (unsigned long long*)e.stage.p;
     PGX_TRY(score_acc_export(ctx, blk, ctx->stream));
     PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
@@ -355,16 +354,7 @@ int pgx_score_allreduce_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
     ExchangeSlot& e = ctx->comm->slot[slot];
     PGX_HIP(ctx, hipEventSynchronize(e.done));
     e.busy = 0; e.reduced = 0;
-    const size_t M = (size_t)e.M, Mp = (size_t)e.Mpad;
-    const int64_t* c = (const int64_t*)e.host;
-    const double* v = (const double*)e.host + Mp;
-    const double* sh = (const double*)e.host + 2 * Mp;
-    if (counts) memcpy(counts, c, M * 8);
-    if (values) memcpy(values, v, M * 8);
-    if (shared) memcpy(shared, sh, M * 8);
-    if (scores)
-        for (size_t m = 0; m < M; ++m)
-            scores[m] = e.has_compound && !(sh[m] == 0.0 && !std::signbit(sh[m]) && exponent > 0) ? v[m] - std::pow(sh[m], (double)exponent) : v[m];
+    unpack_block(e.host, (size_t)e.M, (size_t)e.Mpad, e.has_compound, exponent, counts, values, shared, scores);
     return PGX_OK;
 }
 
