@@ -92,11 +92,14 @@ int pgx_score_upload(pgx_ctx *ctx, const double *models, int M);
  * call returns; with models_out == NULL the call does not wait for the solver (the batch stays on the device). */
 int pgx_solve_minimal(pgx_ctx *ctx, const int32_t *samples, int S, double *models_out);
 /* The same with the samples DRAWN ON THE DEVICE by the in-repo counter-based generator (csrc/rng.hip.h: Philox4x32-10; sample s
- * of batch `batch` under `key` is a pure function of (key, batch, s): m distinct indices of range(n), m = the resident model
- * type's minimal sample size) - gcransac::sampler::UniformSampler (progressivex_python.cpp:121, 215-245; absent upstream, seeded
- * from std::random_device there).  No host RNG, no index upload; pyprogressivex/_rng.py and the oracle produce the same rows.
- * samples_out (may be NULL): S x m indices; models_out as above. */
-int pgx_solve_minimal_sampled(pgx_ctx *ctx, uint64_t key, uint32_t batch, int S, int32_t *samples_out, double *models_out);
+ * of batch `batch` under `key` is a pure function of (key, batch, s); m = the resident model type's minimal sample size).
+ * sampler 0: gcransac::sampler::UniformSampler - m distinct indices of range(n) (progressivex_python.cpp:121, 215-245);
+ * sampler 1: NapsacSampler (sampler id 3 there, the default of findHomographies / findTwoViewMotions) - a uniform centre and m - 1
+ * distinct entries of its row of the resident neighbourhood graph; a centre with fewer neighbours yields the row -1 .. -1 and a
+ * NaN model (the iteration is spent).  Both absent upstream and seeded from std::random_device there.  No host RNG, no index
+ * upload; pyprogressivex/_rng.py and the oracle produce the same rows.  samples_out (may be NULL): S x m indices. */
+enum { PGX_SAMPLER_UNIFORM = 0, PGX_SAMPLER_NAPSAC = 1 };
+int pgx_solve_minimal_sampled(pgx_ctx *ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t *samples_out, double *models_out);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
                     double *scores, uint64_t *masks);

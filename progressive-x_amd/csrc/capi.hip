@@ -420,10 +420,10 @@ int pgx_solve_minimal(pgx_ctx* ctx, const int32_t* samples, int S, double* model
     return solve_minimal_launch(ctx, samples, S, models_out);
 }
 
-int pgx_solve_minimal_sampled(pgx_ctx* ctx, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
+int pgx_solve_minimal_sampled(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
 {
     CTX_GUARD(ctx);
-    return solve_minimal_sampled_launch(ctx, key, batch, S, samples_out, models_out);
+    return solve_minimal_sampled_launch(ctx, sampler, key, batch, S, samples_out, models_out);
 }
 
 int pgx_score_set_global_n(pgx_ctx* ctx, int64_t n_total)

@@ -220,7 +220,7 @@ int graph_build_reverse(pgx_ctx* ctx);
 int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int kind, double radius, int k, int64_t* arcs);
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out, bool resident = false);   // resident: the samples are in ctx->scratch already
-int solve_minimal_sampled_launch(pgx_ctx* ctx, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out);
+int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out);
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, int use_weights, int wpow, double* out, int64_t* count, int64_t* bad);
 int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, int use_weights, int wpow,

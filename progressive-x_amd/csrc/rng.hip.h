@@ -48,4 +48,31 @@ __host__ __device__ inline void sample_distinct(uint64_t key, uint32_t batch, ui
     }
 }
 
+// NAPSAC on the same generator (gcransac::sampler::NapsacSampler, progressivex_python.cpp:241 sampler id 3; absent upstream): word 0
+// draws the centre uniformly, words 1 .. m-1 draw m - 1 DISTINCT entries of the centre's neighbour list (the resident graph's CSR
+// row), by the same "r-th entry not taken yet" rule.  A centre with fewer than m - 1 neighbours gives no sample: the row is all -1,
+// the solvers turn it into a NaN model, the RANSAC iteration is spent (what the reference's failed sample costs).
+__host__ __device__ inline void sample_napsac(uint64_t key, uint32_t batch, uint64_t s, int64_t n, const int* off, const int* idx, int m, int32_t* out)
+{
+    int32_t taken[kMaxSampleSize];
+    uint32_t w[4];
+    philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), batch, 0u, (uint32_t)key, (uint32_t)(key >> 32), w);
+    const int64_t c = (int64_t)(((uint64_t)w[0] * (uint64_t)n) >> 32);
+    const int a0 = off[c], deg = off[c + 1] - a0;
+    if (deg < m - 1) {
+        for (int j = 0; j < m; ++j) out[j] = -1;
+        return;
+    }
+    out[0] = (int32_t)c;
+    for (int j = 1; j < m; ++j) {
+        if ((j & 3) == 0) philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), batch, (uint32_t)(j >> 2), (uint32_t)key, (uint32_t)(key >> 32), w);
+        int64_t r = (int64_t)(((uint64_t)w[j & 3] * (uint64_t)(deg - (j - 1))) >> 32);
+        int pos = 0;
+        for (; pos < j - 1 && taken[pos] <= r; ++pos) ++r;
+        for (int q = j - 1; q > pos; --q) taken[q] = taken[q - 1];
+        taken[pos] = (int32_t)r;
+        out[j] = idx[a0 + r];
+    }
+}
+
 }  // namespace pgx

@@ -427,6 +427,16 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(unsigned long long 
     for (int j = 0; j < m; ++j) samples[(int64_t)s * m + j] = row[j];
 }
 
+__global__ __launch_bounds__(256) void sample_napsac_kernel(unsigned long long key, unsigned batch, int S, int64_t n, const int* __restrict__ off,
+                                                            const int* __restrict__ idx, int m, int* __restrict__ samples)
+{
+    const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (s >= S) return;
+    int32_t row[kMaxSampleSize];
+    sample_napsac(key, batch, (uint64_t)s, n, off, idx, m, row);
+    for (int j = 0; j < m; ++j) samples[(int64_t)s * m + j] = row[j];
+}
+
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out, bool resident)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: points not set");
@@ -501,10 +511,12 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     return PGX_OK;
 }
 
-// pgx_solve_minimal_sampled: S uniform minimal samples from the in-repo generator (key, batch), drawn by the device into the
+// pgx_solve_minimal_sampled: S minimal samples (uniform, or NAPSAC on the resident graph) from the in-repo generator (key, batch), drawn by the device into the
 // solvers' sample buffer - no host RNG, no index upload - then the solver of the resident model type as in pgx_solve_minimal.
-int solve_minimal_sampled_launch(pgx_ctx* ctx, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
+int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
 {
+    if (sampler != 0 && sampler != 1) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: sampler %d (0 uniform, 1 NAPSAC)", sampler);
+    if (sampler == 1 && (ctx->gn != ctx->n || ctx->gE <= 0)) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: NAPSAC needs the neighbourhood graph of the resident points (pgx_graph_build / pgx_set_graph)");
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: points not set");
     if (S <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: empty sample batch");
     int m = 0;
@@ -517,8 +529,12 @@ int solve_minimal_sampled_launch(pgx_ctx* ctx, uint64_t key, uint32_t batch, int
     }
     if (ctx->n < m) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: %lld points, the minimal sample needs %d", (long long)ctx->n, m);
     PGX_TRY(ensure(ctx, ctx->scratch, (size_t)S * m * sizeof(int32_t)));
-    hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n, m,
-                       ctx->scratch.as<int>());
+    if (sampler == 0)
+        hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n, m,
+                           ctx->scratch.as<int>());
+    else
+        hipLaunchKernelGGL(sample_napsac_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n,
+                           ctx->goff.as<int>(), ctx->gidx.as<int>(), m, ctx->scratch.as<int>());
     PGX_HIP(ctx, hipGetLastError());
     if (samples_out) {
         PGX_HIP(ctx, hipMemcpyAsync(samples_out, ctx->scratch.p, (size_t)S * m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

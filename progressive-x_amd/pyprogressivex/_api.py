@@ -6,7 +6,7 @@ findTwoViewMotions ignores scoring_exponent, findLines ignores weights, only fin
 
 Extensions that do not change the reference behaviour when left at their defaults (keyword-only):
   seed=None                     reproducible sampling (the reference seeds from std::random_device)
-  sampler_rng="numpy"           "philox": the uniform sampler draws from the in-repo counter-based generator (_rng.py), on the device when it can
+  sampler_rng="numpy"           "philox": the uniform and NAPSAC samplers draw from the in-repo counter-based generator (_rng.py), on the device when they can
   distributed=None              True: shard the proposal batches over the ranks of this launch (every rank must make the same
                                 call on the same data; checked).  None: only if PGX_MULTI_GPU=1.  Never implicit.
   max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
@@ -116,6 +116,8 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     sampler = sampler_factory(n, rng, graph)
     if sampler_rng == "philox" and type(sampler) is _proposal.UniformSampler:   # the in-repo counter-based generator (device-drawable)
         sampler = _proposal.PhiloxUniformSampler(n, rng)
+    elif sampler_rng == "philox" and type(sampler) is _proposal.NapsacSampler:
+        sampler = _proposal.PhiloxNapsacSampler(n, rng, graph)
     s = _engine.MultiModelSettings()
     s.minimum_number_of_inliers = int(minimum_point_number)          # progressivex_python.cpp:261
     s.inlier_outlier_threshold = float(threshold)                    # :263

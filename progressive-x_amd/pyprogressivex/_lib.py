@@ -402,15 +402,17 @@ class Context:
         self.M = rows
         return out
 
-    def solve_minimal_sampled(self, key, batch, S, fetch=True, fetch_samples=False):
-        """pgx_solve_minimal_sampled: S uniform minimal samples drawn on the device by the in-repo generator (_rng.py gives the
-        same rows) and solved into the resident hypothesis buffer.  Returns (models or None, samples or None)."""
+    def solve_minimal_sampled(self, key, batch, S, fetch=True, fetch_samples=False, sampler="uniform"):
+        """pgx_solve_minimal_sampled: S minimal samples drawn on the device by the in-repo generator (_rng.py gives the same rows:
+        sampler "uniform", or "napsac" on the resident neighbourhood graph) and solved into the resident hypothesis buffer.
+        Returns (models or None, samples or None)."""
         m = {FUNDAMENTAL: 7, HOMOGRAPHY: 4, PNP: 3}.get(self.model_type, 2)
         rows = int(S) * {FUNDAMENTAL: 3, PNP: 4}.get(self.model_type, 1)
         out = np.empty((rows, PARAM_DIM[self.model_type]), dtype=np.float64) if fetch else None
         smp = np.empty((int(S), m), dtype=np.int32) if fetch_samples else None
-        self._ck(self._lib.pgx_solve_minimal_sampled(self._h, C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF),
-                                                     C.c_int(int(S)), _ptr(smp, C.c_int32), _ptr(out, C.c_double)), "pgx_solve_minimal_sampled")
+        self._ck(self._lib.pgx_solve_minimal_sampled(self._h, C.c_int({"uniform": 0, "napsac": 1}[sampler]), C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF),
+                                                     C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int(int(S)), _ptr(smp, C.c_int32), _ptr(out, C.c_double)),
+                 "pgx_solve_minimal_sampled")
         self.M = rows
         return out, smp
 

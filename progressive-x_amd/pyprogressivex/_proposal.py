@@ -86,6 +86,25 @@ class PhiloxUniformSampler(UniformSampler):
         return _rng.uniform_samples(self.key, self.last[0], int(count), self.n, int(m))
 
 
+class PhiloxNapsacSampler(PhiloxUniformSampler):
+    """NapsacSampler on the in-repo generator: a uniform centre and m - 1 distinct members of its neighbour list.  Unlike the
+    numpy-stream NapsacSampler above, a centre with too few neighbours keeps its row (all -1: a NaN model, the iteration is
+    spent) instead of being dropped, so sample s is a pure function of (key, batch, s) and the device can draw the batch."""
+    kind = "napsac"
+
+    def __init__(self, n, rng, graph):
+        super().__init__(n, rng)
+        self.off, self.idx = np.asarray(graph[0], dtype=np.int64), np.asarray(graph[1], dtype=np.int64)
+
+    def draw(self, count, m):
+        from . import _rng
+        if self.n < m or m < 2:
+            return np.zeros((0, m), dtype=np.int64)
+        self.last = (self.batch, int(count), int(m))
+        self.batch += 1
+        return _rng.napsac_samples(self.key, self.last[0], int(count), self.n, int(m), self.off, self.idx)
+
+
 def prosac_growth_function(n, m, t_n):
     """Chum & Matas' PROSAC growth function T'_n as USAC / GC-RANSAC tabulate it [UPSTREAM-MEMORY]: g[i] = number of
     samples after which the hypothesis-generation set grows beyond its i + 1 best points (g[i] = 1 for i < m)."""
@@ -351,7 +370,7 @@ class ProposalEngine:
             philox = getattr(self.sampler, "last", None) if hasattr(self.ctx, "solve_minimal_sampled") else None
             if philox is not None and philox[1] == len(samples):
                 # the batch is drawn on the device from (key, batch): the same rows as `samples` (tests), no index upload
-                models, _ = self.ctx.solve_minimal_sampled(self.sampler.key, philox[0], len(samples))
+                models, _ = self.ctx.solve_minimal_sampled(self.sampler.key, philox[0], len(samples), sampler=getattr(self.sampler, "kind", "uniform"))
             else:
                 models = self.ctx.solve_minimal(samples)
             src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)

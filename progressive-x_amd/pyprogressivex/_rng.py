@@ -49,3 +49,39 @@ def uniform_samples(key, batch, count, n, m, first=0):
         taken[np.arange(count), pos] = r
         out[:, j] = r
     return out
+
+
+def napsac_samples(key, batch, count, n, m, off, idx, first=0):
+    """[count, m] int64: NAPSAC samples (csrc/rng.hip.h sample_napsac) - word 0 draws the centre uniformly, words 1 .. m-1 draw
+    m - 1 DISTINCT entries of the centre's row of the CSR neighbourhood graph (off, idx); a centre with fewer than m - 1
+    neighbours gives the row -1 .. -1 (no sample: the solvers return a NaN model, the iteration is spent)."""
+    if not (2 <= m <= 8):
+        raise ValueError("napsac_samples: need 2 <= m <= 8")
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    off, idx = np.asarray(off, dtype=np.int64), np.asarray(idx, dtype=np.int64)
+    s = np.arange(first, first + count, dtype=np.uint64)
+    blk = lambda b: philox4x32(s & _MASK, s >> _S32, int(batch) & 0xFFFFFFFF, b, key & 0xFFFFFFFF, key >> 32)   # noqa: E731
+    words = blk(0)
+    c = ((words[0].astype(np.uint64) * np.uint64(n)) >> _S32).astype(np.int64)
+    a0, deg = off[c], off[c + 1] - off[c]
+    valid = deg >= m - 1
+    out = np.full((count, m), -1, dtype=np.int64)
+    out[:, 0] = c
+    taken = np.zeros((count, m), dtype=np.int64)
+    for j in range(1, m):
+        if j % 4 == 0:
+            words = blk(j // 4)
+        top = np.maximum(deg - (j - 1), 1).astype(np.uint64)      # (rows without a sample carry a dummy range: discarded below)
+        r = ((words[j % 4].astype(np.uint64) * top) >> _S32).astype(np.int64)
+        pos = np.zeros(count, dtype=np.int64)
+        for q in range(j - 1):
+            hit = (pos == q) & (taken[:, q] <= r)
+            r = r + hit
+            pos = pos + hit
+        for q in range(j - 1, 0, -1):
+            shift = pos < q
+            taken[:, q] = np.where(shift, taken[:, q - 1], taken[:, q])
+        taken[np.arange(count), pos] = r
+        out[:, j] = idx[np.minimum(a0 + r, len(idx) - 1)] if len(idx) else -1
+    out[~valid] = -1
+    return out

@@ -67,8 +67,12 @@ def test_philox_sampler_device_drawn_batches_identical_to_cpu_restatement(monkey
     (P, lab), (Pr, labr) = _both(monkeypatch, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=30, sampler_rng="philox")
     assert P.shape == (9, 4) and np.array_equal(lab, labr) and np.allclose(P, Pr, rtol=1e-8, atol=1e-8)
     assert _me(lab, 3, gt) < 0.05
+    pts, gt, _ = datasets.make_homographies(n_per_plane=300, n_planes=3, n_outliers=400, seed=0)     # NAPSAC (sampler id 3) on the same generator
+    (H, lab), (Hr, labr) = _both(monkeypatch, px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=3,
+                                 seed=2, minimum_point_number=40, neighborhood_ball_radius=100.0, sampler_rng="philox")
+    assert H.shape[0] >= 6 and np.array_equal(lab, labr) and np.allclose(H, Hr, rtol=1e-8, atol=1e-10)
     with pytest.raises(ValueError, match="sampler_rng"):
-        px.findLines(pts, np.array(0), 1000, 1000, sampler_id=0, sampler_rng="mt19937")
+        px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=0, sampler_rng="mt19937")
 
 
 def test_vanishing_points_identical_to_cpu_restatement(monkeypatch):

@@ -51,6 +51,41 @@ def test_philox_sampler_batches():
     assert _proposal.PhiloxUniformSampler(3, np.random.default_rng(0)).draw(10, 4).shape == (0, 4)
 
 
+def test_napsac_samples_are_a_centre_and_distinct_members_of_its_list(oracle):
+    pts = np.random.default_rng(0).random((600, 4)) * 100
+    off, idx, _ = oracle.graph_build(pts, 0, radius=25.0, k=5)     # symmetric lists of the 5 nearest inside the ball: 0 .. ~10 neighbours
+    for m in (2, 4, 7):
+        s = _rng.napsac_samples(77, 2, 3000, 600, m, off, idx)
+        deg = np.diff(off)
+        ok = s[:, 0] >= 0
+        assert ok.any() and (m < 7 or (~ok).any())                     # some centres are short of 6 neighbours
+        assert (s[~ok] == -1).all()
+        for row in s[ok][:400]:
+            members = idx[off[row[0]]:off[row[0] + 1]]
+            assert deg[row[0]] >= m - 1 and np.isin(row[1:], members).all() and len(set(row.tolist())) == m
+        assert np.array_equal(s[50:60], _rng.napsac_samples(77, 2, 10, 600, m, off, idx, first=50))
+    smp = _proposal.PhiloxNapsacSampler(600, np.random.default_rng(1), (off, idx))
+    a = smp.draw(500, 4)
+    assert a.shape == (500, 4) and smp.last == (0, 500, 4) and smp.kind == "napsac"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m", [("line", 2), ("homography", 4), ("fundamental", 7)])
+def test_device_napsac_draws_the_same_rows_and_models(gpu_ctx, name, m):
+    from helpers import make_case
+    mt, pts, models, thr = make_case(name, 3000, 2, seed=5)
+    gpu_ctx.set_points(mt, pts)
+    off, idx, _ = gpu_ctx.graph_build(pts, _lib.GRAPH_KNN_IN_BALL, radius=40.0, k=5)
+    key, batch, S = 0xABCDEF0123456789, 3, 1500
+    got, smp = gpu_ctx.solve_minimal_sampled(key, batch, S, fetch=True, fetch_samples=True, sampler="napsac")
+    want = _rng.napsac_samples(key, batch, S, len(pts), m, off, idx)
+    assert np.array_equal(smp, want) and (want[:, 0] >= 0).any()
+    ref = gpu_ctx.solve_minimal(want.astype(np.int32))
+    assert np.array_equal(got, ref, equal_nan=True)
+    slots = got.shape[0] // S
+    assert np.isnan(got.reshape(S, slots, -1)[want[:, 0] < 0]).all()    # no sample -> NaN models in every slot
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,m", [("line", 2), ("vanishing_point", 2), ("pnp", 3), ("homography", 4), ("fundamental", 7)])
 @pytest.mark.parametrize("n", [8, 1000, 100003])
