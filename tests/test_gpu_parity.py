@@ -1398,6 +1398,22 @@ def test_first_cycle_memo_is_transparent(monkeypatch):
         finally:
             ctx.close()
         return out, hits
+    # a labelling written by anything but pgx_set_labels(zeros) is not a memo start: set zeros, let the greedy solver relabel, expand
+    c = _lib.Context(0)
+    try:
+        c.set_points(_lib.PNP, pts)
+        c.graph_build(raw, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+        Dq = c.pearl_unary(lists[0], thr, lam, want_table=True)
+        c.set_labels(np.zeros(n, np.int32))
+        c.expansion(lam, h)                                   # fills the memo for these columns
+        c.set_labels(np.zeros(n, np.int32))
+        c.greedy_labeling(h)                                  # relabels: the next expansion does NOT start from zeros
+        start = c.get_labels()
+        eq, e, cyc = c.expansion(lam, h)
+        ref, ref_e, ref_cyc = O.expansion(Dq, O.graph_build(raw, 0, radius=20.0, k=5), O.quantize_lambda(lam), O.quantize(h), start)
+        assert np.array_equal(c.get_labels(), ref) and eq == ref_e and cyc == ref_cyc
+    finally:
+        c.close()
     with_memo, hits = run(True)
     without, none = run(False)
     assert none == 0 and hits >= 3 + 2 + 6, hits
