@@ -1086,3 +1086,36 @@ void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t co
         }
     }
 }
+
+void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* off, const int32_t* idx, int m,
+                        int32_t* samples)
+{
+    const uint32_t k[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+    for (int64_t t = 0; t < count; ++t) {
+        const uint64_t s = (uint64_t)(first + t);
+        int32_t* row = samples + t * m;
+        uint32_t w[4];
+        const uint32_t ctr0[4] = {(uint32_t)s, (uint32_t)(s >> 32), batch, 0u};
+        pgxo_philox4x32(ctr0, k, w);
+        const int64_t c = (int64_t)(((uint64_t)w[0] * (uint64_t)n) >> 32);
+        const int64_t a0 = off[c], deg = off[c + 1] - off[c];
+        if (deg < m - 1) {
+            for (int j = 0; j < m; ++j) row[j] = -1;
+            continue;
+        }
+        int64_t taken[8];
+        row[0] = (int32_t)c;
+        for (int j = 1; j < m; ++j) {
+            if (j % 4 == 0) {
+                const uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), batch, (uint32_t)(j / 4)};
+                pgxo_philox4x32(ctr, k, w);
+            }
+            int64_t r = (int64_t)(((uint64_t)w[j % 4] * (uint64_t)(deg - (j - 1))) >> 32);
+            int pos = 0;
+            while (pos < j - 1 && taken[pos] <= r) { ++r; ++pos; }
+            for (int q = j - 1; q > pos; --q) taken[q] = taken[q - 1];
+            taken[pos] = r;
+            row[j] = idx[a0 + r];
+        }
+    }
+}

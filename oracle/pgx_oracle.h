@@ -108,6 +108,9 @@ int pgxo_solve_minimal(int model_type, const double *pts, int64_t n, const int32
  * Replaces gcransac::sampler::UniformSampler (progressivex_python.cpp:121, 215-245; source absent). */
 void pgxo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, int m, int32_t* samples);
+/* NAPSAC on the same generator: a uniform centre + m - 1 distinct entries of its CSR row; rows of -1 where the centre has fewer */
+void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* off, const int32_t* idx, int m,
+                        int32_t* samples);
 
 #ifdef __cplusplus
 }

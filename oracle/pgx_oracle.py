@@ -47,6 +47,7 @@ def lib():
         _lib.pgxo_predicted_unseen_inliers.restype = C.c_uint64
         _lib.pgxo_philox4x32.restype = None
         _lib.pgxo_sample_uniform.restype = None
+        _lib.pgxo_sample_napsac.restype = None
         _lib.pgxo_predicted_unseen_inliers.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
     return _lib
 
@@ -257,6 +258,14 @@ def sample_uniform(key, batch, first, count, n, m):
     out = np.empty((count, m), dtype=np.int32)
     lib().pgxo_sample_uniform(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int64(first), C.c_int64(count),
                               C.c_int64(n), C.c_int(m), _p(out, C.c_int32))
+    return out
+
+
+def sample_napsac(key, batch, first, count, n, off, idx, m):
+    out = np.empty((count, m), dtype=np.int32)
+    off32, idx32 = _i32(off), _i32(idx)
+    lib().pgxo_sample_napsac(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int64(first), C.c_int64(count),
+                             C.c_int64(n), _p(off32, C.c_int32), _p(idx32, C.c_int32), C.c_int(m), _p(out, C.c_int32))
     return out
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The CPU-side native code under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY 5 tooling):
 #   oracle/pgx_oracle.c (the checker of every parity test) and tests/emu/mf_emu.cpp (the max-flow bodies + host driver of
-#   maxflow_body.hip.h / maxflow_driver.inl compiled for the host), driven by their own test files.
+#   maxflow_body.hip.h / maxflow_driver.inl compiled for the host), driven by their own test files (+ tests/test_rng.py: the generator and the samplers of the oracle).
 # usage: bash scripts/sanitize.sh        (from the repo root; ~2 min)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -16,4 +16,4 @@ UBSAN=$(gcc -print-file-name=libubsan.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export PGX_ORACLE_SO="$ROOT/oracle/_san/libpgx_oracle.so" PGX_EMU_SO="$ROOT/tests/emu/_san/libmf_emu.so"
-LD_PRELOAD="$ASAN:$UBSAN" python -m pytest tests/test_oracle.py tests/test_emu.py -x -q -m "not gpu" "$@"
+LD_PRELOAD="$ASAN:$UBSAN" python -m pytest tests/test_oracle.py tests/test_emu.py tests/test_rng.py -x -q -m "not gpu" "$@"

@@ -64,6 +64,7 @@ def test_napsac_samples_are_a_centre_and_distinct_members_of_its_list(oracle):
             members = idx[off[row[0]]:off[row[0] + 1]]
             assert deg[row[0]] >= m - 1 and np.isin(row[1:], members).all() and len(set(row.tolist())) == m
         assert np.array_equal(s[50:60], _rng.napsac_samples(77, 2, 10, 600, m, off, idx, first=50))
+        assert np.array_equal(s, oracle.sample_napsac(77, 2, 0, 3000, 600, off, idx, m))          # the C restatement draws the same rows
     smp = _proposal.PhiloxNapsacSampler(600, np.random.default_rng(1), (off, idx))
     a = smp.draw(500, 4)
     assert a.shape == (500, 4) and smp.last == (0, 500, 4) and smp.kind == "napsac"
