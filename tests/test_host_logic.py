@@ -44,6 +44,21 @@ def test_homography_pipeline_and_single_model_convention(oracle_backend):
     assert Hs.shape == (6, 3) and _me(labs, 2, gt) < 0.05
 
 
+def test_philox_samplers_through_the_pipeline(oracle_backend):
+    """sampler_rng="philox": the uniform (id 0) and NAPSAC (id 3) samplers on the in-repo counter-based generator, host side
+    (the numpy restatement; the GPU context draws the same rows on the device - tests/test_gpu_api.py): same quality, and the
+    stream is a function of the seed alone."""
+    pts, gt, _ = datasets.make_homographies(n_per_plane=150, n_planes=2, n_outliers=150, seed=0)
+    kw = dict(threshold=3.0, conf=0.99, seed=1, minimum_point_number=20, sampler_rng="philox")
+    for sid in (0, 3):
+        H, lab = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=sid, **kw)
+        assert H.shape == (6, 3) and _me(lab, 2, gt) < 0.05
+        H2, lab2 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=sid, **kw)
+        assert np.array_equal(H, H2) and np.array_equal(lab, lab2)
+    H3, lab3 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=1, **kw)      # PROSAC: no philox variant, numpy stream kept
+    assert H3.shape[0] >= 3
+
+
 def test_two_view_motion_pipeline(oracle_backend):
     # the epipolar constraint is weak (uniform outliers often fit, small spurious instances survive): few outliers and
     # a minimum instance size of 80 make the outcome stable across seeds (ME 0.08-0.15 for seeds 1-5)
