@@ -96,10 +96,19 @@ int pgx_solve_minimal(pgx_ctx *ctx, const int32_t *samples, int S, double *model
  * sampler 0: gcransac::sampler::UniformSampler - m distinct indices of range(n) (progressivex_python.cpp:121, 215-245);
  * sampler 1: NapsacSampler (sampler id 3 there, the default of findHomographies / findTwoViewMotions) - a uniform centre and m - 1
  * distinct entries of its row of the resident neighbourhood graph; a centre with fewer neighbours yields the row -1 .. -1 and a
- * NaN model (the iteration is spent).  Both absent upstream and seeded from std::random_device there.  No host RNG, no index
- * upload; pyprogressivex/_rng.py and the oracle produce the same rows.  samples_out (may be NULL): S x m indices. */
-enum { PGX_SAMPLER_UNIFORM = 0, PGX_SAMPLER_NAPSAC = 1 };
+ * NaN model (the iteration is spent);
+ * sampler 2: ProsacSampler (sampler id 1 there; points ordered by quality) - sample s draws m - 1 distinct indices of the best
+ * n_k - 1 points plus point n_k - 1, k = s + 1, n_k = entry s of the table pgx_sampler_prosac_set left on the device.
+ * All absent upstream and seeded from std::random_device there.  No host RNG, no index upload; pyprogressivex/_rng.py and the
+ * oracle produce the same rows.  samples_out (may be NULL): S x m indices. */
+enum { PGX_SAMPLER_UNIFORM = 0, PGX_SAMPLER_NAPSAC = 1, PGX_SAMPLER_PROSAC = 2 };
 int pgx_solve_minimal_sampled(pgx_ctx *ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t *samples_out, double *models_out);
+/* PROSAC's hypothesis-generation set sizes for the resident points: subset_sizes[k - 1] = n_k of sample number k = 1 .. count
+ * (Chum & Matas' growth function T'_n, a sequential floating-point recurrence: tabulated by the host once per sampler - the sample
+ * numbers restart at 1 with every proposal, progressive_x.h:290, so one table of max-iterations entries serves every batch);
+ * 0 = past the convergence bound (GC-RANSAC's 100 000 samples): uniform over all points.  Entries outside 0 .. n: PGX_ERR_INVALID.
+ * pgx_set_points invalidates the table. */
+int pgx_sampler_prosac_set(pgx_ctx *ctx, const int32_t *subset_sizes, int count);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
                     double *scores, uint64_t *masks);

@@ -1087,6 +1087,29 @@ void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t co
     }
 }
 
+/* PROSAC on the same generator (gcransac::sampler::ProsacSampler, progressivex_python.cpp:222; absent upstream [UPSTREAM-MEMORY: the USAC
+ * formulation]): sample first + t uses tops[t] = n_k - m - 1 distinct indices of the best n_k - 1 points plus point n_k - 1;
+ * tops[t] == 0: uniform over all n; tops[t] < m or > n: no sample (-1). */
+void pgxo_sample_prosac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* tops, int m, int32_t* samples)
+{
+    for (int64_t t = 0; t < count; ++t) {
+        int32_t* row = samples + t * m;
+        const int64_t top = tops[t];
+        if (top == 0) {
+            pgxo_sample_uniform(key, batch, first + t, 1, n, m, row);
+        } else if (top < m || top > n) {
+            for (int j = 0; j < m; ++j) row[j] = -1;
+        } else {
+            if (m > 1) {
+                int32_t head[8];
+                pgxo_sample_uniform(key, batch, first + t, 1, top - 1, m - 1, head);
+                for (int j = 0; j < m - 1; ++j) row[j] = head[j];
+            }
+            row[m - 1] = (int32_t)(top - 1);
+        }
+    }
+}
+
 void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* off, const int32_t* idx, int m,
                         int32_t* samples)
 {

@@ -112,6 +112,9 @@ void pgxo_sample_uniform(uint64_t key, uint32_t batch, int64_t first, int64_t co
 void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* off, const int32_t* idx, int m,
                         int32_t* samples);
 
+/* PROSAC on the same generator: tops[t] = the hypothesis-generation set size n_k of sample first + t (0 = uniform over all n) */
+void pgxo_sample_prosac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* tops, int m, int32_t* samples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ def lib():
         _lib.pgxo_philox4x32.restype = None
         _lib.pgxo_sample_uniform.restype = None
         _lib.pgxo_sample_napsac.restype = None
+        _lib.pgxo_sample_prosac.restype = None
         _lib.pgxo_predicted_unseen_inliers.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
     return _lib
 
@@ -266,6 +267,15 @@ def sample_napsac(key, batch, first, count, n, off, idx, m):
     off32, idx32 = _i32(off), _i32(idx)
     lib().pgxo_sample_napsac(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int64(first), C.c_int64(count),
                              C.c_int64(n), _p(off32, C.c_int32), _p(idx32, C.c_int32), C.c_int(m), _p(out, C.c_int32))
+    return out
+
+
+def sample_prosac(key, batch, first, count, n, tops, m):
+    out = np.empty((count, m), dtype=np.int32)
+    tops32 = _i32(tops)
+    assert len(tops32) >= count
+    lib().pgxo_sample_prosac(C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int64(first), C.c_int64(count),
+                             C.c_int64(n), _p(tops32, C.c_int32), C.c_int(m), _p(out, C.c_int32))
     return out
 
 

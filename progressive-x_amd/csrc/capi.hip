@@ -426,6 +426,12 @@ int pgx_solve_minimal_sampled(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t 
     return solve_minimal_sampled_launch(ctx, sampler, key, batch, S, samples_out, models_out);
 }
 
+int pgx_sampler_prosac_set(pgx_ctx* ctx, const int32_t* subset_sizes, int count)
+{
+    CTX_GUARD(ctx);
+    return sampler_prosac_set(ctx, subset_sizes, count);
+}
+
 int pgx_score_set_global_n(pgx_ctx* ctx, int64_t n_total)
 {
     CTX_GUARD(ctx);

@@ -143,6 +143,9 @@ struct pgx_ctx {
     int tile_debug = 0;          // PGX_MF_DEBUG: one stderr line per global relabel
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     pgx::DevBuf scratch;  // misc small device scratch (bucket, energy, ...)
+    pgx::DevBuf prosac_tops;              // pgx_sampler_prosac_set: subset size per sample number (int32 x prosac_count)
+    int prosac_count = 0;
+    int64_t prosac_points_version = -1;   // the table belongs to these points
     void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
     size_t h_res_cap = 0;
     // Host mirror of the score triples: score_finish_kernel also writes (count, value, shared) in the batch's device order
@@ -221,6 +224,7 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
 int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult);
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out, bool resident = false);   // resident: the samples are in ctx->scratch already
 int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out);
+int sampler_prosac_set(pgx_ctx* ctx, const int32_t* tops, int count);
 int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int sel, const int32_t* index, int64_t m,
                 int label, int use_weights, int wpow, double* out, int64_t* count, int64_t* bad);
 int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int K, int use_weights, int wpow,

@@ -75,4 +75,24 @@ __host__ __device__ inline void sample_napsac(uint64_t key, uint32_t batch, uint
     }
 }
 
+// PROSAC on the same generator (gcransac::sampler::ProsacSampler, progressivex_python.cpp:222 sampler id 1; absent upstream, the
+// USAC formulation): the points are ordered by quality; sample number k draws from the best `top` = n_k points - m - 1 DISTINCT
+// ones of the first top - 1 and point top - 1 itself.  n_k comes from Chum & Matas' growth function, a sequential floating-point
+// recurrence the host tabulates once per sampler (the sample numbers restart at 1 with every proposal, progressive_x.h:290, so one
+// table of max-iterations entries serves every batch).  top == 0: past the convergence bound the sampler is uniform over all n;
+// top < m (never produced by the table): no sample, row -1.
+__host__ __device__ inline void sample_prosac(uint64_t key, uint32_t batch, uint64_t s, int64_t n, int top, int m, int32_t* out)
+{
+    if (top == 0) {
+        sample_distinct(key, batch, s, n, m, out);
+        return;
+    }
+    if (top < m || top > n) {
+        for (int j = 0; j < m; ++j) out[j] = -1;
+        return;
+    }
+    if (m > 1) sample_distinct(key, batch, s, top - 1, m - 1, out);
+    out[m - 1] = top - 1;
+}
+
 }  // namespace pgx

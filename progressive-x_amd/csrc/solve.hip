@@ -437,6 +437,32 @@ __global__ __launch_bounds__(256) void sample_napsac_kernel(unsigned long long k
     for (int j = 0; j < m; ++j) samples[(int64_t)s * m + j] = row[j];
 }
 
+__global__ __launch_bounds__(256) void sample_prosac_kernel(unsigned long long key, unsigned batch, int S, int64_t n, const int* __restrict__ tops, int m,
+                                                            int* __restrict__ samples)
+{
+    const int s = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (s >= S) return;
+    int32_t row[kMaxSampleSize];
+    sample_prosac(key, batch, (uint64_t)s, n, tops[s], m, row);
+    for (int j = 0; j < m; ++j) samples[(int64_t)s * m + j] = row[j];
+}
+
+// pgx_sampler_prosac_set: the subset size n_k of PROSAC's sample number k = 1 .. count (0 = uniform over all points)
+int sampler_prosac_set(pgx_ctx* ctx, const int32_t* tops, int count)
+{
+    if (ctx->n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_sampler_prosac_set: points not set");
+    if (!tops || count <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_sampler_prosac_set: empty table");
+    for (int k = 0; k < count; ++k)
+        if (tops[k] < 0 || tops[k] > ctx->n)
+            return fail(ctx, PGX_ERR_INVALID, "pgx_sampler_prosac_set: subset size %d of sample %d is outside 0 .. %lld", tops[k], k + 1, (long long)ctx->n);
+    PGX_TRY(ensure(ctx, ctx->prosac_tops, (size_t)count * sizeof(int32_t)));
+    PGX_HIP(ctx, hipMemcpyAsync(ctx->prosac_tops.p, tops, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the caller's buffer is free on return)
+    ctx->prosac_count = count;
+    ctx->prosac_points_version = ctx->points_version;
+    return PGX_OK;
+}
+
 int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* models_out, bool resident)
 {
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal: points not set");
@@ -511,11 +537,14 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     return PGX_OK;
 }
 
-// pgx_solve_minimal_sampled: S minimal samples (uniform, or NAPSAC on the resident graph) from the in-repo generator (key, batch), drawn by the device into the
-// solvers' sample buffer - no host RNG, no index upload - then the solver of the resident model type as in pgx_solve_minimal.
+// pgx_solve_minimal_sampled: S minimal samples (uniform, NAPSAC on the resident graph, or PROSAC with the resident subset-size table) from the in-repo
+// generator (key, batch), drawn by the device into the solvers' sample buffer - no host RNG, no index upload - then the solver of the resident model type as in pgx_solve_minimal.
 int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32_t batch, int S, int32_t* samples_out, double* models_out)
 {
-    if (sampler != 0 && sampler != 1) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: sampler %d (0 uniform, 1 NAPSAC)", sampler);
+    if (sampler < 0 || sampler > 2) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: sampler %d (0 uniform, 1 NAPSAC, 2 PROSAC)", sampler);
+    if (sampler == 2 && (ctx->prosac_count < S || ctx->prosac_points_version != ctx->points_version))
+        return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: PROSAC needs pgx_sampler_prosac_set for the resident points with at least %d entries (has %d)", S,
+                    ctx->prosac_points_version == ctx->points_version ? ctx->prosac_count : 0);
     if (sampler == 1 && (ctx->gn != ctx->n || ctx->gE <= 0)) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: NAPSAC needs the neighbourhood graph of the resident points (pgx_graph_build / pgx_set_graph)");
     if (ctx->n <= 0 || ctx->model_type < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: points not set");
     if (S <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_solve_minimal_sampled: empty sample batch");
@@ -532,9 +561,12 @@ int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32
     if (sampler == 0)
         hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n, m,
                            ctx->scratch.as<int>());
-    else
+    else if (sampler == 1)
         hipLaunchKernelGGL(sample_napsac_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n,
                            ctx->goff.as<int>(), ctx->gidx.as<int>(), m, ctx->scratch.as<int>());
+    else
+        hipLaunchKernelGGL(sample_prosac_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long)key, batch, S, ctx->n,
+                           ctx->prosac_tops.as<int>(), m, ctx->scratch.as<int>());
     PGX_HIP(ctx, hipGetLastError());
     if (samples_out) {
         PGX_HIP(ctx, hipMemcpyAsync(samples_out, ctx->scratch.p, (size_t)S * m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -118,6 +118,8 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         sampler = _proposal.PhiloxUniformSampler(n, rng)
     elif sampler_rng == "philox" and type(sampler) is _proposal.NapsacSampler:
         sampler = _proposal.PhiloxNapsacSampler(n, rng, graph)
+    elif sampler_rng == "philox" and type(sampler) is _proposal.ProsacSampler:
+        sampler = _proposal.PhiloxProsacSampler(n, rng, sample_size=sampler.prosac_m, convergence_iterations=sampler.t_n)
     s = _engine.MultiModelSettings()
     s.minimum_number_of_inliers = int(minimum_point_number)          # progressivex_python.cpp:261
     s.inlier_outlier_threshold = float(threshold)                    # :263
@@ -195,12 +197,12 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="full", sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="off", sampler_rng="numpy"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n]).
     validity [U-14, keyword-only, not in the reference's signature]: which of the estimator's model-validity stages run -
-    "off" (strict restatement of what is in the snapshot: none), "oriented", "symmetric" (oriented + symmetric-epipolar
-    support) or "full" (+ DEGENSAC, the default: the recollection of gcransac's FundamentalMatrixEstimator::isValidModel;
-    its source is absent from the snapshot - INTEGRATION.md lists the one threshold that deviates from that recollection)."""
+    "off" (the default: strict restatement of what is in the snapshot, i.e. none), "oriented", "symmetric" (oriented +
+    symmetric-epipolar support) or "full" (+ DEGENSAC: the recollection of gcransac's FundamentalMatrixEstimator::isValidModel;
+    its source is absent from the snapshot and no bundled scene measures better with it, so it is opt-in - INTEGRATION.md)."""
     if validity not in ("off", "oriented", "symmetric", "full"):
         raise ValueError("validity should be 'off', 'oriented', 'symmetric' or 'full'")
     corrs = _as_f64(corrs)

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
-    "pgx_score_inliers", "pgx_solve_minimal_sampled", "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
+    "pgx_score_inliers", "pgx_solve_minimal_sampled", "pgx_sampler_prosac_set", "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
 ]
 
 
@@ -404,17 +404,22 @@ class Context:
 
     def solve_minimal_sampled(self, key, batch, S, fetch=True, fetch_samples=False, sampler="uniform"):
         """pgx_solve_minimal_sampled: S minimal samples drawn on the device by the in-repo generator (_rng.py gives the same rows:
-        sampler "uniform", or "napsac" on the resident neighbourhood graph) and solved into the resident hypothesis buffer.
+        sampler "uniform", "napsac" on the resident neighbourhood graph, or "prosac" with the table of sampler_prosac_set) and solved into the resident hypothesis buffer.
         Returns (models or None, samples or None)."""
         m = {FUNDAMENTAL: 7, HOMOGRAPHY: 4, PNP: 3}.get(self.model_type, 2)
         rows = int(S) * {FUNDAMENTAL: 3, PNP: 4}.get(self.model_type, 1)
         out = np.empty((rows, PARAM_DIM[self.model_type]), dtype=np.float64) if fetch else None
         smp = np.empty((int(S), m), dtype=np.int32) if fetch_samples else None
-        self._ck(self._lib.pgx_solve_minimal_sampled(self._h, C.c_int({"uniform": 0, "napsac": 1}[sampler]), C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF),
+        self._ck(self._lib.pgx_solve_minimal_sampled(self._h, C.c_int({"uniform": 0, "napsac": 1, "prosac": 2}[sampler]), C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF),
                                                      C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int(int(S)), _ptr(smp, C.c_int32), _ptr(out, C.c_double)),
                  "pgx_solve_minimal_sampled")
         self.M = rows
         return out, smp
+
+    def sampler_prosac_set(self, subset_sizes):
+        """pgx_sampler_prosac_set: PROSAC's subset size n_k per sample number k = 1 .. len (0 = uniform), for the resident points"""
+        t = np.ascontiguousarray(subset_sizes, dtype=np.int32)
+        self._ck(self._lib.pgx_sampler_prosac_set(self._h, _ptr(t, C.c_int32), C.c_int(len(t))), "pgx_sampler_prosac_set")
 
     def gram(self, kind, sel, params=None, weights=None, wpow=2):
         """pgx_gram: weighted Gram matrix of the design rows of the selected resident points.

@@ -162,6 +162,33 @@ class ProsacSampler(UniformSampler):
         return out
 
 
+class PhiloxProsacSampler(ProsacSampler):
+    """ProsacSampler on the in-repo counter-based generator (csrc/rng.hip.h sample_prosac, _rng.prosac_samples): the growth
+    function stays the host's table (a sequential floating-point recurrence; the sample numbers restart at 1 with every
+    proposal, so the subset sizes of a draw are the same every time and go to the device once - pgx_sampler_prosac_set), the
+    m - 1 random members of every sample come from (key, batch, sample) on the device."""
+    kind = "prosac"
+
+    def __init__(self, n, rng, sample_size=None, convergence_iterations=100000):
+        super().__init__(n, rng, sample_size=sample_size, convergence_iterations=convergence_iterations)
+        self.key = int(rng.integers(0, 2 ** 63))
+        self.batch = 0
+        self.last = None
+        self.tops = None                             # subset size per sample of the latest draw (0 = uniform)
+
+    def draw(self, count, m, first=1):
+        from . import _rng
+        if self.n < m:
+            return np.zeros((0, m), dtype=np.int64)
+        gm = max(m, min(self.n, self.prosac_m or m))
+        k = np.arange(first, first + count, dtype=np.int64)
+        nk = np.minimum(self.n, np.maximum(gm, np.searchsorted(self.growth(gm), k, side="left") + 1))
+        self.tops = np.where(k > self.t_n, 0, nk).astype(np.int32)
+        self.last = (self.batch, int(count), int(m))
+        self.batch += 1
+        return _rng.prosac_samples(self.key, self.last[0], int(count), self.n, int(m), self.tops)
+
+
 class NapsacSampler(UniformSampler):
     """NAPSAC: first point uniform, the remaining m-1 from its neighbourhood ball; samples whose centre has fewer than
     m-1 neighbours are skipped (the reference's sampler fails and the RANSAC iteration is spent) [UPSTREAM-MEMORY]."""
@@ -348,6 +375,7 @@ class ProposalEngine:
         self.n = pts.shape[0]
         self.lo_runs = 0             # statistics of the last proposal
         self.graph_cuts = 0
+        self._prosac_table = None    # the PROSAC subset sizes resident on the device (PhiloxProsacSampler)
 
     def _score(self, models, T2, has_compound, exponent):
         if self.exchange is not None and self.exchange.world > 1:
@@ -370,7 +398,12 @@ class ProposalEngine:
             philox = getattr(self.sampler, "last", None) if hasattr(self.ctx, "solve_minimal_sampled") else None
             if philox is not None and philox[1] == len(samples):
                 # the batch is drawn on the device from (key, batch): the same rows as `samples` (tests), no index upload
-                models, _ = self.ctx.solve_minimal_sampled(self.sampler.key, philox[0], len(samples), sampler=getattr(self.sampler, "kind", "uniform"))
+                kind = getattr(self.sampler, "kind", "uniform")
+                if kind == "prosac" and self._prosac_table is not self.sampler.tops:
+                    if self._prosac_table is None or not np.array_equal(self._prosac_table, self.sampler.tops):
+                        self.ctx.sampler_prosac_set(self.sampler.tops)         # (the same table every proposal: uploaded once)
+                    self._prosac_table = self.sampler.tops
+                models, _ = self.ctx.solve_minimal_sampled(self.sampler.key, philox[0], len(samples), sampler=kind)
             else:
                 models = self.ctx.solve_minimal(samples)
             src = np.repeat(np.arange(len(samples), dtype=np.int64), est.device_slots)

@@ -27,9 +27,10 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=10):
 def uniform_samples(key, batch, count, n, m, first=0):
     """[count, m] int64: samples first .. first + count - 1 of batch `batch` under `key` - m DISTINCT indices of range(n) each
     (csrc/rng.hip.h sample_distinct: position j takes the r-th index not taken yet, r = (word * (n - j)) >> 32)."""
-    if not (1 <= m <= 8) or n < m:
+    if not (1 <= m <= 8) or np.min(n) < m:
         raise ValueError("uniform_samples: need 1 <= m <= 8 <= ... and n >= m")
     key = int(key) & 0xFFFFFFFFFFFFFFFF
+    n = np.asarray(n, dtype=np.int64)                 # (a scalar, or one range per row: prosac_samples)
     s = np.arange(first, first + count, dtype=np.uint64)
     out = np.empty((count, m), dtype=np.int64)
     taken = np.empty((count, m), dtype=np.int64)      # ascending per row
@@ -37,7 +38,7 @@ def uniform_samples(key, batch, count, n, m, first=0):
     for j in range(m):
         if j % 4 == 0:
             words = philox4x32(s & _MASK, s >> _S32, int(batch) & 0xFFFFFFFF, j // 4, key & 0xFFFFFFFF, key >> 32)
-        r = ((words[j % 4].astype(np.uint64) * np.uint64(n - j)) >> _S32).astype(np.int64)
+        r = ((words[j % 4].astype(np.uint64) * (n - j).astype(np.uint64)) >> _S32).astype(np.int64)
         pos = np.zeros(count, dtype=np.int64)
         for q in range(j):                            # step past every taken index <= r, in ascending order
             hit = (pos == q) & (taken[:, q] <= r)
@@ -84,4 +85,26 @@ def napsac_samples(key, batch, count, n, m, off, idx, first=0):
         taken[np.arange(count), pos] = r
         out[:, j] = idx[np.minimum(a0 + r, len(idx) - 1)] if len(idx) else -1
     out[~valid] = -1
+    return out
+
+
+def prosac_samples(key, batch, count, n, m, tops, first=0):
+    """[count, m] int64: PROSAC samples (csrc/rng.hip.h sample_prosac) - row t draws m - 1 DISTINCT indices of the best
+    tops[t] - 1 points plus point tops[t] - 1 (tops = the growth function's subset sizes n_k, _proposal.ProsacSampler);
+    tops[t] == 0: uniform over all n points; tops[t] < m or > n: the row -1 .. -1."""
+    if not (1 <= m <= 8) or n < m:
+        raise ValueError("prosac_samples: need 1 <= m <= 8 and n >= m")
+    tops = np.asarray(tops, dtype=np.int64)[:count]
+    if len(tops) != count:
+        raise ValueError("prosac_samples: one subset size per sample")
+    out = np.full((count, m), -1, dtype=np.int64)
+    late = tops == 0
+    good = (tops >= m) & (tops <= n)
+    if m > 1:
+        rng_n = np.where(good, tops - 1, m - 1)                       # (rows without a PROSAC sample carry a dummy range: overwritten below)
+        out[:, :m - 1] = uniform_samples(key, batch, count, rng_n, m - 1, first=first)
+    out[:, m - 1] = tops - 1
+    if late.any():
+        out[late] = uniform_samples(key, batch, count, n, m, first=first)[late]
+    out[~(late | good)] = -1
     return out

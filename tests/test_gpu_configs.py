@@ -111,14 +111,15 @@ def test_c3_quality_with_the_full_iteration_budget():
     coincides (9.7k + 9.5k of their points, scripts/dbg_c3.py) and the remaining instances, refitted on mixtures, keep
     45-60 % of their motions - the weak (codimension-1) epipolar constraint at work, as on the bundled cubetoy scene."""
     pts, gt, Fs = datasets.make_two_view_motions(seed=0)
-    F, lab = px.findTwoViewMotions(pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
-                                   minimum_point_number=1000, max_iters=2000)
-    K = F.shape[0] // 3
-    me = datasets.misclassification(np.where(lab == K, 0, lab + 1), gt)
-    print(f"C3 findTwoViewMotions: {K} motions, misclassification {me:.4f}")
     # the measured band at this seed, not a sanity bound (VERDICT r3 item 8b: a regression 0.47 -> 0.53 used to pass silently):
-    # 8 motions, ME 0.527 with the U-14 validity stages on (round 3 and round 4 runs; 0.466 with validity="off", round 2)
-    assert K == 8 and 0.50 <= me <= 0.55
+    # default (validity="off", the strict restatement): 8 motions, ME 0.466; with the opt-in U-14 stages 8 motions, ME 0.527
+    for validity, lo, hi in (("off", 0.44, 0.49), ("full", 0.50, 0.55)):
+        F, lab = px.findTwoViewMotions(pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
+                                       minimum_point_number=1000, max_iters=2000, validity=validity)
+        K = F.shape[0] // 3
+        me = datasets.misclassification(np.where(lab == K, 0, lab + 1), gt)
+        print(f"C3 findTwoViewMotions validity={validity}: {K} motions, misclassification {me:.4f}")
+        assert K == 8 and lo <= me <= hi, (validity, K, me)
 
 
 def test_c5_vanishing_point_scoring_all_segments_vs_oracle(gpu_ctx, oracle):

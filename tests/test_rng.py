@@ -70,6 +70,67 @@ def test_napsac_samples_are_a_centre_and_distinct_members_of_its_list(oracle):
     assert a.shape == (500, 4) and smp.last == (0, 500, 4) and smp.kind == "napsac"
 
 
+def test_prosac_samples_follow_the_subset_sizes(oracle):
+    """PROSAC on the in-repo generator: m - 1 distinct indices below n_k - 1 plus point n_k - 1; 0 = uniform over all points;
+    numpy == C restatement; the sampler class feeds the growth function's sizes and restarts the sample numbers per draw."""
+    rng = np.random.default_rng(0)
+    n = 500
+    for m in (1, 2, 3, 4, 7):
+        tops = rng.integers(m, n + 1, 4000)
+        tops[::7] = 0
+        tops[5], tops[6], tops[8], tops[9] = m, n, (m - 1 if m > 1 else n + 1), n + 1
+        a = _rng.prosac_samples(0x1234567890ABCDEF, 3, 4000, n, m, tops)
+        assert np.array_equal(a, oracle.sample_prosac(0x1234567890ABCDEF, 3, 0, 4000, n, tops, m))
+        good, late = (tops >= m) & (tops <= n), tops == 0
+        assert (a[~(good | late)] == -1).all() and (a[good | late] >= 0).all()
+        assert all(len(set(r)) == m for r in a[good | late].tolist())
+        assert (a[good][:, -1] == tops[good] - 1).all() and (a[good][:, :-1] < (tops[good] - 1)[:, None]).all()
+        assert np.array_equal(a[late], _rng.uniform_samples(0x1234567890ABCDEF, 3, 4000, n, m)[late])
+        assert np.array_equal(a[100:150], _rng.prosac_samples(0x1234567890ABCDEF, 3, 50, n, m, tops[100:150], first=100))
+    smp = _proposal.PhiloxProsacSampler(300, np.random.default_rng(2))
+    a = smp.draw(2000, 4)
+    ref = _proposal.ProsacSampler(300, np.random.default_rng(2))
+    assert smp.kind == "prosac" and smp.last == (0, 2000, 4) and np.array_equal(smp.tops, ref.subset_sizes(1, 2000, 4))
+    assert np.array_equal(a[:, 3], smp.tops - 1) and smp.tops[0] == 4 and smp.tops[-1] > 4 and (np.diff(smp.tops) >= 0).all()
+    b = smp.draw(2000, 4)                                              # the next proposal: same subset sizes, new members
+    assert np.array_equal(b[:, 3], a[:, 3]) and not np.array_equal(a[50:], b[50:])
+    late = _proposal.PhiloxProsacSampler(300, np.random.default_rng(2), convergence_iterations=10)
+    c = late.draw(50, 4)
+    assert (late.tops[10:] == 0).all() and (late.tops[:10] > 0).all() and len(np.unique(c[10:, 3])) > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m", [("line", 2), ("pnp", 3), ("homography", 4), ("fundamental", 7)])
+def test_device_prosac_draws_the_same_rows_and_models(gpu_ctx, name, m):
+    from helpers import make_case
+    n = 5000
+    mt, pts, models, thr = make_case(name, n, 2, seed=9)
+    gpu_ctx.set_points(mt, pts)
+    key, batch, S = 0x0123456789ABCDEF, 5, 3000
+    smp = _proposal.PhiloxProsacSampler(n, np.random.default_rng(4), convergence_iterations=2500)
+    smp.key, smp.batch = key, batch
+    want = smp.draw(S, m)
+    assert (smp.tops[2500:] == 0).all() and smp.tops[0] == m
+    with pytest.raises(_lib.PgxError, match="pgx_sampler_prosac_set"):
+        gpu_ctx.solve_minimal_sampled(key, batch, S, sampler="prosac")                 # no table for these points yet
+    gpu_ctx.sampler_prosac_set(smp.tops)
+    got, rows = gpu_ctx.solve_minimal_sampled(key, batch, S, fetch=True, fetch_samples=True, sampler="prosac")
+    assert np.array_equal(rows, want)
+    assert np.array_equal(got, gpu_ctx.solve_minimal(want.astype(np.int32)), equal_nan=True)
+    with pytest.raises(_lib.PgxError, match="entries"):
+        gpu_ctx.solve_minimal_sampled(key, batch, S + 1, sampler="prosac")             # more samples than the table holds
+    with pytest.raises(_lib.PgxError, match="outside"):
+        gpu_ctx.sampler_prosac_set(np.array([m, n + 1], dtype=np.int32))
+    odd = smp.tops.copy()
+    odd[7] = m - 1                                                                     # a size the table never produces: no sample
+    gpu_ctx.sampler_prosac_set(odd)
+    got, rows = gpu_ctx.solve_minimal_sampled(key, batch, S, fetch=True, fetch_samples=True, sampler="prosac")
+    assert np.array_equal(rows, _rng.prosac_samples(key, batch, S, n, m, odd)) and (rows[7] == -1).all()
+    gpu_ctx.set_points(mt, pts)                                                        # new points: the table is gone
+    with pytest.raises(_lib.PgxError, match="pgx_sampler_prosac_set"):
+        gpu_ctx.solve_minimal_sampled(key, batch, S, sampler="prosac")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,m", [("line", 2), ("homography", 4), ("fundamental", 7)])
 def test_device_napsac_draws_the_same_rows_and_models(gpu_ctx, name, m):
