@@ -795,7 +795,7 @@ class PnPEstimator(Estimator):
         P, ok = refine(start, index, weights=weights, wpow=2, iterations=10)
         return [[P[b]] if ok[b] else [] for b in range(B)]
 
-    def _fit_many(self, gram, B, inits):
+    def _fit_many(self, gram, B, inits, iterations=10):
         """`_fit` for B items at once: the same Gauss-Newton iteration with the 6x6 solves, the rotation updates and the
         convergence tests done on [B, ...] arrays - 50 refits x 10 iterations per graph-cut round were 13 us of lstsq + 15 us
         of small-array numpy each, a third of C4's proposal time.  The solve is the pseudo-inverse with lstsq's cut-off
@@ -812,7 +812,7 @@ class PnPEstimator(Estimator):
         running = have.copy()                   # still iterating
         failed = ~have
         eye = np.eye(3)
-        for _ in range(10):
+        for _ in range(iterations):
             act = np.nonzero(running)[0]
             if act.size == 0:
                 break

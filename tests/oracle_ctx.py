@@ -165,12 +165,11 @@ class OracleContext:
         from pyprogressivex import _estimators
         index = np.asarray(index, dtype=np.int64)
         inits = np.asarray(inits, dtype=np.float64).reshape(index.shape[0], 12)
-        assert iterations == 10
 
         def gram(kind, prm, use_w, wp, rows):
             G, bad = self.gram_batch(kind, index[rows], params=prm, weights=weights if use_w else None, wpow=wp)
             return G, np.full(len(rows), index.shape[1], dtype=np.int64), bad
-        fits = _estimators.PnPEstimator()._fit_many(gram, index.shape[0], [inits[b] for b in range(index.shape[0])])
+        fits = _estimators.PnPEstimator()._fit_many(gram, index.shape[0], [inits[b] for b in range(index.shape[0])], iterations=int(iterations))
         ok = np.array([len(f) == 1 for f in fits], dtype=bool)
         P = np.array([f[0] if len(f) == 1 else inits[b] for b, f in enumerate(fits)])
         return P, ok

@@ -61,6 +61,37 @@ def _differ(a, b, tol):
     return a != b
 
 
+def _refine_amplification(gpu, before, call):
+    """The Gauss-Newton pose refit iterates inside ONE call: its 6 x 6 normal equations are summed in lane order on the device and in
+    index order on the oracle, and a selection that mixes two objects makes the iteration diverge (poses at 1e9: scored, never
+    chosen) and amplifies the last-bit difference.  Evidence asked for before calling it that: replayed with 1, 2, .. iterations
+    the two sides agree to 1e-12 after the first one and the distance then grows step by step (no jump from zero)."""
+    pts = next((pa for name, pa, _, _ in reversed(before) if name == "set_points"), None)
+    if pts is None:
+        return None
+    oc = OracleContext()
+    oc.set_points(pts[0], pts[1])
+    gpu.set_points(pts[0], pts[1])
+    kw = dict(call[2])
+    total = int(kw.pop("iterations", 10))
+    dist = []
+    for it in range(1, total + 1):
+        pd, okd = gpu.pnp_refine_batch(*call[1], iterations=it, **kw)
+        po, oko = oc.pnp_refine_batch(*call[1], iterations=it, **kw)
+        if not np.array_equal(okd, oko):
+            return None
+        both = np.asarray(okd, dtype=bool)
+        scale = np.maximum(np.abs(po[both]).max(axis=1, keepdims=True), 1e-300) if both.any() else 1.0
+        dist.append(float((np.abs(pd[both] - po[both]) / scale).max()) if both.any() else 0.0)
+    if dist[0] > 1e-12 or dist[-1] <= 1e-9:
+        return None
+    first = next(k for k, d in enumerate(dist) if d > 1e-9)
+    if first > 0 and dist[first - 1] == 0.0:
+        return None                                   # from bitwise equal to far apart in one step: not rounding
+    return ("rounding amplified by a diverging Gauss-Newton iteration - max relative distance after 1 .. %d iterations: %s"
+            % (total, " ".join(f"{d:.1e}" for d in dist)))
+
+
 def classify(fn, args, kw, gpu):
     """Replays a call that returned different results on the two sides and finds the first context call that explains it.
     "bug": a call whose arguments - and those of every call before it - were bitwise the same on both sides returned different
@@ -83,7 +114,8 @@ def classify(fn, args, kw, gpu):
             if os.environ.get("SOAK_DUMP"):   # the arguments of the call and where the two results part
                 np.set_printoptions(precision=17, linewidth=220)
                 print("   call", i, a[0], "kwargs", {k: v for k, v in a[2].items() if not isinstance(v, np.ndarray)})
-                ra, rb = (a[3], b[3]) if isinstance(a[3], dict) else ({"result": a[3]}, {"result": b[3]})
+                as_dict = lambda r: r if isinstance(r, dict) else ({f"result{j}": v for j, v in enumerate(r)} if isinstance(r, list) else {"result": r})   # noqa: E731
+                ra, rb = as_dict(a[3]), as_dict(b[3])
                 for k in ra:
                     if k in rb and _differ(ra[k], rb[k], 1e-9):
                         x, y = np.asarray(ra[k]), np.asarray(rb[k])
@@ -91,7 +123,21 @@ def classify(fn, args, kw, gpu):
                         print("   field", k, "differs at", w[:6], "device", x[w[:6]] if len(w) else x, "oracle", y[w[:6]] if len(w) else y)
                         if len(w) and a[1] and isinstance(a[1][0], np.ndarray) and a[1][0].ndim == 2:
                             print("   hypotheses", a[1][0][w[:3]], "other positional args", [v for v in a[1][1:] if not isinstance(v, np.ndarray)])
-                np.save(os.environ["SOAK_DUMP"] + f"_call{i}_arg0.npy", a[1][0]) if a[1] and isinstance(a[1][0], np.ndarray) else None
+                for j, v in enumerate(a[1]):
+                    if isinstance(v, np.ndarray):
+                        np.save(os.environ["SOAK_DUMP"] + f"_call{i}_arg{j}.npy", v)
+                for k in ra:
+                    if isinstance(ra[k], np.ndarray):
+                        np.save(os.environ["SOAK_DUMP"] + f"_call{i}_device_{k}.npy", ra[k])
+                        np.save(os.environ["SOAK_DUMP"] + f"_call{i}_oracle_{k}.npy", rb[k])
+                for name, pa, _, _ in reversed(logs[0][:i]):                 # the resident points of that call
+                    if name == "set_points":
+                        np.save(os.environ["SOAK_DUMP"] + "_points.npy", pa[1])
+                        break
+            if a[0] == "pnp_refine_batch" and int(a[2].get("iterations", 10)) > 1:
+                why = _refine_amplification(gpu, logs[0][:i], a)
+                if why:
+                    return "fp-order", f"call {i} {a[0]}: {why}"
             return "bug", f"call {i} {a[0]}: identical inputs so far, results differ"
     return "fp-order", "every call agreed to 1e-9; the returned arrays differ beyond the soak's 1e-7"
 
