@@ -112,14 +112,15 @@ def test_c3_quality_with_the_full_iteration_budget():
     45-60 % of their motions - the weak (codimension-1) epipolar constraint at work, as on the bundled cubetoy scene."""
     pts, gt, Fs = datasets.make_two_view_motions(seed=0)
     # the measured band at this seed, not a sanity bound (VERDICT r3 item 8b: a regression 0.47 -> 0.53 used to pass silently):
-    # default (validity="off", the strict restatement): 8 motions, ME 0.466; with the opt-in U-14 stages 8 motions, ME 0.527
-    for validity, lo, hi in (("off", 0.44, 0.49), ("full", 0.50, 0.55)):
+    # default (validity="off", the strict restatement): 7 motions, ME 0.466 (profiles/round2_api.txt and the round-4 GPU run);
+    # with the opt-in U-14 stages 8 motions, ME 0.527
+    for validity, motions, lo, hi in (("off", 7, 0.44, 0.49), ("full", 8, 0.50, 0.55)):
         F, lab = px.findTwoViewMotions(pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
                                        minimum_point_number=1000, max_iters=2000, validity=validity)
         K = F.shape[0] // 3
         me = datasets.misclassification(np.where(lab == K, 0, lab + 1), gt)
         print(f"C3 findTwoViewMotions validity={validity}: {K} motions, misclassification {me:.4f}")
-        assert K == 8 and lo <= me <= hi, (validity, K, me)
+        assert K == motions and lo <= me <= hi, (validity, K, me)
 
 
 def test_c5_vanishing_point_scoring_all_segments_vs_oracle(gpu_ctx, oracle):
