@@ -11,6 +11,7 @@ Usage: eval_scenes.py [--oracle] [--seeds N] [--l0 greedy|expansion]   (--oracle
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -23,11 +24,22 @@ SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 RECORDED_H = {"unionhouse": 0.006, "unihouse": 0.186, "oldclassicswing": 0.005}    # adelaideH.ipynb:137-142 (cell output)
 RECORDED_F = {"breadcube": 0.017, "cubetoy": 0.012, "book": 0.032}                 # adelaideF.ipynb:149-157
 RECORDED_TLESS = [(8.249, 24.04), (0.949, 12.16)]                                  # example_multi_pose_6d.ipynb:104-109 (deg, mm)
+# wall time of the find* call alone as the same cells print it (unstated CPU, one thread)
+RECORDED_S = {"unionhouse": 0.030, "unihouse": 0.308, "oldclassicswing": 0.089, "breadcube": 0.737, "cubetoy": 0.514, "book": 0.582,
+              "tless": 57.57}
+WALL = {}   # scene -> wall seconds of every find* call made on it (the first call of a process also pays the library start-up)
+
+
+def _timed(scene, fn, *a, **k):
+    t0 = time.perf_counter()
+    out = fn(*a, **k)
+    WALL.setdefault(scene, []).append(time.perf_counter() - t0)
+    return out
 
 
 def homography_scene(scene, seed, **extra):
     corrs, gt = datasets.load_points_with_labels(os.path.join(SCENES, f"{scene}.txt"))
-    H, lab = px.findHomographies(corrs, 1024, 768, 1024, 768, threshold=4.0, conf=0.5, spatial_coherence_weight=0.05,
+    H, lab = _timed(scene, px.findHomographies, corrs, 1024, 768, 1024, 768, threshold=4.0, conf=0.5, spatial_coherence_weight=0.05,
                                  neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                                  minimum_point_number=10, maximum_model_number=6, scoring_exponent=2, sampler_id=3,
                                  do_logging=False, seed=seed, **extra)
@@ -46,7 +58,7 @@ def two_view_scene(scene, seed, **extra):
     corrs, gt = datasets.load_points_with_labels(os.path.join(SCENES, f"{scene}.txt"))
     order = density_order(corrs, 50.0)                                           # sampler_id == 2 branch of the notebook
     corrs, gt = np.ascontiguousarray(corrs[order]), gt[order]
-    F, lab = px.findTwoViewMotions(corrs, 1024, 768, 1024, 768, threshold=0.75, conf=0.5, spatial_coherence_weight=0.5,
+    F, lab = _timed(scene, px.findTwoViewMotions, corrs, 1024, 768, 1024, 768, threshold=0.75, conf=0.5, spatial_coherence_weight=0.5,
                                    neighborhood_ball_radius=50.0, maximum_tanimoto_similarity=0.4, max_iters=10000,
                                    minimum_point_number=7, maximum_model_number=4, sampler_id=2, scoring_exponent=1.0,
                                    do_logging=False, seed=seed, **extra)
@@ -57,7 +69,7 @@ def tless(seed, **extra):
     M = np.loadtxt(os.path.join(SCENES, "tless.txt"), skiprows=1)
     K = np.loadtxt(os.path.join(SCENES, "tless_intrinsics.txt"))
     gt = np.loadtxt(os.path.join(SCENES, "tless_poses.txt"), skiprows=1).reshape(-1, 3, 4)
-    P, lab = px.find6DPoses(M[:, :2], M[:, 2:5], K, 4.0, seed=seed, **extra)       # the notebook passes the threshold only
+    P, lab = _timed("tless", px.find6DPoses, M[:, :2], M[:, 2:5], K, 4.0, seed=seed, **extra)       # the notebook passes the threshold only
     out = []
     for g in gt:                                                                  # calculate_error + the argmin of the notebook
         best = (1e10, 1e10)
@@ -117,6 +129,7 @@ def run(seeds=5, l0=None, quiet=False):
             errs, k = tless(s)
         res["tless"].append(dict(seed=s, poses=k, errors_deg_mm=[(round(a, 2), round(t, 1)) for a, t in errs]))
     res["tless_recorded_deg_mm"] = RECORDED_TLESS
+    res["wall_s"] = {sc: dict(recorded=RECORDED_S[sc], ours=[round(t, 4) for t in ts]) for sc, ts in WALL.items()}
     if not quiet:
         for kind in ("homography", "two_view"):
             for scene, d in res[kind].items():
@@ -125,6 +138,8 @@ def run(seeds=5, l0=None, quiet=False):
         for d in res["tless"]:
             print(f"tless      seed {d['seed']}: {d['poses']} poses, errors (deg, mm) {d['errors_deg_mm']}  "
                   f"recorded {RECORDED_TLESS}")
+        for sc, d in res["wall_s"].items():
+            print(f"wall time  {sc:16s} recorded {d['recorded']:.3f} s (unstated CPU, 1 thread)  ours median {np.median(d['ours']):.3f} s  per seed {d['ours']}")
     return res
 
 
@@ -134,6 +149,7 @@ if __name__ == "__main__":
         from oracle_ctx import OracleContext
         _api._ctx = OracleContext()
     seeds = int(sys.argv[sys.argv.index("--seeds") + 1]) if "--seeds" in sys.argv else 5
+    px.findLines(np.random.default_rng(0).random((50, 2)) * 100, np.array(0), 100, 100, sampler_id=0, seed=0)   # library start-up
     l0 = sys.argv[sys.argv.index("--l0") + 1] if "--l0" in sys.argv else None
     out = run(seeds, l0)
     if "--lambda0" in sys.argv:
