@@ -1073,8 +1073,8 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
-    if (ctx->mf_tile && !source_reach && wq == nullptr && n <= ctx->tile_single_max && n <= 8192 && L <= 64) {   // (the sizes expand_alpha_tile takes)
-        const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed);
+    if (ctx->mf_tile && !source_reach && n <= ctx->tile_single_max && n <= 8192 && L <= 64) {   // (the sizes expand_alpha_tile takes)
+        const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed, wq);
         if (r != PGX_TILE_FALLBACK) return r;
         ctx->tile_fallbacks += 1;   // the one-workgroup solver ran and gave the move back
     }

@@ -98,6 +98,8 @@ struct TView {
     int* ctl;          // region moves enqueued without a host round trip (BatchCtl below), or nullptr
     int skip_rel;      // ... this move relabels nothing if exactly this many moves of the batch have relabelled sites so far (-1: unknown)
     int alpha_apply;   // the label apply writes (= alpha; region mode: the move's label, alpha itself is the dummy 1)
+    const long long* wq = nullptr;   // [E] per-arc weights in the ORIGINAL arc order (the inlier / outlier cut, pointwise.hip), or nullptr
+    const int* goff = nullptr;       // ... and the original CSR offsets: rows keep their entry order, so tile arc a0 + j of site s is arc goff[perm[s]] + j
 };
 
 // ---- per-move setup ----------------------------------------------------------------------------------------------------
@@ -117,9 +119,10 @@ __device__ __forceinline__ void init_site(const TView& v, const int64_t s)
     const int64_t o = v.perm[s];
     long long keep = v.dq[(int64_t)lu * v.n + o];
     const long long take = v.dq[(int64_t)v.alpha * v.n + o];
+    const long long* const wrow = v.wq ? v.wq + v.goff[o] - a0 : nullptr;
     for (int a = a0; a < a1; ++a) {
         const int lq = v.lab[v.idx[a]];
-        const long long w = v.lambda_q * (long long)v.mult[a];
+        const long long w = wrow ? wrow[a] : v.lambda_q * (long long)v.mult[a];
         if (lq == v.alpha) { keep += w; v.cap[a] = 0; }
         else if (lq == lu) v.cap[a] = w;
         else { keep += w / 2; v.cap[a] = w / 2; }
@@ -948,7 +951,8 @@ struct SmallLayout {   // byte offsets inside the small block
 
 // One expansion move on a graph that fits one workgroup (<= 8192 sites): one launch.  Returns PGX_OK (done, *changed set),
 // PGX_TILE_FALLBACK (not handled: the caller runs maxflow.hip; labels untouched) or an error.
-int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed)
+int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed,
+                      const long long* wq)
 {
     if (n > ctx->tile_single_max || n > 8192 || L > kMaxL) return PGX_TILE_FALLBACK;
     PGX_TRY(tile_graph_prepare(ctx));
@@ -977,6 +981,7 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     v.flags = (int*)(sp + SmallLayout::flags);
     v.rg = nullptr; v.ctl = nullptr; v.skip_rel = -1;
     v.alpha_apply = alpha;
+    v.wq = wq; v.goff = wq ? ctx->goff.as<int>() : nullptr;
     *changed = 0;
     v.dbg = nullptr;
     if (ctx->tile_debug) {

@@ -241,7 +241,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
 void maxflow_free(pgx_ctx* ctx);
 constexpr int PGX_TILE_FALLBACK = 1000;   // expand_alpha_tile: not handled, run the level-synchronous path (labels untouched)
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha,
-                      int64_t* changed);
+                      int64_t* changed, const long long* wq = nullptr);
 void tile_free(pgx_ctx* ctx);
 struct MfView;
 constexpr int PGX_REGION_PENDING = 1001;  // expand_alpha_region with ctx->region_defer: enqueued, result by region_result after a synchronisation

@@ -320,7 +320,10 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
     // the terminals swapped - every site starts "outlier", alpha = "inlier", and alpha goes to the sites the SOURCE reaches
     // (maxflow.hip mf_k_src_*: the minimal source side, i.e. exactly "reaches t" of the original orientation, ties -> outlier) -
     // has the ~5 % near the model as its excess sites.  Same flags bit for bit (PGX_GC_FLIP=0 for A/B; GPU test).
-    const bool flip = ctx->gc_flip != 0;
+    // A graph the one-workgroup solver takes (<= 8192 sites: the reference's own scenes) is cut in the original orientation - one
+    // launch instead of the level-synchronous schedule's dozens (0.6 ms -> 0.1 ms per cut on a 187-point scene, a fifth of a
+    // findTwoViewMotions call there); that solver applies alpha to the sites that cannot reach t, i.e. the same flags.
+    const bool flip = ctx->gc_flip != 0 && !(ctx->mf_tile && n <= ctx->tile_single_max && n <= 8192);
     hipLaunchKernelGGL(gc_terms_kernel, g, b, 0, ctx->stream, e, n, ctx->goff.as<int>(), ctx->gidx.as<int>(), lambda, lambda_q, dq,
                        wq, labels, flip ? 0 : 1);
     PGX_HIP(ctx, hipGetLastError());
