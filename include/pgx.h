@@ -109,6 +109,22 @@ int pgx_solve_minimal_sampled(pgx_ctx *ctx, int sampler, uint64_t key, uint32_t 
  * 0 = past the convergence bound (GC-RANSAC's 100 000 samples): uniform over all points.  Entries outside 0 .. n: PGX_ERR_INVALID.
  * pgx_set_points invalidates the table. */
 int pgx_sampler_prosac_set(pgx_ctx *ctx, const int32_t *subset_sizes, int count);
+/* Progressive NAPSAC on the same generator (gcransac::sampler::ProgressiveNapsacSampler<4>(&points, {16, 8, 4, 2}, sample_size,
+ * {w1, h1, w2, h2}, 0.5), progressivex_python.cpp:229-238, sampler id 2 - absent upstream, restated after Barath et al.).  HOST
+ * code, no context and no GPU: every sample updates the hit counters and neighbourhood sizes the next one reads, so a draw is one
+ * sequential chain (csrc/sampler_host.hip).  create: the grid layers over the first four coordinates of pts [n][d] (points in
+ * quality order; sizes = the four image extents; layers = cells per dimension, finest first; m = the minimal sample size, 2 .. 8).
+ * draw: the `count` samples of one proposal (the sampler state restarts, progressive_x.h:290) as count x m indices - sample k <
+ * min(count, max_local) local (centre k, m - 2 distinct members of its growing cell neighbourhood, the neighbourhood's last member),
+ * the others and the points without a large enough cell through PROSAC with subset size tops[k] (0 = uniform); growth_local [n] =
+ * PROSAC's growth function for m - 1 points and max_local samples.  A pure function of (key, batch) and the data:
+ * pyprogressivex/_rng.py pnapsac_samples returns the same rows.  Errors: pgx_global_error. */
+typedef struct pgx_pnapsac pgx_pnapsac;
+int pgx_pnapsac_create(const double *pts, int64_t n, int d, const double *sizes, const int32_t *layers, int n_layers, int m,
+                       pgx_pnapsac **out);
+int pgx_pnapsac_draw(pgx_pnapsac *sampler, uint64_t key, uint32_t batch, int32_t count, const int32_t *tops,
+                     const int64_t *growth_local, int64_t max_local, int32_t *out);
+void pgx_pnapsac_destroy(pgx_pnapsac *sampler);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
                     double *scores, uint64_t *masks);

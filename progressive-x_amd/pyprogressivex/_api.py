@@ -6,7 +6,7 @@ findTwoViewMotions ignores scoring_exponent, findLines ignores weights, only fin
 
 Extensions that do not change the reference behaviour when left at their defaults (keyword-only):
   seed=None                     reproducible sampling (the reference seeds from std::random_device)
-  sampler_rng="numpy"           "philox": the uniform and NAPSAC samplers draw from the in-repo counter-based generator (_rng.py), on the device when they can
+  sampler_rng="numpy"           "philox": the samplers draw from the in-repo counter-based generator (_rng.py) - uniform, NAPSAC and PROSAC on the device inside the solver's launch, Progressive NAPSAC (sequential) in libpgx's host code
   distributed=None              True: shard the proposal batches over the ranks of this launch (every rank must make the same
                                 call on the same data; checked).  None: only if PGX_MULTI_GPU=1.  Never implicit.
   max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
@@ -113,7 +113,10 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
         graph = ctx.graph_build(graph_points, _lib.GRAPH_KNN_IN_BALL, radius=radius, k=5, fetch=fetch)
     if not fetch:
         graph = None
-    sampler = sampler_factory(n, rng, graph)
+    if sampler_rng == "philox" and getattr(sampler_factory, "kind", None) == "pnapsac":   # (sequential: drawn by libpgx's host code)
+        sampler = _proposal.PhiloxProgressiveNapsacSampler(n, rng, *sampler_factory.pnapsac_args)
+    else:
+        sampler = sampler_factory(n, rng, graph)
     if sampler_rng == "philox" and type(sampler) is _proposal.UniformSampler:   # the in-repo counter-based generator (device-drawable)
         sampler = _proposal.PhiloxUniformSampler(n, rng)
     elif sampler_rng == "philox" and type(sampler) is _proposal.NapsacSampler:
@@ -161,6 +164,8 @@ def _sampler_factory(sampler_id, valid, pts=None, sizes=None, sample_size=None, 
             return _proposal.ProgressiveNapsacSampler(n, rng, pts, sizes, sample_size)
         return _proposal.NapsacSampler(n, rng, graph)
     make.unknown = sampler_id not in valid
+    make.kind = valid.get(sampler_id)
+    make.pnapsac_args = (pts, sizes, sample_size)
     make.needs_graph = valid.get(sampler_id) == "napsac"
     make.sampler_id = sampler_id
     return make

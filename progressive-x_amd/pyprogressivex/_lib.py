@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
     "pgx_score_inliers", "pgx_solve_minimal_sampled", "pgx_sampler_prosac_set", "pgx_score_set_global_n", "pgx_score_allreduce", "pgx_score_allreduce_begin", "pgx_score_allreduce_end",
+    "pgx_pnapsac_create", "pgx_pnapsac_draw", "pgx_pnapsac_destroy",
 ]
 
 
@@ -72,6 +73,8 @@ def load():
     lib.pgx_last_error.argtypes = [C.c_void_p]
     lib.pgx_destroy.restype = None
     lib.pgx_destroy.argtypes = [C.c_void_p]
+    lib.pgx_pnapsac_destroy.restype = None
+    lib.pgx_pnapsac_destroy.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -102,6 +105,49 @@ def comm_unique_id():
     if r != 0:
         raise PgxError(f"pgx_comm_unique_id failed ({r}): {lib.pgx_global_error().decode()}")
     return bytes(buf)
+
+
+class PnapsacSampler:
+    """pgx_pnapsac_*: Progressive NAPSAC on the in-repo generator, host code of libpgx.so (csrc/sampler_host.hip) - needs no GPU
+    context.  draw() = the samples of one proposal; _rng.pnapsac_samples is the same function in numpy."""
+
+    def __init__(self, pts, sizes, m, layers=(16, 8, 4, 2)):
+        self._lib = load()
+        pts = _f64(pts)
+        self.n, self.m = int(pts.shape[0]), int(m)
+        sz = np.zeros(4)
+        s = _f64(sizes).reshape(-1)[:4]
+        sz[:len(s)] = s
+        lay = _i32(layers)
+        h = C.c_void_p()
+        r = self._lib.pgx_pnapsac_create(_ptr(pts, C.c_double), C.c_int64(self.n), C.c_int(int(pts.shape[1])), _ptr(sz, C.c_double),
+                                         _ptr(lay, C.c_int32), C.c_int(len(lay)), C.c_int(self.m), C.byref(h))
+        if r != 0:
+            raise PgxError(f"pgx_pnapsac_create failed ({r}): {self._lib.pgx_global_error().decode()}")
+        self._h = h
+
+    def draw(self, key, batch, count, tops, growth_local, max_local):
+        tops = _i32(tops)
+        growth = np.ascontiguousarray(growth_local, dtype=np.int64)
+        if len(tops) < count or len(growth) < self.n:
+            raise ValueError("pgx_pnapsac_draw: one subset size per sample and one growth entry per point")
+        out = np.empty((int(count), self.m), dtype=np.int32)
+        r = self._lib.pgx_pnapsac_draw(self._h, C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int32(int(count)),
+                                       _ptr(tops, C.c_int32), _ptr(growth, C.c_int64), C.c_int64(int(max_local)), _ptr(out, C.c_int32))
+        if r != 0:
+            raise PgxError(f"pgx_pnapsac_draw failed ({r}): {self._lib.pgx_global_error().decode()}")
+        return out.astype(np.int64)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pgx_pnapsac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

@@ -108,3 +108,101 @@ def prosac_samples(key, batch, count, n, m, tops, first=0):
         out[late] = uniform_samples(key, batch, count, n, m, first=first)[late]
     out[~(late | good)] = -1
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Progressive NAPSAC on the same generator (csrc/sampler_host.hip pnapsac_draw): the statement of _proposal.ProgressiveNapsacSampler
+# with every random choice taken from (key, batch, sample number)
+# ---------------------------------------------------------------------------------------------------------------------
+PNAPSAC_LAYERS = (16, 8, 4, 2)     # gcransac::sampler::ProgressiveNapsacSampler<4>(&points, {16, 8, 4, 2}, ...), progressivex_python.cpp:229-238
+
+
+def pnapsac_cells(pts, sizes, layers=PNAPSAC_LAYERS):
+    """Per grid layer: (cell id per point, {cell id: member indices in ascending = quality order}).  Cell coordinate of a point in
+    dimension d = clip(floor(x_d / (size_d / div)), 0, div - 1), id = the coordinates as digits in base div."""
+    pts = np.asarray(pts, dtype=np.float64)[:, :4]
+    n, dims = pts.shape
+    sizes = np.asarray(sizes, dtype=np.float64).reshape(-1)[:dims]
+    out = []
+    for div in layers:
+        cell = np.clip(np.floor(pts / (sizes / div)), 0, div - 1).astype(np.int64)
+        cid = np.zeros(n, dtype=np.int64)
+        for d in range(dims):
+            cid = cid * div + cell[:, d]
+        order = np.argsort(cid, kind="stable")
+        bounds = np.nonzero(np.diff(cid[order]))[0] + 1
+        starts = np.concatenate([[0], bounds]) if n else np.zeros(0, dtype=np.int64)
+        out.append((cid, dict(zip(cid[order][starts].tolist(), np.split(order, bounds)))))
+    return out
+
+
+def _words(s, batch, block, key):
+    """the four words of (sample s, batch, block) under key, as Python ints"""
+    s = np.array([s], dtype=np.uint64)
+    return [int(x[0]) for x in philox4x32(s & _MASK, s >> _S32, int(batch) & 0xFFFFFFFF, block, key & 0xFFFFFFFF, key >> 32)]
+
+
+def pnapsac_samples(key, batch, count, n, m, cells, growth_local, max_local, tops):
+    """[count, m] int64: one draw of Progressive NAPSAC (a fresh sampler state: the hit counters restart with every proposal,
+    progressive_x.h:290).  Sample k < min(count, max_local) is local: centre k (past n points: word 0 uniform), its hit counter
+    and neighbourhood size s_p grow along growth_local, the neighbourhood is the first s_p members of the finest layer's cell that
+    holds that many; the row is m - 2 DISTINCT members before the last one (word 1 + j picks the r-th not taken yet), the last
+    one, the centre.  A point without a large enough cell, and every later sample, is a PROSAC row (prosac_samples' rule with
+    tops[k]).  growth_local = PROSAC's growth function for m - 1 points and max_local samples; tops = n_k of the global sampler."""
+    if not (2 <= m <= 8) or n < m:
+        raise ValueError("pnapsac_samples: need 2 <= m <= 8 and n >= m")
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    tops = np.asarray(tops, dtype=np.int64)
+    growth_local = np.asarray(growth_local, dtype=np.int64)
+    out = np.full((count, m), -1, dtype=np.int64)
+    hits = np.zeros(n, dtype=np.int64)
+    subset = np.full(n, m, dtype=np.int64)
+    layer = np.zeros(n, dtype=np.int64)
+    n_local = min(int(count), int(max_local))
+    glob = np.zeros(count, dtype=bool)
+    glob[n_local:] = True
+    for k in range(n_local):
+        w = _words(k, batch, 0, key)
+        p = k if k < n else (w[0] * n) >> 32
+        hits[p] += 1
+        sp = int(subset[p])
+        while sp < n and hits[p] > growth_local[sp - 1]:
+            sp += 1
+        subset[p] = sp
+        lay, nb = int(layer[p]), None
+        while lay < len(cells):
+            cid, members = cells[lay]
+            nb = members[int(cid[p])]
+            if len(nb) >= sp:
+                break
+            lay += 1
+            nb = None
+        layer[p] = lay
+        if nb is None:
+            glob[k] = True
+            continue
+        others = nb[:sp]
+        others = others[others != p]
+        if len(others) < m - 1:
+            glob[k] = True
+            continue
+        taken = []
+        for j in range(m - 2):
+            if (1 + j) % 4 == 0:
+                w = _words(k, batch, (1 + j) // 4, key)
+            r = (w[(1 + j) % 4] * (len(others) - 1 - j)) >> 32
+            pos = 0
+            while pos < j and taken[pos] <= r:
+                r += 1
+                pos += 1
+            taken.insert(pos, r)
+            out[k, j] = others[r]
+            hits[others[r]] += 1
+        out[k, m - 2] = others[-1]
+        hits[others[-1]] += 1
+        out[k, m - 1] = p
+    gi = np.nonzero(glob)[0]
+    if len(gi):
+        allg = prosac_samples(key, batch, count, n, m, tops)
+        out[gi] = allg[gi]
+    return out

@@ -58,8 +58,11 @@ def test_philox_samplers_through_the_pipeline(oracle_backend):
             assert H.shape == (6, 3) and _me(lab, 2, gt) < 0.05, sid
         H2, lab2 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=sid, **kw)
         assert np.array_equal(H, H2) and np.array_equal(lab, lab2)
-    H3, lab3 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=2, **kw)      # P-NAPSAC: sequential per-point state, numpy stream kept
+    # P-NAPSAC (id 2): sequential per-point state - drawn by libpgx's host code (csrc/sampler_host.hip) from the same generator
+    H3, lab3 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=2, **kw)
     assert H3.shape[0] >= 3
+    H4, lab4 = px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=2, **kw)
+    assert np.array_equal(H3, H4) and np.array_equal(lab3, lab4)
 
 
 def test_two_view_motion_pipeline(oracle_backend):

@@ -99,6 +99,63 @@ def test_prosac_samples_follow_the_subset_sizes(oracle):
     assert (late.tops[10:] == 0).all() and (late.tops[:10] > 0).all() and len(np.unique(c[10:, 3])) > 10
 
 
+@pytest.mark.parametrize("n,m,count,variant", [(300, 7, 1000, "plain"), (187, 7, 10000, "plain"), (50, 4, 400, "duplicates"), (2000, 4, 3000, "outside"),
+                                               (8, 7, 50, "plain"), (40, 2, 100, "plain"), (3000, 7, 4000, "clustered")])
+def test_progressive_napsac_native_draw_equals_the_numpy_restatement(n, m, count, variant):
+    """Progressive NAPSAC on the in-repo generator: libpgx.so's host code (csrc/sampler_host.hip, pgx_pnapsac_*; no GPU involved)
+    against _rng.pnapsac_samples row for row; the grid cells are those of the numpy-stream sampler of _proposal.py; rows are m
+    distinct indices; a local row ends with (the last member of the centre's neighbourhood, the centre = the sample number)."""
+    rng = np.random.default_rng(n + m)
+    sizes = [1024.0, 768.0, 1024.0, 768.0]
+    pts = rng.random((n, 4)) * sizes
+    if variant == "duplicates":
+        pts[:20] = pts[0]
+    if variant == "outside":
+        pts[:, 0] = 2000.0                     # beyond the image: clipped into the last cell
+        pts[::7, 1] = -5.0
+    if variant == "clustered":
+        pts[:, :2] = pts[:, :2] * 0.05 + 300.0
+    ref = _proposal.ProgressiveNapsacSampler(n, rng, pts, sizes, m)
+    cells = _rng.pnapsac_cells(pts, sizes)
+    for (c1, m1), (c2, m2) in zip(cells, ref.cells):
+        assert np.array_equal(c1, c2) and set(m1) == set(m2) and all(np.array_equal(m1[k], m2[k]) for k in m2)
+    tops = ref.prosac.subset_sizes(1, count, m)
+    nat = _lib.PnapsacSampler(pts, sizes, m)
+    key = int(rng.integers(0, 1 << 63))
+    for batch in (0, 3):
+        a = _rng.pnapsac_samples(key, batch, count, n, m, cells, ref.growth_local, ref.max_local, tops)
+        b = nat.draw(key, batch, count, tops, ref.growth_local, ref.max_local)
+        assert b.dtype == np.int64 and np.array_equal(a, b)
+        assert (b >= 0).all() and (b < n).all() and all(len(set(r)) == m for r in b.tolist())
+    assert not np.array_equal(a, nat.draw(key, 0, count, tops, ref.growth_local, ref.max_local))     # another batch, other rows
+    n_local = min(count, ref.max_local)
+    local = b[:n_local][b[:n_local, m - 1] == np.arange(n_local)]          # (rows that fell back to PROSAC end with n_k - 1 instead)
+    assert len(local) > 0 or n < 2 * m
+    nat.close()
+
+
+def test_progressive_napsac_sampler_class_and_error_paths():
+    rng = np.random.default_rng(5)
+    pts = rng.random((120, 4)) * 500
+    s = _proposal.PhiloxProgressiveNapsacSampler(120, np.random.default_rng(1), pts, [500, 500, 500, 500], 4)
+    a = s.draw(300, 4)
+    s.reset()
+    b = s.draw(300, 4)
+    assert a.shape == (300, 4) and not np.array_equal(a, b)                       # every proposal: a new batch
+    s2 = _proposal.PhiloxProgressiveNapsacSampler(120, np.random.default_rng(1), pts, [500, 500, 500, 500], 4)
+    assert np.array_equal(a, s2.draw(300, 4))                                     # a function of the call's seed
+    with pytest.raises(ValueError):
+        s.draw(10, 5)
+    assert _proposal.PhiloxProgressiveNapsacSampler(3, np.random.default_rng(1), pts[:3], [500] * 4, 4).draw(10, 4).shape == (0, 4)
+    with pytest.raises(_lib.PgxError):
+        _lib.PnapsacSampler(pts, [500] * 4, 1)                                    # sample size 1: no neighbourhood to draw from
+    with pytest.raises(_lib.PgxError):
+        _lib.PnapsacSampler(pts, [500] * 4, 4, layers=(0,))
+    nat = _lib.PnapsacSampler(pts, [500] * 4, 4)
+    with pytest.raises(ValueError):
+        nat.draw(1, 0, 50, np.zeros(10, np.int32), np.ones(120, np.int64), 60)   # fewer subset sizes than samples
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,m", [("line", 2), ("pnp", 3), ("homography", 4), ("fundamental", 7)])
 def test_device_prosac_draws_the_same_rows_and_models(gpu_ctx, name, m):
