@@ -75,6 +75,10 @@ def test_philox_sampler_device_drawn_batches_identical_to_cpu_restatement(monkey
     (H, lab), (Hr, labr) = _both(monkeypatch, px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=1,
                                  seed=3, minimum_point_number=40, sampler_rng="philox")
     assert H.shape[0] >= 6 and np.array_equal(lab, labr) and np.allclose(H, Hr, rtol=1e-8, atol=1e-10)
+    # Progressive NAPSAC (sampler id 2): drawn by the library's host code on both sides, solved and scored on the device here
+    (H, lab), (Hr, labr) = _both(monkeypatch, px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=2,
+                                 seed=4, minimum_point_number=40, sampler_rng="philox")
+    assert H.shape[0] >= 6 and np.array_equal(lab, labr) and np.allclose(H, Hr, rtol=1e-8, atol=1e-10)
     with pytest.raises(ValueError, match="sampler_rng"):
         px.findHomographies(pts, 1000, 1000, 1000, 1000, sampler_id=0, sampler_rng="mt19937")
 
