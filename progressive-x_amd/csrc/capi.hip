@@ -107,6 +107,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_NO_GROUP")) ctx->group_filter = std::atoi(b) ? 0 : 1;
     if (const char* b = std::getenv("PGX_VERIFY")) ctx->verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_TILE")) ctx->mf_tile = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_TILE_BATCH")) ctx->mf_tile_batch = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_MEMO")) ctx->mf_memo = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
@@ -954,7 +955,10 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
             std::vector<int> ev((size_t)(ctx->L > 0 ? ctx->L : 1), 0);
             PGX_TRY(expand_cycle_l0(ctx, hq, ch.data(), ev.data()));
             for (int alpha = 0; alpha < ctx->L; ++alpha) changed_total += ch[(size_t)alpha];
-        } else if (region_moves_apply(ctx) && !(ctx->mf_tile && ctx->dq_n <= ctx->tile_single_max)) {
+        } else if ((ctx->mf_tile && ctx->mf_tile_batch && ctx->dq_n <= ctx->tile_single_max && ctx->dq_n <= 8192 && ctx->L <= 64) ||
+                   (region_moves_apply(ctx) && !(ctx->mf_tile && ctx->dq_n <= ctx->tile_single_max))) {
+            // (graphs of <= 8192 sites - the reference's own scenes: every move is ONE launch of the one-workgroup solver,
+            //  maxflow_tile.hip expand_alpha_tile; batched the same way, a read-back per move was two thirds of a move's time)
             // Region moves (maxflow_tile.hip): the moves of the cycle are enqueued back to back and resolved together - one
             // host round trip per batch instead of one per move.  A move that declines poisons the rest of its batch on the device
             // (they return untouched); it is solved by the general path and the cycle resumes behind it.  The skip rule below is

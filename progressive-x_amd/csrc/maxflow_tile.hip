@@ -550,6 +550,11 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         if (c > T) return;                  // too large for this workgroup: the next launch takes it
         if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
         v.n = c;
+    } else if (v.ctl) {
+        // a whole-graph move enqueued in a batch (pgx_expansion on a graph of <= 8192 sites: the moves of a cycle back to back, one
+        // read-back per batch): behind a move that gave up, or under the skip rule, it returns untouched - as the region moves do
+        if (batch_skips(v.ctl, v.skip_rel)) return;
+        if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
     }
     const int tile_n = (int)v.n;
     int cnt_alpha = 0;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         if (changed) add32_ag(&v.flags[1], changed);
         st32<SC_AG>(&v.flags[4], rounds + 1);
         st32<SC_AG>(&v.flags[5], gave_up);
-        if (region && v.ctl) {
+        if (v.ctl) {
             if (gave_up) st32<SC_AG>(&v.ctl[0], 1);
             else if (changed) add32_ag(&v.ctl[1], 1);
         }
@@ -871,6 +876,7 @@ struct TileState {
     int64_t n = 0, E = 0;
     int64_t version = -1;     // graph_version this copy was built from
     DevBuf perm, inv, off, idx, rev, mult, tmp;
+    bool slot_is_tile[64] = {};   // per slot of the current batch: a whole-graph move (expand_alpha_tile) rather than a region move
     DevBuf cap, ex, rt, f, d, lab, small, dbg;
     DevBuf rg_slot, rg_need, rg_site, rg_off, rg_idx, rg_rev, rg_cap, rg_site_state;   // region moves (expand_alpha_region)
     DevBuf rg_small, rg_ctl;  // kRegionSlots small blocks (one per move in flight) and the batch's control words
@@ -949,6 +955,10 @@ struct SmallLayout {   // byte offsets inside the small block
 
 }  // namespace
 
+constexpr int kRegionSlots = 64;   // moves in flight per batch (one per label: kMaxL)
+constexpr size_t kRegionBlock = (SmallLayout::bytes + sizeof(RegionInfo) + 255) / 256 * 256;   // a move's small block + region info
+constexpr size_t kRegionHostOff = SmallLayout::flags;   // the host mirror has the device layout: a slot's flags[8] | count, bad, cnt_alpha sit at this offset of its block
+
 // One expansion move on a graph that fits one workgroup (<= 8192 sites): one launch.  Returns PGX_OK (done, *changed set),
 // PGX_TILE_FALLBACK (not handled: the caller runs maxflow.hip; labels untouched) or an error.
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed,
@@ -966,7 +976,13 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     PGX_TRY(ensure(ctx, ts->lab, (size_t)n * 4));
     PGX_TRY(ensure(ctx, ts->small, SmallLayout::bytes));
     if (!ts->h_small) PGX_HIP(ctx, hipHostMalloc(&ts->h_small, SmallLayout::bytes, hipHostMallocDefault));
-    char* sp = (char*)ts->small.p;
+    // enqueued in a batch (pgx_expansion, ctx->region_defer): the move's small block is a slot of the batch - cleared by
+    // region_batch_begin, read back by region_batch_fetch, interpreted by region_result - and nothing here waits for the device
+    const bool defer = ctx->region_defer != 0 && wq == nullptr;
+    if (defer && (ctx->region_slot < 0 || ctx->region_slot >= kRegionSlots || !ts->rg_small.p || !ts->rg_ctl.p))
+        return fail(ctx, PGX_ERR_INVALID, "batched move: slot %d not prepared", ctx->region_slot);
+    char* sp = defer ? (char*)ts->rg_small.p + (size_t)ctx->region_slot * kRegionBlock : (char*)ts->small.p;
+    if (defer) ts->slot_is_tile[ctx->region_slot] = true;
     TView v;
     v.n = n; v.L = L; v.alpha = alpha; v.lambda_q = lambda_q; v.h_q = h_q;
     v.dq = dq; v.labels = labels;
@@ -979,7 +995,9 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     v.hub_d = (int*)(sp + SmallLayout::hub_d);
     v.hub_exists = (int*)(sp + SmallLayout::hub_exists);
     v.flags = (int*)(sp + SmallLayout::flags);
-    v.rg = nullptr; v.ctl = nullptr; v.skip_rel = -1;
+    v.rg = nullptr;
+    v.ctl = defer ? ts->rg_ctl.as<int>() : nullptr;
+    v.skip_rel = defer ? ctx->region_skip_rel : -1;
     v.alpha_apply = alpha;
     v.wq = wq; v.goff = wq ? ctx->goff.as<int>() : nullptr;
     *changed = 0;
@@ -989,11 +1007,12 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
         PGX_HIP(ctx, hipMemsetAsync(ts->dbg.p, 0, 16 * 8, ctx->stream));
         v.dbg = ts->dbg.as<unsigned long long>();
     }
-    PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes, ctx->stream));
+    if (!defer) PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes, ctx->stream));
     const int sweeps = ctx->tile_sweeps, max_rounds = 4096;
     if (n <= 4096) hipLaunchKernelGGL((t_move_kernel<1024, 4, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
     else hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
     PGX_HIP(ctx, hipGetLastError());
+    if (defer) return PGX_REGION_PENDING;
     char* hs = (char*)ts->h_small;
     PGX_HIP(ctx, hipMemcpyAsync(hs, sp, SmallLayout::bytes, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1025,9 +1044,6 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
 // initialisation (t-links, arcs) and the label count are this function's first kernel, fused with the search for open sites.  PGX_OK: done, *changed set.  PGX_TILE_FALLBACK: declined - the labels are untouched and mv's state is
 // initialised and intact, the general path continues from it.  The caller checks the applicability conditions of the first
 // line (maxflow.hip): when they fail nothing has been initialised.
-constexpr int kRegionSlots = 64;   // moves in flight per batch (one per label: kMaxL)
-constexpr size_t kRegionBlock = (SmallLayout::bytes + sizeof(RegionInfo) + 255) / 256 * 256;   // a move's small block + region info
-constexpr size_t kRegionHostOff = SmallLayout::flags;   // the host mirror has the device layout: a slot's flags[8] | count, bad, cnt_alpha sit at this offset of its block
 
 int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
 {
@@ -1055,6 +1071,7 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
     }
     if (!ts->h_rg) PGX_HIP(ctx, hipHostMalloc(&ts->h_rg, kRegionSlots * kRegionBlock, hipHostMallocDefault));
     char* sp = (char*)ts->rg_small.p + (size_t)slot * kRegionBlock;
+    ts->slot_is_tile[slot] = false;
     TView v;
     v.n = 0; v.L = 2; v.alpha = 1; v.alpha_apply = mv.alpha; v.lambda_q = mv.lambda_q; v.h_q = mv.h_q;
     v.dq = nullptr; v.labels = mv.labels;
@@ -1136,6 +1153,17 @@ int region_result(pgx_ctx* ctx, int slot, int alpha, int* status, int64_t* chang
     if (ctx->tile_debug >= 2)
         std::fprintf(stderr, "[region] alpha=%d open=%d bad=%d rounds=%d gave_up=%d taken=%d changed=%d\n", alpha, h[8], h[9], h[4], h[5], h[6], h[1]);
     *changed = 0;
+    const bool whole = ts->slot_is_tile[slot];   // a batched whole-graph move: accounted like expand_alpha_tile's own
+    if (whole && h[5] != 0) { *status = 1; return PGX_OK; }   // (the caller runs the move again, unbatched: counted there)
+    if (whole && h[6] != 0) {
+        ctx->stats[0] += 1;
+        ctx->paths[0] += 1;
+        ctx->stats[2] += h[4];
+        *changed = h[1];
+        ctx->stats[4] += *changed;
+        *status = 0;
+        return PGX_OK;
+    }
     if (h[5] != 0 || h[7] != 0) { ts->region_rejects += 1; ctx->paths[4] += 1; *status = 1; return PGX_OK; }
     if (h[6] == 0) { *status = 2; return PGX_OK; }
     ts->region_moves += 1;

@@ -130,6 +130,7 @@ struct pgx_ctx {
     int64_t graph_version = 0;   // bumped whenever the resident graph changes (graph_build_reverse)
     pgx::DevBuf gorder;          // sites in the Morton order of the coordinates the graph was built on (graph.hip); gorder_n == gn when valid
     int64_t gorder_n = 0;
+    int mf_tile_batch = 1;       // PGX_MF_TILE_BATCH=0: one host round trip per one-workgroup move (A/B)
     int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
     int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
