@@ -27,12 +27,13 @@ RECORDED_TLESS = [(8.249, 24.04), (0.949, 12.16)]                               
 # wall time of the find* call alone as the same cells print it (unstated CPU, one thread)
 RECORDED_S = {"unionhouse": 0.030, "unihouse": 0.308, "oldclassicswing": 0.089, "breadcube": 0.737, "cubetoy": 0.514, "book": 0.582,
               "tless": 57.57}
+EXTRA = {}  # keyword-only extensions applied to every call (--sampler-rng philox)
 WALL = {}   # scene -> wall seconds of every find* call made on it (the first call of a process also pays the library start-up)
 
 
 def _timed(scene, fn, *a, **k):
     t0 = time.perf_counter()
-    out = fn(*a, **k)
+    out = fn(*a, **{**k, **EXTRA})
     WALL.setdefault(scene, []).append(time.perf_counter() - t0)
     return out
 
@@ -149,6 +150,8 @@ if __name__ == "__main__":
         from oracle_ctx import OracleContext
         _api._ctx = OracleContext()
     seeds = int(sys.argv[sys.argv.index("--seeds") + 1]) if "--seeds" in sys.argv else 5
+    if "--sampler-rng" in sys.argv:   # "philox": every sampler on the in-repo generator (device-drawn / libpgx host code)
+        EXTRA["sampler_rng"] = sys.argv[sys.argv.index("--sampler-rng") + 1]
     px.findLines(np.random.default_rng(0).random((50, 2)) * 100, np.array(0), 100, 100, sampler_id=0, seed=0)   # library start-up
     l0 = sys.argv[sys.argv.index("--l0") + 1] if "--l0" in sys.argv else None
     out = run(seeds, l0)
