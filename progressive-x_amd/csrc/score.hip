@@ -310,8 +310,19 @@ __global__ __launch_bounds__(64 * kGroupWaves) void score_group_kernel(
         for (int q = 0; q < R::D; ++q) pt[q] = pts_g[((int64_t)g * R::D + q) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 8; ++q) p32[q] = 0.0f;
+        if constexpr (RowFromPoint<MT>::in1 >= RowFromPoint<MT>::in0) {
+            // the generic f32 row (sp_prep_kernel) recomputed from the f64 row just loaded - the same operations, the same bits -
+            // instead of a second 24-byte row per point from memory (24 MB of 89 fetched per launch at 10^6 points)
 #pragma unroll
-        for (int q = 0; q < F32::kRowVals; ++q) p32[q] = p32_g[((int64_t)g * 8 + q) * 64 + lane];
+            for (int q = 0; q < R::D; ++q) p32[q] = (float)pt[q];
+            double pm = 1.0;
+#pragma unroll
+            for (int q = RowFromPoint<MT>::in0; q <= RowFromPoint<MT>::in1; ++q) { const double a = fabs(pt[q]); if (!(a <= pm)) pm = a; }
+            p32[5] = (float)(pm * 1.000001);
+        } else {
+#pragma unroll
+            for (int q = 0; q < F32::kRowVals; ++q) p32[q] = p32_g[((int64_t)g * 8 + q) * 64 + lane];
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < R::D; ++q) pt[q] = pts[jj * R::D + q];

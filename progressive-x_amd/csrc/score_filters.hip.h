@@ -144,6 +144,13 @@ template <int MT> struct Filter32 {
 // hypotheses look at the same image region): 74 % of the (wave, group) pairs of the metric batch.
 // kGroupInflate, kGroupRow, kSuper: pgx_internal.h (shared with setpoints.hip, which builds the rows on the device)
 
+// Model types whose f32 row is the generic one of setpoints.hip sp_prep_kernel - (float) of every coordinate, then the scale
+// max(1, |coordinates in0 .. in1|) * 1.000001 in slot 5: the group kernel derives it from the f64 row instead of loading it.
+template <int MT> struct RowFromPoint { static constexpr int in0 = 0, in1 = -1; };           // in1 < in0: no (the row is loaded)
+template <> struct RowFromPoint<kPnP> { static constexpr int in0 = 2, in1 = 4; };            // setpoints.hip: obs0 = 0, in0 = 2, in1 = 4
+template <> struct RowFromPoint<kHomography> { static constexpr int in0 = 0, in1 = 3; };     // obs0 = 2, in0 = 0, in1 = 3
+template <> struct RowFromPoint<kHomographySym> { static constexpr int in0 = 0, in1 = 3; };
+
 template <> struct Filter32<kPnP> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 6, kGroupVals = 9;

@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "scripts")]
 import eval_scenes as E
 import numpy as np
+if os.environ.get("SCENE_RNG"):
+    E.EXTRA["sampler_rng"] = os.environ["SCENE_RNG"]
 E.px.findLines(np.random.default_rng(0).random((50, 2)) * 100, np.array(0), 100, 100, sampler_id=0, seed=0)
 for scene in sys.argv[1:]:
     fn = E.homography_scene if scene in E.RECORDED_H else (E.two_view_scene if scene in E.RECORDED_F else (lambda sc, seed: E.tless(seed)))
