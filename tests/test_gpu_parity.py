@@ -645,6 +645,34 @@ def test_each_mincut_path_is_the_one_that_ran(mincut_ctx, oracle):
         assert paths["level_synchronous"] == 0 and paths["region"] == 0 and paths["tile_handed_back"] == 0
 
 
+@pytest.mark.parametrize("n,lam,h,L", [(700, 0.3, 2.0, 3), (3000, 0.2, 3.0, 7), (8000, 0.1, 10.0, 5)])
+def test_batched_one_workgroup_moves_equal_unbatched(oracle, monkeypatch, n, lam, h, L):
+    """Graphs of <= 8192 sites: pgx_expansion enqueues the one-workgroup moves of a cycle back to back (the region moves' batch
+    slots, poison word and on-device skip rule; one read-back per batch).  Same labels, energy, cycles and work counters as one
+    host round trip per move (PGX_MF_TILE_BATCH=0), and the oracle's result; a second expansion from the optimum is one empty cycle."""
+    Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=7 * n + L)
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
+    seen = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("PGX_MF_TILE_BATCH", batch)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(np.zeros(n, np.int32))
+            eq, _, cycles = ctx.expansion(lam, h)
+            assert np.array_equal(ctx.get_labels(), ref_labels) and eq == ref_e and cycles == ref_cycles, batch
+            st, paths = ctx.expansion_stats(), ctx.expansion_paths()
+            assert paths["one_workgroup"] > 0 and paths["region"] == 0 and paths["level_synchronous"] == 0
+            seen[batch] = (st["mincuts"], st["relabelled_sites"], st["skipped_moves"], paths["one_workgroup"])
+            eq2, _, cycles2 = ctx.expansion(lam, h)
+            assert eq2 == eq and cycles2 == 1
+        finally:
+            ctx.close()
+    assert seen["1"] == seen["0"]
+
+
 @pytest.mark.parametrize("n,lam,h,L", [(30000, 0.15, 4.0, 6), (60000, 0.3, 0.0, 5), (60000, 0.05, 12.0, 9)])
 def test_region_moves_match_oracle(oracle, monkeypatch, n, lam, h, L):
     """Graphs beyond the one-workgroup limit: a move whose OPEN sites (no t-link left after the source / sink saturation)
