@@ -532,6 +532,8 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     __shared__ TileLds<T> lds;
     __shared__ int s_cnt;
     __shared__ unsigned long long s_stuck;
+    __shared__ unsigned long long s_pool[kMaxL];
+    __shared__ int s_open;
     const int tid = (int)threadIdx.x;
     const bool region = v.rg != nullptr;   // the arrays hold a prepared problem of rg->count sites, no hubs
     if (region) {
@@ -580,6 +582,27 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
         cnt_alpha = lds.hubmin[v.alpha];
         for (int i = tid; i < tile_n; i += NT) init_site(v, i);
         __syncthreads();
+        // A move nobody can want: no site without a t-link (only such a site can fail to reach t - and takes alpha then, ties
+        // included) and every label's hub drains into its members' t-links with capacity to spare (sum of their rt > h, strictly:
+        // at equality every member's t-link may end saturated).  Then every site reaches t whatever is pushed, the cut is empty and
+        // nothing is relabelled: decided here, before the first search - most moves of a steady-state cycle end this way, and the
+        // search + count they skip is half of a move's time on the reference's scenes.
+        if (tid < kMaxL) s_pool[tid] = 0ull;
+        if (tid == 0) s_open = 0;
+        __syncthreads();
+        bool open = false;
+        for (int i = tid; i < tile_n; i += NT) {
+            const int l = v.lab[i];
+            if (l == v.alpha) continue;
+            const long long r = v.rt[i];   // (written by this thread in init_site)
+            if (r <= 0) open = true;
+            else if (v.h_q > 0) atomicAdd(&s_pool[l], (unsigned long long)r);
+        }
+        if (open) s_open = 1;
+        __syncthreads();
+        const bool thin = tid < v.L && v.h_q > 0 && tid != v.alpha && lds.hubmin[tid] > 0 && s_pool[tid] <= (unsigned long long)v.h_q;
+        const int thin_any = __syncthreads_or(thin ? 1 : 0);
+        if (s_open == 0 && thin_any == 0) return;   // flags stay zero: nothing relabelled, no rounds, not given up
     }
     int rounds = 0, gave_up = 0;
     long long hub_left_prev = -1;
