@@ -16,7 +16,7 @@ def run(scene, seed, thr):
                                    neighborhood_ball_radius=50.0, maximum_tanimoto_similarity=0.4, max_iters=10000,
                                    minimum_point_number=7, maximum_model_number=4, sampler_id=2, scoring_exponent=1.0, seed=seed)
     return round(float(datasets.misclassification(lab, gt)), 3), F.shape[0] // 3
-for thr in (0.75, 0.5, 0.45, 0.375, 0.3, 0.25):
+for thr in (float(x) for x in (sys.argv[1:] or ["0.75", "0.5", "0.45", "0.375", "0.3", "0.25"])):
     for scene in ("cubetoy", "breadcube", "book"):
         r = [run(scene, s, thr) for s in range(10)]
         print(f"thr {thr:5.3f} {scene:10s} median {np.median([x[0] for x in r]):.3f}  {[x[0] for x in r]}  models {[x[1] for x in r]}", flush=True)
