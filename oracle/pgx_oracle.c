@@ -1142,3 +1142,96 @@ void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t cou
         }
     }
 }
+
+/* Progressive NAPSAC on the same generator (gcransac::sampler::ProgressiveNapsacSampler<4>, progressivex_python.cpp:229-238; absent
+ * upstream [UPSTREAM-MEMORY]): the statement of pyprogressivex/_rng.py pnapsac_samples in C - the checker of libpgx.so's host code
+ * (csrc/sampler_host.hip).  pts [n][d] in quality order, grid layers over the first min(d, 4) coordinates. */
+typedef struct { int64_t cid; int32_t idx; } pnap_pair;
+static int pnap_cmp(const void *a, const void *b)
+{
+    const pnap_pair *x = (const pnap_pair *)a, *y = (const pnap_pair *)b;
+    if (x->cid != y->cid) return x->cid < y->cid ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);   /* members in ascending index = quality order */
+}
+
+int pgxo_sample_pnapsac(const double *pts, int64_t n, int d, const double *sizes, const int32_t *layers, int n_layers, int m,
+                        uint64_t key, uint32_t batch, int32_t count, const int32_t *tops, const int64_t *growth_local, int64_t max_local,
+                        int32_t *samples)
+{
+    if (n < m || m < 2 || m > 8 || n_layers < 1 || n_layers > 16) return -1;
+    const int dims = d < 4 ? d : 4;
+    const uint32_t k2[2] = {(uint32_t)key, (uint32_t)(key >> 32)};
+    /* per layer: members sorted by (cell, index), the start of every point's cell run and its length */
+    pnap_pair *pairs = (pnap_pair *)malloc((size_t)n_layers * (size_t)n * sizeof(pnap_pair));
+    int32_t *run0 = (int32_t *)malloc((size_t)n_layers * (size_t)n * sizeof(int32_t));
+    int32_t *runlen = (int32_t *)malloc((size_t)n_layers * (size_t)n * sizeof(int32_t));
+    int64_t *hits = (int64_t *)calloc((size_t)n, sizeof(int64_t));
+    int32_t *subset = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    int32_t *layer = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    int32_t *others = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    if (!pairs || !run0 || !runlen || !hits || !subset || !layer || !others) { free(pairs); free(run0); free(runlen); free(hits); free(subset); free(layer); free(others); return -2; }
+    for (int l = 0; l < n_layers; ++l) {
+        pnap_pair *pl = pairs + (size_t)l * (size_t)n;
+        const int div = layers[l];
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t id = 0;
+            for (int q = 0; q < dims; ++q) {
+                double c = floor(pts[i * d + q] / (sizes[q] / (double)div));
+                c = c > 0.0 ? (c > (double)(div - 1) ? (double)(div - 1) : c) : 0.0;
+                id = id * div + (int64_t)c;
+            }
+            pl[i].cid = id;
+            pl[i].idx = (int32_t)i;
+        }
+        qsort(pl, (size_t)n, sizeof(pnap_pair), pnap_cmp);
+        for (int64_t a = 0; a < n;) {
+            int64_t b = a;
+            while (b < n && pl[b].cid == pl[a].cid) ++b;
+            for (int64_t q = a; q < b; ++q) { run0[(size_t)l * (size_t)n + (size_t)pl[q].idx] = (int32_t)a; runlen[(size_t)l * (size_t)n + (size_t)pl[q].idx] = (int32_t)(b - a); }
+            a = b;
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) subset[i] = m;
+    const int64_t n_local = (int64_t)count < max_local ? (int64_t)count : max_local;
+    for (int64_t k = 0; k < count; ++k) {
+        int32_t *row = samples + k * m;
+        int global = k >= n_local;
+        if (!global) {
+            uint32_t w[4];
+            uint32_t ctr[4] = {(uint32_t)k, (uint32_t)((uint64_t)k >> 32), batch, 0u};
+            pgxo_philox4x32(ctr, k2, w);
+            const int64_t p = k < n ? k : (int64_t)(((uint64_t)w[0] * (uint64_t)n) >> 32);
+            hits[p] += 1;
+            int64_t sp = subset[p];
+            while (sp < n && hits[p] > growth_local[sp - 1]) ++sp;
+            subset[p] = (int32_t)sp;
+            int lay = layer[p];
+            const pnap_pair *nb = NULL;
+            for (; lay < n_layers; ++lay)
+                if ((int64_t)runlen[(size_t)lay * (size_t)n + (size_t)p] >= sp) { nb = pairs + (size_t)lay * (size_t)n + (size_t)run0[(size_t)lay * (size_t)n + (size_t)p]; break; }
+            layer[p] = lay;
+            int cnt = 0;
+            if (nb) for (int64_t q = 0; q < sp; ++q) if (nb[q].idx != (int32_t)p) others[cnt++] = nb[q].idx;
+            if (!nb || cnt < m - 1) global = 1;
+            else {
+                int32_t taken[8];
+                for (int j = 0; j < m - 2; ++j) {
+                    if (((1 + j) & 3) == 0) { ctr[3] = (uint32_t)((1 + j) >> 2); pgxo_philox4x32(ctr, k2, w); }
+                    int64_t r = (int64_t)(((uint64_t)w[(1 + j) & 3] * (uint64_t)(cnt - 1 - j)) >> 32);
+                    int pos = 0;
+                    for (; pos < j && taken[pos] <= r; ++pos) ++r;
+                    for (int q = j; q > pos; --q) taken[q] = taken[q - 1];
+                    taken[pos] = (int32_t)r;
+                    row[j] = others[r];
+                    hits[others[r]] += 1;
+                }
+                row[m - 2] = others[cnt - 1];
+                hits[others[cnt - 1]] += 1;
+                row[m - 1] = (int32_t)p;
+            }
+        }
+        if (global) pgxo_sample_prosac(key, batch, k, 1, n, tops + k, m, row);
+    }
+    free(pairs); free(run0); free(runlen); free(hits); free(subset); free(layer); free(others);
+    return 0;
+}

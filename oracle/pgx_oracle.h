@@ -114,6 +114,10 @@ void pgxo_sample_napsac(uint64_t key, uint32_t batch, int64_t first, int64_t cou
 
 /* PROSAC on the same generator: tops[t] = the hypothesis-generation set size n_k of sample first + t (0 = uniform over all n) */
 void pgxo_sample_prosac(uint64_t key, uint32_t batch, int64_t first, int64_t count, int64_t n, const int32_t* tops, int m, int32_t* samples);
+/* Progressive NAPSAC, one draw (a fresh sampler state), count x m indices; 0 on success */
+int pgxo_sample_pnapsac(const double *pts, int64_t n, int d, const double *sizes, const int32_t *layers, int n_layers, int m,
+                        uint64_t key, uint32_t batch, int32_t count, const int32_t *tops, const int64_t *growth_local, int64_t max_local,
+                        int32_t *samples);
 
 #ifdef __cplusplus
 }

@@ -279,6 +279,27 @@ def sample_prosac(key, batch, first, count, n, tops, m):
     return out
 
 
+def sample_pnapsac(key, batch, count, pts, sizes, m, tops, growth_local, max_local, layers=(16, 8, 4, 2)):
+    """Progressive NAPSAC on the in-repo generator, one draw: [count, m] int32 (pgxo_sample_pnapsac)"""
+    pts = _f64(pts)
+    n, d = pts.shape
+    sz = np.zeros(4)
+    sv = _f64(sizes).reshape(-1)[:4]
+    sz[:len(sv)] = sv
+    lay = _i32(layers)
+    tops32 = _i32(tops)
+    growth = np.ascontiguousarray(growth_local, dtype=np.int64)
+    assert len(tops32) >= count and len(growth) >= n
+    out = np.empty((count, m), dtype=np.int32)
+    lib().pgxo_sample_pnapsac.restype = C.c_int
+    r = lib().pgxo_sample_pnapsac(_p(pts, C.c_double), C.c_int64(n), C.c_int(d), _p(sz, C.c_double), _p(lay, C.c_int32), C.c_int(len(lay)), C.c_int(m),
+                                  C.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), C.c_uint32(int(batch) & 0xFFFFFFFF), C.c_int32(int(count)),
+                                  _p(tops32, C.c_int32), _p(growth, C.c_int64), C.c_int64(int(max_local)), _p(out, C.c_int32))
+    if r != 0:
+        raise ValueError(f"pgxo_sample_pnapsac: {r}")
+    return out
+
+
 def residual_sum(model_type, pts, model, labels, label):
     pts = _f64(pts); model = _f64(model); labels = _i32(labels)
     return lib().pgxo_residual_sum(C.c_int(model_type), _p(pts, C.c_double), C.c_int64(pts.shape[0]),

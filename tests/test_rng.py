@@ -101,9 +101,9 @@ def test_prosac_samples_follow_the_subset_sizes(oracle):
 
 @pytest.mark.parametrize("n,m,count,variant", [(300, 7, 1000, "plain"), (187, 7, 10000, "plain"), (50, 4, 400, "duplicates"), (2000, 4, 3000, "outside"),
                                                (8, 7, 50, "plain"), (40, 2, 100, "plain"), (3000, 7, 4000, "clustered")])
-def test_progressive_napsac_native_draw_equals_the_numpy_restatement(n, m, count, variant):
+def test_progressive_napsac_native_draw_equals_the_numpy_restatement(oracle, n, m, count, variant):
     """Progressive NAPSAC on the in-repo generator: libpgx.so's host code (csrc/sampler_host.hip, pgx_pnapsac_*; no GPU involved)
-    against _rng.pnapsac_samples row for row; the grid cells are those of the numpy-stream sampler of _proposal.py; rows are m
+    against _rng.pnapsac_samples and the oracle's C restatement (pgxo_sample_pnapsac) row for row; the grid cells are those of the numpy-stream sampler of _proposal.py; rows are m
     distinct indices; a local row ends with (the last member of the centre's neighbourhood, the centre = the sample number)."""
     rng = np.random.default_rng(n + m)
     sizes = [1024.0, 768.0, 1024.0, 768.0]
@@ -126,6 +126,7 @@ def test_progressive_napsac_native_draw_equals_the_numpy_restatement(n, m, count
         a = _rng.pnapsac_samples(key, batch, count, n, m, cells, ref.growth_local, ref.max_local, tops)
         b = nat.draw(key, batch, count, tops, ref.growth_local, ref.max_local)
         assert b.dtype == np.int64 and np.array_equal(a, b)
+        assert np.array_equal(a, oracle.sample_pnapsac(key, batch, count, pts, sizes, m, tops, ref.growth_local, ref.max_local))
         assert (b >= 0).all() and (b < n).all() and all(len(set(r)) == m for r in b.tolist())
     assert not np.array_equal(a, nat.draw(key, 0, count, tops, ref.growth_local, ref.max_local))     # another batch, other rows
     n_local = min(count, ref.max_local)
