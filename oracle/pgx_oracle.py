@@ -20,10 +20,10 @@ FIXED_ONE = 1 << 32
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "pgx_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("pgx_oracle.c", "pgx_oracle.h", "progx_replay.c", "progx_replay.h", "bk_maxflow.c")]
     if os.environ.get("PGX_ORACLE_SO"):
         return _SO
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs if os.path.exists(f)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

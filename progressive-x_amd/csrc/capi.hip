@@ -129,7 +129,7 @@ void pgx_destroy(pgx_ctx* ctx)
                       &ctx->red_partials, &ctx->red_out, &ctx->dq, &ctx->kmodels, &ctx->labels, &ctx->goff,
                       &ctx->gidx, &ctx->gmult, &ctx->grev, &ctx->scratch, &ctx->fit_scratch, &ctx->pts_s, &ctx->pts32_s,
                       &ctx->pmax_s, &ctx->comp_s, &ctx->pperm, &ctx->gbounds, &ctx->masks_s, &ctx->cull_lists, &ctx->cull_counts, &ctx->gc, &ctx->gc_sel,
-                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->weights_scratch};
+                      &ctx->weights, &ctx->stats_buf, &ctx->pts_g, &ctx->p32_g, &ctx->weights_scratch, &ctx->memo.snaps, &ctx->prosac_tops};
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -267,8 +267,10 @@ int pgx_set_points(pgx_ctx* ctx, int model_type, const double* points, int64_t n
     ctx->model_type = model_type; ctx->D = d; ctx->P = p; ctx->n = n;
     ctx->points_version += 1;
     ctx->labels_all_zero = 0;
-    ctx->M = 0; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
+    ctx->M = 0; ctx->last_acc = nullptr; ctx->dq_n = 0; ctx->L = 0; ctx->labels_n = 0;
     ctx->weights_n = 0;  // weights belong to a point set
+    ctx->score_global_n = 0;   // the fixed-point scale of a sharded job belongs to that job's point set
+    if (ctx->memo.snaps.p) { (void)hipStreamSynchronize(ctx->stream); release(ctx->memo.snaps); ctx->memo.cap = 0; ctx->memo.valid = 0; ctx->memo.n = 0; }   // first-cycle snapshots of the old point set
     // upload + every derived copy on the device (setpoints.hip): filter scales, f32 rows, Morton order, group bounds
     const int rc = !ctx->setpoints_host ? set_points_device(ctx, model_type, points, n) : set_points_host(ctx, model_type, points, n, d);
     if (rc != PGX_OK) {   // half-built copies (an allocation failed midway): no resident problem, every later call fails cleanly
@@ -409,7 +411,7 @@ int pgx_score_upload(pgx_ctx* ctx, const double* models, int M)
     PGX_HIP(ctx, hipMemcpyAsync(ctx->perm.p, hp, pbytes, hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipEventRecord(ctx->ev_models, ctx->stream));
     ctx->h_models_busy = 1;
-    ctx->M = M;
+    ctx->M = M; ctx->last_acc = nullptr;
     return PGX_OK;
 }
 

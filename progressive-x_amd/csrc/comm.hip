@@ -68,6 +68,7 @@ struct ExchangeSlot {
     hipEvent_t scored = nullptr, done = nullptr;
     int M = 0, Mpad = 0, has_compound = 0, busy = 0;
     int reduced = 0;   // begun by pgx_score_allreduce_begin: `host` holds ONE block counts | values | shared, not one per rank
+    int local_fail = 0; // this rank contributed the poison word instead of accumulators (export_or_poison)
 };
 
 struct CommState {
@@ -304,6 +305,31 @@ int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
 // any order and the reduced table is bitwise the table of ONE GPU scoring all the points (the ranks agree on q through
 // pgx_score_set_global_n).  Cull, dispatch and the group kernel's work all divide by the number of ranks, which sharding the
 // hypotheses does not do (the fixed ~60 us of a step).  After the call pgx_score_fetch returns the reduced table.
+// A rank whose launch could not take the integer-accumulator path (NaN / Inf in ITS slice of the points, the per-slice U / T
+// guard, filters switched off) must not skip the collective - the other ranks would wait in it for ever.  Every rank
+// always enters the all-reduce: the block carries one extra word, 0 from a rank that exported its accumulators and 1 (behind an
+// all-zero block) from a rank that could not; a non-zero sum raises PGX_ERR_INVALID on EVERY rank after the reduction.
+static int export_or_poison(pgx_ctx* ctx, unsigned long long* blk, size_t W, hipStream_t stream, int* local_fail)
+{
+    *local_fail = 0;
+    if (ctx->last_acc != nullptr && ctx->last_score_path == 2 && ctx->last_acc_M == ctx->M && ctx->last_acc_Mpad == ctx->Mpad) {
+        PGX_TRY(score_acc_export(ctx, blk, stream));
+        PGX_HIP(ctx, hipMemsetAsync(blk + W, 0, 64, stream));
+        return PGX_OK;
+    }
+    *local_fail = 1;
+    PGX_HIP(ctx, hipMemsetAsync(blk, 0, (W + 8) * 8, stream));
+    PGX_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(blk + W), 1u, 1, stream));
+    return PGX_OK;
+}
+
+static int poisoned(pgx_ctx* ctx, const char* who, unsigned long long bad_ranks, int local_fail)
+{
+    return fail(ctx, PGX_ERR_INVALID, "%s: %llu rank(s) could not take the group-major path (integer accumulators)%s; the reduced table is invalid. "
+                                      "The path needs sorted points, the f32 filter and the cull (the defaults) and finite points in every slice",
+                who, bad_ranks, local_fail ? " - this rank is one of them" : "");
+}
+
 int pgx_score_allreduce(pgx_ctx* ctx)
 {
     if (!ctx || !ctx->comm) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce: communicator not initialised");
@@ -311,10 +337,15 @@ int pgx_score_allreduce(pgx_ctx* ctx)
     if (ctx->M <= 0 || !ctx->counts.p) return fail(ctx, PGX_ERR_INVALID, "pgx_score_allreduce: nothing launched");
     PGX_HIP(ctx, hipSetDevice(ctx->device));
     const size_t W = (size_t)3 * (size_t)ctx->Mpad;
-    PGX_TRY(ensure(ctx, ctx->g_counts, W * 8));
+    PGX_TRY(ensure(ctx, ctx->g_counts, (W + 8) * 8));
     unsigned long long* blk = (unsigned long long*)ctx->g_counts.p;
-    PGX_TRY(score_acc_export(ctx, blk, ctx->stream));
-    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W, ncclUint64, ncclSum, ctx->comm->comm, ctx->stream));
+    int local_fail = 0;
+    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail));
+    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W + 8, ncclUint64, ncclSum, ctx->comm->comm, ctx->stream));
+    unsigned long long bad = 0;
+    PGX_HIP(ctx, hipMemcpyAsync(&bad, blk + W, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return poisoned(ctx, "pgx_score_allreduce", bad, local_fail);
     PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, ctx->last_qscale, ctx->counts.as<long long>(), ctx->values.as<double>(),
                              ctx->shared.as<double>(), ctx->stream));
     ctx->mirror_valid = 0;   // the host mirror holds this rank's partial table
@@ -330,18 +361,21 @@ int pgx_score_allreduce_begin(pgx_ctx* ctx, int slot)
     CommState* cs = ctx->comm;
     const size_t W = (size_t)3 * (size_t)ctx->Mpad, need = W * 8;
     ExchangeSlot* ep = nullptr;
-    PGX_TRY(slot_prepare(ctx, "pgx_score_allreduce_begin", slot, need, need, &ep));
+    PGX_TRY(slot_prepare(ctx, "pgx_score_allreduce_begin", slot, need + 64, need + 64, &ep));
     ExchangeSlot& e = *ep;
     unsigned long long* blk = (unsigned long long*)e.stage.p;
-    PGX_TRY(score_acc_export(ctx, blk, ctx->stream));
+    int local_fail = 0;
+    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail));     // never skips the collective (see above)
     PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
     PGX_HIP(ctx, hipStreamWaitEvent(cs->xstream, e.scored, 0));
-    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W, ncclUint64, ncclSum, cs->comm, cs->xstream));
+    PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W + 8, ncclUint64, ncclSum, cs->comm, cs->xstream));
     long long* res = (long long*)e.gathered.p;
-    PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, ctx->last_qscale, res, (double*)res + ctx->Mpad, (double*)res + 2 * (size_t)ctx->Mpad, cs->xstream));
+    PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, local_fail ? 1.0 : ctx->last_qscale, res, (double*)res + ctx->Mpad,
+                             (double*)res + 2 * (size_t)ctx->Mpad, cs->xstream));
     PGX_HIP(ctx, hipMemcpyAsync(e.host, e.gathered.p, need, hipMemcpyDeviceToHost, cs->xstream));
+    PGX_HIP(ctx, hipMemcpyAsync((char*)e.host + need, blk + W, 8, hipMemcpyDeviceToHost, cs->xstream));
     PGX_HIP(ctx, hipEventRecord(e.done, cs->xstream));
-    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1; e.reduced = 1;
+    e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1; e.reduced = 1; e.local_fail = local_fail;
     return PGX_OK;
 }
 
@@ -354,6 +388,8 @@ int pgx_score_allreduce_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
     ExchangeSlot& e = ctx->comm->slot[slot];
     PGX_HIP(ctx, hipEventSynchronize(e.done));
     e.busy = 0; e.reduced = 0;
+    const unsigned long long bad = *(const unsigned long long*)((const char*)e.host + (size_t)3 * (size_t)e.Mpad * 8);
+    if (bad) return poisoned(ctx, "pgx_score_allreduce_end", bad, e.local_fail);
     unpack_block(e.host, (size_t)e.M, (size_t)e.Mpad, e.has_compound, exponent, counts, values, shared, scores);
     return PGX_OK;
 }

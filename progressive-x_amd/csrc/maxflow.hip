@@ -1008,6 +1008,7 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
     if (ctx->labels_n != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: labels not set (or wrong length)");
     if (ctx->labels_max >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, L);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
+    if (L - 1 > ctx->labels_max) ctx->labels_max = L - 1;   // the cycle may write every label
     if (!ctx->mf) {
         ctx->mf = new MaxflowState();
         PGX_HIP(ctx, hipHostMalloc((void**)&ctx->mf->h_flags, 64, hipHostMallocDefault));
@@ -1054,6 +1055,7 @@ int expand_alpha_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int alpha, 
     if (ctx->labels_max >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, L);
     if (alpha < 0 || alpha >= L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: alpha %d out of range", alpha);
     if (L > kMfMaxLabels) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: at most %d labels (got %d)", kMfMaxLabels, L);
+    if (alpha > ctx->labels_max) ctx->labels_max = alpha;   // the move may write alpha: a later, smaller table must see it
     if (lambda_q <= 0) return expand_alpha_l0(ctx, h_q, alpha, changed);
     return expand_alpha_on(ctx, n, L, ctx->dq.as<long long>(), ctx->labels.as<int>(), nullptr, lambda_q, h_q, alpha, changed);
 }

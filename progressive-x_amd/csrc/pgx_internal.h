@@ -83,6 +83,7 @@ struct pgx_ctx {
     unsigned long long* last_acc = nullptr;   // integer accumulators [nrep][3][Mpad] of the last group-major launch (device order), or nullptr
     int last_nrep = 0;
     double last_qscale = 0.0;
+    int last_acc_M = 0, last_acc_Mpad = 0;    // the batch the accumulators belong to (an upload / solve after the launch makes them stale)
     pgx::DevBuf models, pcnt, pval, psh, counts, values, shared, masks;
     pgx::DevBuf perm;        // perm[sorted position] = caller's hypothesis index (locality ordering, capi.hip)
     int score_sort = 1;      // PGX_NO_SORT=1 keeps the caller's order (A/B)

@@ -600,6 +600,9 @@ __global__ __launch_bounds__(256) void score_acc_import_kernel(const unsigned lo
 
 int score_acc_export(pgx_ctx* ctx, unsigned long long* out, hipStream_t stream)
 {
+    if (ctx->last_acc != nullptr && (ctx->last_acc_M != ctx->M || ctx->last_acc_Mpad != ctx->Mpad))
+        return fail(ctx, PGX_ERR_INVALID, "integer accumulators are stale: the batch changed (upload / solve) since the last launch (%d of %d then, %d of %d now)",
+                    ctx->last_acc_M, ctx->last_acc_Mpad, ctx->M, ctx->Mpad);
     if (ctx->last_acc == nullptr || ctx->last_score_path != 2)
         return fail(ctx, PGX_ERR_INVALID, "point-sharded exchange: the last launch did not run the group-major path (integer accumulators); "
                                           "it needs sorted points, the f32 filter and the cull (the defaults)");
@@ -790,7 +793,7 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
                                ctx->shared.as<double>(), nrep, mirror);
             PGX_HIP(ctx, hipGetLastError());
             ctx->mirror_valid = mirror != nullptr;
-            ctx->last_acc = acc; ctx->last_nrep = nrep; ctx->last_qscale = qscale;
+            ctx->last_acc = acc; ctx->last_nrep = nrep; ctx->last_qscale = qscale; ctx->last_acc_M = ctx->M; ctx->last_acc_Mpad = ctx->Mpad;
             if (ctx->score_profile >= 2) PGX_HIP(ctx, hipEventRecord(ctx->kev[3], ctx->stream));
             ctx->last_score_path = 2;
             return PGX_OK;

@@ -483,7 +483,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->M = Mtot;
+        ctx->M = Mtot; ctx->last_acc = nullptr;
         return PGX_OK;
     }
     if (ctx->model_type == kPnP) {
@@ -498,7 +498,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->M = Mtot;
+        ctx->M = Mtot; ctx->last_acc = nullptr;
         return PGX_OK;
     }
     if (ctx->model_type == kHomography) {
@@ -513,7 +513,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         if (models_out)
             PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->M = S;
+        ctx->M = S; ctx->last_acc = nullptr;
         return PGX_OK;
     }
     if (ctx->model_type != kLine2D && ctx->model_type != kVanishingPoint)
@@ -533,7 +533,7 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
     if (models_out)
         PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->M = S;
+    ctx->M = S; ctx->last_acc = nullptr;
     return PGX_OK;
 }
 

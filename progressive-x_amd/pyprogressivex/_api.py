@@ -75,7 +75,7 @@ def _unknown_sampler(sampler_id):
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
          do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-         local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy"):
+         local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
     n = pts.shape[0]
     if sampler_rng not in ("numpy", "philox"):
         raise ValueError("sampler_rng should be 'numpy' or 'philox'")
@@ -95,7 +95,7 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
             type(estimator).__name__, float(radius), getattr(sampler_factory, "sampler_id", None), float(threshold), float(conf),
             float(spatial_coherence_weight), float(maximum_tanimoto_similarity), int(max_iters), int(minimum_point_number),
             int(maximum_model_number), int(scoring_exponent), seed, int(max_outer_iterations), str(neighborhood),
-            str(local_optimization), str(labeling_l0)))
+            str(local_optimization), str(labeling_l0), str(sampler_rng), getattr(estimator, "validity", None), str(pearl_abs)))
         if seed is None:
             seed = parallel.shared_seed()
     rng = np.random.default_rng(seed)
@@ -138,8 +138,16 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
     if labeling_l0 not in ("greedy", "expansion"):
         raise ValueError("labeling_l0 should be 'greedy' or 'expansion'")
     s.labeling_l0 = str(labeling_l0)
+    if pearl_abs not in ("double", "int"):
+        raise ValueError("pearl_abs should be 'double' or 'int'")
+    s.pearl_abs = str(pearl_abs)        # [U-16] which abs() PEARL.h:465 resolves to
+    if trace is not None and hasattr(trace, "begin"):
+        # diagnostics hook (_engine.EV_*): what the run is made of, for a replay of its decisions (tests/)
+        trace.begin(dict(model_type=estimator.model_type, points=pts, graph_points=graph_points, radius=float(radius),
+                         neighborhood=str(neighborhood), sample_size=int(estimator.sample_size),
+                         nonminimal_sample_size=int(estimator.nonminimal_sample_size), settings=s))
     px = _engine.ProgressiveX(ctx, estimator, pts, graph, sampler, s, scoring_exponent=scoring_exponent,
-                              do_logging=do_logging, graph_resident=resident, exchange=exchange)
+                              do_logging=do_logging, graph_resident=resident, exchange=exchange, trace=trace)
     models, stats = px.run()
     labeling = np.asarray(stats.labeling, dtype=np.int64).astype(np.int32)     # bindings.cpp:152-156
     return models, labeling, stats
@@ -175,7 +183,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                      do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -194,7 +202,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 3), labels
 
 
@@ -202,7 +210,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="off", sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="off", sampler_rng="numpy", trace=None, pearl_abs="double"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n]).
     validity [U-14, keyword-only, not in the reference's signature]: which of the estimator's model-validity stages run -
     "off" (the default: strict restatement of what is in the snapshot, i.e. none), "oriented", "symmetric" (oriented +
@@ -228,7 +236,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 3), labels
 
 
@@ -239,7 +247,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                         do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -256,7 +264,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
                              weights=_weights(weights, n), seed=seed, max_outer_iterations=max_outer_iterations,
-                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng)
+                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 3), labels
 
 
@@ -264,7 +272,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
               do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -282,7 +290,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 3), labels
 
 
@@ -290,7 +298,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
                 minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
                 neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
     import time
     x1 = _as_f64(x1y1)
@@ -325,5 +333,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 4), labels

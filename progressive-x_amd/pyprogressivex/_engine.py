@@ -18,6 +18,15 @@ import numpy as np
 from . import _proposal
 
 
+# Decision events of the two loops below, handed to the optional `trace=` hook (diagnostics; the reference's analogue is its
+# do_logging narration).  An object with .proposal(model_or_None, inliers, iterations), .refit(inlier_number, fits) and
+# .event(code, a, b, c, x, y) receives every input the loops take from the proposal engine / the refit solver and every
+# decision they make; tests/ compares the stream with an independent replay of progressive_x.h / PEARL.h (oracle/progx_replay.c,
+# whose header documents the fields).
+(EV_OUTER, EV_PROPOSAL_EMPTY, EV_PROPOSAL, EV_VALIDATION, EV_UNACCEPTED, EV_SINGLE_MODEL, EV_PEARL_ITER, EV_REFIT_SKIP, EV_REFIT,
+ EV_REJECT, EV_PEARL_END, EV_LABELING, EV_COMPOUND, EV_UNSEEN, EV_BREAK) = range(1, 16)
+
+
 class MultiModelSettings:
     """progx::MultiModelSettings (progressive_x.h:32-73) with the defaults of its constructor."""
 
@@ -43,6 +52,10 @@ class MultiModelSettings:
         self.local_optimization = "auto"      # "auto": graph-cut LO when 0 < lambda < 1, else LSQ refits; "lsq": always LSQ
         # not in the reference: its outer loop is hard-capped at 10 proposals (progressive_x.h:272)
         self.max_outer_iterations = 10
+        # [U-16] PEARL.h:465 calls an unqualified abs(energy - previous_energy) behind #include <math.h>.  With libstdc++ / MSVC
+        # headers the double overload is visible in the global namespace ("double", the default); a toolchain that resolves it
+        # to int abs(int) truncates the difference first, so convergence fires whenever |dE| < 1 ("int").
+        self.pearl_abs = "double"
 
     def set_confidence(self, c):  # :49-53
         self.confidence = c
@@ -75,7 +88,8 @@ class Model:
 def predicted_unseen_inliers(one_minus_confidence, sample_size, iteration_number, covered, point_number):
     """progressive_x.h:495-513 (size_t arithmetic: point_number - covered wraps if covered > point_number)."""
     unseen = (point_number - covered) % (1 << 64)
-    ratio = math.pow(1.0 - math.pow(one_minus_confidence, 1.0 / iteration_number), 1.0 / sample_size)
+    one_over_iteration_number = 1.0 / iteration_number if iteration_number else math.inf   # (1.0 / 0 in C++: +inf, no guard upstream)
+    ratio = math.pow(1.0 - math.pow(one_minus_confidence, one_over_iteration_number), 1.0 / sample_size)
     v = unseen * ratio
     return int(math.floor(v + 0.5)) if v >= 0 else int(math.ceil(v - 0.5))  # std::round: halves away from zero
 
@@ -85,7 +99,7 @@ def predicted_unseen_inliers(one_minus_confidence, sample_size, iteration_number
 # ---------------------------------------------------------------------------------------------------------------------
 class Pearl:
     def __init__(self, ctx, estimator, pts, threshold, spatial_coherence_weight, minimum_inlier_number, point_weights,
-                 maximum_iteration_number=100, do_logging=False, labeling_l0="greedy"):
+                 maximum_iteration_number=100, do_logging=False, labeling_l0="greedy", trace=None, pearl_abs="double"):
         self.ctx, self.est, self.pts = ctx, estimator, pts
         self.threshold = threshold
         self.lam = spatial_coherence_weight
@@ -96,6 +110,10 @@ class Pearl:
         self.point_weights = point_weights
         self.do_logging = do_logging
         self.labeling_l0 = labeling_l0   # U-8 switch, see labeling()
+        self.trace = trace
+        if pearl_abs not in ("double", "int"):
+            raise ValueError("pearl_abs should be 'double' or 'int'")
+        self.pearl_abs = pearl_abs       # U-16 switch, see run()
         self.n = pts.shape[0]
         self.has_engine = False      # alpha_expansion_engine != nullptr
         self.outliers_number = 0
@@ -161,12 +179,24 @@ class Pearl:
                 continue
             cand[k] = np.asarray(fits[k][0], dtype=np.float64).reshape(-1)
             tried.append(k)
+        accepted = set()
+        after = None
         if tried:
             after = self.ctx.residual_sums(cand)
             for k in tried:
                 if after[k] < before[k]:                              # :393
                     models[k].descriptor = cand[k].copy()
+                    accepted.add(k)
                     changed = True
+        if self.trace is not None:                                    # in the reference's per-instance order
+            for k in range(K):
+                cnt = self.points_per_instance[k]
+                if k in small:
+                    self.trace.event(EV_REFIT_SKIP, k, cnt)
+                    continue
+                self.trace.refit(cnt, fits[k])
+                one = len(fits[k]) == 1
+                self.trace.event(EV_REFIT, k, cnt, 2 * len(fits[k]) + (k in accepted), float(before[k]), float(after[k]) if one else 0.0)
         return changed
 
     # PEARL.h:275-315
@@ -179,6 +209,8 @@ class Pearl:
                 del self.points_per_instance[k]
                 del models[k]
                 changed = True
+                if self.trace is not None:
+                    self.trace.event(EV_REJECT, k, cnt)
                 if self.do_logging:
                     print(f"[Optimization] Instance {k} is rejected due to having too few inliers ({cnt}).")
         return changed
@@ -194,16 +226,26 @@ class Pearl:
             if self.do_logging:
                 print(f"[Optimization] Iteration {iteration_number}.")
             init_prev = iteration_number > 1 and not model_rejected           # :429-431
+            models_before = len(models)
             e = self.labeling(models, init_prev)                              # :434
             if e is not None:
                 energy = e
+            if self.trace is not None:
+                self.trace.event(EV_PEARL_ITER, iteration_number, models_before, int(init_prev), float(energy))
             if self.do_logging:
                 print(f"[Optimization] The energy of the labeling is {energy}.")
             params_changed = self.parameter_estimation(models)               # :453
             model_rejected = self.reject_instances(models)                   # :458
-            if (not model_rejected and not params_changed and abs(energy - previous_energy) < self.epsilon
-                    and iteration_number > 1):                               # :463-467
+            delta = energy - previous_energy
+            if self.pearl_abs == "int":                                       # [U-16] int abs(int): truncation towards zero first
+                abs_delta = float(abs(int(delta))) if -2147483648.0 < delta < 2147483648.0 else sys.float_info.max
+            else:
+                abs_delta = abs(delta)
+            if not model_rejected and not params_changed and abs_delta < self.epsilon and iteration_number > 1:   # :463-467
                 convergence = True
+            if self.trace is not None:
+                self.trace.event(EV_PEARL_END, iteration_number, 2 * int(params_changed) + int(model_rejected),
+                                 2 * len(models) + int(convergence))
             previous_energy = energy
         self.iterations += iteration_number
         return True
@@ -221,8 +263,9 @@ class Pearl:
 # ---------------------------------------------------------------------------------------------------------------------
 class ProgressiveX:
     def __init__(self, ctx, estimator, pts, graph, sampler, settings, scoring_exponent=2, do_logging=False,
-                 exchange=None, graph_resident=False):
+                 exchange=None, graph_resident=False, trace=None):
         self.ctx, self.est, self.pts, self.graph = ctx, estimator, pts, graph
+        self.trace = trace
         self.graph_resident = graph_resident   # built by ctx.graph_build: already on the device
         self.sampler, self.settings = sampler, settings
         self.scoring_exponent = int(scoring_exponent)   # setExponent(const int) truncates (scoring_function...h:39)
@@ -246,13 +289,16 @@ class ProgressiveX:
             self.ctx.set_graph(*self.graph)
         self.pearl = Pearl(self.ctx, self.est, self.pts, s.inlier_outlier_threshold, s.spatial_coherence_weight,
                            s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging,
-                           labeling_l0=getattr(s, "labeling_l0", "greedy"))                      # :527-534
+                           labeling_l0=getattr(s, "labeling_l0", "greedy"), trace=self.trace,
+                           pearl_abs=getattr(s, "pearl_abs", "double"))                          # :527-534
         self.engine = _proposal.ProposalEngine(self.ctx, self.est, self.pts, self.sampler, s, self.exchange)
 
     # progressive_x.h:565-591
     def is_putative_model_valid(self, model, inlier_number):
         s = self.settings
         if inlier_number < max(self.est.sample_size, s.minimum_number_of_inliers):            # :574
+            if self.trace is not None:
+                self.trace.event(EV_VALIDATION, 0, 1, 0, float("nan"))
             return False
         # lowest preference slot no live model holds: slots of proposals that failed this test and of instances PEARL removed
         # are reused (each is N * 8 bytes on the device)
@@ -261,15 +307,20 @@ class ProgressiveX:
         r = self.ctx.preference(model.descriptor, self.T2, model.slot)                        # :578-579
         denom = r["pref_sqnorm"] + r["comp_sqnorm"] - r["dot"]
         tanimoto = r["dot"] / denom if denom != 0.0 else float("nan")                          # :583-585 (0/0 -> NaN)
-        if s.maximum_tanimoto_similarity < tanimoto:                                           # :587 (NaN -> valid)
-            return False
-        return True
+        valid = not (s.maximum_tanimoto_similarity < tanimoto)                                 # :587 (NaN -> valid)
+        if self.trace is not None:
+            self.trace.event(EV_VALIDATION, int(valid), 0 if valid else 2, 0, float(tanimoto))
+        return valid
 
     # progressive_x.h:597-624
     def update_compound_model(self):
         if len(self.models) == 0:
+            if self.trace is not None:
+                self.trace.event(EV_COMPOUND, 0, 0, 0, float(np.sum(self.ctx.get_compound())))
             return
-        self.ctx.compound_update([m.slot for m in self.models])    # max over the STORED (stale) preference vectors
+        comp = self.ctx.compound_update([m.slot for m in self.models], want_compound=self.trace is not None)   # max over the STORED (stale) preference vectors
+        if self.trace is not None:
+            self.trace.event(EV_COMPOUND, len(self.models), 0, 0, float(np.sum(comp)))
 
     # progressive_x.h:251-489
     def run(self):
@@ -280,7 +331,11 @@ class ProgressiveX:
         number_of_ransac_iterations = 0
         unaccepted = 0
         self._log("The main iteration is started...")
+        tr = self.trace
+        break_reason = 0
         for current_iteration in range(s.max_outer_iterations):                               # :272 (hard 10 upstream)
+            if tr is not None:
+                tr.event(EV_OUTER, current_iteration)
             self._log("-------------------------------------------")
             self._log(f"Iteration {current_iteration + 1}.")
             it_stats = dict(time_of_proposal_engine=0.0, time_of_model_validation=0.0, time_of_optimization=0.0,
@@ -291,10 +346,16 @@ class ProgressiveX:
                                    weights=s.point_weights)
             it_stats["time_of_proposal_engine"] = time.perf_counter() - t0
             if prop is None or prop["model"] is None:                                         # :301-303
+                if tr is not None:
+                    tr.proposal(None, None, 0)
+                    tr.event(EV_PROPOSAL_EMPTY)
                 continue
             putative = Model(prop["model"])
             inliers = prop["inliers"]
             number_of_ransac_iterations += prop["iterations"]                                 # :317-318
+            if tr is not None:
+                tr.proposal(putative.descriptor, inliers, prop["iterations"])
+                tr.event(EV_PROPOSAL, len(inliers), int(prop["iterations"]), int(number_of_ransac_iterations))
             self._log(f"A model proposed with {len(inliers)} inliers\nin {it_stats['time_of_proposal_engine']} "
                       f"seconds ({prop['iterations']} iterations).")
             # ---- validation (:334)
@@ -304,7 +365,10 @@ class ProgressiveX:
                 self._log("The model is not accepted to be added to the compound instances. The number of "
                           f"consecutively rejected proposals is {unaccepted} (< {s.max_proposal_number_without_change})")
                 unaccepted += 1                                                               # :342 (never reset)
+                if tr is not None:
+                    tr.event(EV_UNACCEPTED, unaccepted)
                 if unaccepted == s.max_proposal_number_without_change:
+                    break_reason = 1
                     break
                 continue
             it_stats["time_of_model_validation"] = time.perf_counter() - t0
@@ -317,9 +381,13 @@ class ProgressiveX:
                 st.inliers_of_each_model.append(inliers)                                      # :378-379
                 st.labeling[:] = 1                                                            # :382
                 st.labeling[inliers] = 0                                                      # :383-384
+                if tr is not None:
+                    tr.event(EV_SINGLE_MODEL, len(inliers))
             else:
                 self.pearl.run(self.models)                                                   # :390
                 st.labeling, model_number = self.pearl.get_labeling()                         # :396
+                if tr is not None:
+                    tr.event(EV_LABELING, model_number, len(self.models))
                 if model_number != len(self.models):
                     self._log("Models have been removed during the optimization.\n")
             it_stats["time_of_optimization"] = time.perf_counter() - t0
@@ -332,15 +400,14 @@ class ProgressiveX:
                       f"{it_stats['time_of_compound_model_update']} seconds.")
             it_stats["number_of_instances"] = len(self.models)
             # ---- predicted unseen inliers (:447-457)
-            if number_of_ransac_iterations > 0:
-                if len(self.models) == 1:
-                    covered = len(st.inliers_of_each_model)    # quirk :451 — the COUNT of models (= 1), not of inliers
-                else:
-                    covered = self.n - self.pearl.outliers_number
-                unseen = predicted_unseen_inliers(s.one_minus_confidence, self.est.sample_size,
-                                                  number_of_ransac_iterations, covered, self.n)
+            if len(self.models) == 1:
+                covered = len(st.inliers_of_each_model)    # quirk :451 — the COUNT of stored inlier sets, not of inliers
             else:
-                unseen = self.n
+                covered = self.n - self.pearl.outliers_number
+            unseen = predicted_unseen_inliers(s.one_minus_confidence, self.est.sample_size,
+                                              number_of_ransac_iterations, covered, self.n)
+            if tr is not None:
+                tr.event(EV_UNSEEN, covered, unseen)
             st.iteration_statistics.append(it_stats)
             st.total_time_of_proposal_engine += it_stats["time_of_proposal_engine"]
             st.total_time_of_model_validation += it_stats["time_of_model_validation"]
@@ -349,9 +416,13 @@ class ProgressiveX:
             self._log(f"The predicted number of inliers (with confidence {s.confidence})\nnot covered by the compound "
                       f"instance is {unseen}.")
             if unseen < s.minimum_number_of_inliers:                                          # :468
+                break_reason = 2
                 break
             if len(self.models) >= s.maximum_model_number:                                    # :472
+                break_reason = 3
                 break
+        if tr is not None:
+            tr.event(EV_BREAK, break_reason)
         st.processing_time = time.perf_counter() - t_main
         st.pearl_iterations = self.pearl.iterations
         st.expansion_cycles = self.pearl.cycles

@@ -1,0 +1,70 @@
+"""tests/test_replay.py on the MI355X: the drop-in calls run through libpgx.so, their decisions (accept / reject per proposal,
+PEARL iteration by iteration: energy, refit acceptance, rejections, model count, convergence; break reason), final labels and
+model set must equal the independent replay of progressive_x.h / PEARL.h (oracle/progx_replay.c) - VERDICT r4 item 1."""
+import numpy as np
+import pytest
+
+import progx_replay as R
+import pyprogressivex as px
+import replay_helpers as H
+from pyprogressivex import _api, datasets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gpu_api(monkeypatch):
+    monkeypatch.setattr(_api, "_ctx", None)       # the package creates its libpgx context lazily (raises without a GPU)
+
+
+def test_c1_lines_gpu_decisions_equal_the_replay(gpu_api):
+    pts, gt, _ = datasets.make_lines(seed=0)
+    out, rec, rep = H.run_and_replay(px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99, sampler_id=0, seed=1,
+                                     minimum_point_number=50)
+    assert H.assert_agree(out, rec, rep, 1) == 3
+    verdicts, after, brk = H.summary(rec.events)
+    assert verdicts[:3] == [1, 1, 1] and after[-1] == 3 and brk == [R.BREAK_LOOP_RAN_OUT]
+
+
+@pytest.mark.parametrize("l0", ["greedy", "expansion"])
+def test_c2_homographies_gpu_decisions_equal_the_replay(gpu_api, l0):
+    pts, gt, _ = datasets.make_homographies(seed=0)
+    out, rec, rep = H.run_and_replay(px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=0,
+                                     seed=1, minimum_point_number=50, labeling_l0=l0)
+    assert H.assert_agree(out, rec, rep, 3) == 5
+
+
+def test_three_object_pnp_gpu_decisions_equal_the_replay(gpu_api):
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=600, n_objects=3, n_outliers=600, seed=0)
+    out, rec, rep = H.run_and_replay(px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=30)
+    assert H.assert_agree(out, rec, rep, 3) == 3
+
+
+def test_six_vanishing_points_gpu_decisions_equal_the_replay(gpu_api):
+    pts, gt, _ = datasets.make_vanishing_points(n_inliers=3000, n_vps=6, n_outliers=3000, seed=0)
+    out, rec, rep = H.run_and_replay(px.findVanishingPoints, pts, np.array(0), 1000, 1000, threshold=1.5, conf=0.99, sampler_id=0,
+                                     seed=1, minimum_point_number=100, spatial_coherence_weight=0.05, neighborhood_ball_radius=15.0)
+    assert H.assert_agree(out, rec, rep, 1) >= 4
+
+
+def test_philox_device_sampled_run_gpu_decisions_equal_the_replay(gpu_api):
+    pts, gt, _ = datasets.make_homographies(seed=0)
+    out, rec, rep = H.run_and_replay(px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=0,
+                                     seed=1, minimum_point_number=50, sampler_rng="philox")
+    assert H.assert_agree(out, rec, rep, 3) >= 4
+
+
+def test_u16_int_abs_gpu(gpu_api):
+    pts, gt, _ = datasets.make_lines(seed=0)
+    out, rec, rep = H.run_and_replay(px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99, sampler_id=0, seed=1,
+                                     minimum_point_number=50, pearl_abs="int")
+    H.assert_agree(out, rec, rep, 1)
+
+
+@pytest.mark.parametrize("scenario", H.SCENARIOS, ids=lambda f: f.__name__[9:])
+def test_scripted_quirk_gpu(gpu_ctx, monkeypatch, scenario):
+    scenario(gpu_ctx, monkeypatch)
+
+
+def test_scripted_stale_preference_vectors_gpu(gpu_ctx, monkeypatch, oracle):
+    H.scenario_stale_preference_vectors(gpu_ctx, monkeypatch, oracle)
