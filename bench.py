@@ -101,6 +101,128 @@ def cpu_baseline(pts, hyps, T2, comp, budget_s=15.0):
     return out
 
 
+def cpu_labelling_baseline(bk_c5=False):
+    """SURVEY 8(d) metric 3 / BASELINE.md 3 on the host: ONE alpha-expansion from the all-zero labelling (what every PEARL::run starts
+    with, PEARL.h:507-551) at C3 and C5 size, single thread, on the problems the GPU legs solved (CPU_LABELLING).  Two solvers of the
+    oracle: Boykov-Kolmogorov (oracle/bk_maxflow.c: the algorithm GCoptimization uses behind PEARL.h:550) and Dinic; they return
+    identical labels (unique minimal sink side) and the FASTER one is the baseline of a config - BK wins by 3-15x on the plain
+    pairwise networks but loses to Dinic when the label-cost hubs (one node joined to every site of a label) are in play at 2e5
+    sites, so C5's BK run (~110 s) is opt-in (--cpu-labelling-bk-c5; measured once: profiles/).  C4 (1e6 sites, Dinic 402 s) is
+    beyond a bench budget: see DESIGN.md."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pgx_oracle as O
+    out = {"kind": "port", "cores": 1, "solver": "faster of Boykov-Kolmogorov (oracle/bk_maxflow.c) and Dinic (oracle/pgx_oracle.c) per config",
+           "unit": "expansion cycles/s, min-cuts/s of one expansion from zeros", "configs": {}}
+    for key, (Dq, graph, lam, h, gpu_labels) in CPU_LABELLING.items():
+        n, L = Dq.shape
+        lq, hq = O.quantize_lambda(lam), O.quantize(h)
+        z = np.zeros(n, np.int32)
+        rec = {"sites": int(n), "labels": int(L), "arcs": int(len(graph[1])), "lambda": lam, "label_cost": h}
+        runs = {}
+        if key != "c5" or bk_c5:
+            t0 = time.perf_counter()
+            lab, e, cyc, cuts = O.expansion_bk(Dq, graph, lq, hq, z)
+            runs["bk"] = (time.perf_counter() - t0, lab, cyc, cuts)
+        t0 = time.perf_counter()
+        lab, e, cyc = O.expansion(Dq, graph, lq, hq, z)
+        runs["dinic"] = (time.perf_counter() - t0, lab, cyc, cyc * L)
+        for name, (t, lab, cyc, cuts) in runs.items():
+            rec[name + "_s"] = t
+            rec[name + "_labels_equal_gpu"] = bool(np.array_equal(lab, gpu_labels))
+        best = min(runs, key=lambda k2: runs[k2][0])
+        t, lab, cyc, cuts = runs[best]
+        rec.update(solver=best, seconds=t, cycles=int(cyc), mincuts=int(cuts), cycles_per_s=cyc / t, mincuts_per_s=cuts / t)
+        if "bk" not in runs:
+            rec["bk_s"] = None
+            rec["bk_note"] = "not run by default (label-cost hubs: ~110 s, profiles/round5_cpu_labelling.txt); --cpu-labelling-bk-c5 runs it"
+        out["configs"][key] = rec
+    if "c5" in out["configs"]:      # the headline pair of the block: C5 is BASELINE's alpha-expansion config ("full spatial k-NN graph")
+        out["cycles_per_s"] = out["configs"]["c5"]["cycles_per_s"]
+        out["mincuts_per_s"] = out["configs"]["c5"]["mincuts_per_s"]
+        out["sample"] = "one whole expansion from zeros at C5 size (2e5 sites, k-NN(8) graph, 7 labels), not a sub-sample"
+    return out
+
+
+def api_legs(datasets, c3=None, c5=None, c4=None):
+    """Wall time of the drop-in calls: the five find* entry points on the BASELINE configs C1-C5 with
+    the arguments of scripts/bench_api.py, the cap-lifted C4 call (16 objects), and the reference's bundled scenes with the
+    notebooks' exact arguments (tests/golden/scenes: data files of the reference kept as fixtures; recorded = the wall time the
+    reference's notebooks print, unstated CPU, one thread)."""
+    import contextlib
+    import io
+    import pyprogressivex as px
+    legs = {}
+    px.findLines(np.random.default_rng(0).random((50, 2)) * 100, np.array(0), 100, 100, sampler_id=0, seed=0)   # the package's context
+
+    def me(labels, K, gt):
+        return float(datasets.misclassification(np.where(labels == K, 0, labels + 1), gt))
+
+    def timed(key, rows, gt, fn, *a, **kw):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):        # find6DPoses prints its neighbourhood time (progressivex_python.cpp:109)
+                t0 = time.perf_counter()
+                models, labels = fn(*a, **kw)
+                dt = time.perf_counter() - t0
+            K = models.shape[0] // rows
+            legs[key] = {"wall_s": dt, "models": int(K), "points": int(len(labels)), "misclassification": me(labels, K, gt)}
+        except Exception as e:       # never fail the bench over a secondary leg
+            legs[key] = {"error": str(e)}
+    pts, gt, _ = datasets.make_lines(seed=0)
+    timed("c1_findLines", 1, gt, px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99, sampler_id=0, seed=1, minimum_point_number=50)
+    pts, gt, _ = datasets.make_homographies(seed=0)
+    timed("c2_findHomographies", 3, gt, px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=0, seed=1,
+          minimum_point_number=50)
+    pts, gt, _ = c3 if c3 is not None else datasets.make_two_view_motions(seed=0)
+    timed("c3_findTwoViewMotions", 3, gt, px.findTwoViewMotions, pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
+          minimum_point_number=1000, max_iters=2000)
+    pts, gt, _ = c5 if c5 is not None else datasets.make_vanishing_points(seed=0)
+    timed("c5_findVanishingPoints", 1, gt, px.findVanishingPoints, pts, np.array(0), 1000, 1000, threshold=1.5, conf=0.99, sampler_id=0, seed=1,
+          minimum_point_number=2000, spatial_coherence_weight=0.05, neighborhood_ball_radius=10.0)
+    x1, x2, K, gt = c4 if c4 is not None else datasets.make_poses(seed=0)[:4]
+    timed("c4_find6DPoses", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048)
+    # BASELINE config C4 names 16 objects; the reference's outer loop stops at 10 proposals (progressive_x.h:272): the same call with
+    # the cap lifted (keyword-only extension) returns all of them
+    timed("c4_find6DPoses_16_objects", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048,
+          max_outer_iterations=20)
+    scenes = os.path.join(ROOT, "tests", "golden", "scenes")
+    recorded = {"unionhouse": 0.030, "unihouse": 0.308, "oldclassicswing": 0.089, "breadcube": 0.737, "cubetoy": 0.514, "book": 0.582,
+                "tless": 57.57}      # dataset_comparison/adelaideH.ipynb:137-142, adelaideF.ipynb:149-157, example_multi_pose_6d.ipynb
+    out = {}
+    for scene in ("unionhouse", "unihouse", "oldclassicswing", "breadcube", "cubetoy", "book", "tless"):
+        try:
+            ts = []
+            for seed in range(3):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    if scene == "tless":
+                        M = np.loadtxt(os.path.join(scenes, "tless.txt"), skiprows=1)
+                        Km = np.loadtxt(os.path.join(scenes, "tless_intrinsics.txt"))
+                        t0 = time.perf_counter()
+                        px.find6DPoses(M[:, :2], M[:, 2:5], Km, 4.0, seed=seed)
+                    elif scene in ("unionhouse", "unihouse", "oldclassicswing"):
+                        corrs, g = datasets.load_points_with_labels(os.path.join(scenes, f"{scene}.txt"))
+                        t0 = time.perf_counter()
+                        px.findHomographies(corrs, 1024, 768, 1024, 768, threshold=4.0, conf=0.5, spatial_coherence_weight=0.05,
+                                            neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
+                                            minimum_point_number=10, maximum_model_number=6, scoring_exponent=2, sampler_id=3, seed=seed)
+                    else:
+                        corrs, g = datasets.load_points_with_labels(os.path.join(scenes, f"{scene}.txt"))
+                        c32 = corrs.astype(np.float32)      # the notebook's density ordering (sampler_id == 2 branch), outside the timed call
+                        d = np.sqrt(((c32[:, None, :] - c32[None, :, :]) ** 2).sum(-1))
+                        corrs = np.ascontiguousarray(corrs[np.argsort((d <= 50.0).sum(1))[::-1]])
+                        t0 = time.perf_counter()
+                        px.findTwoViewMotions(corrs, 1024, 768, 1024, 768, threshold=0.75, conf=0.5, spatial_coherence_weight=0.5,
+                                              neighborhood_ball_radius=50.0, maximum_tanimoto_similarity=0.4, max_iters=10000,
+                                              minimum_point_number=7, maximum_model_number=4, sampler_id=2, scoring_exponent=1.0, seed=seed)
+                    ts.append(time.perf_counter() - t0)
+            out[scene] = {"wall_s_median": float(np.median(ts)), "wall_s": [round(t, 4) for t in ts], "recorded_s": recorded[scene]}
+        except Exception as e:
+            out[scene] = {"error": str(e)}
+    legs["bundled_scenes"] = out
+    legs["note"] = ("wall time of the find* call alone (host marshalling, graph build, proposals, PEARL, read-backs), library already loaded; "
+                    "bundled scenes: median of seeds 0-2, notebooks' arguments; recorded_s: what the reference's notebooks print (unstated CPU)")
+    return legs
+
+
 def timed_steps(ctx, step, steps, warmup):
     """(seconds per step by the wall clock, mean HIP-event ms of the scoring kernels) of `step` on one context.  The wall clock
     runs with the events off - two event records around every kernel cost ~30 us of a step - and five more steps with the
@@ -330,7 +452,10 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
     return legs
 
 
-def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, radius, k):
+CPU_LABELLING = {}      # config key -> (Dq [n, L] int64, (off, idx, mult), lam, h, labels the GPU ended with): inputs of cpu_labelling_baseline
+
+
+def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, radius, k, keep_for_cpu=None):
     """SURVEY 8(d) metric 3 at one config's (N, K, E): the PEARL labelling step (PEARL.h:476-555) = unary table + one full
     alpha-expansion from the all-zero labelling (what the first iteration of every PEARL::run does), on the neighbourhood
     graph built on the device.  expansion cycles/s and min-cuts/s are of that expansion; a PEARL iteration's labelling part
@@ -367,7 +492,23 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
             t = time.perf_counter() - t0
             best = t if best is None or t < best else best
         st = c.expansion_stats()
+        paths = c.expansion_paths()
+        if keep_for_cpu is not None:      # the same problem for the CPU solvers: the device-built graph and unary table (bit-identical to
+            graph = c.graph_fetch()       # the oracle's, tests/test_fullsize_pins.py) and the labels to check them against
+            CPU_LABELLING[keep_for_cpu] = (c.pearl_unary(models, thr, lam, want_table=True), graph, lam, h, c.get_labels())
+        n_sites, n_arcs = int(len(pts)), int(arcs)
+        # SURVEY 8(d) "expansion_step": a push-relabel sweep reads N (8 B excess + 4 B height) + E (4 B idx + 8 B cap); a level of the
+        # global relabel reads N x 4 B of heights.  Only the level-synchronous solver counts sweeps / levels (one-workgroup and region
+        # moves keep their state in LDS): for them the figure is the bytes of the moves that fell back to it.
+        alg = (n_sites * 12 + n_arcs * 12) * int(st["sweeps"]) + n_sites * 4 * int(st["bfs_levels"])
+        roof = {"bound": "hbm", "achieved": alg / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / best / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": alg, "formula": "(N 12 + E 12) x sweeps + N 4 x bfs_levels (SURVEY 8d), over the expansion's wall time",
+                "launches_per_expansion": int(st["sweeps"]) + int(st["bfs_levels"]) + int(st["global_relabels"]),
+                "moves_by_solver": {k2: int(v2) for k2, v2 in paths.items()},
+                "note": "latency bound: every sweep / level is one dependent launch (~12 us at N = 1e6) that moves a few MB; "
+                        "the fraction says how far from a streaming pass the solver is, not how busy HBM is"}
         return {"config": name, "sites": int(len(pts)), "labels": int(len(models)) + 1, "arcs": int(arcs), "lambda": lam, "label_cost": h,
+                "roofline_labelling": roof,
                 "graph_build_ms": 1e3 * t_graph, "unary_ms": 1e3 * t_unary, "expansion_ms": 1e3 * best, "cycles": int(cycles), "energy": e,
                 "expansion_cycles_per_sec": cycles / best, "mincuts_per_sec": st["mincuts"] / best,
                 "pearl_labelling_iterations_per_sec": 1.0 / (t_unary + best),
@@ -391,10 +532,10 @@ def labelling_legs(_lib, datasets, raw, pts, poses, thr):
                                                 _lib.GRAPH_KNN_IN_BALL, 200.0, 5))
     p3, _, m3 = datasets.make_two_view_motions(seed=0)
     guard("labelling_c3", lambda: labelling_leg(_lib, "C3 two-view 1e5/8 motions", _lib.FUNDAMENTAL, p3, m3, 0.75, 0.1, 14.0, p3,
-                                                _lib.GRAPH_KNN_IN_BALL, 50.0, 5))
+                                                _lib.GRAPH_KNN_IN_BALL, 50.0, 5, keep_for_cpu="c3"))
     p5, _, m5 = datasets.make_vanishing_points(seed=0)
     guard("labelling_c5", lambda: labelling_leg(_lib, "C5 vanishing points 2e5/6, k-NN(8) on midpoints", _lib.VANISHING_POINT, p5, m5, 1.5, 0.1,
-                                                20.0, 0.5 * (p5[:, :2] + p5[:, 2:]), _lib.GRAPH_KNN, 0.0, 8))
+                                                20.0, 0.5 * (p5[:, :2] + p5[:, 2:]), _lib.GRAPH_KNN, 0.0, 8, keep_for_cpu="c5"))
     guard("labelling_c4", lambda: labelling_leg(_lib, "C4 6D pose 1e6/10 of 16 objects", _lib.PNP, pts, poses, thr, 0.1, 6.0, raw,
                                                 _lib.GRAPH_KNN_IN_BALL, 20.0, 5))
     return legs
@@ -482,6 +623,7 @@ def main():
                          "GPU holds all points (all-gather); weak: --hyps hypotheses per GPU, all points on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--cpu-labelling-bk-c5", action="store_true", help="also time Boykov-Kolmogorov on the C5 expansion (~110 s of CPU)")
     args = ap.parse_args()
 
     from pyprogressivex import _lib, datasets, parallel
@@ -673,6 +815,13 @@ def main():
             out["legs"] = secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt_labels, T2, args.steps, args.warmup)
             out["legs"].update(labelling_legs(_lib, datasets, np.column_stack([x1, x2]), pts, gt[:10], thr))
             try:
+                out["legs"]["api"] = api_legs(datasets, c4=(x1, x2, K, gt_labels))
+            except Exception as e:
+                out["legs"]["api"] = {"error": str(e)}
+            for key in ("labelling_c2", "labelling_c3", "labelling_c5", "labelling_c4"):      # next to the contract's `roofline`
+                if isinstance(out["legs"].get(key), dict) and "roofline_labelling" in out["legs"][key]:
+                    out.setdefault("roofline_labelling", {})[key[10:]] = out["legs"][key]["roofline_labelling"]
+            try:
                 out["legs"]["strong_scaling_projection"] = strong_scaling_legs(ctx, parallel, hyps, T2, args.steps, args.warmup)
             except Exception as e:       # never fail the bench over a secondary leg
                 out["legs"]["strong_scaling_projection"] = {"error": str(e)}
@@ -688,6 +837,16 @@ def main():
                                    "the CPU port evaluates every pair exactly, the GPU path decides most pairs by bounds - "
                                    "pair-for-pair on EXECUTED evaluations the ratio is speedup_executed")
             out["speedup_executed"] = out["executed_pairs_per_sec"] / cb["value"]
+            if CPU_LABELLING:
+                try:
+                    cb["labelling"] = cpu_labelling_baseline(bk_c5=args.cpu_labelling_bk_c5)
+                    for key, rec in cb["labelling"]["configs"].items():      # the GPU's expansion of the same problem next to it
+                        g = out.get("legs", {}).get("labelling_" + key, {})
+                        if "expansion_ms" in g:
+                            rec["gpu_expansion_s"] = g["expansion_ms"] * 1e-3
+                            rec["gpu_over_cpu"] = rec["seconds"] / (g["expansion_ms"] * 1e-3)
+                except Exception as e:
+                    cb["labelling"] = {"error": str(e)}
         line = json.dumps(out)
     else:
         line = None

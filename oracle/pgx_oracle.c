@@ -8,6 +8,7 @@
  * Reference paths below are relative to /root/reference/src/pyprogressivex/.
  */
 #include "pgx_oracle.h"
+#include "bk_maxflow.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -472,9 +473,9 @@ int64_t pgxo_energy(int64_t n, int L, const int64_t *Dq, const int32_t *off, con
  * (BK: free nodes default to SOURCE = take alpha) [U-5].  Label costs via one auxiliary node per
  * label (Delong et al., IJCV 2012): labels in use other than alpha pay h unless all their sites move;
  * alpha pays h if it is unused and any site moves. */
-int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
-                      const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
-                      int64_t *flow_value)
+static int expand_alpha_impl(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                             const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
+                             int64_t *flow_value, int use_bk)
 {
     int64_t *cnt = (int64_t *)calloc((size_t)L, sizeof(int64_t));
     int32_t *var = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
@@ -501,8 +502,14 @@ int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, c
     int64_t narcs_est = 2 * na /* t-links */ + 2 * (int64_t)nhub;
     if (use_pair) narcs_est += off[n];
     if (use_lc) narcs_est += 2 * na * 2;
+    /* the same network for either solver: EDGE(u, v, c, rc) between variable / hub nodes, FROM_S(v, c), TO_T(v, c) */
     dinic_t g;
-    dn_init(&g, nn, 2 * narcs_est + 16);
+    bk_graph *bk = NULL;
+    if (use_bk) bk = bk_create((int)(na + nhub), narcs_est + 8);
+    else dn_init(&g, nn, 2 * narcs_est + 16);
+#define EDGE(u, v, c, rc) do { if (use_bk) bk_add_edge(bk, (u), (v), (c), (rc)); else dn_add(&g, (u), (v), (c), (rc)); } while (0)
+#define FROM_S(v, c) do { if (use_bk) bk_add_tweights(bk, (v), (c), 0); else dn_add(&g, S, (v), (c), 0); } while (0)
+#define TO_T(v, c) do { if (use_bk) bk_add_tweights(bk, (v), 0, (c)); else dn_add(&g, (v), T, (c), 0); } while (0)
 
     for (int64_t i = 0; i < n; ++i) {
         if (var[i] < 0) continue;
@@ -515,32 +522,61 @@ int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, c
                 const int64_t w = lambda_q * (int64_t)mult[a];
                 if (var[j] < 0) keep += w;                   /* neighbour already alpha */
                 else if (i < j) {
-                    if (labels[j] == li) dn_add(&g, var[i], var[j], w, w);
-                    else { keep += w; dn_add(&g, var[i], var[j], w, 0); } /* Kolmogorov-Zabih form */
+                    if (labels[j] == li) EDGE(var[i], var[j], w, w);
+                    else { keep += w; EDGE(var[i], var[j], w, 0); } /* Kolmogorov-Zabih form */
                 }
             }
-        dn_add(&g, S, var[i], keep, 0);
-        dn_add(&g, var[i], T, take, 0);
+        FROM_S(var[i], keep);
+        TO_T(var[i], take);
         if (use_lc) {
-            if (hub_of_label[li] >= 0) dn_add(&g, hub_of_label[li], var[i], PGXO_INF, 0);
-            if (hub_of_label[alpha] >= 0) dn_add(&g, var[i], hub_of_label[alpha], PGXO_INF, 0);
+            if (hub_of_label[li] >= 0) EDGE(hub_of_label[li], var[i], PGXO_INF, 0);
+            if (hub_of_label[alpha] >= 0) EDGE(var[i], hub_of_label[alpha], PGXO_INF, 0);
         }
     }
     if (use_lc)
         for (int l = 0; l < L; ++l) {
             if (hub_of_label[l] < 0) continue;
-            if (l == alpha) dn_add(&g, hub_of_label[l], T, h_q, 0);
-            else dn_add(&g, S, hub_of_label[l], h_q, 0);
+            if (l == alpha) TO_T(hub_of_label[l], h_q);
+            else FROM_S(hub_of_label[l], h_q);
         }
-    const int64_t f = dn_maxflow(&g, S, T);
-    if (flow_value) *flow_value = f;
-    uint8_t *reach = (uint8_t *)malloc((size_t)nn);
-    dn_sink_side(&g, T, reach);
+#undef EDGE
+#undef FROM_S
+#undef TO_T
     int changed = 0;
-    for (int64_t i = 0; i < n; ++i)
-        if (var[i] >= 0 && !reach[var[i]]) { labels[i] = alpha; ++changed; }
-    free(reach); dn_free(&g); free(hub_of_label); free(var); free(cnt);
+    if (use_bk) {
+        /* BK: what_segment(i, default = SOURCE): sites in the sink tree keep their label, everything else takes alpha [U-5] */
+        const int64_t f = bk_maxflow(bk);
+        if (flow_value) *flow_value = f;
+        for (int64_t i = 0; i < n; ++i)
+            if (var[i] >= 0 && !bk_in_sink_tree(bk, var[i])) { labels[i] = alpha; ++changed; }
+        bk_destroy(bk);
+    } else {
+        const int64_t f = dn_maxflow(&g, S, T);
+        if (flow_value) *flow_value = f;
+        uint8_t *reach = (uint8_t *)malloc((size_t)nn);
+        dn_sink_side(&g, T, reach);
+        for (int64_t i = 0; i < n; ++i)
+            if (var[i] >= 0 && !reach[var[i]]) { labels[i] = alpha; ++changed; }
+        free(reach); dn_free(&g);
+    }
+    free(hub_of_label); free(var); free(cnt);
     return changed;
+}
+
+int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                      const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
+                      int64_t *flow_value)
+{
+    return expand_alpha_impl(n, L, Dq, off, idx, mult, lambda_q, h_q, alpha, labels, flow_value, 0);
+}
+
+/* The same move solved by Boykov-Kolmogorov (bk_maxflow.c): the solver family GCoptimization uses behind PEARL.h:550.  Same
+ * labels as the Dinic form by uniqueness of the minimal sink side; exists for the CPU labelling baseline (bench.py). */
+int pgxo_expand_alpha_bk(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                         const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
+                         int64_t *flow_value)
+{
+    return expand_alpha_impl(n, L, Dq, off, idx, mult, lambda_q, h_q, alpha, labels, flow_value, 1);
 }
 
 /* GCO-v3 "standard cycles" loop [U-5] as driven by PEARL.h:550-551 (max 1000 cycles). */
@@ -562,6 +598,50 @@ int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, cons
     if (energy_q) *energy_q = new_e;
     if (cycles) *cycles = c;
     return 0;
+}
+
+/* pgxo_expansion with every move solved by BK; mincuts (may be NULL) counts the moves that built a network */
+int pgxo_expansion_bk(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                      const int32_t *mult, int64_t lambda_q, int64_t h_q, int32_t *labels, int max_cycles,
+                      int64_t *energy_q, int *cycles, int64_t *mincuts)
+{
+    int64_t new_e = pgxo_energy(n, L, Dq, off, idx, mult, lambda_q, h_q, labels);
+    int64_t old_e = new_e + 1, cuts = 0;
+    int c = 0;
+    for (int cycle = 1; cycle <= max_cycles; ++cycle) {
+        if (new_e == old_e) break;
+        old_e = new_e;
+        for (int alpha = 0; alpha < L; ++alpha) {
+            pgxo_expand_alpha_bk(n, L, Dq, off, idx, mult, lambda_q, h_q, alpha, labels, NULL);
+            ++cuts;
+        }
+        new_e = pgxo_energy(n, L, Dq, off, idx, mult, lambda_q, h_q, labels);
+        c = cycle;
+    }
+    if (energy_q) *energy_q = new_e;
+    if (cycles) *cycles = c;
+    if (mincuts) *mincuts = cuts;
+    return 0;
+}
+
+/* plain s-t max-flow by BK on an explicit arc list (cross-check against pgxo_maxflow / scipy) */
+int64_t pgxo_maxflow_bk(int nnodes, int64_t narcs, const int32_t *from, const int32_t *to,
+                        const int64_t *cap, int s, int t, uint8_t *sink_side)
+{
+    bk_graph *g = bk_create(nnodes, narcs + 1);
+    for (int64_t a = 0; a < narcs; ++a) {
+        if (from[a] == s && to[a] != t) bk_add_tweights(g, to[a], cap[a], 0);
+        else if (to[a] == t && from[a] != s) bk_add_tweights(g, from[a], 0, cap[a]);
+        else if (from[a] != s && from[a] != t && to[a] != s && to[a] != t) bk_add_edge(g, from[a], to[a], cap[a], 0);
+    }
+    int64_t f = bk_maxflow(g);
+    for (int64_t a = 0; a < narcs; ++a) if (from[a] == s && to[a] == t) f += cap[a];
+    if (sink_side) {
+        for (int i = 0; i < nnodes; ++i) sink_side[i] = (uint8_t)bk_in_sink_tree(g, i);
+        sink_side[t] = 1; sink_side[s] = 0;
+    }
+    bk_destroy(g);
+    return f;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -83,6 +83,16 @@ int pgxo_expand_alpha(int64_t n, int L, const int64_t *Dq, const int32_t *off, c
 int pgxo_expansion(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
                    const int32_t *mult, int64_t lambda_q, int64_t h_q, int32_t *labels, int max_cycles,
                    int64_t *energy_q, int *cycles);
+/* the same move / loop with Boykov-Kolmogorov as the solver (bk_maxflow.c: the algorithm behind GCoptimization, PEARL.h:550);
+ * identical labels by uniqueness of the minimal sink side - used for the CPU labelling baseline of bench.py */
+int pgxo_expand_alpha_bk(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                         const int32_t *mult, int64_t lambda_q, int64_t h_q, int alpha, int32_t *labels,
+                         int64_t *flow_value);
+int pgxo_expansion_bk(int64_t n, int L, const int64_t *Dq, const int32_t *off, const int32_t *idx,
+                      const int32_t *mult, int64_t lambda_q, int64_t h_q, int32_t *labels, int max_cycles,
+                      int64_t *energy_q, int *cycles, int64_t *mincuts);
+int64_t pgxo_maxflow_bk(int nnodes, int64_t narcs, const int32_t *from, const int32_t *to,
+                        const int64_t *cap, int s, int t, uint8_t *sink_side);
 /* U-8: GCO-v3's no-smooth-cost special cases (greedy facility location with per-label costs; argmin without) */
 int pgxo_greedy_labeling(int64_t n, int L, const int64_t *Dq, int64_t h_q, int32_t *labels, int64_t *energy_q);
 /* 8f rank 4: GC-RANSAC's inlier/outlier graph cut, graph built as upstream's Energy::add_term1/add_term2 would [U-12].

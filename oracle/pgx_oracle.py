@@ -211,6 +211,38 @@ def expansion(Dq, graph, lambda_q, h_q, labels, max_cycles=1000):
     return labels, int(e.value), int(cyc.value)
 
 
+def expansion_bk(Dq, graph, lambda_q, h_q, labels, max_cycles=1000):
+    """pgxo_expansion with Boykov-Kolmogorov as the min-cut solver (oracle/bk_maxflow.c) -> (labels, energy_q, cycles, mincuts)"""
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels).copy()
+    n, L = Dq.shape
+    po, pi, pm, keep = _graph_args(graph)
+    e = C.c_int64(); cyc = C.c_int(); cuts = C.c_int64()
+    lib().pgxo_expansion_bk(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), po, pi, pm, C.c_int64(lambda_q),
+                            C.c_int64(h_q), _p(labels, C.c_int32), C.c_int(max_cycles), C.byref(e), C.byref(cyc), C.byref(cuts))
+    return labels, int(e.value), int(cyc.value), int(cuts.value)
+
+
+def expand_alpha_bk(Dq, graph, lambda_q, h_q, alpha, labels):
+    Dq = np.ascontiguousarray(Dq, dtype=np.int64); labels = _i32(labels).copy()
+    n, L = Dq.shape
+    po, pi, pm, keep = _graph_args(graph)
+    flow = C.c_int64()
+    changed = lib().pgxo_expand_alpha_bk(C.c_int64(n), C.c_int(L), _p(Dq, C.c_int64), po, pi, pm,
+                                         C.c_int64(lambda_q), C.c_int64(h_q), C.c_int(alpha),
+                                         _p(labels, C.c_int32), C.byref(flow))
+    return labels, int(changed), int(flow.value)
+
+
+def maxflow_bk(nnodes, frm, to, cap, s, t):
+    frm = _i32(frm); to = _i32(to); cap = np.ascontiguousarray(cap, dtype=np.int64)
+    side = np.zeros(nnodes, dtype=np.uint8)
+    fn = lib().pgxo_maxflow_bk
+    fn.restype = C.c_int64
+    f = fn(C.c_int(nnodes), C.c_int64(len(frm)), _p(frm, C.c_int32), _p(to, C.c_int32),
+           _p(cap, C.c_int64), C.c_int(s), C.c_int(t), _p(side, C.c_uint8))
+    return int(f), side
+
+
 def greedy_labeling(Dq, h_q):
     """U-8: GCO-v3's labelling of an energy without smooth costs (greedy facility location) -> (labels, energy_q, opened)"""
     Dq = np.ascontiguousarray(Dq, dtype=np.int64)

@@ -228,13 +228,18 @@ static void pearl_parameter_estimation(pearl_t *P, model_vec *models_, int *chan
         for (uint64_t j = 0; j < inlier_number; ++j)
             sum_of_residuals_after += pgxo_residual(P->s->model_type, P->pts + (size_t)current_inliers[j] * P->d, fitted);
         /* :393-399 strictly smaller; setDescriptor leaves the preference vector as it was (stale) */
-        int accepted = 0;
-        if (sum_of_residuals_after < sum_of_residuals_before) {
+        int accepted = sum_of_residuals_after < sum_of_residuals_before, tie = 0;
+        if (P->s->refit_tie_rtol > 0.0 && c->t->refit_accepted && c->t->refit_accepted[r] >= 0 &&
+            fabs(sum_of_residuals_after - sum_of_residuals_before) <= P->s->refit_tie_rtol * fabs(sum_of_residuals_before)) {
+            /* a numerical tie (progx_replay.h, refit_tie_rtol): the order of the additions decides, follow the recording */
+            tie = accepted != (c->t->refit_accepted[r] != 0);
+            accepted = c->t->refit_accepted[r] != 0;
+        }
+        if (accepted) {
             memcpy(models_->data[instance_idx].descriptor, fitted, (size_t)P->p * sizeof(double));
             *changed_ = 1;
-            accepted = 1;
         }
-        emit(P->log, PGXR_EV_REFIT, (int64_t)instance_idx, (int64_t)inlier_number, 2 + accepted, sum_of_residuals_before,
+        emit(P->log, PGXR_EV_REFIT, (int64_t)instance_idx, (int64_t)inlier_number, 2 + accepted + 4 * tie, sum_of_residuals_before,
              sum_of_residuals_after);
     }
 }

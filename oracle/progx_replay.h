@@ -46,6 +46,11 @@ typedef struct {
     double one_minus_confidence;
     double inlier_outlier_threshold;
     double spatial_coherence_weight;
+    /* 0: every decision is the replay's own.  > 0 (the GPU tests use 1e-12): PEARL.h:393 compares two sums of ~n doubles whose
+     * last bits depend on the summation order (sequential upstream and here, a fixed tree on the GPU); when the two sums agree
+     * to this relative tolerance the comparison is a numerical tie and the replay follows the recorded run's choice
+     * (pgxr_trace.refit_accepted), marking the event (bit 2 of REFIT's c).  Anything outside the tolerance stays independent. */
+    double refit_tie_rtol;
 } pgxr_settings;
 
 typedef struct {
@@ -62,6 +67,7 @@ typedef struct {
     const int64_t *refit_inliers;  /* inlier_number of the call (checked: a different number here means the labelling diverged) */
     const int32_t *refit_models_n; /* current_models.size() */
     const double *refit_models;    /* n_refits x param_dim: current_models.back().descriptor */
+    const int8_t *refit_accepted;  /* what the recording run decided at PEARL.h:393 (1 / 0, -1 unknown); only read for ties, may be NULL */
 } pgxr_trace;
 
 /* event codes; fields a, b, c are integers, x, y doubles */
@@ -74,7 +80,7 @@ enum {
     PGXR_EV_SINGLE_MODEL = 6,   /* a = inliers written as label 0 (:378-384) */
     PGXR_EV_PEARL_ITER = 7,     /* a = iteration_number, b = models before, c = initialize_with_previous_labeling, x = energy */
     PGXR_EV_REFIT_SKIP = 8,     /* a = instance, b = inlier number (< nonMinimalSampleSize, PEARL.h:365) */
-    PGXR_EV_REFIT = 9,          /* a = instance, b = inlier number, c = models returned * 2 + accepted, x = sum before, y = sum after (0 if c/2 != 1) */
+    PGXR_EV_REFIT = 9,          /* a = instance, b = inlier number, c = models returned * 2 + accepted (+ 4: a tie steered by the trace), x = sum before, y = sum after (0 if c/2 != 1) */
     PGXR_EV_REJECT = 10,        /* a = instance index at the time of removal, b = its inlier number (PEARL.h:293-312) */
     PGXR_EV_PEARL_END = 11,     /* a = iteration_number, b = params changed * 2 + model rejected, c = models after * 2 + convergence */
     PGXR_EV_LABELING = 12,      /* a = instance_number_ of getLabeling (max label), b = models.size() */

@@ -24,14 +24,14 @@ class _Settings(C.Structure):
                 ("sample_size", C.c_uint64), ("nonminimal_sample_size", C.c_uint64), ("minimum_number_of_inliers", C.c_uint64),
                 ("max_proposal_number_without_change", C.c_uint64), ("maximum_model_number", C.c_uint64),
                 ("maximum_tanimoto_similarity", C.c_double), ("one_minus_confidence", C.c_double),
-                ("inlier_outlier_threshold", C.c_double), ("spatial_coherence_weight", C.c_double)]
+                ("inlier_outlier_threshold", C.c_double), ("spatial_coherence_weight", C.c_double), ("refit_tie_rtol", C.c_double)]
 
 
 class _Trace(C.Structure):
     _fields_ = [("n_proposals", C.c_int32), ("pad_", C.c_int32), ("models", C.POINTER(C.c_double)), ("empty", C.POINTER(C.c_uint8)),
                 ("inlier_off", C.POINTER(C.c_int64)), ("inliers", C.POINTER(C.c_int64)), ("iterations", C.POINTER(C.c_uint64)),
                 ("n_refits", C.c_int64), ("refit_inliers", C.POINTER(C.c_int64)), ("refit_models_n", C.POINTER(C.c_int32)),
-                ("refit_models", C.POINTER(C.c_double))]
+                ("refit_models", C.POINTER(C.c_double)), ("refit_accepted", C.POINTER(C.c_int8))]
 
 
 class _Event(C.Structure):
@@ -52,7 +52,7 @@ class TraceRecorder:
     def __init__(self):
         self.info = None
         self.proposals = []     # (descriptor or None, inliers, iterations)
-        self.refits = []        # (inlier_number, [models])
+        self.refits = []        # (inlier_number, [models], accepted or None)
         self.events = []        # (code, a, b, c, x, y)
 
     def begin(self, info):
@@ -62,14 +62,15 @@ class TraceRecorder:
         self.proposals.append((None if model is None else np.array(model, dtype=np.float64).reshape(-1),
                                None if inliers is None else np.array(inliers, dtype=np.int64).reshape(-1), int(iterations)))
 
-    def refit(self, inlier_number, fits):
-        self.refits.append((int(inlier_number), [np.array(f, dtype=np.float64).reshape(-1) for f in fits]))
+    def refit(self, inlier_number, fits, accepted=None):
+        self.refits.append((int(inlier_number), [np.array(f, dtype=np.float64).reshape(-1) for f in fits],
+                            None if accepted is None else bool(accepted)))
 
     def event(self, code, a=0, b=0, c=0, x=0.0, y=0.0):
         self.events.append((int(code), int(a), int(b), int(c), float(x), float(y)))
 
 
-def settings_from(info, max_outer_iterations=None):
+def settings_from(info, max_outer_iterations=None, refit_tie_rtol=0.0):
     """the replay's settings out of what TraceRecorder.begin received (plain attribute reads of the run's MultiModelSettings)"""
     s = info["settings"]
     big = (1 << 64) - 1
@@ -85,7 +86,7 @@ def settings_from(info, max_outer_iterations=None):
                 maximum_tanimoto_similarity=float(s.maximum_tanimoto_similarity),
                 one_minus_confidence=float(s.one_minus_confidence),
                 inlier_outlier_threshold=float(s.inlier_outlier_threshold),
-                spatial_coherence_weight=float(s.spatial_coherence_weight))
+                spatial_coherence_weight=float(s.spatial_coherence_weight), refit_tie_rtol=float(refit_tie_rtol))
 
 
 def replay(settings, pts, graph, proposals, refits, max_events=200000, max_models=256):
@@ -123,13 +124,17 @@ def replay(settings, pts, graph, proposals, refits, max_events=200000, max_model
     r_inl = np.zeros(max(R, 1), dtype=np.int64)
     r_n = np.zeros(max(R, 1), dtype=np.int32)
     r_m = np.zeros((max(R, 1), p))
-    for r, (cnt, fits) in enumerate(refits):
+    r_acc = np.full(max(R, 1), -1, dtype=np.int8)
+    for r, rec in enumerate(refits):
+        cnt, fits = rec[0], rec[1]
         r_inl[r] = cnt
         r_n[r] = len(fits)
         if len(fits) >= 1:
             r_m[r] = fits[-1]        # current_models.back()
+        if len(rec) > 2 and rec[2] is not None:
+            r_acc[r] = 1 if rec[2] else 0
     tr = _Trace(P, 0, O._p(models, C.c_double), O._p(empty, C.c_uint8), O._p(off, C.c_int64), O._p(inliers, C.c_int64),
-                O._p(its, C.c_uint64), R, O._p(r_inl, C.c_int64), O._p(r_n, C.c_int32), O._p(r_m, C.c_double))
+                O._p(its, C.c_uint64), R, O._p(r_inl, C.c_int64), O._p(r_n, C.c_int32), O._p(r_m, C.c_double), O._p(r_acc, C.c_int8))
     g = None
     if graph is not None:
         g = tuple(np.ascontiguousarray(a, dtype=np.int32) for a in graph)
@@ -145,7 +150,8 @@ def replay(settings, pts, graph, proposals, refits, max_events=200000, max_model
     if rc < 0:
         raise ReplayError(int(rc), lib.pgxr_last_error().decode())
     events = [(e.code, e.a, e.b, e.c, e.x, e.y) for e in ev[:rc]]
-    return dict(events=events, labels=labels, models=out_models[:out_n.value].copy(), consumed=(consumed[0], consumed[1]))
+    ties = sum(1 for e in events if e[0] == EV_REFIT and e[3] & 4)
+    return dict(events=events, labels=labels, models=out_models[:out_n.value].copy(), consumed=(consumed[0], consumed[1]), ties=ties)
 
 
 def compare_events(got, ref, rtol_sums=1e-9, atol_tanimoto=1e-12):
@@ -153,6 +159,8 @@ def compare_events(got, ref, rtol_sums=1e-9, atol_tanimoto=1e-12):
     indices) must be equal; energies are 2^-32 fixed-point values and must be EQUAL; the Tanimoto similarity and the residual /
     compound sums are floating-point reductions whose summation order differs between a GPU tree and a sequential loop."""
     for k, (g, r) in enumerate(zip(got, ref)):
+        if r[0] == EV_REFIT and r[3] & 4:
+            r = r[:3] + (r[3] & 3,) + r[4:]          # a tie the replay resolved the recording's way (refit_tie_rtol): same decision
         if g[:4] != r[:4]:
             return f"event {k}: {EVENT_NAMES.get(g[0], g[0])}{g[1:]} != {EVENT_NAMES.get(r[0], r[0])}{r[1:]}"
         code = g[0]

@@ -194,7 +194,7 @@ class Pearl:
                 if k in small:
                     self.trace.event(EV_REFIT_SKIP, k, cnt)
                     continue
-                self.trace.refit(cnt, fits[k])
+                self.trace.refit(cnt, fits[k], k in accepted)
                 one = len(fits[k]) == 1
                 self.trace.event(EV_REFIT, k, cnt, 2 * len(fits[k]) + (k in accepted), float(before[k]), float(after[k]) if one else 0.0)
         return changed

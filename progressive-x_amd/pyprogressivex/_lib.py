@@ -424,14 +424,22 @@ class Context:
         self._ck(self._lib.pgx_graph_build(self._h, _ptr(pts, C.c_double), C.c_int64(pts.shape[0]), C.c_int(pts.shape[1]),
                                            C.c_int(int(kind)), C.c_double(float(radius)), C.c_int(int(k)), C.byref(arcs)),
                  "pgx_graph_build")
+        self._built_graph = (int(pts.shape[0]), int(arcs.value))
         if not fetch:
             return arcs.value
-        off = np.empty(pts.shape[0] + 1, dtype=np.int32)
-        idx = np.empty(max(arcs.value, 1), dtype=np.int32)
-        mult = np.empty(max(arcs.value, 1), dtype=np.int32)
+        return self.graph_fetch()
+
+    def graph_fetch(self):
+        """CSR (off, idx, mult) of the graph pgx_graph_build left resident (pgx_graph_fetch)."""
+        if getattr(self, "_built_graph", None) is None:
+            raise PgxError("graph_fetch: no graph was built on this context")
+        n, arcs = self._built_graph
+        off = np.empty(n + 1, dtype=np.int32)
+        idx = np.empty(max(arcs, 1), dtype=np.int32)
+        mult = np.empty(max(arcs, 1), dtype=np.int32)
         self._ck(self._lib.pgx_graph_fetch(self._h, _ptr(off, C.c_int32), _ptr(idx, C.c_int32), _ptr(mult, C.c_int32)),
                  "pgx_graph_fetch")
-        return off, idx[:arcs.value], mult[:arcs.value]
+        return off, idx[:arcs], mult[:arcs]
 
     def solve_minimal(self, samples, fetch=True):
         """pgx_solve_minimal: hypotheses of the 2-point line / 2-segment vanishing point solvers, generated from the

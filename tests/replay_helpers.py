@@ -21,12 +21,13 @@ def graph_for(info):
     return O.graph_build(info["graph_points"], 0, radius=info["radius"], k=5)
 
 
-def run_and_replay(fn, *args, **kw):
-    """fn(*args, trace=recorder, **kw) -> (result of the call, recorder, replay dict)"""
+def run_and_replay(fn, *args, refit_tie_rtol=0.0, **kw):
+    """fn(*args, trace=recorder, **kw) -> (result of the call, recorder, replay dict).  refit_tie_rtol: progx_replay.h - the GPU
+    files pass 1e-12 (tree sums against sequential sums at PEARL.h:393), the CPU file leaves every decision to the replay."""
     rec = R.TraceRecorder()
     out = fn(*args, trace=rec, **kw)
     info = rec.info
-    rep = R.replay(R.settings_from(info), info["points"], graph_for(info), rec.proposals, rec.refits)
+    rep = R.replay(R.settings_from(info, refit_tie_rtol=refit_tie_rtol), info["points"], graph_for(info), rec.proposals, rec.refits)
     return out, rec, rep
 
 
@@ -73,7 +74,10 @@ class IdentityRefitLines(_estimators.LineEstimator):
         return [[] if k in skip else [np.asarray(inits[k], dtype=np.float64).copy()] for k in range(K)]
 
 
-def scripted_run(ctx, monkeypatch, pts, script, est=None, **settings):
+DEFAULT_TIE = 0.0     # the GPU file raises it to 1e-12 (tree sums against sequential sums: progx_replay.h refit_tie_rtol)
+
+
+def scripted_run(ctx, monkeypatch, pts, script, est=None, refit_tie_rtol=None, **settings):
     """ProgressiveX.run on `ctx` with the scripted engine; settings are attributes of MultiModelSettings.
     Returns (models, statistics, recorder, replay)."""
     est = est or _estimators.LineEstimator()
@@ -92,7 +96,8 @@ def scripted_run(ctx, monkeypatch, pts, script, est=None, **settings):
     models, st = px.run()
     info = dict(model_type=est.model_type, points=pts, sample_size=est.sample_size, nonminimal_sample_size=est.nonminimal_sample_size,
                 settings=s)
-    rep = R.replay(R.settings_from(info), pts, None, rec.proposals, rec.refits)
+    rep = R.replay(R.settings_from(info, refit_tie_rtol=DEFAULT_TIE if refit_tie_rtol is None else refit_tie_rtol), pts, None,
+                   rec.proposals, rec.refits)
     diff = R.compare_events(rec.events, rep["events"])
     assert diff is None, diff + "\n--- run ---\n" + R.narrate(rec.events) + "\n--- replay ---\n" + R.narrate(rep["events"])
     assert np.array_equal(np.asarray(st.labeling, dtype=np.int64), rep["labels"])
