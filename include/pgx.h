@@ -227,10 +227,6 @@ int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
  * moves restored from the memo of the previous expansion from the all-zero labelling (same unary columns: not solved again), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
  * (maxflow.hip), [4]=region moves declined (too many open sites / a sink that could not be promoted), [5]=tile moves handed back */
 int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
-/* global relabels of the level-synchronous solver that ran as an INCREMENTAL repair of the previous search's heights instead of a
- * full reverse BFS (same exact distances, hence the same cut: PEARL.h:550-551's min-cut is unchanged), since pgx_create:
- * [0]=repairs done, [1]=repairs given up (the full search ran instead), [2]=repair rounds, [3]=reserved */
-int pgx_expansion_relabels(pgx_ctx *ctx, int64_t out[4]);
 
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by
  * PEARL::parameterEstimation (PEARL.h:374-380) and by the proposal engine's local optimisation.  The device accumulates

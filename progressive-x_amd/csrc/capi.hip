@@ -110,7 +110,6 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_MF_TILE_BATCH")) ctx->mf_tile_batch = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_MEMO")) ctx->mf_memo = std::atoi(b) ? 1 : 0;
-    if (const char* b = std::getenv("PGX_MF_INCR")) ctx->mf_incremental = std::atoi(b) > 0 ? std::atoi(b) : 0;
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -1064,13 +1063,6 @@ int pgx_expansion_paths(pgx_ctx* ctx, int64_t paths[6])
     for (int k = 0; k < 6; ++k) paths[k] = ctx->paths[k];
     paths[1] = ctx->memo_hits;
     paths[5] = ctx->tile_fallbacks;
-    return PGX_OK;
-}
-
-int pgx_expansion_relabels(pgx_ctx* ctx, int64_t out[4])
-{
-    if (!ctx || !out) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_relabels: NULL argument");
-    maxflow_repair_stats(ctx, out);
     return PGX_OK;
 }
 

@@ -32,8 +32,6 @@ struct MaxflowState {
     DevBuf bar;              // word 8: arrival ticket of the kernels that publish the flags to the host (zeroed once)
     int next_stamp = 1;
     int64_t mark_n = 0;
-    int64_t repair_stats[4] = {0, 0, 0, 0};   // incremental relabels: done / given up / rounds / suspects (pgx_expansion_relabels)
-    int* dbg_d0 = nullptr;     // PGX_MF_DEBUG=6: [64] counters | [n] labels of the previous search
     int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
 };
 
@@ -655,131 +653,6 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
     }
 }
 
-// ---- incremental global relabel (maxflow_body.hip.h) ------------------------------------------------------------------------------
-constexpr int kRepairCap = 16384;      // suspects one repair handles (two LDS lists of this size: 128 KB of the CU's 160)
-constexpr int kRepairThreads = 1024;
-constexpr int kRepairPer = kRepairCap / kRepairThreads;
-
-// (1) the suspect list (`order`, count in fcount[0]): every labelled site that lost its support.  Only the sites the sweeps of this
-// round TOUCHED (on a work list: mark >= first_stamp) can have changed anything - they pushed (an arc of theirs may have saturated)
-// or were relabelled (whoever leaned on them lost that support) - so only they and their neighbours are tested: a pass over mark[]
-// plus a few thousand rows instead of all 6 M arcs.  flags[0] = highest height seen among the touched sites (the top of the table
-// can only have moved there).
-__global__ __launch_bounds__(kMfBlock) void mf_k_repair_scan(MfView v, int first_stamp, int stamp)
-{
-    const int64_t rounded = (v.n + kMfBlock - 1) / kMfBlock * kMfBlock;
-    for (int64_t u0 = (int64_t)blockIdx.x * kMfBlock; u0 < rounded; u0 += (int64_t)gridDim.x * kMfBlock) {
-        const int64_t u = u0 + threadIdx.x;
-        const bool touched = u < v.n && v.mark[u] >= first_stamp && v.d[u] != kMfDead;
-        // (workgroup-uniform trip counts are not needed: mf_append_hd ballots over the lanes that are active)
-        bool s0 = false;
-        if (touched) s0 = mf_repair_suspect(v, u) && mf_list_claim(v, (int)u, stamp);
-        mf_append_hd(&v.fcount[0], v.order, (int)u, s0);
-        const int a_lo = touched ? v.off[u] : 0, a_hi = touched ? v.off[u + 1] : 0;
-        for (int a = a_lo; __any(a < a_hi); ++a) {
-            bool sw = false;
-            int w = 0;
-            if (a < a_hi) {
-                w = v.idx[a];
-                // w leaned on u only over a residual arc w -> u
-                if (v.tot[a] - mf_ld64(&v.cap[a]) > 0 && v.mark[w] < first_stamp) sw = mf_repair_suspect(v, w) && mf_list_claim(v, w, stamp);
-            }
-            mf_append_hd(&v.fcount[0], v.order, w, sw);
-        }
-    }
-}
-
-// (2) one workgroup: rounds of { every listed site computes 1 + its lowest residual neighbour | barrier | the raised ones store it,
-// stay listed and list the sites that leaned on them } until nobody is raised.  Heights are read and written with agent-scope
-// atomics (no stale lines of the CU's vector cache across the barriers).
-__global__ __launch_bounds__(kRepairThreads) void mf_k_repair(MfView v, int stamp0, int max_rounds)
-{
-    __shared__ int s_list[2][kRepairCap];
-    __shared__ int s_cnt[2];
-    __shared__ int s_top, s_fail;
-    const int tid = (int)threadIdx.x;
-    int count = v.fcount[0];
-    if (tid == 0) { s_cnt[0] = count; s_cnt[1] = 0; s_top = 0; s_fail = 0; }
-    if (count > kRepairCap) {   // (uniform)
-        if (tid == 0) { v.flags[9] = 1; v.flags[10] = -count; }
-        return;
-    }
-    for (int i = tid; i < count; i += kRepairThreads) s_list[0][i] = v.order[i];
-    __syncthreads();
-    int cur = 0, round = 0;
-    for (; count > 0 && round < max_rounds; ++round) {
-        const int stamp = stamp0 + round;
-        int old_d[kRepairPer], new_d[kRepairPer];
-#pragma unroll
-        for (int j = 0; j < kRepairPer; ++j) {
-            const int i = tid + j * kRepairThreads;
-            old_d[j] = new_d[j] = kMfInf;
-            if (i < count) {
-                const int u = s_list[cur][i];
-                old_d[j] = mf_ld32(&v.d[u]);
-                if (old_d[j] != kMfInf) {
-                    const int h = mf_repair_height(v, u);
-                    new_d[j] = h > old_d[j] ? h : old_d[j];   // heights never come down (they are lower bounds already)
-                }
-            }
-        }
-        __syncthreads();   // every read of this round is done before the first write
-        const int nxt = cur ^ 1;
-#pragma unroll
-        for (int j = 0; j < kRepairPer; ++j) {
-            const int i = tid + j * kRepairThreads;
-            if (i >= count || new_d[j] == old_d[j]) continue;      // supported (or already unreachable): leaves the list
-            const int u = s_list[cur][i];
-            mf_st32(&v.d[u], new_d[j]);
-            if (new_d[j] != kMfInf) {
-                atomicMax(&s_top, new_d[j]);
-                if (mf_list_claim(v, u, stamp)) {                   // raised: looked at again next round
-                    const int at = atomicAdd(&s_cnt[nxt], 1);
-                    if (at < kRepairCap) s_list[nxt][at] = u; else s_fail = 1;
-                }
-            }
-            for (int a = v.off[u]; a < v.off[u + 1]; ++a) {          // whoever stood exactly one level above u over a residual arc into it
-                if (v.tot[a] - mf_ld64(&v.cap[a]) <= 0) continue;
-                const int w = v.idx[a];
-                if (mf_ld32(&v.d[w]) != old_d[j] + 1) continue;
-                if (!mf_list_claim(v, w, stamp)) continue;
-                const int at = atomicAdd(&s_cnt[nxt], 1);
-                if (at < kRepairCap) s_list[nxt][at] = w; else s_fail = 1;
-            }
-        }
-        __syncthreads();
-        count = s_cnt[nxt];
-        const bool fail = s_fail != 0;
-        __syncthreads();
-        if (tid == 0) s_cnt[cur] = 0;
-        cur = nxt;
-        if (fail) { count = -1; break; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (count != 0) v.flags[9] = 1;                               // overflow, or still climbing at the budget: a pocket cut off from t
-        v.flags[10] = round;
-        if (s_top > v.flags[0]) v.flags[0] = s_top;
-    }
-}
-
-// (3) lowest height per label over the labelled sites (the hubs' distances are 1 + that)
-__global__ __launch_bounds__(kMfBlock) void mf_k_repair_hubmin(MfView v, int, int)
-{
-    __shared__ int s_min[kMfMaxLabels];
-    if (threadIdx.x < kMfMaxLabels) s_min[threadIdx.x] = kMfInf;
-    __syncthreads();
-    for (int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x; u < v.n; u += (int64_t)gridDim.x * kMfBlock) {
-        const int du = v.d[u];
-        if (du >= 1 && du != kMfInf) {
-            const int lu = v.labels[u];
-            if (v.hub_exists[lu]) mf_acc_min(&s_min[lu], du);
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < v.L && s_min[threadIdx.x] != kMfInf) mf_report_min(&v.hub_chk[threadIdx.x], s_min[threadIdx.x]);
-}
-
 __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub, int seq)
 {
     if (blockIdx.x != 0) return;
@@ -793,8 +666,6 @@ __global__ void mf_k_single(MfView v, int what, int a0, int a1, int a2, int* pub
     case 0: mf_body_hub_setup(v); break;
     case 1: mf_body_bfs_reset(v); break;
     case 2: mf_body_bfs_finish(v, a0, a1); break;
-    case 4: mf_body_repair_begin(v); break;
-    case 5: mf_body_repair_finish(v, a0); break;
     }
 }
 
@@ -837,27 +708,6 @@ int graph_build_reverse(pgx_ctx* ctx)
 
 namespace {
 
-
-// PGX_MF_DEBUG=6 (measurement, lab notebook round 5): against the labels d0 of the previous search, after the sweeps that followed
-// it - out[0] = lowest old level at which a site lost every supporting arc (a residual arc to a site one level nearer t; level 1:
-// residual capacity to t), out[1] = such sites, out[2] = sites the sweeps relabelled, out[3] = labelled sites, out[4 + min(k, 59)] =
-// histogram of the unsupported sites' old levels
-__global__ __launch_bounds__(kMfBlock) void mf_k_debug_support(MfView v, const int* __restrict__ d0, int* __restrict__ out)
-{
-    const int64_t u = (int64_t)blockIdx.x * kMfBlock + threadIdx.x;
-    if (u >= v.n) return;
-    const int k = d0[u];
-    if (k <= 0 || k >= v.hmax) return;
-    atomicAdd(&out[3], 1);
-    if (v.d[u] != k) atomicAdd(&out[2], 1);
-    bool sup = false;
-    if (k == 1) sup = v.rt[u] > 0 || v.f[u] > 0;
-    else {
-        for (int a = v.off[u]; a < v.off[u + 1] && !sup; ++a) sup = v.cap[a] > 0 && d0[v.idx[a]] == k - 1;
-        if (v.f[u] > 0) sup = true;   // (a route through its label's hub: not analysed, counted as supported)
-    }
-    if (!sup) { atomicMin(&out[0], k); atomicAdd(&out[1], 1); atomicAdd(&out[4 + (k < 59 ? k : 59)], 1); }
-}
 
 struct HipBackend {
     pgx_ctx* ctx;
@@ -978,33 +828,12 @@ struct HipBackend {
         (void)hipMemcpy(&x, dptr, sizeof(T), hipMemcpyDeviceToHost);
         return x;
     }
-    void debug_snapshot(const MfView& v)
-    {
-        if (!st->dbg_d0) (void)hipMalloc((void**)&st->dbg_d0, sizeof(int) * (size_t)ctx->gn + 64 * sizeof(int));
-        (void)hipMemcpyAsync(st->dbg_d0 + 64, v.d, sizeof(int) * (size_t)v.n, hipMemcpyDeviceToDevice, ctx->stream);
-    }
-    void debug_support(const MfView& v, int it)
-    {
-        if (!st->dbg_d0 || v.off == nullptr) return;
-        int h[64];
-        for (int k = 0; k < 64; ++k) h[k] = 0;
-        h[0] = kMfInf;
-        (void)hipMemcpyAsync(st->dbg_d0, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(mf_k_debug_support, dim3(blocks), dim3(kMfBlock), 0, ctx->stream, v, st->dbg_d0 + 64, st->dbg_d0);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipMemcpy(h, st->dbg_d0, sizeof(h), hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[mf-support] alpha=%d before_relabel=%d first_unsupported_level=%d unsupported=%d relabelled=%d labelled=%d hist:", v.alpha, it,
-                     h[0] == kMfInf ? -1 : h[0], h[1], h[2], h[3]);
-        for (int k = 1; k < 60; ++k) if (h[4 + k]) std::fprintf(stderr, " %d:%d", k, h[4 + k]);
-        std::fprintf(stderr, "\n");
-    }
     void debug_dump(const MfView& v, int nact)
     {
         for (int l = 0; l < v.L; ++l)
             if (peek(v.hub_exists + l))
                 std::fprintf(stderr, "    hub %d: e=%lld d=%d cnt=%d\n", l, peek(v.hub_e + l), peek(v.bfs_hub_d + l), peek(v.cnt + l));
         if (peek(v.has_alpha_hub)) std::fprintf(stderr, "    hubA: rt=%lld d=%d\n", peek(v.hubA_rt), peek(v.bfs_hubA_d));
-        if (ctx->tile_debug == 6) return;
         if (ctx->tile_debug == 4) {  // level sizes of the BFS that just ran (nact carries the last level)
             std::vector<int> lv((size_t)nact + 2);
             (void)hipStreamSynchronize(ctx->stream);
@@ -1034,22 +863,6 @@ struct HipBackend {
                      n_stuck, s_stuck / 4294967296.0, n_exit, s_rt / 4294967296.0, n_relay);
     }
     void bfs_finish(const MfView& v, int slot, int last_level) { single(v, 2, slot, last_level); }
-    // incremental global relabel (maxflow_body.hip.h): enqueues scan + repair + hub check; the caller counts the active sites and
-    // reads the flags - flags[9] != 0: the repair gave up, run the full search
-    void repair(const MfView& v, int slot, int max_rounds, int first_stamp)
-    {
-        single(v, 4);
-        const int stamp = take_stamps(v, max_rounds + 3);
-        hipLaunchKernelGGL(mf_k_repair_scan, dim3(blocks < 1024u ? blocks : 1024u), dim3(kMfBlock), 0, ctx->stream, v, first_stamp, stamp);
-        check();
-        hipLaunchKernelGGL(mf_k_repair, dim3(1), dim3(kRepairThreads), 0, ctx->stream, v, stamp + 1, max_rounds);
-        check();
-        if (v.h_q > 0) {
-            hipLaunchKernelGGL(mf_k_repair_hubmin, dim3(blocks < kAggBlocks ? blocks : kAggBlocks), dim3(kMfBlock), 0, ctx->stream, v, 0, 0);
-            check();
-        }
-        single(v, 5, slot);
-    }
     void count_active(const MfView& v)   // always followed by a read-back (maxflow_driver.inl): its last workgroup publishes
     {
         if (!publish || !st->h_pub) { agg(mf_k_agg<kCountActive>, v, (int*)nullptr, (int*)nullptr, 0); return; }
@@ -1123,11 +936,6 @@ struct HipBackend {
 };
 
 }  // namespace
-
-void maxflow_repair_stats(const pgx_ctx* ctx, int64_t out[4])
-{
-    for (int k = 0; k < 4; ++k) out[k] = ctx->mf ? ctx->mf->repair_stats[k] : 0;
-}
 
 void maxflow_free(pgx_ctx* ctx)
 {
@@ -1295,7 +1103,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
         st->mark_n = n;
         st->next_stamp = 1;
     }
-    const size_t small_bytes = (size_t)(L + 1 + 3 + 4) * 8 + (size_t)(10 * L + 2 + 3 + kMfFlags + 2) * 4 + 64;
+    const size_t small_bytes = (size_t)(L + 1 + 3 + 4) * 8 + (size_t)(9 * L + 2 + 3 + kMfFlags + 2) * 4 + 64;
     PGX_TRY(ensure(ctx, st->small, small_bytes));
     char* sp = (char*)st->small.p;
     MfView v;
@@ -1323,8 +1131,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.lvl = st->front.as<int>() + n;
     v.has_alpha_hub = (int*)sp; sp += 4;
     v.bfs_hubA_d = (int*)sp; sp += 4;
-    v.flags = (int*)sp; sp += (size_t)kMfFlags * 4;
-    v.hub_chk = (int*)sp;
+    v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
     v.gate = 1;   // an unused alpha is handled by the stranded-excess test (maxflow_body.hip.h); the materialised hub stays in the bodies for the CPU emulation
 
@@ -1342,8 +1149,6 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     tune.debug = ctx->tile_debug;
     tune.bfs_hint = st->bfs_hint;
     tune.source_reach = source_reach ? 1 : 0;
-    tune.incremental = source_reach ? 0 : ctx->mf_incremental;   // (the source-side variant keeps its own schedule)
-    tune.repair_stats = st->repair_stats;
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
     if (!source_reach && wq == nullptr && pair && L <= 64 && region_moves_apply(ctx)) {   // (then expand_alpha_region runs its first kernel = the per-site initialisation)

@@ -86,7 +86,6 @@ struct MfView {
                                    //      0 last BFS level that labelled a site, 1 work-left (boolean, being
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep,
                                    //      6 a list-mode sweep pushed into a beta hub (all members must take part again)
-    int* hub_chk;                  // [L] incremental relabel: min member height per label, recomputed after the repair (mf_body_repair_finish)
     int hmax;                      // heights >= hmax are treated as unreachable
     int gate;                      // 1: an unused alpha is handled by the stuck-excess test instead of a hub (see below)
 };
@@ -360,100 +359,6 @@ PGX_HD void mf_body_bfs_finish(const MfView& v, int slot, int last_level)
     for (int r = 0; r < 3; ++r) { v.hubA_min[r] = ~0ull; v.hubA_want[r] = 0; }
     v.hubA_min[slot] = pk;
     if (v.has_alpha_hub[0] && v.hubA_e[0] > 0 && v.bfs_hubA_d[0] != kMfInf) v.flags[1] = 1;  // the hub can still deliver
-}
-
-// (host/device wrappers for kernels: the atomics above are picked per compilation pass inside PGX_HD functions only)
-PGX_HD void mf_append_hd(int* counter, int* list, int value, bool want) { mf_append(counter, list, value, want); }
-PGX_HD int mf_ld32(const int* p) { return mf_load32(p); }
-PGX_HD void mf_st32(int* p, int x) { mf_store32(p, x); }
-PGX_HD long long mf_ld64(const long long* p) { return mf_load64(p); }
-
-// ---- incremental global relabel (round 5; maxflow.hip mf_k_repair_scan / mf_k_repair) -------------------------------------------
-// Between two searches of a move the sweeps only REMOVE admissible arcs (a saturating push) and raise heights, so exact distances
-// can only grow, and they change only for sites that lost every supporting arc - a residual arc to a site exactly one level nearer
-// t - and for the sites behind them.  In the tail of a hard move that is a few hundred to a few thousand of ~10^6 labelled sites
-// (measured, lab notebook round 5), while a full search is 65-200 level launches.  The repair: (1) one pass over all sites lists the
-// unsupported ones; (2) ONE workgroup raises them to 1 + min over their residual arcs, re-examines whoever leaned on a raised site,
-// and repeats until every listed site is supported again.  Heights stay lower bounds throughout (a raise never exceeds
-// 1 + a lower bound of a residual neighbour), and at the fixed point every labelled site has a path of exactly d arcs to t, so
-// the heights are the exact distances the full search would write: the same cut, bit for bit.  Anything the repair cannot
-// finish within its budget (too many suspects, a pocket cut off from t that would climb for ever, a hub whose distance changed)
-// raises flags[9] and the driver runs the full search instead.
-// one thread, before the scan: the flags a search resets, the hub distances stay
-PGX_HD void mf_body_repair_begin(const MfView& v)
-{
-    v.fcount[0] = 0;   // number of suspects (list in `order`)
-    v.flags[1] = 0;
-    v.flags[3] = 0;
-    v.flags[4] = 1;
-    v.flags[8] = 0;
-    v.flags[11] = 0;
-    v.flags[6] = 0;
-    v.flags[7] = 0;
-    v.flags[9] = 0;    // repair failed: run the full search
-    v.flags[10] = 0;   // rounds the repair ran (diagnostics)
-    v.acnt[0] = v.acnt[1] = 0;
-    for (int l = 0; l < v.L; ++l) v.hub_chk[l] = kMfInf;
-}
-
-// 1 + the lowest height u can reach over one residual arc (t itself, its label's hub, a neighbour); kMfInf if there is none.
-// Loads in batches of eight arcs (capacities and heads together, then the heads' heights), as mf_body_sweep: one arc at a time is a
-// chain of three dependent round trips per arc, and the repair's single workgroup has only 16 waves to hide them.
-PGX_HD int mf_repair_height(const MfView& v, int64_t u)
-{
-    const long long rtu = v.rt[u];
-    const int lu = v.labels[u];
-    const int a_lo = v.off[u], a_hi = v.off[u + 1];
-    const long long fu = v.f[u];
-    if (rtu > 0) return 1;
-    int m = kMfInf;
-    if (fu > 0 && v.hub_exists[lu]) m = v.bfs_hub_d[lu];
-    for (int a0 = a_lo; a0 < a_hi; a0 += 8) {
-        long long c[8];
-        int w[8], h[8];
-        for (int j = 0; j < 8; ++j) {
-            const bool in = a0 + j < a_hi;
-            c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
-            w[j] = in ? v.idx[a0 + j] : 0;
-        }
-        for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
-        for (int j = 0; j < 8; ++j)
-            if (h[j] >= 0 && h[j] < m) m = h[j];
-    }
-    if (m == kMfInf || m + 1 >= v.hmax) return kMfInf;
-    return m + 1;
-}
-
-// Is w (any site) labelled and without support?  (the scan's test, for the neighbours of a touched site)
-PGX_HD bool mf_repair_suspect(const MfView& v, int64_t w)
-{
-    const int dw = mf_load32(&v.d[w]);
-    if (dw < 1 || dw == kMfInf || dw >= v.hmax) return false;
-    const int h = mf_repair_height(v, w);
-    return h != dw;   // (h < dw cannot happen: heights are valid; h > dw or kMfInf: no arc into level dw - 1)
-}
-
-// one thread, after the repair and the recount of the hubs' lowest members: a hub whose distance changed invalidates what its
-// members with f > 0 assumed (-> full search); otherwise what mf_body_bfs_finish does, without the level table
-PGX_HD void mf_body_repair_finish(const MfView& v, int slot)
-{
-    v.flags[3] = 0;
-    for (int l = 0; l < v.L; ++l) {
-        if (v.hub_exists[l]) {
-            const int hd = v.hub_chk[l] == kMfInf ? kMfInf : v.hub_chk[l] + 1;
-            if (hd != v.bfs_hub_d[l]) {
-                if (v.hub_exists[l] == 2) v.flags[9] = 1;   // some member may hold f > 0: its support through the hub was assumed
-                v.bfs_hub_d[l] = hd;
-            }
-        }
-        const int hd = v.bfs_hub_d[l];
-        for (int r = 0; r < 3; ++r) v.hub_min[r * v.L + l] = kMfInf;
-        v.hub_min[slot * v.L + l] = hd == kMfInf ? kMfInf : hd - 1;
-        if (v.hub_exists[l] && v.hub_e[l] > 0 && hd != kMfInf) { v.flags[1] = 1; v.flags[7] = 1; }
-    }
-    const unsigned long long pk = v.hubA_min[0];
-    for (int r = 0; r < 3; ++r) { v.hubA_min[r] = ~0ull; v.hubA_want[r] = 0; }
-    v.hubA_min[slot] = pk;
 }
 
 // After a global relabel: does site u hold excess that can reach t?

@@ -25,10 +25,6 @@ struct MfTuning {
     int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
     int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
     int preinit = 0;          // init_sites has already run for this move (the region path declined it); count_and_setup has not
-    int incremental = 0;      // > 0: a search that follows one with at most this many active sites is first tried as an incremental repair
-                              // of the previous search's heights (maxflow_body.hip.h "incremental global relabel"); 0 = every search is a full BFS
-    int repair_rounds = 384;  // rounds the repair may take before it gives up (a pocket cut off from t climbs one level per round)
-    int64_t* repair_stats = nullptr;   // (may be null) [4]: repairs done / given up / rounds / -
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
@@ -46,34 +42,14 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
     stats[0] += 1;
     int sweep_id = 0;
     bool converged = false;
-    int prev_active = -1, prev_last = 1;   // of the previous search of this move
-    int round_stamp = -1;                   // first work-list stamp of the sweeps since then (-1: they ran over all sites)
-    bool prev_hub_idle = false;
     for (int it = 0; it < tune.max_relabels && !converged; ++it) {
         // ---- global relabel
         const auto t_search = std::chrono::steady_clock::now();   // (PGX_MF_DEBUG: wall time of the search, read-backs included)
-        if (tune.debug == 6 && it > 0) be.debug_support(v, it);   // how much of the previous search's labelling is still exact (lab notebook, round 5)
+        be.bfs_reset(v);
+        be.bfs_init(v);
         int level = 1, last = 1;
         const int slot = (sweep_id + 2) % 3;
         int fl[kMfFlags];
-        bool repaired = false;
-        // In the tail of a hard move a few hundred sites hold excess and the sweeps touched a few thousand heights of ~10^6: repair those
-        // instead of relabelling everything (5 launches instead of 65-200).  Needs a complete previous search of this move, no hub
-        // with excess (their members' pulls are not modelled) and no materialised alpha hub.
-        if (tune.incremental > 0 && it > 0 && v.gate && v.off != nullptr && prev_hub_idle && round_stamp >= 0 && prev_active >= 0 && prev_active <= tune.incremental) {
-            be.repair(v, slot, tune.repair_rounds, round_stamp);
-            be.count_active(v);
-            be.read_flags(v, fl);
-            repaired = fl[9] == 0;
-            if (tune.repair_stats) { tune.repair_stats[repaired ? 0 : 1] += 1; tune.repair_stats[2] += fl[10] > 0 ? fl[10] : 0; }
-            if (tune.debug)
-                std::fprintf(stderr, "[mf-repair] alpha=%d relabel=%d %s rounds=%d top=%d active_sites=%d us=%.0f\n", v.alpha, it, repaired ? "ok" : "GAVE UP",
-                             fl[10], fl[0], fl[3], std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_search).count());
-            if (repaired) { last = fl[0] > 1 ? fl[0] : 1; level = 0; }
-        }
-        if (!repaired) {
-        be.bfs_reset(v);
-        be.bfs_init(v);
         {
             // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
             // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
@@ -112,12 +88,8 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
                 be.read_flags(v, fl);
             }
         }
-        }   // (!repaired)
-        prev_active = fl[3]; prev_last = last; prev_hub_idle = fl[7] == 0;
-        (void)prev_last;
         stats[2] += 1;
         stats[3] += level;
-        if (tune.debug == 6) be.debug_snapshot(v);
         if (fl[1] == 0) { converged = true; break; }
         if (tune.debug)
             std::fprintf(stderr, "[mf] alpha=%d relabel=%d levels=%d active_sites=%d hub=%d search_us=%.0f\n", v.alpha, it, level, fl[3], fl[7],
@@ -127,7 +99,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // One launch per level: after a deep search (86 levels at C4) the pass costs more than the list sweeps it saves
         // (find6DPoses PEARL 2.96 -> 2.70 s without it), after a shallow one (7 levels at C5) it pays (2.7 vs 3.2 s).  A move
         // that still needs many relabels gets it back: it is what moved excess along 100-arc paths in round 1.
-        if (!repaired && tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {   // (a repair leaves no level table)
+        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {
             const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
             for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
@@ -137,7 +109,6 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         bool list_mode = tune.list_div > 0 && v.off != nullptr && fl[7] == 0 && (int64_t)fl[3] * tune.list_div <= v.n;
         const int budget = list_mode ? tune.sweeps_list : tune.sweeps_per_relabel;
         const int stamp = be.take_stamps(v, budget + 2);
-        round_stamp = list_mode ? stamp : -1;
         if (list_mode) be.build_list(v, stamp);
         int parity = 0, s = 0;
         bool round_done = false;
@@ -164,7 +135,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             // per bounce towards "unreachable" - the next search settles that at once.  (The inlier / outlier cut of a 10^6-point
             // pose problem spent ~80 of the 96 list sweeps of a round this way.)
             if (tune.stall_sweeps > 0 && fl[11] >= (tune.stall_sweeps > last + 2 ? tune.stall_sweeps : last + 2)) break;
-            if (list_mode && fl[6] != 0) { list_mode = false; round_stamp = -1; }   // (sweeps over all sites from here on: every site is "touched")
+            if (list_mode && fl[6] != 0) list_mode = false;
         }
     }
     if (!converged) return 1;

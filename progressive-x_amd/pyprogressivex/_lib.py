@@ -429,12 +429,6 @@ class Context:
             return arcs.value
         return self.graph_fetch()
 
-    def expansion_relabels(self):
-        """incremental global relabels of the level-synchronous solver since pgx_create (pgx_expansion_relabels)"""
-        out = (C.c_int64 * 4)()
-        self._ck(self._lib.pgx_expansion_relabels(self._h, out), "pgx_expansion_relabels")
-        return dict(done=int(out[0]), given_up=int(out[1]), rounds=int(out[2]))
-
     def graph_fetch(self):
         """CSR (off, idx, mult) of the graph pgx_graph_build left resident (pgx_graph_fetch)."""
         if getattr(self, "_built_graph", None) is None:

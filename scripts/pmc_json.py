@@ -15,6 +15,9 @@ for line in open(src):
         vals[(name.split("<")[0], parts[0])] = (float(parts[1]), float(parts[-1]))
 fetch = sum(v[0] for (k, c), v in vals.items() if c == "FETCH_SIZE")
 write = sum(v[0] for (k, c), v in vals.items() if c == "WRITE_SIZE")
+# the group kernel writes nothing but its accumulator atomics (an L2-resident 48 KB table): WRITE_SIZE tallies each atomic as a 32-byte
+# request although no HBM byte moves (profiles/round5_fetch_calibration.txt: 2^24 atomics -> 524 288 KiB), so this part is not traffic
+atomic_write = vals.get(("pgx::score_group_kernel", "WRITE_SIZE"), (0.0, 0.0))[0]
 busy = None
 key = ("pgx::score_group_kernel", "SQ_ACTIVE_INST_VALU")
 if key in vals:
@@ -26,5 +29,5 @@ if key in vals:
     quad_cycles, avg_ns = vals[key]
     lds_busy = quad_cycles * 4.0 / (256 * avg_ns * 2.4)
 insts = vals.get(("pgx::score_group_kernel", "SQ_INSTS_VALU"), (None, None))[0]
-print(json.dumps({"source": committed_as, "fetch_kib": fetch, "write_kib": write, "valu_busy_frac": busy, "lds_busy_frac": lds_busy,
+print(json.dumps({"source": committed_as, "fetch_kib": fetch, "write_kib": write, "atomic_write_kib": atomic_write, "valu_busy_frac": busy, "lds_busy_frac": lds_busy,
                   "valu_wave_instructions": insts}))

@@ -67,9 +67,6 @@ struct EmuBackend {
         for (int u : lv) mf_body_wave(v, u, k);
     }
     void debug_dump(const MfView&, int) {}
-    void debug_support(const MfView&, int) {}
-    void repair(const MfView&, int, int, int) {}   // (GPU only: MfTuning::incremental stays 0 here)
-    void debug_snapshot(const MfView&) {}
     void bfs_finish(const MfView& v, int slot, int last_level) { mf_body_bfs_finish(v, slot, last_level); }
     void count_active(const MfView& v) { each([&](int64_t u) { if (mf_body_count_active(v, u)) v.flags[1] = 1; }); dump(v, "after bfs"); }
     int next_stamp = 1;
