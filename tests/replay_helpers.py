@@ -27,6 +27,8 @@ def run_and_replay(fn, *args, refit_tie_rtol=0.0, **kw):
     rec = R.TraceRecorder()
     out = fn(*args, trace=rec, **kw)
     info = rec.info
+    if info is None:          # an unknown sampler id: the call returns zero models before any loop runs (progressivex_python.cpp:240-245)
+        return out, rec, None
     rep = R.replay(R.settings_from(info, refit_tie_rtol=refit_tie_rtol), info["points"], graph_for(info), rec.proposals, rec.refits)
     return out, rec, rep
 

@@ -105,3 +105,10 @@ def test_expansion_soak_slice_through_region_moves(oracle, seed, monkeypatch):
     from soak_expansion import soak
     monkeypatch.setenv("PGX_MF_TILE", "0")
     assert soak(seed, 120, verbose=False, max_n=2500) == 0
+
+
+def test_replay_soak_slice():
+    """60 random drop-in calls through libpgx, every decision against the independent replay of progressive_x.h / PEARL.h
+    (tests/soak_replay.py; the long campaigns are in profiles/)"""
+    import soak_replay
+    assert soak_replay.soak(2024, 60, verbose=False) == 0

@@ -419,3 +419,22 @@ def test_sharding_is_opt_in(monkeypatch):
         parallel.default_exchange(NoComm(), distributed=True)
     monkeypatch.setenv("WORLD_SIZE", "1")
     assert parallel.default_exchange(NoComm(), distributed=True) is None        # one rank: nothing to shard
+
+
+def test_vectorised_fisher_yates_keeps_the_generator_stream():
+    """_proposal._fisher_yates_rows (all rows at once) against the per-row scalar loop it replaced: same rows, same generator
+    state afterwards - every seeded result of the package is unchanged by the vectorisation."""
+    from pyprogressivex import _proposal as P
+    for seed in range(120):
+        r0 = np.random.default_rng(seed)
+        m = int(r0.integers(2, 8))
+        count = int(r0.integers(1, 300))
+        tops = r0.integers(m, m + int(r0.choice([1, 3, 10, 50, 1000])), count).astype(np.int64)
+        bad = np.nonzero(r0.random(count) < 0.6)[0]
+        a, b = np.zeros((count, m), np.int64), np.zeros((count, m), np.int64)
+        ra, rb = np.random.default_rng(seed + 7), np.random.default_rng(seed + 7)
+        P._fisher_yates_rows(ra, a, tops, bad, m)
+        P._fisher_yates_rows_scalar(rb, b, tops, bad, m)
+        assert np.array_equal(a, b) and ra.random() == rb.random()
+        for r in bad:
+            assert len(set(a[r])) == m and a[r].max() < tops[r]

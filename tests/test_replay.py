@@ -116,3 +116,10 @@ def test_a_divergent_trace_is_reported_not_swallowed():
     with pytest.raises(R.ReplayError) as e:                # the loop wants more proposals than were recorded
         R.replay(s, pts, None, props[:1], [])
     assert e.value.code == -2
+
+
+def test_replay_soak_slice_cpu(cpu_api):
+    """25 random small calls (the generator of tests/soak_replay.py) on the oracle-backed context: every decision equals the replay,
+    with NO tie tolerance (both sides sum sequentially)"""
+    import soak_replay
+    assert soak_replay.soak(7, 25, verbose=False, tie=0.0) == 0
