@@ -1149,6 +1149,16 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     tune.debug = ctx->tile_debug;
     tune.bfs_hint = st->bfs_hint;
     tune.source_reach = source_reach ? 1 : 0;
+    {   // schedule knobs for A/B runs (any schedule gives the same cut; defaults = the measured ones in maxflow_driver.inl)
+        static const int e_wave_max = std::getenv("PGX_MF_WAVE_MAX") ? std::atoi(std::getenv("PGX_MF_WAVE_MAX")) : -1;
+        static const int e_wave_from = std::getenv("PGX_MF_WAVE_FROM") ? std::atoi(std::getenv("PGX_MF_WAVE_FROM")) : -1;
+        static const int e_sweeps_list = std::getenv("PGX_MF_SWEEPS_LIST") ? std::atoi(std::getenv("PGX_MF_SWEEPS_LIST")) : -1;
+        static const int e_stall = std::getenv("PGX_MF_STALL") ? std::atoi(std::getenv("PGX_MF_STALL")) : -1;
+        if (e_wave_max >= 0) tune.wave_max = e_wave_max;
+        if (e_wave_from >= 0) tune.wave_from = e_wave_from;
+        if (e_sweeps_list > 0) tune.sweeps_list = e_sweeps_list;
+        if (e_stall >= 0) tune.stall_sweeps = e_stall;
+    }
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.
     if (!source_reach && wq == nullptr && pair && L <= 64 && region_moves_apply(ctx)) {   // (then expand_alpha_region runs its first kernel = the per-site initialisation)

@@ -19,7 +19,8 @@ struct MfTuning {
     int max_relabels = 4096;  // hard cap on global relabels per move
     int debug = 0;            // PGX_MF_DEBUG: one stderr line per global relabel
     int wave = 1;             // run the level-ordered wave pass after each global relabel
-    int wave_max = 24;        // ... only after searches at most this deep (0 = always; PGX_MF_WAVE_MAX), or from the 12th relabel of a move on
+    int wave_max = 24;        // ... only after searches at most this deep (0 = always; PGX_MF_WAVE_MAX), or from the wave_from-th relabel of a move on
+    int wave_from = 12;       // (PGX_MF_WAVE_FROM)
     int list_div = 8;         // sweeps visit a work list instead of all sites when <= n / list_div sites are active (0 = never)
     int sweeps_list = 96;     // sweeps per global relabel in list mode (they cost a fraction of a full sweep)
     int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
@@ -99,7 +100,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // One launch per level: after a deep search (86 levels at C4) the pass costs more than the list sweeps it saves
         // (find6DPoses PEARL 2.96 -> 2.70 s without it), after a shallow one (7 levels at C5) it pays (2.7 vs 3.2 s).  A move
         // that still needs many relabels gets it back: it is what moved excess along 100-arc paths in round 1.
-        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= 12)) {
+        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= tune.wave_from)) {
             const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
             for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;

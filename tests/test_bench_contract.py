@@ -40,6 +40,37 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(d["value"] - n * m * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_round5_fields_labelling_baseline_roofline_and_api_legs():
+    """the labelling leg of the CPU baseline, a labelling roofline per config and the drop-in calls' wall times
+    travel in the driver-run line"""
+    d, path = _latest_line()
+    if int(re.findall(r"round(\d+)_", os.path.basename(path))[0]) < 5:
+        return
+    lab = d["cpu_baseline"]["labelling"]
+    assert lab["kind"] == "port" and lab["cores"] == 1 and lab["cycles_per_s"] > 0 and lab["mincuts_per_s"] > 0
+    for key in ("c3", "c5"):
+        c = lab["configs"][key]
+        assert c["solver"] in ("bk", "dinic") and c["seconds"] > 0 and c["cycles"] >= 1 and c["mincuts"] == c["cycles"] * c["labels"]
+        assert c[c["solver"] + "_labels_equal_gpu"] is True          # the CPU solver and the GPU ended on the same labelling
+        assert abs(c["cycles_per_s"] - c["cycles"] / c["seconds"]) < 1e-9 * c["cycles_per_s"]
+    assert lab["configs"]["c3"]["bk_labels_equal_gpu"] and lab["configs"]["c3"]["dinic_labels_equal_gpu"]
+    rl = d["roofline_labelling"]
+    for key in ("c2", "c3", "c5", "c4"):
+        r = rl[key]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        leg = d["legs"]["labelling_" + key]
+        alg = (leg["sites"] * 12 + leg["arcs"] * 12) * leg["sweeps"] + leg["sites"] * 4 * leg["bfs_levels"]     # SURVEY 8(d)
+        assert r["algorithmic_bytes"] == alg
+        assert abs(r["achieved"] - alg / (leg["expansion_ms"] * 1e-3) / 1e9) <= 1e-9 * max(r["achieved"], 1.0)
+        assert r["launches_per_expansion"] == leg["sweeps"] + leg["bfs_levels"] + leg["global_relabels"]
+    api = d["legs"]["api"]
+    for key in ("c1_findLines", "c2_findHomographies", "c3_findTwoViewMotions", "c5_findVanishingPoints", "c4_find6DPoses",
+                "c4_find6DPoses_16_objects"):
+        assert api[key]["wall_s"] > 0 and api[key]["models"] >= 1
+    for scene in ("unionhouse", "unihouse", "oldclassicswing", "breadcube", "cubetoy", "book", "tless"):
+        assert api["bundled_scenes"][scene]["wall_s_median"] > 0 and api["bundled_scenes"][scene]["recorded_s"] > 0
+
+
 def test_bench_py_keeps_the_driver_flags_and_defaults():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
