@@ -202,7 +202,10 @@ int pgx_device_info(pgx_ctx* ctx, char* name, int name_len, int* cu_count, int64
     hipDeviceProp_t prop;
     PGX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     if (name && name_len > 0) {
-        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        // some boxes report an empty marketing name (the driver's bench box did: "device": " (gfx950:...)"): say what is known
+        char fallback[64];
+        snprintf(fallback, sizeof fallback, "AMD GPU, %d CUs", prop.multiProcessorCount);
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name[0] ? prop.name : fallback, prop.gcnArchName);
     }
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
