@@ -1,6 +1,6 @@
 #!/bin/bash
 # The CPU-side native code under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY 5 tooling):
-#   oracle/pgx_oracle.c (the checker of every parity test) and tests/emu/mf_emu.cpp (the max-flow bodies + host driver of
+#   oracle/pgx_oracle.c + bk_maxflow.c + progx_replay.c (the checkers of every parity test) and tests/emu/mf_emu.cpp (the max-flow bodies + host driver of
 #   maxflow_body.hip.h / maxflow_driver.inl compiled for the host), driven by their own test files (+ tests/test_rng.py: the generator and the samplers of the oracle),
 #   and csrc/sampler_host.hip (the one piece of host code in libpgx.so with its own data structures) under tests/emu/pnapsac_driver.cpp.
 # usage: bash scripts/sanitize.sh        (from the repo root; ~2 min)
@@ -17,7 +17,8 @@ UBSAN=$(gcc -print-file-name=libubsan.so)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export PGX_ORACLE_SO="$ROOT/oracle/_san/libpgx_oracle.so" PGX_EMU_SO="$ROOT/tests/emu/_san/libmf_emu.so"
-LD_PRELOAD="$ASAN:$UBSAN" python -m pytest tests/test_oracle.py tests/test_emu.py tests/test_rng.py -x -q -m "not gpu" "$@"
+# (round 5: + the Boykov-Kolmogorov solver and the control-flow replay, oracle/bk_maxflow.c / progx_replay.c, under their tests)
+LD_PRELOAD="$ASAN:$UBSAN" python -m pytest tests/test_oracle.py tests/test_emu.py tests/test_rng.py tests/test_oracle_bk.py tests/test_replay.py -x -q -m "not gpu" "$@"
 # csrc/sampler_host.hip (Progressive NAPSAC: host code of libpgx.so) compiled host-only with the same sanitizers and driven on
 # 200 random problems (duplicates, points outside the image, subset sizes 0 / m .. n): must come back clean, leaks included
 mkdir -p build/san
