@@ -92,7 +92,22 @@ def _refine_amplification(gpu, before, call):
             % (total, " ".join(f"{d:.1e}" for d in dist)))
 
 
-def classify(fn, args, kw, gpu):
+class _WithoutShortcuts:
+    """the GPU context without its device-only shortcuts (pgx_score_inliers: the inlier list compacted on the device, where the
+    oracle-backed context unpacks the mask row - the same set, tests/test_gpu_parity.py): both sides then make the SAME sequence of
+    context calls and classify() can compare them call by call"""
+    HIDDEN = ("score_inliers",)
+
+    def __init__(self, inner):
+        self._i = inner
+
+    def __getattr__(self, name):
+        if name in self.HIDDEN:
+            raise AttributeError(name)
+        return getattr(self._i, name)
+
+
+def classify(fn, args, kw, gpu, _aligned=False):
     """Replays a call that returned different results on the two sides and finds the first context call that explains it.
     "bug": a call whose arguments - and those of every call before it - were bitwise the same on both sides returned different
     integers, or floats further than 1e-9 apart.  "fp-order": the first difference is a floating-point sum within 1e-9 (Gram
@@ -107,6 +122,13 @@ def classify(fn, args, kw, gpu):
     _api._ctx = gpu
     for i, (a, b) in enumerate(zip(*logs)):
         if a[0] != b[0]:
+            if not _aligned and (a[0] in _WithoutShortcuts.HIDDEN or b[0] in _WithoutShortcuts.HIDDEN):
+                # the sequences part at a device-only shortcut, not at a result: compare again with the shortcut hidden (round 5: two
+                # find6DPoses calls of a 1 200-call campaign were reported as "bug" here; aligned, both are the Gauss-Newton
+                # amplification below - profiles/round5_soak_campaign.txt)
+                kind, why = classify(fn, args, kw, _WithoutShortcuts(gpu), _aligned=True)
+                _api._ctx = gpu
+                return kind, why
             return "bug", f"call {i}: {a[0]} on the device, {b[0]} on the oracle, identical inputs so far"
         if _differ(a[1], b[1], 0.0) or _differ(a[2], b[2], 0.0):
             return "fp-order", f"call {i} {a[0]} is the first whose arguments differ (in rounding, or in the sign of a homogeneous model: every result before it agreed to 1e-9)"

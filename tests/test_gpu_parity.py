@@ -1773,3 +1773,66 @@ def test_set_points_device_non_finite_points_disable_the_sorted_path(oracle):
             ctx.close()
         ref = oracle.score(mt, q, models, T2)
         assert np.array_equal(got["counts"], ref["counts"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the point-sharded exchange never skips its collective, stale accumulators are refused, labels_max follows the moves
+# ----------------------------------------------------------------------------------------------------------------------
+def test_allreduce_raises_on_every_rank_instead_of_skipping_the_collective(gpu_ctx):
+    """A rank whose launch did not take the integer-accumulator path (here: a slice with an infinite coordinate, which switches the
+    sorted copies and the f32 filter off) used to return an error BEFORE ncclAllReduce while its peers waited in it for ever.
+    Now every rank enters the reduction - this one with a zero block and a poison word - and the error is raised after it, in the
+    serial and in the pipelined form; a healthy launch afterwards reduces normally."""
+    from pyprogressivex import _lib
+    mt, pts, models, thr = make_case("pnp", 20011, 200, seed=3)
+    T2 = 2.25 * thr * thr
+    bad = pts.copy()
+    bad[17, 2] = np.inf
+    gpu_ctx.comm_init(1, 0, _lib.comm_unique_id())
+    try:
+        gpu_ctx.set_points(mt, bad)
+        gpu_ctx.score_upload(models)
+        gpu_ctx.score_launch(T2, has_compound=False)
+        with pytest.raises(_lib.PgxError, match="could not take the group-major path.*this rank is one of them"):
+            gpu_ctx.score_allreduce()
+        gpu_ctx.score_launch(T2, has_compound=False)
+        gpu_ctx.score_allreduce_begin(0)                               # enqueued: the collective runs
+        with pytest.raises(_lib.PgxError, match="could not take the group-major path"):
+            gpu_ctx.score_allreduce_end(0, 2)
+        gpu_ctx.comm_barrier()                                          # the slot was released: the communicator is usable
+        gpu_ctx.set_points(mt, pts)
+        direct = gpu_ctx.score(models, T2, has_compound=False, exponent=2)
+        gpu_ctx.score_launch(T2, has_compound=False)
+        gpu_ctx.score_allreduce()
+        got = gpu_ctx.score_fetch(2)
+        assert np.array_equal(got["counts"], direct["counts"]) and np.array_equal(got["values"], direct["values"])
+        # accumulators belong to the batch they were launched for: an upload in between makes them stale
+        gpu_ctx.score_launch(T2, has_compound=False)
+        gpu_ctx.score_upload(models[:100])
+        with pytest.raises(_lib.PgxError, match="could not take the group-major path"):
+            gpu_ctx.score_allreduce()
+    finally:
+        gpu_ctx.comm_destroy()
+
+
+def test_labels_written_by_moves_are_range_checked_against_a_smaller_table(gpu_ctx):
+    """labels_max used to follow pgx_set_labels only: after moves on a 4-label table wrote label 3, a warm start on a 3-label table
+    passed the guard and indexed the per-label tables out of range"""
+    from pyprogressivex import _lib
+    pts, gt, lines = datasets_lines()
+    gpu_ctx.set_points(_lib.LINE2D, pts)
+    three = np.asarray(lines, dtype=np.float64).reshape(3, 3)
+    gpu_ctx.pearl_unary(three, 2.0, 0.0)                                # L = 4
+    gpu_ctx.set_labels(np.zeros(len(pts), np.int32))
+    gpu_ctx.expansion(0.0, 5.0)                                         # writes labels up to 3
+    assert int(gpu_ctx.get_labels().max()) == 3
+    gpu_ctx.pearl_unary(three[:2], 2.0, 0.0)                            # L = 3, labels kept (a warm start)
+    with pytest.raises(_lib.PgxError, match="out of range"):
+        gpu_ctx.expansion(0.0, 5.0)
+    with pytest.raises(_lib.PgxError, match="out of range"):
+        gpu_ctx.energy(0.0, 5.0)
+
+
+def datasets_lines():
+    from pyprogressivex import datasets
+    return datasets.make_lines(n_per_line=300, n_lines=3, n_outliers=300, seed=2)
