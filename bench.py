@@ -188,8 +188,12 @@ def api_legs(datasets, c3=None, c5=None, c4=None):
     timed("c4_find6DPoses", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048)
     # BASELINE config C4 names 16 objects; the reference's outer loop stops at 10 proposals (progressive_x.h:272): the same call with
     # the cap lifted (keyword-only extension) returns all of them
-    timed("c4_find6DPoses_16_objects", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048,
+    timed("c4_find6DPoses_cap_lifted", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048,
           max_outer_iterations=20)
+    # ... and stops at 12-14: at 10^6 points the reference's score value - shared^2 (exponent 2 for this driver) turns negative for every
+    # further object (scripts/c4_missing.py).  With the penalty's exponent at 1 (second keyword-only extension) all 16 come back.
+    timed("c4_find6DPoses_16_objects", 3, gt, px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048,
+          max_outer_iterations=32, scoring_exponent=1)
     scenes = os.path.join(ROOT, "tests", "golden", "scenes")
     recorded = {"unionhouse": 0.030, "unihouse": 0.308, "oldclassicswing": 0.089, "breadcube": 0.737, "cubetoy": 0.514, "book": 0.582,
                 "tless": 57.57}      # dataset_comparison/adelaideH.ipynb:137-142, adelaideF.ipynb:149-157, example_multi_pose_6d.ipynb

@@ -296,10 +296,16 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
 
 def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_weight=0.1,
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
-                minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10,
+                minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10, scoring_exponent=2,
                 neighborhood="flann_like",
                      local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
-    """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n])."""
+    """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n]).
+    scoring_exponent [keyword-only, not in the reference's signature]: the driver never calls setScoringExponent, so the class default
+    2 applies (progressive_x.h:183) - the default here.  The compound-model score is value - shared^exponent
+    (scoring_function_with_compound_model.h:110-121): at 10^6 points a new object's incidental overlap with a dozen accepted models
+    (~300-500 units of shared support) squared exceeds its whole value (~47 000), its score goes negative and junk hypotheses win the
+    proposal - the call stops at 12-14 of BASELINE config C4's 16 objects (scripts/c4_missing.py).  exponent = 1 keeps the penalty
+    on the scale of the support."""
     import time
     x1 = _as_f64(x1y1)
     n, dim = _shape2(x1)
@@ -332,6 +338,6 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              threshold=threshold / f, conf=conf, spatial_coherence_weight=spatial_coherence_weight,
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
-                             scoring_exponent=2, do_logging=False, seed=seed,
+                             scoring_exponent=int(scoring_exponent), do_logging=False, seed=seed,
                              max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
     return _stack(est, models, 4), labels

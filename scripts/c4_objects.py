@@ -21,7 +21,7 @@ for cap in [int(a) for a in sys.argv[1:]] or [20, 32]:
     rec = R.TraceRecorder()
     with contextlib.redirect_stdout(io.StringIO()):
         t0 = time.perf_counter()
-        P, lab = px.find6DPoses(x1, x2, K, seed=1, minimum_point_number=5000, max_iters=int(os.environ.get("C4_MAX_ITERS", "2048")), max_outer_iterations=cap, trace=rec, conf=float(os.environ.get("C4_CONF", "0.9")), maximum_tanimoto_similarity=float(os.environ.get("C4_TANI", "0.9")))
+        P, lab = px.find6DPoses(x1, x2, K, seed=1, minimum_point_number=5000, max_iters=int(os.environ.get("C4_MAX_ITERS", "2048")), max_outer_iterations=cap, trace=rec, conf=float(os.environ.get("C4_CONF", "0.9")), maximum_tanimoto_similarity=float(os.environ.get("C4_TANI", "0.9")), scoring_exponent=int(os.environ.get("C4_EXPONENT", "2")))
         dt = time.perf_counter() - t0
     k = P.shape[0] // 3
     verdicts = [(e[1], e[2]) for e in rec.events if e[0] == R.EV_VALIDATION]
