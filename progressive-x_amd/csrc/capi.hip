@@ -764,6 +764,7 @@ int pgx_set_labels(pgx_ctx* ctx, const int32_t* labels, int64_t n)
     if (lo < 0) return fail(ctx, PGX_ERR_INVALID, "pgx_set_labels: negative label %d", (int)lo);
     ctx->labels_max = hi;
     ctx->labels_all_zero = hi == 0 ? 1 : 0;
+    ctx->last_done.valid = 0;   // (the labels are the caller's now)
     PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, labels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -884,6 +885,7 @@ int pgx_expand_alpha(pgx_ctx* ctx, double lambda, double label_cost, int alpha, 
     PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
     for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
     ctx->labels_all_zero = 0;
+    ctx->last_done.valid = 0;
     PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
     if (changed) *changed = ch;
     return PGX_OK;
@@ -898,10 +900,26 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
     int64_t lq, hq;
     PGX_TRY(flow_params(ctx, lambda, label_cost, &lq, &hq));
     for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
+    // ---- identical call (pgx_internal.h ExpansionDone): the labels are those the last expansion left at a fixed point, and columns,
+    // weights and graph are what it was computed from => one verifying cycle of no-ops and the same energy, without running it
+    pgx_ctx::ExpansionDone& last = ctx->last_done;
+    const bool ident_known = ctx->L > 0 && (int)ctx->unary_ident.size() == ctx->L && ctx->labels_n == ctx->dq_n;
+    if (ctx->mf_memo && last.valid && ident_known && max_cycles >= 1 && last.lq == lq && last.hq == hq && last.n == ctx->dq_n &&
+        (lq <= 0 || last.graph_version == ctx->graph_version) && last.ident == ctx->unary_ident) {
+        if (ctx->labels_max >= ctx->L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, ctx->L);
+        ctx->memo_hits += ctx->L;
+        ctx->stats[7] += ctx->L;   // "moves skipped because the labelling had not changed since that label's last move, which relabelled nothing"
+        if (energy_q) *energy_q = last.energy_q;
+        if (energy) *energy = (double)last.energy_q / 4294967296.0;
+        if (cycles) *cycles = 1;
+        return PGX_OK;
+    }
+    last.valid = 0;
     int64_t new_e = 0;
     PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
     int64_t old_e = new_e + 1;
     int done = 0;
+    int64_t last_cycle_changed = -1;
     int64_t version = 0;
     std::vector<int64_t> noop_at((size_t)(ctx->L > 0 ? ctx->L : 1), -1);
     // ---- first-cycle memo (pgx_internal.h ExpansionMemo): usable when this expansion starts from the all-zero labelling on columns
@@ -1033,6 +1051,12 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
         // a cycle that relabels nothing leaves the energy unchanged by construction: skip the recomputation
         if (changed_total > 0) PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
         done = cycle;
+        last_cycle_changed = changed_total;
+    }
+    if (ident_known && done >= 1 && last_cycle_changed == 0) {   // a fixed point of the whole cycle (a final cycle that moved ties at equal energy is not)
+        last.valid = 1;
+        last.ident = ctx->unary_ident;
+        last.lq = lq; last.hq = hq; last.n = ctx->dq_n; last.graph_version = ctx->graph_version; last.energy_q = new_e;
     }
     if (energy_q) *energy_q = new_e;
     if (energy) *energy = (double)new_e / 4294967296.0;

@@ -114,6 +114,15 @@ struct pgx_ctx {
         int64_t n = 0, lq = 0, hq = 0, graph_version = -1;
         int cap = 0;
     } memo;
+    // The last pgx_expansion that ended on a FIXED POINT (its final cycle relabelled nothing), with what it was computed from: a call
+    // with the same columns, weights, graph and the labels it left is the same deterministic computation - one cycle of no-ops, the same
+    // energy - and is answered from here (capi.hip pgx_expansion).  PEARL ends every run with exactly such a call: the iteration that
+    // finds "nothing changed" labels once more with the models and the warm start of the one before (PEARL.h:429-467).
+    struct ExpansionDone {
+        int valid = 0;
+        std::vector<std::string> ident;
+        int64_t lq = 0, hq = 0, n = 0, graph_version = -1, energy_q = 0;
+    } last_done;
     std::vector<std::string> unary_ident; // per label: what its unary column was computed from (pgx_pearl_unary); empty = unknown (injected table)
     int64_t points_version = 0;           // bumped by pgx_set_points
     int labels_all_zero = 0;              // the resident labelling is the all-zero one pgx_set_labels uploaded (no move has run since)

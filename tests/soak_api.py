@@ -96,7 +96,7 @@ class _WithoutShortcuts:
     """the GPU context without its device-only shortcuts (pgx_score_inliers: the inlier list compacted on the device, where the
     oracle-backed context unpacks the mask row - the same set, tests/test_gpu_parity.py): both sides then make the SAME sequence of
     context calls and classify() can compare them call by call"""
-    HIDDEN = ("score_inliers",)
+    HIDDEN = ("score_inliers", "solve_minimal_sampled")
 
     def __init__(self, inner):
         self._i = inner

@@ -1836,3 +1836,54 @@ def test_labels_written_by_moves_are_range_checked_against_a_smaller_table(gpu_c
 def datasets_lines():
     from pyprogressivex import datasets
     return datasets.make_lines(n_per_line=300, n_lines=3, n_outliers=300, seed=2)
+
+
+def test_identical_expansion_call_is_answered_from_the_fixed_point(monkeypatch):
+    """PEARL ends every run with a labelling call whose models and warm start are those of the call before (the iteration that finds
+    "nothing changed", PEARL.h:429-467).  pgx_expansion answers such a call - same unary columns, weights, graph, and the labels the
+    last expansion left at a fixed point - without running it: one verifying cycle of no-ops, the same energy.  Must be invisible:
+    equal to a context with the memo off and to the oracle; anything that touches labels, columns or weights in between runs for real."""
+    import pgx_oracle as O
+    from pyprogressivex import _lib
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=2500, n_objects=4, n_outliers=4000, seed=8)
+    pts, f = datasets.normalize_pnp(x1, x2, K)
+    n = pts.shape[0]
+    lam, h, thr = 0.1, 6.0, 4.0 / f
+    raw = np.column_stack([x1, x2])
+    graph = O.graph_build(raw, 0, radius=20.0, k=5)
+
+    def run(memo):
+        monkeypatch.setenv("PGX_MF_MEMO", "1" if memo else "0")
+        ctx = _lib.Context(0)
+        out = []
+        try:
+            ctx.set_points(_lib.PNP, pts)
+            ctx.graph_build(raw, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+            Dq = ctx.pearl_unary(poses[:4], thr, lam, want_table=True)
+            ctx.set_labels(np.zeros(n, np.int32))
+            out.append(ctx.expansion(lam, h) + (ctx.get_labels(),))                  # 0: from zeros
+            hits0 = ctx.expansion_paths()["memo"]
+            ctx.pearl_unary(poses[:4], thr, lam)                                      # the same models again, labels untouched
+            out.append(ctx.expansion(lam, h) + (ctx.get_labels(),))                  # 1: the identical call
+            hits1 = ctx.expansion_paths()["memo"]
+            mincuts1 = ctx.expansion_stats()["mincuts"]
+            out.append(ctx.expansion(lam, 7.0) + (ctx.get_labels(),))                # 2: another label cost: runs
+            ctx.pearl_unary(poses[:4], thr, lam)
+            ctx.set_labels(out[1][3])                                                 # the caller's labels (same content): runs
+            out.append(ctx.expansion(lam, h) + (ctx.get_labels(),))                  # 3
+            mincuts3 = ctx.expansion_stats()["mincuts"] + ctx.expansion_stats().get("skipped_moves", 0)
+            ctx.pearl_unary(np.vstack([poses[:3], poses[3:4] + 1e-6]), thr, lam)      # a refitted model: runs
+            out.append(ctx.expansion(lam, h) + (ctx.get_labels(),))                  # 4
+        finally:
+            ctx.close()
+        return out, Dq, (hits0, hits1, mincuts1, mincuts3)
+    with_memo, Dq, (hits0, hits1, mincuts1, mincuts3) = run(True)
+    without, _, (w0, w1, wm1, _) = run(False)
+    for k, (a, b) in enumerate(zip(with_memo, without)):
+        assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[3], b[3]), k
+    assert hits1 - hits0 == 5 and mincuts1 == 0                  # the identical call solved no min-cut (5 labels = 5 moves answered)
+    assert w1 == w0 and wm1 > 0                                  # ... and with the memo off it did
+    assert mincuts3 > 0
+    assert with_memo[1][2] == 1 and with_memo[1][0] == with_memo[0][0] and np.array_equal(with_memo[1][3], with_memo[0][3])
+    ref, ref_e, ref_cyc = O.expansion(Dq, graph, O.quantize_lambda(lam), O.quantize(h), with_memo[0][3])    # the oracle, from the fixed point
+    assert np.array_equal(ref, with_memo[1][3]) and ref_e == with_memo[1][0] and ref_cyc == 1
