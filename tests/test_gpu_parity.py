@@ -1887,3 +1887,16 @@ def test_identical_expansion_call_is_answered_from_the_fixed_point(monkeypatch):
     assert with_memo[1][2] == 1 and with_memo[1][0] == with_memo[0][0] and np.array_equal(with_memo[1][3], with_memo[0][3])
     ref, ref_e, ref_cyc = O.expansion(Dq, graph, O.quantize_lambda(lam), O.quantize(h), with_memo[0][3])    # the oracle, from the fixed point
     assert np.array_equal(ref, with_memo[1][3]) and ref_e == with_memo[1][0] and ref_cyc == 1
+
+
+def test_graph_fetch_returns_the_resident_graph(gpu_ctx, oracle):
+    """Context.graph_fetch (bench.py hands the device-built graph to the CPU labelling baseline): the CSR pgx_graph_build left resident"""
+    from pyprogressivex import _lib
+    rng = np.random.default_rng(3)
+    pts = rng.random((5000, 2)) * 300
+    arcs = gpu_ctx.graph_build(pts, _lib.GRAPH_KNN, k=6, fetch=False)
+    got = gpu_ctx.graph_fetch()
+    ref = oracle.graph_build(pts, 2, k=6)
+    assert arcs == len(ref[1])
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)

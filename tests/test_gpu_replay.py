@@ -80,3 +80,14 @@ def test_scripted_quirk_gpu(gpu_ctx, monkeypatch, scenario):
 
 def test_scripted_stale_preference_vectors_gpu(gpu_ctx, monkeypatch, oracle):
     H.scenario_stale_preference_vectors(gpu_ctx, monkeypatch, oracle)
+
+
+def test_c3_full_size_gpu_decisions_equal_the_replay(gpu_api):
+    """BASELINE config C3 at full size (1e5 correspondences, 8 motions): the whole findTwoViewMotions call - 10 proposals, ~244 PEARL
+    iterations with their refit decisions, rejections and convergence tests - against the independent replay (lambda = 0: GCO's
+    special-case labelling, so the replay's labellings are the oracle's greedy solver on 1e5 x 9 tables)."""
+    pts, gt, _ = datasets.make_two_view_motions(seed=0)
+    out, rec, rep = _rr(px.findTwoViewMotions, pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
+                        minimum_point_number=1000, max_iters=2000)
+    assert H.assert_agree(out, rec, rep, 3) == 7
+    assert sum(e[0] == R.EV_PEARL_ITER for e in rec.events) > 200
