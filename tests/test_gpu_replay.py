@@ -91,3 +91,15 @@ def test_c3_full_size_gpu_decisions_equal_the_replay(gpu_api):
                         minimum_point_number=1000, max_iters=2000)
     assert H.assert_agree(out, rec, rep, 3) == 7
     assert sum(e[0] == R.EV_PEARL_ITER for e in rec.events) > 200
+
+
+def test_c5_full_size_gpu_decisions_equal_the_replay(gpu_api):
+    """BASELINE config C5 at full size (2e5 segments, 6 vanishing points, spatial coherence on): the whole findVanishingPoints call -
+    10 proposals, 229 PEARL iterations, ~1 500 refit decisions - against the independent replay, whose 229 labellings are the oracle's
+    Dinic expansions on the 2e5-site graph (about two minutes of host time: the longest test of the suite, and the one that ties the
+    device's region moves, the first-cycle memo and the identical-call answer to an independent computation of every PEARL step)."""
+    pts, gt, _ = datasets.make_vanishing_points(seed=0)
+    out, rec, rep = _rr(px.findVanishingPoints, pts, np.array(0), 1000, 1000, threshold=1.5, conf=0.99, sampler_id=0, seed=1,
+                        minimum_point_number=2000, spatial_coherence_weight=0.05, neighborhood_ball_radius=10.0)
+    assert H.assert_agree(out, rec, rep, 1) == 9
+    assert sum(e[0] == R.EV_PEARL_ITER for e in rec.events) > 200
