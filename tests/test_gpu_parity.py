@@ -1900,3 +1900,24 @@ def test_graph_fetch_returns_the_resident_graph(gpu_ctx, oracle):
     assert arcs == len(ref[1])
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+
+
+def test_global_n_of_a_sharded_job_does_not_outlive_its_point_set(gpu_ctx):
+    """pgx_score_set_global_n fixes the fixed-point scale of a point-sharded job; it used to persist across pgx_set_points, so an
+    unrelated later problem on the same context summed at another scale.  After set_points the scale is the point set's own:
+    the integer accumulators equal those of a context that never saw the sharded job."""
+    mt, pts, models, thr = make_case("pnp", 9001, 150, seed=5)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.score_upload(models)
+    gpu_ctx.score_launch(T2, has_compound=False)
+    clean = gpu_ctx.score_accumulators()
+    gpu_ctx.score_set_global_n(50_000_000)
+    gpu_ctx.score_launch(T2, has_compound=False)
+    sharded = gpu_ctx.score_accumulators()
+    assert np.array_equal(clean["counts"], sharded["counts"]) and not np.array_equal(clean["values_q"], sharded["values_q"])   # another scale while the job is declared
+    gpu_ctx.set_points(mt, pts)                                 # a new problem: the declaration is gone
+    gpu_ctx.score_upload(models)
+    gpu_ctx.score_launch(T2, has_compound=False)
+    again = gpu_ctx.score_accumulators()
+    assert np.array_equal(again["counts"], clean["counts"]) and np.array_equal(again["values_q"], clean["values_q"])
