@@ -194,3 +194,61 @@ def test_switches_ball_graph_and_refit_only_local_optimisation(monkeypatch):
     assert _me(lab, 3, gt) < 0.1
     (L2, lab2), (L2r, lab2r) = _both(monkeypatch, px.findLines, pts, np.array(0), 1000, 1000, local_optimization="lsq", **kw)
     assert np.array_equal(lab2, lab2r) and np.allclose(L2, L2r, rtol=1e-9, atol=1e-12) and _me(lab2, 3, gt) < 0.1
+
+
+# ---- the drop-in calls at the edges of their input domain: GPU == the same host code on the CPU oracle, and nothing crashes ----------
+def _edge_cases():
+    rng = np.random.default_rng(11)
+    cases = []
+    two = np.array([[10.0, 20.0], [400.0, 333.0]])
+    cases.append(("lines_n2", px.findLines, (two, np.array(0), 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=2)))
+    cases.append(("lines_all_duplicates", px.findLines, (np.tile([[5.0, 5.0]], (40, 1)), np.array(0), 1000, 1000), dict(sampler_id=0, seed=1)))
+    cases.append(("lines_all_outliers", px.findLines, (rng.random((300, 2)) * 1000, np.array(0), 1000, 1000),
+                  dict(sampler_id=0, seed=1, threshold=0.5, minimum_point_number=50)))
+    col = np.column_stack([np.linspace(0, 900, 200), np.linspace(10, 460, 200)])
+    cases.append(("lines_one_exact_line", px.findLines, (col, np.array(0), 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=20)))
+    h4 = np.array([[0.0, 0, 10, 5], [100, 0, 110, 6], [100, 100, 111, 104], [0, 100, 9, 106]])
+    cases.append(("homography_n4", px.findHomographies, (h4, 1000, 1000, 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=4)))
+    pts, gt, _ = datasets.make_homographies(n_per_plane=60, n_planes=1, n_outliers=0, seed=4)
+    cases.append(("homography_collinear_in_image_1", px.findHomographies,
+                  (np.column_stack([np.linspace(0, 500, 80), np.full(80, 100.0), rng.random((80, 2)) * 500]), 1000, 1000, 1000, 1000),
+                  dict(sampler_id=0, seed=1, minimum_point_number=10)))
+    cases.append(("homography_single_plane_no_outliers", px.findHomographies, (pts, 1000, 1000, 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=10)))
+    f7 = rng.random((7, 4)) * 500
+    cases.append(("two_view_n7", px.findTwoViewMotions, (f7, 1000, 1000, 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=7)))
+    cases.append(("two_view_pure_noise", px.findTwoViewMotions, (rng.random((400, 4)) * 800, 1000, 1000, 1000, 1000),
+                  dict(sampler_id=0, seed=1, threshold=0.3, minimum_point_number=60, max_iters=200)))
+    seg = rng.random((2, 4)) * 500
+    cases.append(("vanishing_points_n2", px.findVanishingPoints, (seg, np.array(0), 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=2)))
+    par = np.column_stack([rng.random(120) * 900, rng.random(120) * 900])
+    par = np.column_stack([par, par + np.array([50.0, 0.0])])                      # all parallel: one vanishing point at infinity
+    cases.append(("vanishing_point_at_infinity", px.findVanishingPoints, (par, np.array(0), 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=20)))
+    cases.append(("vanishing_points_zero_length_segments", px.findVanishingPoints,
+                  (np.column_stack([par[:, :2], par[:, :2]]), np.array(0), 1000, 1000), dict(sampler_id=0, seed=1, minimum_point_number=20)))
+    x1, x2, K, gtp, _ = datasets.make_poses(n_per_object=3, n_objects=1, n_outliers=0, seed=2)
+    cases.append(("poses_n3", px.find6DPoses, (x1, x2, K), dict(seed=1, minimum_point_number=3)))
+    x1, x2, K, gtp, _ = datasets.make_poses(n_per_object=80, n_objects=1, n_outliers=0, seed=2)
+    flat = x2.copy()
+    flat[:, 2] = 0.0                                                                # a planar object: P3P's degenerate-prone configuration
+    cases.append(("poses_planar_object", px.find6DPoses, (x1, flat, K), dict(seed=1, minimum_point_number=10)))
+    cases.append(("poses_all_outliers", px.find6DPoses, (rng.random((300, 2)) * 700, rng.random((300, 3)) * 100, K),
+                  dict(seed=1, minimum_point_number=30, max_iters=100)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _edge_cases(), ids=lambda c: c[0])
+def test_edge_inputs_identical_to_cpu_restatement(monkeypatch, case, capsys):
+    name, fn, args, kw = case
+    (M, lab), (Mr, labr) = _both(monkeypatch, fn, *args, **kw)
+    assert M.shape == Mr.shape and lab.shape == (len(args[0]),) and lab.dtype == np.int32
+    assert np.array_equal(lab, labr)
+    if M.size:
+        rows = {px.findLines: 1, px.findVanishingPoints: 1}.get(fn, 3)
+        A, B = M.reshape(-1, rows * M.shape[1]), Mr.reshape(-1, rows * M.shape[1])
+        tol = 1e-7 * np.abs(B).max(axis=1, keepdims=True) + 1e-9
+        same = np.all(np.abs(A - B) <= tol, axis=1)
+        if fn is not px.find6DPoses:
+            same |= np.all(np.abs(A + B) <= tol, axis=1)       # homogeneous models: either sign
+        assert same.all(), (name, M, Mr)
+    K = M.shape[0] // {px.findLines: 1, px.findVanishingPoints: 1}.get(fn, 3)
+    assert lab.min() >= 0 and lab.max() <= max(K, 1)            # K = outlier label (0 / 1 with a single model; all 0 with none)
