@@ -16,6 +16,54 @@ def _latest_line():
         return json.loads(f.read().strip().splitlines()[-1]), files[-1]
 
 
+def _latest_detail():
+    """the full record of the same run: up to round 5 the line itself, from round 6 on the BENCH_DETAIL line printed before it"""
+    d, path = _latest_line()
+    with open(path) as f:
+        for ln in f.read().strip().splitlines():
+            if ln.startswith("BENCH_DETAIL "):
+                return json.loads(ln[len("BENCH_DETAIL "):]), path
+    return d, path
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_last_line_fits_the_drivers_tail_and_parses():
+    """BENCH_r05.json.parsed was null: the line had grown to 24.5 KB and the driver keeps an 8 188-byte tail of stdout.  The last
+    line is now bench.compact_line(record); it must stay under 8 000 bytes with every block the judge reads in it - checked on the
+    committed line of the last GPU run and on the compact form of the largest full record under profiles/."""
+    bench = _bench_module()
+    assert bench.MAX_LINE_BYTES <= 8000
+    d, path = _latest_line()
+    with open(path) as f:
+        last = f.read().strip().splitlines()[-1]
+    if int(re.findall(r"round(\d+)_", os.path.basename(path))[0]) >= 6:
+        assert len(last) < 8000, (path, len(last))
+    full, _ = _latest_detail()
+    c = bench.compact_line(full)
+    line = json.dumps(c)
+    assert len(line) < 8000, len(line)
+    back = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in back, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in back["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in back["cpu_baseline"], key
+    assert set(back["roofline_labelling"]) >= {"c2", "c3", "c5", "c4"} and "labelling" in back["cpu_baseline"]
+    # a record three times the size still yields a parseable line: the optional blocks are shed before the contract keys
+    fat = json.loads(json.dumps(full))
+    fat["legs"]["api"]["bundled_scenes"].update({f"scene{i}": {"wall_s_median": 1.0, "recorded_s": 1.0, "pad": "x" * 40} for i in range(400)})
+    assert len(json.dumps(bench.compact_line(fat))) < 8000
+
+
 def test_committed_bench_line_has_the_contract_fields():
     d, path = _latest_line()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -29,7 +77,7 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # achieved = algorithmic bytes per launch / the dominant kernel's average launch duration
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-4 * r["achieved"]    # (6 significant digits in the compact line)
     n, m = d["config"]["points"], d["config"]["hypotheses_per_gpu"]
     assert r["algorithmic_bytes_per_launch"] == n * 5 * 8 + m * 12 * 8 + m * 16 + n * 8      # SURVEY 8(d) + the compound vector
     c = d["cpu_baseline"]
@@ -43,7 +91,7 @@ def test_committed_bench_line_has_the_contract_fields():
 def test_round5_fields_labelling_baseline_roofline_and_api_legs():
     """the labelling leg of the CPU baseline, a labelling roofline per config and the drop-in calls' wall times
     travel in the driver-run line"""
-    d, path = _latest_line()
+    d, path = _latest_detail()
     if int(re.findall(r"round(\d+)_", os.path.basename(path))[0]) < 5:
         return
     lab = d["cpu_baseline"]["labelling"]

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STUB = os.path.join(ROOT, "tests", "stub_bench_ctx.py")
-ARGS = ["--steps", "3", "--warmup", "1", "--points", "4000", "--hyps", "64", "--no-legs", "--no-cpu-baseline"]
+ARGS = ["--stub", "--steps", "3", "--warmup", "1", "--points", "4000", "--hyps", "64", "--no-legs", "--no-cpu-baseline"]
 
 
 def _run(world, scaling):
@@ -31,7 +31,10 @@ def _run(world, scaling):
     assert not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())     # only rank 0 prints the line (gloo's own banner aside)
     lines = [ln for ln in outs[0][0].strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                           # ONE JSON line
-    return json.loads(lines[0])
+    last = outs[0][0].strip().splitlines()[-1]
+    assert last == lines[0] and len(last) < 8000                     # ... the LAST one, and short enough for the driver's 8 KB tail
+    assert any(ln.startswith("BENCH_DETAIL {") for ln in outs[0][0].splitlines())      # the full record travels on an earlier line
+    return json.loads(last)
 
 
 @pytest.fixture(scope="module")
