@@ -641,6 +641,7 @@ def compact_line(out):
     alg = r["algorithmic_bytes_per_launch"]
     c["roofline"] = {k: _r(r[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw", "kernel", "kernel_ms",
                                            "kernel_ms_samples", "algorithmic_bytes_per_launch")}
+    c["roofline"]["frac"] = c["roofline"]["achieved"] / c["roofline"]["peak"]      # frac = achieved / peak holds exactly on the printed numbers
     c["roofline"]["traffic_over_algorithmic"] = _r(r["traffic"] / alg, 4) if r["traffic"] else None
     c["roofline"]["traffic_raw_over_algorithmic"] = _r(r["traffic_raw"] / alg, 4) if r["traffic_raw"] else None
     c["roofline"]["traffic_source"] = f"{PMC['source']} @ {PMC.get('commit', '?')} (constant, not this run; raw = 2 FETCH + WRITE as r1-r4)"
