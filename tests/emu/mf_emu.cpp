@@ -68,7 +68,22 @@ struct EmuBackend {
     }
     void debug_dump(const MfView&, int) {}
     void bfs_finish(const MfView& v, int slot, int last_level) { mf_body_bfs_finish(v, slot, last_level); }
-    void count_active(const MfView& v) { each([&](int64_t u) { if (mf_body_count_active(v, u)) v.flags[1] = 1; }); dump(v, "after bfs"); }
+    void count_active(const MfView& v)
+    {
+        each([&](int64_t u) { if (mf_body_count_active(v, u)) { v.flags[1] = 1; v.flags[3] += 1; } });
+        if (std::getenv("MF_EMU_TRACE")) {   // scripts/exp_emu_hard_moves.py: what a round starts from
+            long long ea = 0, es = 0, r = 0; int64_t reach = 0; int maxd = 0; double sumd = 0; int na = 0;
+            for (int64_t u = 0; u < v.n; ++u) {
+                if (v.labels[u] == v.alpha) continue;
+                if (v.d[u] != kMfInf) { ea += v.ex[u]; ++reach; if (v.ex[u] > 0) { if (v.d[u] > maxd) maxd = v.d[u]; sumd += v.d[u]; ++na; } }
+                else es += v.ex[u];
+                r += v.rt[u];
+            }
+            std::fprintf(stderr, "    excess that reaches t %.3f, stranded %.3f, deficit %.3f, sites that reach t %lld; sites with excess: deepest level %d, mean %.1f\n",
+                         ea / 4294967296.0, es / 4294967296.0, r / 4294967296.0, (long long)reach, maxd, na ? sumd / na : 0.0);
+        }
+        dump(v, "after bfs");
+    }
     int next_stamp = 1;
     int take_stamps(const MfView&, int count) { const int s = next_stamp; next_stamp += count; return s; }
     void build_list(const MfView& v, int stamp)
@@ -205,6 +220,10 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     MfTuning tune;
     if (sweeps_per_relabel > 0) { tune.sweeps_per_relabel = tune.sweeps_list = sweeps_per_relabel; tune.sweep_check = 1; }
     if (const char* e = std::getenv("MF_EMU_LIST_DIV")) tune.list_div = std::atoi(e);
+    if (const char* e = std::getenv("MF_EMU_SWEEPS_LIST")) tune.sweeps_list = std::atoi(e);
+    if (const char* e = std::getenv("MF_EMU_STALL")) tune.stall_sweeps = std::atoi(e);
+    if (std::getenv("MF_EMU_TRACE")) tune.debug = 1;
+    if (const char* e = std::getenv("MF_EMU_WAVE_FROM")) tune.wave_from = std::atoi(e);
     int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int r = mf_expand_alpha(be, v, tune, changed, st);
     if (stats) for (int k = 0; k < 8; ++k) stats[k] = st[k];
