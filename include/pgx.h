@@ -227,6 +227,12 @@ int pgx_expansion_stats(pgx_ctx *ctx, int64_t stats[8]);
  * moves restored from the memo of the previous expansion from the all-zero labelling (same unary columns: not solved again), [2]=one workgroup on the compacted region of open sites, [3]=level-synchronous launches
  * (maxflow.hip), [4]=region moves declined (too many open sites / a sink that could not be promoted), [5]=tile moves handed back */
 int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
+/* how the level-synchronous solver (maxflow.hip; the max-flow behind PEARL.h:549-551) spent its dependent steps since pgx_create:
+ * [0]=launches of the persistent one-XCD round kernel (maxflow_xcd.hip.h), [1]=rounds (search + list sweeps) run inside them,
+ * [2]=of those launches, the ones that ended with no listed site reaching t, [3]=global relabels run as one launch (level loop
+ * inside), [4]=sites visited by the list sweeps inside those launches (a multiple of 16), [5]=sites visited by the list sweeps
+ * launched one by one (the labelling roofline charges a list sweep by its list, not by the graph), [6..7] reserved (0) */
+int pgx_expansion_schedule(pgx_ctx *ctx, int64_t out[8]);
 
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by
  * PEARL::parameterEstimation (PEARL.h:374-380) and by the proposal engine's local optimisation.  The device accumulates

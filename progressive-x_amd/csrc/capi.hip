@@ -110,6 +110,11 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_MF_TILE_BATCH")) ctx->mf_tile_batch = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_MEMO")) ctx->mf_memo = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_XCD")) ctx->mf_xcd = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_XCD_SEARCH")) ctx->mf_xcd_search = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_XCD_MIN_DEPTH")) ctx->mf_xcd_min_depth = std::atoi(b);
+    if (const char* b = std::getenv("PGX_MF_XCD_MAXN")) ctx->mf_xcd_max_n = std::atoll(b);
+    if (const char* b = std::getenv("PGX_MF_SWEEPS")) ctx->mf_sweeps = std::atoi(b);
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -1091,6 +1096,12 @@ int pgx_expansion_paths(pgx_ctx* ctx, int64_t paths[6])
     paths[1] = ctx->memo_hits;
     paths[5] = ctx->tile_fallbacks;
     return PGX_OK;
+}
+
+int pgx_expansion_schedule(pgx_ctx* ctx, int64_t out[8])
+{
+    if (!ctx || !out) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_schedule: NULL argument");
+    return maxflow_schedule_stats(ctx, out);
 }
 
 int pgx_bucket(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)

@@ -32,6 +32,9 @@ struct MaxflowState {
     DevBuf bar;              // word 8: arrival ticket of the kernels that publish the flags to the host (zeroed once)
     int next_stamp = 1;
     int64_t mark_n = 0;
+    DevBuf xcd;              // XcdCtl of the persistent one-XCD rounds (maxflow_xcd.hip.h)
+    int* h_xcd = nullptr;    // pinned host copy of its result words
+    int64_t xcd_launches = 0, xcd_rounds = 0, xcd_done = 0, xcd_swept16 = 0, xcd_searches = 0;
     int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
 };
 
@@ -709,6 +712,12 @@ int graph_build_reverse(pgx_ctx* ctx)
 namespace {
 
 
+}  // namespace
+}  // namespace pgx
+#include "maxflow_xcd.hip.h"
+namespace pgx {
+namespace {
+
 struct HipBackend {
     pgx_ctx* ctx;
     MaxflowState* st;
@@ -921,6 +930,75 @@ struct HipBackend {
         agg(mf_k_agg<kApply>, v, st->h_pub, st->bar.as<int>() + 8, ++st->pub_seq);
         pub_pending = true;
     }
+    // ---- persistent launches on one XCD (maxflow_xcd.hip.h); false = not available / declined (the move goes on with level launches)
+    int xcd_enabled = 1;
+    int64_t xcd_max_n = 300000;   // (pgx_ctx::mf_xcd_max_n) measured (scripts/ab_expansion.py): C3 (1e5 sites) 32.8 -> 29.2 ms, C5 (2e5) 78.0 -> 69.0, C4 (1e6) 286 -> 325: frontiers of
+                                  // ~1e4 sites and a 180 MB working set want the whole GPU's memory parallelism, not one XCD's (PGX_MF_XCD_MAXN)
+    int xcd_spp() const
+    {
+        const int deg = ctx->max_degree > 0 ? ctx->max_degree : 1;
+        int spp = (kXcdStage / 2) / deg;
+        if (spp > kXcdBlock / 8) spp = kXcdBlock / 8;
+        return spp;
+    }
+    XcdCtl* xcd_prepare()
+    {
+        if (ensure(ctx, st->xcd, 512) != PGX_OK) return nullptr;
+        if (!st->h_xcd && hipHostMalloc((void**)&st->h_xcd, 128, hipHostMallocDefault) != hipSuccess) return nullptr;
+        hipError_t e = hipMemsetAsync(st->xcd.p, 0, 512, ctx->stream);
+        if (e != hipSuccess) { if (err == hipSuccess) err = e; return nullptr; }
+        return (XcdCtl*)st->xcd.p;
+    }
+    void xcd_prof(XcdCtl* c, const char* what)
+    {
+        unsigned long long pr[8];
+        (void)hipMemcpy(pr, c->prof, sizeof(pr), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "    xcd %s us: first list %.0f, level 1 %.0f, level 2 %.0f, levels %.0f, list passes %.0f; of all that in barriers %.0f\n", what,
+                     pr[0] * 0.01, pr[1] * 0.01, pr[2] * 0.01, pr[3] * 0.01, pr[4] * 0.01, pr[5] * 0.01);
+    }
+    // the further hub-free rounds of a hard move
+    bool xcd_rounds(const MfView& v, const MfTuning& tune, int out[8])
+    {
+        const int spp = xcd_spp();
+        if (!xcd_enabled || spp < 4 || v.n > xcd_max_n) return false;   // (spp < 4: rows too long for the staging buffer)
+        XcdCtl* c = xcd_prepare();
+        if (!c) return false;
+        const int stamp0 = take_stamps(v, tune.xcd_max_rounds * (tune.sweeps_list + 3) + 8);
+        hipLaunchKernelGGL(mf_k_xcd_rounds, dim3(kXcdGrid), dim3(kXcdBlock), 0, ctx->stream, v, c, tune.xcd_max_rounds, tune.sweeps_list,
+                           tune.stall_sweeps, stamp0, spp);
+        check();
+        hipError_t e = hipMemcpyAsync(st->h_xcd, c->out, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { if (err == hipSuccess) err = e; return false; }
+        for (int k = 0; k < 8; ++k) out[k] = st->h_xcd[k];
+        if (tune.debug) xcd_prof(c, "rounds");
+        st->xcd_launches += 1;
+        st->xcd_rounds += out[0];
+        st->xcd_done += out[3] == 1 ? 1 : 0;
+        st->xcd_swept16 += out[6];
+        return out[4] > 0;
+    }
+    // one global relabel with the level loop inside the launch; fills the flags the driver reads after a search
+    bool xcd_search(const MfView& v, int slot, int fl[kMfFlags], int* cnt_alpha, int* levels)
+    {
+        const int spp = xcd_spp();
+        if (!xcd_enabled || spp < 4 || v.n > xcd_max_n) return false;
+        XcdCtl* c = xcd_prepare();
+        if (!c) return false;
+        hipLaunchKernelGGL(mf_k_xcd_search, dim3(kXcdGrid), dim3(kXcdBlock), 0, ctx->stream, v, c, slot, spp);
+        check();
+        static_assert(sizeof(int) * (8 + 16) <= 128, "pinned read-back buffer");
+        hipError_t e = hipMemcpyAsync(st->h_xcd, c->out, (8 + 16) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);   // out[8] | flags[16]
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { if (err == hipSuccess) err = e; return false; }
+        if (st->h_xcd[3] != 1) return false;   // declined (hub flow in play) or nobody on XCC 0
+        for (int k = 0; k < kMfFlags; ++k) fl[k] = st->h_xcd[8 + k];
+        *cnt_alpha = st->h_xcd[8 + kMfFlags];
+        *levels = st->h_xcd[1];
+        if (ctx->tile_debug) xcd_prof(c, "search");
+        st->xcd_searches += 1;
+        return true;
+    }
     void keep_source_reachable_only(const MfView& v)
     {
         const int stamp = take_stamps(v, 1);
@@ -942,11 +1020,32 @@ void maxflow_free(pgx_ctx* ctx)
     if (!ctx->mf) return;
     MaxflowState* st = ctx->mf;
     release(st->cap); release(st->tot); release(st->ex); release(st->rt); release(st->d); release(st->f); release(st->g);
-    release(st->small); release(st->front); release(st->lists); release(st->bar);
+    release(st->small); release(st->front); release(st->lists); release(st->bar); release(st->xcd);
+    if (st->h_xcd) (void)hipHostFree(st->h_xcd);
     if (st->h_flags) (void)hipHostFree(st->h_flags);
     if (st->h_pub) (void)hipHostFree(st->h_pub);
     delete st;
     ctx->mf = nullptr;
+}
+
+// pgx_expansion_schedule: how the level-synchronous solver spent its dependent steps since pgx_create
+int maxflow_schedule_stats(pgx_ctx* ctx, int64_t out[8])
+{
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    MaxflowState* st = ctx->mf;
+    if (!st) return PGX_OK;
+    out[0] = st->xcd_launches;
+    out[1] = st->xcd_rounds;
+    out[2] = st->xcd_done;
+    out[3] = st->xcd_searches;
+    out[4] = st->xcd_swept16 * 16;
+    if (st->bar.p) {
+        long long sw = 0;
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_HIP(ctx, hipMemcpy(&sw, (const long long*)st->bar.p + 6, sizeof(sw), hipMemcpyDeviceToHost));
+        out[5] = sw;
+    }
+    return PGX_OK;
 }
 
 // lambda = 0: one reduction pass, a host decision over <= 64 labels, one apply pass (maxflow_l0.hip.h)
@@ -1133,6 +1232,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     v.bfs_hubA_d = (int*)sp; sp += 4;
     v.flags = (int*)sp;
     v.hmax = (int)((n + L + 3 < (int64_t)kMfInf) ? (n + L + 3) : (int64_t)kMfInf - 1);
+    v.swept = nullptr;
     v.gate = 1;   // an unused alpha is handled by the stranded-excess test (maxflow_body.hip.h); the materialised hub stays in the bodies for the CPU emulation
 
     HipBackend be{ctx, st, (unsigned)((n + kMfBlock - 1) / kMfBlock), pair, 1};
@@ -1140,6 +1240,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
         PGX_TRY(ensure(ctx, st->bar, 64));
         PGX_HIP(ctx, hipMemsetAsync(st->bar.p, 0, 64, ctx->stream));
     }
+    v.swept = (long long*)st->bar.p + 6;   // bytes 48..55 of the once-zeroed block
     if (!st->h_pub) {
         PGX_HIP(ctx, hipHostMalloc((void**)&st->h_pub, 64, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(st->h_pub, 0, 64);
@@ -1158,6 +1259,12 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
         if (e_wave_from >= 0) tune.wave_from = e_wave_from;
         if (e_sweeps_list > 0) tune.sweeps_list = e_sweeps_list;
         if (e_stall >= 0) tune.stall_sweeps = e_stall;
+        tune.xcd = ctx->mf_xcd;
+        tune.xcd_search = ctx->mf_xcd_search;
+        tune.xcd_search_min = ctx->mf_xcd_min_depth;
+        be.xcd_enabled = ctx->mf_xcd || ctx->mf_xcd_search;
+        be.xcd_max_n = ctx->mf_xcd_max_n;
+        if (ctx->mf_sweeps > 0) { tune.sweeps_per_relabel = tune.sweeps_list = ctx->mf_sweeps; if (tune.sweep_check > ctx->mf_sweeps) tune.sweep_check = ctx->mf_sweeps; }
     }
     // A move with few OPEN sites (no t-link: excess or relay) is solved by one workgroup on their compacted sub-graph
     // (maxflow_tile.hip expand_alpha_region); it needs the t-links and arcs set up here first and leaves them intact when it declines.

@@ -86,6 +86,7 @@ struct MfView {
                                    //      0 last BFS level that labelled a site, 1 work-left (boolean, being
                                    //      accumulated), 2 sites relabelled by apply, 4 work-left of the last finished sweep,
                                    //      6 a list-mode sweep pushed into a beta hub (all members must take part again)
+    long long* swept;              // [1] sum of the work-list lengths swept so far (never cleared: pgx_expansion_schedule), or nullptr
     int hmax;                      // heights >= hmax are treated as unreachable
     int gate;                      // 1: an unused alpha is handled by the stuck-excess test instead of a hub (see below)
 };
@@ -668,7 +669,10 @@ PGX_HD void mf_body_sweep_epilogue(const MfView& v, int cur, int next, int consu
     v.flags[1] = 0;
     v.flags[11] = v.flags[8] ? 0 : v.flags[11] + 1;   // sweeps in a row without any flow reaching t (the driver then searches again)
     v.flags[8] = 0;
-    if (consumed >= 0) v.acnt[consumed] = 0;
+    if (consumed >= 0) {
+        if (v.swept) v.swept[0] += v.acnt[consumed];   // (one thread per sweep: what a list sweep actually visited, for the labelling roofline)
+        v.acnt[consumed] = 0;
+    }
 }
 
 // excess that cannot reach t any more (valid after the last global relabel): the gain of the move
@@ -677,6 +681,93 @@ PGX_HD long long mf_body_stuck_excess(const MfView& v, int64_t u)
     if (v.labels[u] == v.alpha || v.d[u] != kMfInf) return 0;
     const long long e = mf_load64(&v.ex[u]);
     return e > 0 ? e : 0;
+}
+
+// ---- hub-free rounds inside ONE launch on ONE XCD (maxflow_xcd.hip.h; round 6) -------------------------------------------
+// The rounds of a hard move after the first (the excess that escaped its cluster - a hundred units on a few hundred
+// sites - squeezing through a sparse sea in Dinic-like phases) touch frontiers and work lists of a few thousand sites: every level
+// and every sweep is a chain of dependent accesses, and a launch per step costs 12-18 us for ~2 us of work.  One persistent launch
+// whose workgroups all sit on the same XCD shares that XCD's L2 as a coherent point: plain stores (write-through L1) + loads that
+// bypass the L1 (sc1) need NO fence, and a barrier over its 32 workgroups costs 0.75-1.0 us (scripts/micro/xcd_scope_bench.hip) against
+// 4.2-5.8 with the release / acquire pair round 4 measured.  The step below is mf_body_sweep without hubs (n-links and t-links
+// only): ignoring the hub arcs is valid - a subset of the residual arcs - and convergence is only ever declared by the ordinary
+// search WITH hubs that follows (maxflow_driver.inl), so these rounds can never change a result, only leave less to do.
+// Every load of mutable state bypasses the L1; rt[u] and d[u] are written by the site's own step only (plain stores).
+PGX_HD void mf_plain_store64(long long* p, long long v) { *p = v; }
+PGX_HD void mf_plain_store32(int* p, int v) { *p = v; }
+
+// (host/device wrappers for the kernel of maxflow_xcd.hip.h: kernels may only call PGX_HD functions)
+PGX_HD long long mf_hd_load64(const long long* p) { return mf_load64(p); }
+PGX_HD int mf_hd_load32(const int* p) { return mf_load32(p); }
+PGX_HD bool mf_hd_cas32(int* p, int expected, int desired) { return mf_cas32(p, expected, desired); }
+PGX_HD bool mf_hd_claim(int* mark, int stamp) { return mf_claim(mark, stamp); }
+
+struct MfTailOut {
+    int pushed_to;   // site that received flow along an n-link, or -1
+    bool moved;      // flow reached t
+    bool listed;     // the site still holds excess that reaches t (by the labels it ended on)
+};
+
+PGX_HD void mf_body_tail_step(const MfView& v, int64_t u, MfTailOut* o)
+{
+    o->pushed_to = -1;
+    o->moved = false;
+    o->listed = false;
+    long long e = mf_load64(&v.ex[u]);
+    int du = mf_load32(&v.d[u]);
+    const long long rtu = mf_load64(&v.rt[u]);
+    const int a_lo = v.off[u], a_hi = v.off[u + 1];
+    if (e <= 0 || du == kMfInf || du == kMfDead) return;
+    if (rtu > 0) {  // u -> t
+        const long long dl = e < rtu ? e : rtu;
+        mf_plain_store64(&v.rt[u], rtu - dl);
+        mf_add64(&v.ex[u], -dl);
+        e -= dl;
+        o->moved = true;
+    }
+    if (e > 0) {
+        int best_h = kMfInf, best_a = -1;
+        long long best_c = 0;
+        for (int a0 = a_lo; a0 < a_hi; a0 += 8) {   // batched loads, as in mf_body_sweep
+            long long c[8];
+            int w[8], h[8];
+            for (int j = 0; j < 8; ++j) {
+                const bool in = a0 + j < a_hi;
+                c[j] = in ? mf_load64(&v.cap[a0 + j]) : 0;
+                w[j] = in ? v.idx[a0 + j] : 0;
+            }
+            for (int j = 0; j < 8; ++j) h[j] = c[j] > 0 ? mf_load32(&v.d[w[j]]) : kMfInf;
+            for (int j = 0; j < 8; ++j)
+                if (h[j] < best_h) { best_h = h[j]; best_a = a0 + j; best_c = c[j]; }
+        }
+        if (best_h == kMfInf) {
+            du = kMfInf;   // no residual arc leads anywhere that reaches t
+            mf_plain_store32(&v.d[u], du);
+        } else if (du > best_h) {
+            const long long dl = e < best_c ? e : best_c;   // only this site lowers the capacity of its own arcs
+            const int to = v.idx[best_a];
+            mf_add64(&v.cap[best_a], -dl);
+            mf_add64(&v.cap[v.rev[best_a]], dl);
+            mf_add64(&v.ex[u], -dl);
+            mf_add64(&v.ex[to], dl);
+            e -= dl;
+            o->pushed_to = to;
+        } else {
+            du = best_h + 1;
+            if (du >= v.hmax) du = kMfInf;
+            mf_plain_store32(&v.d[u], du);
+        }
+    }
+    o->listed = du != kMfInf && e > 0;
+}
+
+// reverse BFS without hubs: frontier site w (level k - 1) labels its unlabelled neighbours that have residual capacity to it
+// (mf_body_bfs_expand with the hub bookkeeping removed); level 2 runs bottom-up: an unlabelled site looks for a level-1 neighbour
+PGX_HD bool mf_body_tail_level2(const MfView& v, int64_t u)
+{
+    for (int a = v.off[u]; a < v.off[u + 1]; ++a)
+        if (mf_load64(&v.cap[a]) > 0 && mf_load32(&v.d[v.idx[a]]) == 1) return true;
+    return false;
 }
 
 // ---- apply the cut ---------------------------------------------------------------------------------------------

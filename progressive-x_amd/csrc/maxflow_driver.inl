@@ -26,6 +26,12 @@ struct MfTuning {
     int stall_sweeps = 8;     // leave a round after max(this, depth of the search + 2) consecutive sweeps without flow reaching t (0 = never)
     int source_reach = 0;     // take alpha only where the SOURCE reaches (minimal source side), see maxflow.hip mf_k_src_*
     int preinit = 0;          // init_sites has already run for this move (the region path declined it); count_and_setup has not
+    int xcd = 0;              // 1: after a round whose sweeps ended with work left, the further hub-free rounds run in one persistent launch on one XCD
+                              // (maxflow_xcd.hip.h) before the next ordinary search; PGX_MF_XCD
+    int xcd_max_rounds = 64;
+    int xcd_search = 0;       // 1: a search predicted deeper than xcd_search_min levels (depth of the previous search of its kind) runs its level loop inside
+                              // one launch on one XCD (maxflow_xcd.hip.h mf_k_xcd_search) while the hubs are passive; PGX_MF_XCD_SEARCH
+    int xcd_search_min = 24;
     int* bfs_hint = nullptr;  // in/out (may be null) [2]: depth of the previous FIRST search of a move / of the previous later search; sizes the first batch
 };
 
@@ -43,15 +49,28 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
     stats[0] += 1;
     int sweep_id = 0;
     bool converged = false;
+    bool xcd_declined = false;
     for (int it = 0; it < tune.max_relabels && !converged; ++it) {
         // ---- global relabel
         const auto t_search = std::chrono::steady_clock::now();   // (PGX_MF_DEBUG: wall time of the search, read-backs included)
-        be.bfs_reset(v);
-        be.bfs_init(v);
         int level = 1, last = 1;
         const int slot = (sweep_id + 2) % 3;
         int fl[kMfFlags];
-        {
+        int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
+        bool xs = false;   // this search ran inside one launch (no level table: no wave pass behind it)
+        if (tune.xcd_search && !xcd_declined && v.gate && v.off != nullptr && hint && *hint > tune.xcd_search_min) {
+            int ca = -1, xl = 0;
+            if (be.xcd_search(v, slot, fl, &ca, &xl)) {
+                xs = true;
+                level = xl;
+                last = fl[0];
+                if (cnt_alpha < 0) cnt_alpha = ca;
+                *hint = last > 1 ? last : 1;
+            } else xcd_declined = true;   // a member holds hub flow (or the launch is unavailable): level launches for the rest of the move
+        }
+        if (!xs) {
+            be.bfs_reset(v);
+            be.bfs_init(v);
             // A read-back costs about as much as three empty level launches: most searches are ~9 levels deep (one batch of
             // eight, then four), deep ones double the batch up to 64.  `last` = the last level that labelled a site.
             // The first batch is sized by the depth of the previous search of the same kind - the first search of a move (from
@@ -59,7 +78,6 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             // about equally deep from move to move; a fixed batch of eight launched most of its levels on empty frontiers
             // at C5.  A search whose last labelled level is `last` needs the levels 2 .. last + 2.
             int first = tune.bfs_batch;
-            int* hint = tune.bfs_hint ? tune.bfs_hint + (it > 0 ? 1 : 0) : nullptr;
             if (hint && *hint > 0) first = *hint + 2 < 64 ? *hint + 2 : 64;
             // The search's epilogue and the count of active sites are enqueued right behind the first batch and ONE read-back
             // brings everything: with the batch sized by the hint the search is nearly always complete (two synchronisations
@@ -100,7 +118,7 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
         // One launch per level: after a deep search (86 levels at C4) the pass costs more than the list sweeps it saves
         // (find6DPoses PEARL 2.96 -> 2.70 s without it), after a shallow one (7 levels at C5) it pays (2.7 vs 3.2 s).  A move
         // that still needs many relabels gets it back: it is what moved excess along 100-arc paths in round 1.
-        if (tune.wave && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= tune.wave_from)) {
+        if (tune.wave && !xs && v.off != nullptr && (tune.wave_max <= 0 || last <= tune.wave_max || it >= tune.wave_from)) {
             const int kstart = last + 1 < level ? last + 1 : level;  // levels beyond `last` are empty
             for (int k = kstart; k >= 1; --k) be.wave(v, k);
             stats[5] += 1;
@@ -130,13 +148,29 @@ int mf_expand_alpha(Backend& be, const MfView& v, const MfTuning& tune, int64_t*
             if ((s + 1) % tune.sweep_check != 0) continue;
             be.read_flags(v, fl);
             if (tune.debug == 5) std::fprintf(stderr, "[mf-sweeps] alpha=%d it=%d s=%d work=%d stall=%d hub=%d list=%d active0=%d\n", v.alpha, it, s + 1, fl[4], fl[11], fl[7], (int)list_mode, fl[3]);
-            if (fl[4] == 0) break;
+            if (fl[4] == 0) { round_done = true; break; }
             // No flow has reached t for longer than the search was deep (a site `last` levels out needs that many sweeps to
             // deliver): what still moves is excess bouncing between sites that cannot reach t any more, climbing a level or two
             // per bounce towards "unreachable" - the next search settles that at once.  (The inlier / outlier cut of a 10^6-point
             // pose problem spent ~80 of the 96 list sweeps of a round this way.)
             if (tune.stall_sweeps > 0 && fl[11] >= (tune.stall_sweeps > last + 2 ? tune.stall_sweeps : last + 2)) break;
             if (list_mode && fl[6] != 0) list_mode = false;
+        }
+        // ---- the sweeps ended with work left (budget or stall rule): a hard move.  Its further rounds are short chains of dependent
+        // steps on a few thousand sites: they run without hubs in ONE launch on one XCD (maxflow_xcd.hip.h) and leave a preflow from
+        // which the next ordinary search - the only place where the move is declared finished - has little or nothing left to do.
+        if (tune.xcd && !round_done && v.off != nullptr && v.gate && fl[7] == 0 && (int64_t)fl[3] * tune.list_div <= v.n) {
+            int xo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const auto t_xcd = std::chrono::steady_clock::now();
+            if (be.xcd_rounds(v, tune, xo)) {
+                stats[2] += xo[0];
+                stats[3] += xo[1];
+                stats[1] += xo[2];
+                stats[6] += xo[2];
+                if (tune.debug)
+                    std::fprintf(stderr, "[mf] alpha=%d xcd rounds=%d levels=%d sweeps=%d status=%d workgroups=%d first_list=%d us=%.0f\n", v.alpha, xo[0], xo[1], xo[2], xo[3], xo[4], xo[5],
+                                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_xcd).count());
+            }
         }
     }
     if (!converged) return 1;

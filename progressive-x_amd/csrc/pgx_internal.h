@@ -144,6 +144,11 @@ struct pgx_ctx {
     int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
     int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
+    int mf_xcd = 1;              // PGX_MF_XCD=0: no persistent one-XCD rounds (maxflow_xcd.hip.h); read at pgx_create like the switches above
+    int mf_xcd_search = 1;       // PGX_MF_XCD_SEARCH=0: no one-launch global relabels
+    int mf_xcd_min_depth = 24;   // PGX_MF_XCD_MIN_DEPTH: a search runs as one launch when the previous search of its kind was deeper than this
+    long long mf_xcd_max_n = 300000;   // PGX_MF_XCD_MAXN: graphs beyond this stay on level launches (measured: maxflow.hip)
+    int mf_sweeps = 0;           // PGX_MF_SWEEPS: sweeps per round, list mode and all-sites alike (0 = the measured defaults; tests shorten the rounds)
     int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
     int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
@@ -250,6 +255,7 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
 int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, const long long* wq, int64_t lambda_q,
                     int64_t h_q, int alpha, int64_t* changed, bool source_reach = false);
 void maxflow_free(pgx_ctx* ctx);
+int maxflow_schedule_stats(pgx_ctx* ctx, int64_t out[8]);   // maxflow.hip
 constexpr int PGX_TILE_FALLBACK = 1000;   // expand_alpha_tile: not handled, run the level-synchronous path (labels untouched)
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha,
                       int64_t* changed, const long long* wq = nullptr);

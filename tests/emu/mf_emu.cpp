@@ -148,6 +148,112 @@ struct EmuBackend {
         for (int l = 0; l < v.L; ++l) if (v.hub_exists[l] && v.hub_e[l] > 0) s += v.hub_e[l];
         return s;
     }
+    // ---- the hub-free rounds of maxflow_xcd.hip.h, sequentially, with the same per-site step (host-logic check of the schedule:
+    // list invariant, filter pass, stall rule, what the kernel leaves behind; the memory model of the launch is the GPU tests' job)
+    bool xcd_on = false;
+    int xcd_searches = 0, xcd_round_launches = 0;
+    // mf_k_xcd_search: the whole global relabel in one call, hubs passive (declines otherwise)
+    bool xcd_search(const MfView& v, int slot, int fl[kMfFlags], int* cnt_alpha, int* levels)
+    {
+        if (!xcd_on) return false;
+        if (v.has_alpha_hub[0]) return false;
+        for (int l = 0; l < v.L; ++l) if (v.hub_exists[l] == 2) return false;
+        mf_body_bfs_reset(v);
+        std::vector<int> fr, nf;
+        bool any1 = false;
+        auto hub = [&](int64_t u, int k) { const int lu = v.labels[u]; if (v.hub_exists[lu] && k + 1 < v.bfs_hub_d[lu]) v.bfs_hub_d[lu] = k + 1; };
+        for (int64_t u = 0; u < v.n; ++u) {
+            if (v.labels[u] == v.alpha) continue;
+            v.d[u] = v.rt[u] > 0 ? 1 : kMfInf;
+            if (v.d[u] == 1) { any1 = true; hub(u, 1); }
+        }
+        for (int64_t u = 0; u < v.n; ++u)
+            if (v.labels[u] != v.alpha && v.d[u] == kMfInf && mf_body_tail_level2(v, u)) fr.push_back((int)u);
+        for (int u : fr) { v.d[u] = 2; hub(u, 2); }
+        int k = 3, depth = any1 ? 1 : 0;
+        for (; !fr.empty(); ++k) {
+            depth = k - 1;
+            nf.clear();
+            if (shuffle) std::shuffle(fr.begin(), fr.end(), rng);
+            for (int w : fr)
+                for (int a = v.off[w]; a < v.off[w + 1]; ++a) {
+                    const int u = v.idx[a];
+                    if (v.tot[a] - v.cap[a] > 0 && v.d[u] == kMfInf) { v.d[u] = k; hub(u, k); nf.push_back(u); }
+                }
+            fr.swap(nf);
+        }
+        v.flags[0] = depth;
+        mf_body_bfs_finish(v, slot, depth + 1 > 2 ? depth + 1 : 2);
+        int act = 0;
+        for (int64_t u = 0; u < v.n; ++u) act += (v.labels[u] != v.alpha && v.ex[u] > 0 && v.d[u] != kMfInf) ? 1 : 0;
+        v.flags[3] = act;
+        if (act > 0) v.flags[1] = 1;
+        for (int i = 0; i < kMfFlags; ++i) fl[i] = v.flags[i];
+        *cnt_alpha = v.cnt[v.alpha];
+        *levels = k;
+        ++xcd_searches;
+        return true;
+    }
+    bool xcd_rounds(const MfView& v, const MfTuning& tune, int out[8])
+    {
+        if (!xcd_on) return false;
+        std::vector<int> list, next;
+        for (int64_t u = 0; u < v.n; ++u) if (v.labels[u] != v.alpha && v.ex[u] > 0) list.push_back((int)u);
+        int stamp = take_stamps(v, tune.xcd_max_rounds * (tune.sweeps_list + 3) + 4);
+        int rounds = 0, levels = 0, nsweeps = 0, status = 2;
+        out[5] = (int)list.size();
+        while (rounds < tune.xcd_max_rounds) {
+            ++rounds;
+            std::vector<int> fr, nf;
+            for (int64_t u = 0; u < v.n; ++u) if (v.labels[u] != v.alpha) v.d[u] = v.rt[u] > 0 ? 1 : kMfInf;
+            for (int64_t u = 0; u < v.n; ++u)
+                if (v.labels[u] != v.alpha && v.d[u] == kMfInf && mf_body_tail_level2(v, u)) fr.push_back((int)u);
+            for (int u : fr) v.d[u] = 2;   // (after the pass: the device's level-2 pass reads only d == 1)
+            int k = 3, depth = 2;
+            for (; !fr.empty(); ++k) {
+                depth = k - 1;
+                nf.clear();
+                if (shuffle) std::shuffle(fr.begin(), fr.end(), rng);
+                for (int w : fr)
+                    for (int a = v.off[w]; a < v.off[w + 1]; ++a) {
+                        const int u = v.idx[a];
+                        if (v.tot[a] - v.cap[a] > 0 && v.d[u] == kMfInf) { v.d[u] = k; nf.push_back(u); }
+                    }
+                fr.swap(nf);
+            }
+            levels += k;
+            const int stall_limit = tune.stall_sweeps > depth + 2 ? tune.stall_sweeps : depth + 2;
+            int stall = 0;
+            bool none_left = false;
+            for (int s = 0; s <= tune.sweeps_list; ++s, ++stamp) {
+                if (list.empty()) { none_left = true; break; }
+                next.clear();
+                bool moved = false;
+                if (shuffle) std::shuffle(list.begin(), list.end(), rng);
+                for (int u : list) {
+                    if (s == 0) {
+                        if (v.ex[u] > 0 && v.d[u] != kMfInf && mf_claim(&v.mark[u], stamp)) next.push_back(u);
+                        continue;
+                    }
+                    MfTailOut o;
+                    mf_body_tail_step(v, u, &o);
+                    moved |= o.moved;
+                    if (o.listed && mf_claim(&v.mark[u], stamp)) next.push_back(u);
+                    if (o.pushed_to >= 0 && mf_claim(&v.mark[o.pushed_to], stamp)) next.push_back(o.pushed_to);
+                }
+                list.swap(next);
+                if (s > 0) {
+                    ++nsweeps;
+                    stall = moved ? 0 : stall + 1;
+                    if (stall >= stall_limit) { ++stamp; break; }
+                }
+            }
+            if (none_left) { status = 1; break; }
+        }
+        out[0] = rounds; out[1] = levels; out[2] = nsweeps; out[3] = status; out[4] = 1;
+        ++xcd_round_launches;
+        return true;
+    }
     void apply(const MfView& v) { each([&](int64_t u) { if (mf_body_apply(v, u)) v.flags[2] += 1; }); }
 };
 
@@ -214,6 +320,7 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     v.bfs_hubA_d = bfs_hubA_d.data(); v.hub_min = hub_min.data(); v.hubA_min = hubA_min.data();
     v.flags = flags.data();
     v.order = order.data(); v.lvl = lvl.data(); v.fcount = fcount.data(); v.act[0] = act0.data(); v.act[1] = act1.data(); v.acnt = acnt.data(); v.mark = mark.data();
+    v.swept = nullptr;
     v.hmax = (int)(n + L + 3);
     v.gate = std::getenv("MF_EMU_NO_GATE") ? 0 : 1;
     EmuBackend be(n, order_seed);
@@ -223,9 +330,19 @@ extern "C" int emu_expand_alpha(int64_t n, int L, const int64_t* Dq_point_major,
     if (const char* e = std::getenv("MF_EMU_SWEEPS_LIST")) tune.sweeps_list = std::atoi(e);
     if (const char* e = std::getenv("MF_EMU_STALL")) tune.stall_sweeps = std::atoi(e);
     if (std::getenv("MF_EMU_TRACE")) tune.debug = 1;
+    if (const char* e = std::getenv("MF_EMU_XCD")) {   // bit 0: rounds, bit 1: searches (with the depth threshold at 0 so that small problems take it)
+        const int x = std::atoi(e);
+        tune.xcd = x & 1;
+        tune.xcd_search = (x >> 1) & 1;
+        tune.xcd_search_min = 0;
+        be.xcd_on = x != 0;
+    }
+    int hint[2] = {1, 1};
+    if (tune.xcd_search) tune.bfs_hint = hint;
     if (const char* e = std::getenv("MF_EMU_WAVE_FROM")) tune.wave_from = std::atoi(e);
     int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int r = mf_expand_alpha(be, v, tune, changed, st);
+    st[7] = (int64_t)be.xcd_searches * 1000000 + be.xcd_round_launches;   // (what of the above ran the one-launch way)
     if (stats) for (int k = 0; k < 8; ++k) stats[k] = st[k];
     return r;
 }

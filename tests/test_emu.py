@@ -90,3 +90,40 @@ def test_closed_form_lambda0_move_matches_oracle_with_ties(emu, oracle):
         ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, 0, hq, alpha, lab)
         got, ch, _ = emu_expand(emu, Dq, graph, 0, hq, alpha, lab)
         assert np.array_equal(got, ref) and ch == ref_changed, (trial, n, L, hq, alpha)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_one_launch_schedules_leave_the_cut_unchanged(emu, oracle, monkeypatch, mode):
+    """Round 6 (maxflow_xcd.hip.h): the later rounds of a move without hubs in one call (bit 0) and a whole global relabel in one
+    call while the hubs are passive (bit 1), emulated sequentially with the product's own per-site step.  Rounds are cut short
+    (one sweep per round) so that moves end their sweeps with work left and the new paths are the ones that run; the labels must
+    be the oracle's on problems full of ties, with and without label costs, in natural and shuffled order."""
+    monkeypatch.setenv("MF_EMU_XCD", str(mode))
+    rng = np.random.default_rng(60 + mode)
+    taken = 0
+    for trial in range(300):
+        n, L = int(rng.integers(2, 60)), int(rng.integers(2, 6))
+        Dq = rng.integers(0, 20, (n, L)).astype(np.int64)
+        graph = random_sym_graph(rng, n, float(rng.choice([0.05, 0.1, 0.3])))
+        lq, hq = int(rng.integers(1, 5)) * 2, int(rng.choice([0, 3, 10, 40]))
+        lab = rng.integers(0, L, n).astype(np.int32)
+        if rng.random() < 0.3:
+            lab[:] = rng.integers(0, L)
+        alpha = int(rng.integers(0, L))
+        ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, lab)
+        for seed, spr in ((0, 1), (trial + 1, 1), (trial + 7, 2)):
+            got, ch, st = emu_expand(emu, Dq, graph, lq, hq, alpha, lab, seed=seed, sweeps_per_relabel=spr)
+            assert np.array_equal(got, ref), (trial, seed)
+            assert ch == ref_changed
+            taken += int(st[7])
+    assert taken % 1000000 > 50 if mode & 1 else True     # round launches
+    assert taken // 1000000 > 50 if mode & 2 else True    # one-launch searches
+    # a whole cycle on a realistic energy
+    Dq, graph = realistic_labeling_problem(3000, L=6, lam=0.3, seed=3)
+    lq, hq = oracle.quantize_lambda(0.3), oracle.quantize(10.0)
+    lab = np.zeros(3000, np.int32)
+    for alpha in range(6):
+        ref, _, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, lab)
+        got, _, st = emu_expand(emu, Dq, graph, lq, hq, alpha, lab, seed=alpha, sweeps_per_relabel=2)
+        assert np.array_equal(got, ref)
+        lab = ref

@@ -645,6 +645,58 @@ def test_each_mincut_path_is_the_one_that_ran(mincut_ctx, oracle):
         assert paths["level_synchronous"] == 0 and paths["region"] == 0 and paths["tile_handed_back"] == 0
 
 
+@pytest.mark.parametrize("mode", ["rounds", "searches", "both", "both_one_xcd_budget"])
+def test_one_launch_schedules_match_oracle(oracle, monkeypatch, mode):
+    """Round 6 (csrc/maxflow_xcd.hip.h): the later rounds of a move and whole global relabels as ONE persistent launch on one XCD
+    (fence-free barrier over the XCD's workgroups, plain stores + L1-bypassing loads).  Forced on for every level-synchronous move
+    (depth threshold 0, rounds cut to 2 sweeps so that moves end them with work left): full expansions on realistic energies and
+    single moves on small problems full of ties must give the oracle's labels, energies and cycle counts, and
+    pgx_expansion_schedule must show that the new launches ran."""
+    for key, val in {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0", "PGX_MF_XCD": "0" if mode == "searches" else "1",
+                     "PGX_MF_XCD_SEARCH": "0" if mode == "rounds" else "1", "PGX_MF_XCD_MIN_DEPTH": "0", "PGX_MF_MEMO": "0",
+                     "PGX_MF_SWEEPS": "96" if mode == "both_one_xcd_budget" else "2"}.items():
+        monkeypatch.setenv(key, val)
+    ctx = _lib.Context(0)
+    try:
+        for n, lam, h in ((3000, 0.3, 10.0), (20000, 0.1, 6.0), (20000, 0.45, 0.0), (60000, 0.2, 3.0)):
+            Dq, graph = realistic_labeling_problem(n, L=6, lam=lam, seed=n)
+            lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+            ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(np.zeros(n, np.int32))
+            eq, e, cycles = ctx.expansion(lam, h)
+            assert np.array_equal(ctx.get_labels(), ref_labels) and eq == ref_e and cycles == ref_cycles, (mode, n)
+        rng = np.random.default_rng(606)
+        for trial in range(40):
+            n, L = int(rng.integers(2, 400)), int(rng.integers(2, 7))
+            Dq = (rng.integers(0, 1 << 8, (n, L)) << 24).astype(np.int64)      # coarse costs: ties everywhere
+            graph = random_sym_graph(rng, n, float(rng.choice([0.02, 0.2])))
+            lam, h = float(rng.choice([0.1, 0.45])), float(rng.choice([0.0, 0.01, 2.0]))
+            lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+            labels = rng.integers(0, L, n).astype(np.int32)
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(labels)
+            for alpha in rng.permutation(L):
+                ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, int(alpha), labels)
+                assert ctx.expand_alpha(lam, h, int(alpha)) == ref_changed
+                labels = ctx.get_labels()
+                assert np.array_equal(labels, ref), (mode, trial, alpha)
+        sched = ctx.expansion_schedule()
+        if mode != "searches":
+            assert sched["xcd_round_launches"] > 0 and sched["xcd_rounds"] >= sched["xcd_round_launches"]
+        else:
+            assert sched["xcd_round_launches"] == 0
+        if mode != "rounds":
+            assert sched["xcd_searches"] > 0
+        else:
+            assert sched["xcd_searches"] == 0
+        assert ctx.expansion_paths()["level_synchronous"] > 0
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("n,lam,h,L", [(700, 0.3, 2.0, 3), (3000, 0.2, 3.0, 7), (8000, 0.1, 10.0, 5)])
 def test_batched_one_workgroup_moves_equal_unbatched(oracle, monkeypatch, n, lam, h, L):
     """Graphs of <= 8192 sites: pgx_expansion enqueues the one-workgroup moves of a cycle back to back (the region moves' batch
