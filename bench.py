@@ -53,6 +53,13 @@ F32_FLOPS_PER_FILTER_TEST = 31   # Filter32<PnP>::reject: 13 FMA (2 flops) + 3 m
 PMC_TRAFFIC_RAW = int((2 * PMC["fetch_kib"] + PMC["write_kib"]) * 1024)
 PMC_TRAFFIC_DEFAULT = int((2 * PMC["fetch_kib"] + PMC["write_kib"] - PMC.get("atomic_write_kib", 0.0)) * 1024)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes of ONE expansion from zeros per config from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every min-cut
+# kernel (scripts/profile_labelling.sh): {"c4": {"bytes": ..., "source": ...}, ...}; absent until the pass has been run
+PMC_LABELLING = {}
+_pl = os.path.join(ROOT, "profiles", "pmc_labelling.json")
+if os.path.exists(_pl):
+    with open(_pl) as _f:
+        PMC_LABELLING = json.load(_f)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64 counting an FMA as 2 flops; parity mode may not contract => 39.3 usable
 FLOPS_PER_PAIR = {"pnp": 25, "fundamental": 33, "vanishing_point": 24}   # exact residual + score update, docs/lab-notebook.md 5.1
 
@@ -497,11 +504,13 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
         best = None
         for _ in range(3):
             c.set_labels(np.zeros(len(pts), np.int32))
+            sched0 = c.expansion_schedule()
             t0 = time.perf_counter()
             eq, e, cycles = c.expansion(lam, h)
             t = time.perf_counter() - t0
             best = t if best is None or t < best else best
         st = c.expansion_stats()
+        sched = {k2: v2 - sched0[k2] for k2, v2 in c.expansion_schedule().items()}      # of the last repetition, like `st`
         paths = c.expansion_paths()
         if keep_for_cpu is not None:      # the same problem for the CPU solvers: the device-built graph and unary table (bit-identical to
             graph = c.graph_fetch()       # the oracle's, tests/test_fullsize_pins.py) and the labels to check them against
@@ -510,13 +519,29 @@ def labelling_leg(_lib, name, mt, pts, models, thr, lam, h, graph_points, kind, 
         # SURVEY 8(d) "expansion_step": a push-relabel sweep reads N (8 B excess + 4 B height) + E (4 B idx + 8 B cap); a level of the
         # global relabel reads N x 4 B of heights.  Only the level-synchronous solver counts sweeps / levels (one-workgroup and region
         # moves keep their state in LDS): for them the figure is the bytes of the moves that fell back to it.
-        alg = (n_sites * 12 + n_arcs * 12) * int(st["sweeps"]) + n_sites * 4 * int(st["bfs_levels"])
+        # nearly all sweeps are LIST sweeps that visit a few hundred sites, and charging each the whole graph made the
+        # fraction meaningless.  A list sweep is charged by its list - sites visited (device counters, pgx_expansion_schedule) x (12 B +
+        # the site's share of the arcs x 12 B) - and only the sweeps over all sites by the graph; `frac_survey_formula` keeps the
+        # old figure for comparison with rounds 1-5.
+        all_sweeps = int(st["sweeps"]) - int(st["list_sweeps"])
+        list_sites = int(sched["list_sites"]) + int(sched["xcd_list_sites"])
+        per_site = 12.0 + 12.0 * n_arcs / max(1, n_sites)
+        alg_survey = (n_sites * 12 + n_arcs * 12) * int(st["sweeps"]) + n_sites * 4 * int(st["bfs_levels"])
+        alg = int((n_sites * 12 + n_arcs * 12) * all_sweeps + list_sites * per_site + n_sites * 4 * int(st["bfs_levels"]))
+        steps = int(st["sweeps"]) + int(st["bfs_levels"]) + int(st["global_relabels"])
+        inside = int(sched["xcd_levels"]) + int(sched["xcd_sweeps"])
+        traffic = PMC_LABELLING.get(keep_for_cpu or name[:2].lower())
         roof = {"bound": "hbm", "achieved": alg / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / best / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes": alg, "formula": "(N 12 + E 12) x sweeps + N 4 x bfs_levels (SURVEY 8d), over the expansion's wall time",
-                "launches_per_expansion": int(st["sweeps"]) + int(st["bfs_levels"]) + int(st["global_relabels"]),
+                "algorithmic_bytes": alg, "algorithmic_bytes_survey_formula": alg_survey, "frac_survey_formula": alg_survey / best / 1e9 / HBM_PEAK_GBS,
+                "formula": "(N 12 + E 12) x sweeps over all sites + list sites x (12 + 12 E / N) + N 4 x bfs_levels, over the expansion's wall time "
+                           "(survey formula: every sweep charged the whole graph)",
+                "all_site_sweeps": all_sweeps, "list_sweeps": int(st["list_sweeps"]), "list_sites_visited": list_sites,
+                "dependent_steps": steps, "steps_inside_persistent_launches": inside,
+                "launches_per_expansion": steps - inside + int(sched["xcd_round_launches"]) + int(sched["xcd_searches"]),
+                "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                 "moves_by_solver": {k2: int(v2) for k2, v2 in paths.items()},
-                "note": "latency bound: every sweep / level is one dependent launch (~12 us at N = 1e6) that moves a few MB; "
-                        "the fraction says how far from a streaming pass the solver is, not how busy HBM is"}
+                "note": "latency bound: every sweep / level is one dependent step (a launch of ~12 us at N = 1e6, or ~5 us inside a persistent "
+                        "one-XCD launch on graphs <= 3e5 sites) that moves little; the fraction says how far from a streaming pass the solver is"}
         return {"config": name, "sites": int(len(pts)), "labels": int(len(models)) + 1, "arcs": int(arcs), "lambda": lam, "label_cost": h,
                 "roofline_labelling": roof,
                 "graph_build_ms": 1e3 * t_graph, "unary_ms": 1e3 * t_unary, "expansion_ms": 1e3 * best, "cycles": int(cycles), "energy": e,
@@ -674,12 +699,12 @@ def compact_line(out):
         if isinstance(g, dict) and "roofline_labelling" in g:
             q = g["roofline_labelling"]
             rl[key] = {"frac": _r(q["frac"], 4), "achieved": _r(q["achieved"], 5), "bytes": q["algorithmic_bytes"],
-                       "launches": q["launches_per_expansion"], "expansion_ms": _r(g["expansion_ms"], 5), "mincuts": g.get("mincuts"),
+                       "frac_survey_formula": _r(q.get("frac_survey_formula"), 4), "traffic": q.get("traffic"),
+                       "steps": q.get("dependent_steps"), "launches": q["launches_per_expansion"], "list_sites": q.get("list_sites_visited"),
+                       "expansion_ms": _r(g["expansion_ms"], 5), "mincuts": g.get("mincuts"),
                        "moves": {k: v for k, v in q.get("moves_by_solver", {}).items() if v}}
-            if "traffic" in q:
-                rl[key]["traffic"] = q["traffic"]
     if rl:
-        rl["unit"] = "GB/s of 8000; bytes = SURVEY 8(d) formula, list sweeps charged by list length (DESIGN 4.3)"
+        rl["unit"] = "achieved GB/s of 8000; bytes: list sweeps charged by the sites they visit (frac_survey_formula: every sweep the whole graph); traffic: PMC bytes per expansion"
         c["roofline_labelling"] = rl
     api = legs.get("api")
     if isinstance(api, dict):

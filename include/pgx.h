@@ -193,6 +193,9 @@ int pgx_set_graph(pgx_ctx *ctx, int64_t n, const int32_t *off, const int32_t *id
 enum { PGX_GRAPH_KNN_IN_BALL = 0, PGX_GRAPH_BALL = 1, PGX_GRAPH_KNN = 2 };
 int pgx_graph_build(pgx_ctx *ctx, const double *points, int64_t n, int d, int kind, double radius, int k, int64_t *arcs);
 int pgx_graph_fetch(pgx_ctx *ctx, int32_t *off, int32_t *idx, int32_t *mult);
+/* sites and directed arcs of the graph resident NOW (after pgx_graph_build or pgx_set_graph; 0, 0 when none): what the buffers
+ * of pgx_graph_fetch must hold (a caller that cached the sizes of an earlier graph would be overrun) */
+int pgx_graph_size(pgx_ctx *ctx, int64_t *n, int64_t *arcs);
 
 /* ---- a8/a19: GCoptimizationGeneralGraph::{setLabel, expansion, whatLabel} as used by PEARL::labeling
  * (PEARL.h:507-551).  lambda = spatial coherence weight of ONE directed neighbour entry (PEARL.h:76-78),
@@ -231,7 +234,8 @@ int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
  * [0]=launches of the persistent one-XCD round kernel (maxflow_xcd.hip.h), [1]=rounds (search + list sweeps) run inside them,
  * [2]=of those launches, the ones that ended with no listed site reaching t, [3]=global relabels run as one launch (level loop
  * inside), [4]=sites visited by the list sweeps inside those launches (a multiple of 16), [5]=sites visited by the list sweeps
- * launched one by one (the labelling roofline charges a list sweep by its list, not by the graph), [6..7] reserved (0) */
+ * launched one by one (the labelling roofline charges a list sweep by its list, not by the graph), [6]=BFS levels and [7]=list
+ * sweeps that ran inside those persistent launches (dependent steps that were not launches) */
 int pgx_expansion_schedule(pgx_ctx *ctx, int64_t out[8]);
 
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by

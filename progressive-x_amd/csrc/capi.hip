@@ -110,6 +110,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_MF_TILE_BATCH")) ctx->mf_tile_batch = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_REGION")) ctx->mf_region = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_MEMO")) ctx->mf_memo = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_MF_DONE_VERIFY")) ctx->mf_done_verify = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_XCD")) ctx->mf_xcd = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_XCD_SEARCH")) ctx->mf_xcd_search = std::atoi(b) ? 1 : 0;
     if (const char* b = std::getenv("PGX_MF_XCD_MIN_DEPTH")) ctx->mf_xcd_min_depth = std::atoi(b);
@@ -751,7 +752,7 @@ int pgx_set_unary_q(pgx_ctx* ctx, const int64_t* Dq, int64_t n, int L)
             if (v > mx) mx = v;
         }
     ctx->dq_max = mx;
-    ctx->unary_ident.clear();   // an injected table has no identity: no first-cycle memo
+    ctx->unary_ident.clear();   // an injected table has no identity: no first-cycle memo, no identical-call shortcut
     PGX_TRY(ensure(ctx, ctx->dq, tmp.size() * sizeof(int64_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->dq.p, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -770,6 +771,7 @@ int pgx_set_labels(pgx_ctx* ctx, const int32_t* labels, int64_t n)
     ctx->labels_max = hi;
     ctx->labels_all_zero = hi == 0 ? 1 : 0;
     ctx->last_done.valid = 0;   // (the labels are the caller's now)
+    ctx->labels_version += 1;
     PGX_TRY(ensure(ctx, ctx->labels, (size_t)n * sizeof(int32_t)));
     PGX_HIP(ctx, hipMemcpyAsync(ctx->labels.p, labels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -856,6 +858,14 @@ int pgx_graph_fetch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult)
     return graph_fetch_launch(ctx, off, idx, mult);
 }
 
+int pgx_graph_size(pgx_ctx* ctx, int64_t* n, int64_t* arcs)
+{
+    if (!ctx || !n || !arcs) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_size: NULL argument");
+    *n = ctx->gn > 0 ? ctx->gn : 0;
+    *arcs = ctx->gn > 0 ? ctx->gE : 0;
+    return PGX_OK;
+}
+
 static int flow_params(pgx_ctx* ctx, double lambda, double label_cost, int64_t* lambda_q, int64_t* h_q)
 {
     if (!(lambda >= 0.0) || !(label_cost >= 0.0))
@@ -891,6 +901,7 @@ int pgx_expand_alpha(pgx_ctx* ctx, double lambda, double label_cost, int alpha, 
     for (int k = 0; k < 8; ++k) ctx->stats[k] = 0;
     ctx->labels_all_zero = 0;
     ctx->last_done.valid = 0;
+    ctx->labels_version += 1;
     PGX_TRY(expand_alpha_launch(ctx, lq, hq, alpha, &ch));
     if (changed) *changed = ch;
     return PGX_OK;
@@ -898,6 +909,8 @@ int pgx_expand_alpha(pgx_ctx* ctx, double lambda, double label_cost, int alpha, 
 
 // GCO-v3 "standard cycles" loop [U-5] as PEARL drives it (PEARL.h:550-551): cycle over the labels in index order until
 // a whole cycle leaves the energy unchanged, at most max_cycles cycles.
+static thread_local bool done_verify_running = false;   // (PGX_MF_DONE_VERIFY: the nested call must run the real cycle)
+
 int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles, int64_t* energy_q, double* energy,
                   int* cycles)
 {
@@ -910,16 +923,30 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
     pgx_ctx::ExpansionDone& last = ctx->last_done;
     const bool ident_known = ctx->L > 0 && (int)ctx->unary_ident.size() == ctx->L && ctx->labels_n == ctx->dq_n;
     if (ctx->mf_memo && last.valid && ident_known && max_cycles >= 1 && last.lq == lq && last.hq == hq && last.n == ctx->dq_n &&
-        (lq <= 0 || last.graph_version == ctx->graph_version) && last.ident == ctx->unary_ident) {
+        (lq <= 0 || last.graph_version == ctx->graph_version) && last.ident == ctx->unary_ident &&
+        last.labels_version == ctx->labels_version && !done_verify_running) {
         if (ctx->labels_max >= ctx->L) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: label %d out of range (the unary table has %d labels)", ctx->labels_max, ctx->L);
         ctx->memo_hits += ctx->L;
         ctx->stats[7] += ctx->L;   // "moves skipped because the labelling had not changed since that label's last move, which relabelled nothing"
+        if (ctx->mf_done_verify) {   // debug mode: run the cycle the shortcut stands for and insist on what it promises
+            int64_t eq2 = 0;
+            int cyc2 = 0;
+            const int64_t want_e = last.energy_q;
+            done_verify_running = true;
+            const int rc = pgx_expansion(ctx, lambda, label_cost, max_cycles, &eq2, nullptr, &cyc2);
+            done_verify_running = false;
+            if (rc != PGX_OK) return rc;
+            if (eq2 != want_e || cyc2 != 1 || ctx->stats[4] != 0)
+                return fail(ctx, PGX_ERR_INVALID, "pgx_expansion (PGX_MF_DONE_VERIFY): the identical-call shortcut would have answered energy %lld, 1 cycle, 0 changes; "
+                                                  "the real cycle gave energy %lld, %d cycle(s), %lld change(s)", (long long)want_e, (long long)eq2, cyc2, (long long)ctx->stats[4]);
+        }
         if (energy_q) *energy_q = last.energy_q;
         if (energy) *energy = (double)last.energy_q / 4294967296.0;
         if (cycles) *cycles = 1;
         return PGX_OK;
     }
     last.valid = 0;
+    ctx->labels_version += 1;   // (the moves below write the labels)
     int64_t new_e = 0;
     PGX_TRY(energy_launch(ctx, lq, hq, &new_e));
     int64_t old_e = new_e + 1;
@@ -1062,6 +1089,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
         last.valid = 1;
         last.ident = ctx->unary_ident;
         last.lq = lq; last.hq = hq; last.n = ctx->dq_n; last.graph_version = ctx->graph_version; last.energy_q = new_e;
+        last.labels_version = ctx->labels_version;
     }
     if (energy_q) *energy_q = new_e;
     if (energy) *energy = (double)new_e / 4294967296.0;

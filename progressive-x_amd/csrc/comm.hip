@@ -309,13 +309,19 @@ int pgx_score_allgather_end(pgx_ctx* ctx, int slot, int exponent, int64_t* count
 // guard, filters switched off) must not skip the collective - the other ranks would wait in it for ever.  Every rank
 // always enters the all-reduce: the block carries one extra word, 0 from a rank that exported its accumulators and 1 (behind an
 // all-zero block) from a rank that could not; a non-zero sum raises PGX_ERR_INVALID on EVERY rank after the reduction.
-static int export_or_poison(pgx_ctx* ctx, unsigned long long* blk, size_t W, hipStream_t stream, int* local_fail)
+// local_rc: what went wrong HERE when the export itself failed (a launch error inside score_acc_export): the rank still enters the
+// collective behind a zero block + the poison word and returns that error afterwards (any early return before the
+// all-reduce leaves the other ranks waiting in it).  What cannot be routed this way is a rank that cannot size or hold the block at
+// all - nothing launched (no Mpad to agree on), the block's allocation failing, a slot misused: caller errors, documented in pgx.h.
+static int export_or_poison(pgx_ctx* ctx, unsigned long long* blk, size_t W, hipStream_t stream, int* local_fail, int* local_rc)
 {
     *local_fail = 0;
+    *local_rc = PGX_OK;
     if (ctx->last_acc != nullptr && ctx->last_score_path == 2 && ctx->last_acc_M == ctx->M && ctx->last_acc_Mpad == ctx->Mpad) {
-        PGX_TRY(score_acc_export(ctx, blk, stream));
-        PGX_HIP(ctx, hipMemsetAsync(blk + W, 0, 64, stream));
-        return PGX_OK;
+        int rc = score_acc_export(ctx, blk, stream);
+        if (rc == PGX_OK && hipMemsetAsync(blk + W, 0, 64, stream) != hipSuccess) rc = fail(ctx, PGX_ERR_HIP, "score exchange: clearing the poison word failed");
+        if (rc == PGX_OK) return PGX_OK;
+        *local_rc = rc;
     }
     *local_fail = 1;
     PGX_HIP(ctx, hipMemsetAsync(blk, 0, (W + 8) * 8, stream));
@@ -339,12 +345,13 @@ int pgx_score_allreduce(pgx_ctx* ctx)
     const size_t W = (size_t)3 * (size_t)ctx->Mpad;
     PGX_TRY(ensure(ctx, ctx->g_counts, (W + 8) * 8));
     unsigned long long* blk = (unsigned long long*)ctx->g_counts.p;
-    int local_fail = 0;
-    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail));
+    int local_fail = 0, local_rc = PGX_OK;
+    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail, &local_rc));
     PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W + 8, ncclUint64, ncclSum, ctx->comm->comm, ctx->stream));
     unsigned long long bad = 0;
     PGX_HIP(ctx, hipMemcpyAsync(&bad, blk + W, 8, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (local_rc != PGX_OK) return local_rc;     // (this rank's own failure, reported after the collective every rank was waiting in)
     if (bad) return poisoned(ctx, "pgx_score_allreduce", bad, local_fail);
     PGX_TRY(score_acc_import(ctx, blk, ctx->M, ctx->Mpad, ctx->last_qscale, ctx->counts.as<long long>(), ctx->values.as<double>(),
                              ctx->shared.as<double>(), ctx->stream));
@@ -364,8 +371,8 @@ int pgx_score_allreduce_begin(pgx_ctx* ctx, int slot)
     PGX_TRY(slot_prepare(ctx, "pgx_score_allreduce_begin", slot, need + 64, need + 64, &ep));
     ExchangeSlot& e = *ep;
     unsigned long long* blk = (unsigned long long*)e.stage.p;
-    int local_fail = 0;
-    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail));     // never skips the collective (see above)
+    int local_fail = 0, local_rc = PGX_OK;
+    PGX_TRY(export_or_poison(ctx, blk, W, ctx->stream, &local_fail, &local_rc));     // never skips the collective (see above)
     PGX_HIP(ctx, hipEventRecord(e.scored, ctx->stream));
     PGX_HIP(ctx, hipStreamWaitEvent(cs->xstream, e.scored, 0));
     PGX_NCCL(ctx, g_rccl.AllReduce(blk, blk, W + 8, ncclUint64, ncclSum, cs->comm, cs->xstream));
@@ -376,7 +383,7 @@ int pgx_score_allreduce_begin(pgx_ctx* ctx, int slot)
     PGX_HIP(ctx, hipMemcpyAsync((char*)e.host + need, blk + W, 8, hipMemcpyDeviceToHost, cs->xstream));
     PGX_HIP(ctx, hipEventRecord(e.done, cs->xstream));
     e.M = ctx->M; e.Mpad = ctx->Mpad; e.has_compound = ctx->score_has_compound; e.busy = 1; e.reduced = 1; e.local_fail = local_fail;
-    return PGX_OK;
+    return local_rc;     // (a failed export is reported here, AFTER the collective was entered; _end then reports the poisoned table on every rank)
 }
 
 int pgx_score_allreduce_end(pgx_ctx* ctx, int slot, int exponent, int64_t* counts, double* values, double* shared, double* scores)

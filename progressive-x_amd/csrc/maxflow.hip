@@ -34,7 +34,7 @@ struct MaxflowState {
     int64_t mark_n = 0;
     DevBuf xcd;              // XcdCtl of the persistent one-XCD rounds (maxflow_xcd.hip.h)
     int* h_xcd = nullptr;    // pinned host copy of its result words
-    int64_t xcd_launches = 0, xcd_rounds = 0, xcd_done = 0, xcd_swept16 = 0, xcd_searches = 0;
+    int64_t xcd_launches = 0, xcd_rounds = 0, xcd_done = 0, xcd_swept16 = 0, xcd_searches = 0, xcd_levels = 0, xcd_sweeps = 0;
     int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
 };
 
@@ -976,6 +976,8 @@ struct HipBackend {
         st->xcd_rounds += out[0];
         st->xcd_done += out[3] == 1 ? 1 : 0;
         st->xcd_swept16 += out[6];
+        st->xcd_levels += out[1];
+        st->xcd_sweeps += out[2];
         return out[4] > 0;
     }
     // one global relabel with the level loop inside the launch; fills the flags the driver reads after a search
@@ -997,6 +999,7 @@ struct HipBackend {
         *levels = st->h_xcd[1];
         if (ctx->tile_debug) xcd_prof(c, "search");
         st->xcd_searches += 1;
+        st->xcd_levels += *levels;
         return true;
     }
     void keep_source_reachable_only(const MfView& v)
@@ -1045,6 +1048,8 @@ int maxflow_schedule_stats(pgx_ctx* ctx, int64_t out[8])
         PGX_HIP(ctx, hipMemcpy(&sw, (const long long*)st->bar.p + 6, sizeof(sw), hipMemcpyDeviceToHost));
         out[5] = sw;
     }
+    out[6] = st->xcd_levels;
+    out[7] = st->xcd_sweeps;
     return PGX_OK;
 }
 

@@ -122,7 +122,11 @@ struct pgx_ctx {
         int valid = 0;
         std::vector<std::string> ident;
         int64_t lq = 0, hq = 0, n = 0, graph_version = -1, energy_q = 0;
+        int64_t labels_version = -1;   // pgx_ctx::labels_version when the fixed point was recorded (the unary table's identity is `ident`)
     } last_done;
+    int64_t labels_version = 0;           // bumped by EVERY writer of `labels` (pgx_set_labels, every expansion move, the greedy labelling): the
+                                          // identical-call shortcut compares it instead of trusting each writer to clear last_done
+    int mf_done_verify = 0;               // PGX_MF_DONE_VERIFY=1: on a shortcut hit run the real verifying cycle and check 0 changes + equal energy
     std::vector<std::string> unary_ident; // per label: what its unary column was computed from (pgx_pearl_unary); empty = unknown (injected table)
     int64_t points_version = 0;           // bumped by pgx_set_points
     int labels_all_zero = 0;              // the resident labelling is the all-zero one pgx_set_labels uploaded (no move has run since)

@@ -836,6 +836,7 @@ int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* op
     ctx->labels_max = L - 1;
     ctx->labels_all_zero = 0;   // (the labelling is no longer the uploaded all-zero one: no first-cycle memo for the next pgx_expansion)
     ctx->last_done.valid = 0;
+    ctx->labels_version += 1;
     const int blocks = (int)((n + kPwBlock - 1) / kPwBlock);
     const long long* dq = ctx->dq.as<long long>();
     int* labels = ctx->labels.as<int>();

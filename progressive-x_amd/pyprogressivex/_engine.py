@@ -19,12 +19,27 @@ from . import _proposal
 
 
 # Decision events of the two loops below, handed to the optional `trace=` hook (diagnostics; the reference's analogue is its
-# do_logging narration).  An object with .proposal(model_or_None, inliers, iterations), .refit(inlier_number, fits) and
-# .event(code, a, b, c, x, y) receives every input the loops take from the proposal engine / the refit solver and every
-# decision they make; tests/ compares the stream with an independent replay of progressive_x.h / PEARL.h (oracle/progx_replay.c,
-# whose header documents the fields).
+# do_logging narration).  The hook is an object with ALL of
+#     .proposal(model_or_None, inliers_or_None, iterations)      what the outer loop took from the proposal engine
+#     .refit(inlier_number, fits, accepted)                      what PEARL took from the refit solver for one instance, and whether it kept it
+#     .event(code, a=0, b=0, c=0, x=0.0, y=0.0)                  a decision (codes below)
+# and optionally .begin(info) (the drop-in API describes the run: points, graph, settings).  It receives every input the loops take
+# from the proposal engine / the refit solver and every decision they make; tests/ compares the stream with an independent replay of
+# progressive_x.h / PEARL.h (oracle/progx_replay.c, whose header documents the fields).  check_trace_hook() refuses an object that
+# lacks one of the three required methods when the loops are built, not in the middle of a run.
 (EV_OUTER, EV_PROPOSAL_EMPTY, EV_PROPOSAL, EV_VALIDATION, EV_UNACCEPTED, EV_SINGLE_MODEL, EV_PEARL_ITER, EV_REFIT_SKIP, EV_REFIT,
  EV_REJECT, EV_PEARL_END, EV_LABELING, EV_COMPOUND, EV_UNSEEN, EV_BREAK) = range(1, 16)
+
+
+def check_trace_hook(trace):
+    """None, or an object with callable .proposal / .refit / .event (see above); .begin is optional."""
+    if trace is None:
+        return None
+    missing = [name for name in ("proposal", "refit", "event") if not callable(getattr(trace, name, None))]
+    if missing:
+        raise TypeError("trace hook lacks " + ", ".join("." + m for m in missing) +
+                        ": it needs .proposal(model, inliers, iterations), .refit(inlier_number, fits, accepted) and .event(code, a, b, c, x, y)")
+    return trace
 
 
 class MultiModelSettings:
@@ -110,7 +125,7 @@ class Pearl:
         self.point_weights = point_weights
         self.do_logging = do_logging
         self.labeling_l0 = labeling_l0   # U-8 switch, see labeling()
-        self.trace = trace
+        self.trace = check_trace_hook(trace)
         if pearl_abs not in ("double", "int"):
             raise ValueError("pearl_abs should be 'double' or 'int'")
         self.pearl_abs = pearl_abs       # U-16 switch, see run()
@@ -265,7 +280,7 @@ class ProgressiveX:
     def __init__(self, ctx, estimator, pts, graph, sampler, settings, scoring_exponent=2, do_logging=False,
                  exchange=None, graph_resident=False, trace=None):
         self.ctx, self.est, self.pts, self.graph = ctx, estimator, pts, graph
-        self.trace = trace
+        self.trace = check_trace_hook(trace)
         self.graph_resident = graph_resident   # built by ctx.graph_build: already on the device
         self.sampler, self.settings = sampler, settings
         self.scoring_exponent = int(scoring_exponent)   # setExponent(const int) truncates (scoring_function...h:39)

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch", "pgx_score_debug_geometry",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
-    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_graph_size",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
@@ -424,16 +424,22 @@ class Context:
         self._ck(self._lib.pgx_graph_build(self._h, _ptr(pts, C.c_double), C.c_int64(pts.shape[0]), C.c_int(pts.shape[1]),
                                            C.c_int(int(kind)), C.c_double(float(radius)), C.c_int(int(k)), C.byref(arcs)),
                  "pgx_graph_build")
-        self._built_graph = (int(pts.shape[0]), int(arcs.value))
         if not fetch:
             return arcs.value
         return self.graph_fetch()
 
+    def graph_size(self):
+        """(sites, directed arcs) of the graph resident now (pgx_graph_size); (0, 0) when none."""
+        n, arcs = C.c_int64(), C.c_int64()
+        self._ck(self._lib.pgx_graph_size(self._h, C.byref(n), C.byref(arcs)), "pgx_graph_size")
+        return int(n.value), int(arcs.value)
+
     def graph_fetch(self):
-        """CSR (off, idx, mult) of the graph pgx_graph_build left resident (pgx_graph_fetch)."""
-        if getattr(self, "_built_graph", None) is None:
-            raise PgxError("graph_fetch: no graph was built on this context")
-        n, arcs = self._built_graph
+        """CSR (off, idx, mult) of the resident graph (pgx_graph_fetch).  The buffers are sized by what is resident NOW - asked of
+        the library, not remembered from the last graph_build: set_graph / set_points may have replaced the graph since."""
+        n, arcs = self.graph_size()
+        if n <= 0:
+            raise PgxError("graph_fetch: no graph is resident on this context")
         off = np.empty(n + 1, dtype=np.int32)
         idx = np.empty(max(arcs, 1), dtype=np.int32)
         mult = np.empty(max(arcs, 1), dtype=np.int32)
@@ -623,7 +629,7 @@ class Context:
         st = np.zeros(8, dtype=np.int64)
         self._ck(self._lib.pgx_expansion_schedule(self._h, _ptr(st, C.c_int64)), "pgx_expansion_schedule")
         return dict(xcd_round_launches=int(st[0]), xcd_rounds=int(st[1]), xcd_launches_finished=int(st[2]), xcd_searches=int(st[3]),
-                    xcd_list_sites=int(st[4]), list_sites=int(st[5]))
+                    xcd_list_sites=int(st[4]), list_sites=int(st[5]), xcd_levels=int(st[6]), xcd_sweeps=int(st[7]))
 
     def bucket(self, L, want_order=True):
         counts = np.zeros(L, dtype=np.int64)

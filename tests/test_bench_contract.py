@@ -107,10 +107,23 @@ def test_round5_fields_labelling_baseline_roofline_and_api_legs():
         r = rl[key]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
         leg = d["legs"]["labelling_" + key]
-        alg = (leg["sites"] * 12 + leg["arcs"] * 12) * leg["sweeps"] + leg["sites"] * 4 * leg["bfs_levels"]
-        assert r["algorithmic_bytes"] == alg
+        survey = (leg["sites"] * 12 + leg["arcs"] * 12) * leg["sweeps"] + leg["sites"] * 4 * leg["bfs_levels"]
+        steps = leg["sweeps"] + leg["bfs_levels"] + leg["global_relabels"]
+        if "algorithmic_bytes_survey_formula" in r:      # round 6: a list sweep is charged by the sites it visited
+            assert r["algorithmic_bytes_survey_formula"] == survey
+            alg = int((leg["sites"] * 12 + leg["arcs"] * 12) * r["all_site_sweeps"] + r["list_sites_visited"] * (12.0 + 12.0 * leg["arcs"] / leg["sites"])
+                      + leg["sites"] * 4 * leg["bfs_levels"])
+            assert r["all_site_sweeps"] == leg["sweeps"] - leg["list_sweeps"] and r["list_sweeps"] == leg["list_sweeps"]
+            assert r["algorithmic_bytes"] == alg <= survey
+            assert r["dependent_steps"] == steps and 0 <= r["steps_inside_persistent_launches"] <= steps
+            assert r["launches_per_expansion"] <= steps
+            if r["list_sweeps"] > 0:
+                assert 0 < r["list_sites_visited"] < r["list_sweeps"] * leg["sites"]
+        else:
+            alg = survey
+            assert r["algorithmic_bytes"] == alg
+            assert r["launches_per_expansion"] == steps
         assert abs(r["achieved"] - alg / (leg["expansion_ms"] * 1e-3) / 1e9) <= 1e-9 * max(r["achieved"], 1.0)
-        assert r["launches_per_expansion"] == leg["sweeps"] + leg["bfs_levels"] + leg["global_relabels"]
     api = d["legs"]["api"]
     for key in ("c1_findLines", "c2_findHomographies", "c3_findTwoViewMotions", "c5_findVanishingPoints", "c4_find6DPoses",
                 "c4_find6DPoses_16_objects"):

@@ -1973,3 +1973,74 @@ def test_global_n_of_a_sharded_job_does_not_outlive_its_point_set(gpu_ctx):
     gpu_ctx.score_launch(T2, has_compound=False)
     again = gpu_ctx.score_accumulators()
     assert np.array_equal(again["counts"], clean["counts"]) and np.array_equal(again["values_q"], clean["values_q"])
+
+
+@pytest.mark.gpu
+def test_identical_call_shortcut_under_its_verifying_mode_and_across_every_label_writer(monkeypatch):
+    """ADVICE r5: the shortcut's precondition is one counter, pgx_ctx::labels_version, bumped by every writer of the labels
+    (pgx_set_labels, pgx_expand_alpha, the greedy labelling, pgx_expansion's own moves) and compared on a hit.  PGX_MF_DONE_VERIFY=1
+    runs the real verifying cycle behind every hit and fails the call unless it relabels nothing at the same energy: with it on, a
+    PEARL-like sequence must behave exactly as with it off, and a hit must never follow any of the writers."""
+    import pgx_oracle as O
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=1500, n_objects=3, n_outliers=2500, seed=11)
+    pts, f = datasets.normalize_pnp(x1, x2, K)
+    n = pts.shape[0]
+    lam, h, thr = 0.1, 6.0, 4.0 / f
+    raw = np.column_stack([x1, x2])
+
+    def sequence(verify):
+        monkeypatch.setenv("PGX_MF_DONE_VERIFY", "1" if verify else "0")
+        monkeypatch.setenv("PGX_MF_MEMO", "1")
+        ctx = _lib.Context(0)
+        out = []
+        try:
+            ctx.set_points(_lib.PNP, pts)
+            ctx.graph_build(raw, _lib.GRAPH_KNN_IN_BALL, radius=20.0, k=5, fetch=False)
+
+            def again():
+                ctx.pearl_unary(poses[:3], thr, lam)
+                h0 = ctx.expansion_paths()["memo"]
+                r = ctx.expansion(lam, h)
+                out.append(r + (ctx.get_labels(), ctx.expansion_paths()["memo"] - h0))
+            ctx.pearl_unary(poses[:3], thr, lam)
+            ctx.set_labels(np.zeros(n, np.int32))
+            out.append(ctx.expansion(lam, h) + (ctx.get_labels(), 0))
+            again()                                        # 1: a hit
+            ctx.expand_alpha(lam, h, 1)                    # a single move (changes nothing at the fixed point, but it is a writer)
+            again()                                        # 2: must run
+            again()                                        # 3: a hit again
+            ctx.set_labels(out[-1][3])                     # the caller's labels, same content
+            again()                                        # 4: must run
+            ctx.greedy_labeling(h)                         # another writer
+            ctx.pearl_unary(poses[:3], thr, lam)
+            ctx.set_labels(out[1][3])
+            again()                                        # 5: must run
+        finally:
+            ctx.close()
+        return out
+    plain, checked = sequence(False), sequence(True)
+    for k, (a, b) in enumerate(zip(plain, checked)):
+        assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[3], b[3]), k
+    assert [r[4] > 0 for r in plain] == [False, True, False, True, False, False]      # hits exactly where nothing wrote the labels
+    graph = O.graph_build(raw, 0, radius=20.0, k=5)
+    Dq = O.unary_q(O.PNP, pts, poses[:3], thr, lam)
+    ref_labels, ref_e, _ = O.expansion(Dq, graph, O.quantize_lambda(lam), O.quantize(h), np.zeros(n, np.int32))
+    assert np.array_equal(plain[1][3], ref_labels) and plain[1][0] == ref_e
+
+
+@pytest.mark.gpu
+def test_graph_fetch_sizes_follow_the_resident_graph(gpu_ctx, oracle):
+    """graph_fetch sized its buffers from the last graph_build; a larger graph set since (pgx_set_graph) overran them.
+    The sizes now come from pgx_graph_size at the time of the fetch."""
+    rng = np.random.default_rng(5)
+    small = rng.random((300, 2)) * 100
+    built = gpu_ctx.graph_build(small, _lib.GRAPH_KNN, k=3)
+    assert gpu_ctx.graph_size() == (300, len(built[1]))
+    big = oracle.graph_build(rng.random((5000, 2)) * 100, 2, k=8)
+    gpu_ctx.set_graph(*big)
+    assert gpu_ctx.graph_size() == (5000, len(big[1]))
+    for a, b in zip(gpu_ctx.graph_fetch(), big):
+        assert np.array_equal(a, b)
+    again = gpu_ctx.graph_build(small, _lib.GRAPH_KNN, k=3)
+    for a, b in zip(again, built):
+        assert np.array_equal(a, b)

@@ -123,3 +123,23 @@ def test_replay_soak_slice_cpu(cpu_api):
     with NO tie tolerance (both sides sum sequentially)"""
     import soak_replay
     assert soak_replay.soak(7, 25, verbose=False, tie=0.0) == 0
+
+
+def test_trace_hook_contract_is_checked_when_the_loops_are_built():
+    """ADVICE r5: the hook's documented interface is .proposal / .refit(inlier_number, fits, accepted) / .event (+ optional .begin);
+    an object that lacks one of them is refused up front instead of raising in the middle of PEARL"""
+    from pyprogressivex import _engine
+
+    class Half:
+        def event(self, *a, **k):
+            pass
+
+        def proposal(self, *a):
+            pass
+    with pytest.raises(TypeError, match=r"\.refit"):
+        _engine.check_trace_hook(Half())
+    assert _engine.check_trace_hook(None) is None
+    rec = R.TraceRecorder()
+    assert _engine.check_trace_hook(rec) is rec
+    rec.refit(7, [np.zeros(3)], True)          # the three-argument form the loops call
+    assert rec.refits[0][0] == 7 and rec.refits[0][2] is True
