@@ -299,7 +299,7 @@ template <> struct Filter32<kHomography> {
 // radii (rA, rB, rC), rM = radius of the midpoints, hmin = the shortest half length,
 //   |N^_i| >= |N^(centre)| - (|v0| rA + |v1| rB + |v2| rC),   D_i <= D(centre) + |v2| rM,
 // and no member is an inlier when hmin (|N^c| - R_N) > T'' (Dc + R_D), under the trust test at Dc - R_D with the group's
-// largest P.  Groups are built from the Morton order of (mx, my, orientation) - setpoints.hip.
+// largest P.  Groups are 64 consecutive segments of the Hough order of their lines (theta, rho, length) - setpoints.hip sp_vp_rows_kernel.
 template <> struct Filter32<kVanishingPoint> {
     static constexpr bool enabled = true;
     static constexpr int kRowVals = 7, kGroupVals = 12;
@@ -344,10 +344,16 @@ template <> struct Filter32<kVanishingPoint> {
         const float ly = __builtin_fmaf(-g[3], v[2], v[0]);
         const float D2 = __builtin_fmaf(lx, lx, ly * ly);
         const float RD = fabsf(v[2]) * g[8] * 1.001f;
-        const float tt = __builtin_fmaf(ln.e2, g[11], __builtin_fmaf(ln.e1, g[10], ln.e0)) + RD;  // trust at Dc - R_D
+        const float tt0 = __builtin_fmaf(ln.e2, g[11], __builtin_fmaf(ln.e1, g[10], ln.e0));
+        const float tt = tt0 + RD;  // trust at Dc - R_D
         const float L = fabsf(N) - RN * 1.001f - 1.9073486328125e-6f /* 32 u */ * S;
         const float G = L * g[9] * ln.invT - RD;
-        return (D2 >= tt * tt * 1.001f) && (G > 0.0f) && (G * G > D2 * 1.004f);
+        // Trust: every member's D must stay above t(Pmax).  Two lower bounds on D_i: Dc - R_D (midpoints within rM of the centre), and
+        // the member's own |N^_i| >= L - the distance of the vanishing point from the segment's LINE never exceeds its distance from the
+        // midpoint ON that line (D_i = |v2| |m_i - vp| >= |v2| dist(vp, line_i) = |N^_i|).  The second one is what lets groups of
+        // collinear segments spread over the whole image (Hough order, setpoints.hip) be culled: their rM is hundreds of pixels.
+        const bool trust = (D2 >= tt * tt * 1.001f) || (L >= tt0 * 1.01f);
+        return trust && (G > 0.0f) && (G * G > D2 * 1.004f);
     }
 };
 

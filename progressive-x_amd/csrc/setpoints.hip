@@ -326,10 +326,17 @@ __device__ __forceinline__ VpFeat vp_features(const double* __restrict__ r)
     return f;
 }
 
-// f32 row (a, b, c, mx, my, P, P^2, 0) and the sort key: Morton code of (mx, my, orientation), 10 bits each
-__global__ __launch_bounds__(kSpBlock) void sp_vp_rows_kernel(const double* __restrict__ pts, int64_t n, double x0, double xinv, double y0,
-                                                              double yinv, float* __restrict__ p32, unsigned* __restrict__ keys,
-                                                              unsigned* __restrict__ vals)
+// f32 row (a, b, c, mx, my, P, P^2, 0) and the sort key.
+// Order (round 6): the group bound works on the LINE of a segment - N^ = v . (a, b, c) / h is the distance of the vanishing point from
+// the line through the segment, in Hough terms the point (theta, rho) against the sinusoid of the vanishing point - so groups must be
+// compact in (theta, rho), not in (midpoint, orientation): segments of one line anywhere in the image share a row, segments that
+// merely lie close to each other do not.  Key = bit-interleaved (theta, rho') with 10 bits each, rho' = the signed distance of the
+// line from the CENTRE of the bounding box (all 10 bits in use wherever the origin is), and 3 bits of log2(half length) under the
+// top three rounds (the bound scales with the shortest member, hmin).  The bound is valid for any grouping (its radii are those of
+// the actual members), so the order changes work only: 37 % -> 19 % surviving (hypothesis, group) pairs on the C5 set against a
+// floor of 14 % that hold an inlier (scripts/analysis_vp_order.py); rounds 2-5 sorted by Morton(mx, my, orientation).
+__global__ __launch_bounds__(kSpBlock) void sp_vp_rows_kernel(const double* __restrict__ pts, int64_t n, double cx, double cy, double rh,
+                                                              float* __restrict__ p32, unsigned* __restrict__ keys, unsigned* __restrict__ vals)
 {
     const int64_t i = (int64_t)blockIdx.x * kSpBlock + threadIdx.x;
     if (i >= n) return;
@@ -341,12 +348,19 @@ __global__ __launch_bounds__(kSpBlock) void sp_vp_rows_kernel(const double* __re
     q[7] = 0.0f;
     // orientation of the canonical direction (b, -a) = (dx, dy) / 2 with dx >= 0: angle in (-pi/2, pi/2]
     const double th = atan2(-f.a, f.b);
-    const double t[3] = {(f.mx - x0) * xinv, (f.my - y0) * yinv, (th + 1.5707963267948966) * (1024.0 / 3.141592653589793)};
-    unsigned key = 0;
+    const double rho = (f.a * cx + f.b * cy + f.c) / f.h;           // NaN for a zero-length segment: quantised to 0 below
+    const double t[3] = {(th + 1.5707963267948966) * (1024.0 / 3.141592653589793), rh > 0.0 ? (rho + rh) * (512.0 / rh) : 0.0,
+                         rh > 0.0 ? (log2(f.h / rh) + 10.0) * 0.8 : 0.0};
+    unsigned v[3];
     for (int k = 0; k < 3; ++k) {
-        unsigned v = t[k] > 0.0 ? (unsigned)t[k] : 0u;
-        if (v > 1023u) v = 1023u;
-        for (int b = 0; b < 10; ++b) key |= ((v >> b) & 1u) << (b * 3 + 2 - k);
+        const unsigned lim = k == 2 ? 7u : 1023u;
+        v[k] = t[k] > 0.0 ? (t[k] < (double)lim ? (unsigned)t[k] : lim) : 0u;      // (NaN compares false: 0)
+    }
+    unsigned key = 0;
+    for (int level = 0; level < 10; ++level) {     // most significant bits first
+        key = (key << 1) | ((v[0] >> (9 - level)) & 1u);
+        key = (key << 1) | ((v[1] >> (9 - level)) & 1u);
+        if (level < 3) key = (key << 1) | ((v[2] >> (2 - level)) & 1u);
     }
     keys[i] = key;
     vals[i] = (unsigned)i;
@@ -582,7 +596,7 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
     ctx->point_sort = 0;
     ctx->comp_dirty = 1;
     if (model_type == kVanishingPoint && ctx->group_filter && ctx->filter_enabled == 1 && !(flags & 1u) && n >= 1) {
-        // ---- segments: f32 feature rows, Morton order of (midpoint, orientation), group rows of the normalised features
+        // ---- segments: f32 feature rows, Hough order of the segments' lines (sp_vp_rows_kernel), group rows of the normalised features
         const double xa = std::fmin(key_f64(st[0]), key_f64(st[2])), xb = std::fmax(key_f64(st[5]), key_f64(st[7]));
         const double ya = std::fmin(key_f64(st[1]), key_f64(st[3])), yb = std::fmax(key_f64(st[6]), key_f64(st[8]));
         const int64_t groups = (n + 63) / 64, supers = (groups + kSuper - 1) / kSuper, padded = groups * 64;
@@ -596,8 +610,9 @@ int set_points_device(pgx_ctx* ctx, int model_type, const double* points, int64_
         unsigned* v_in = (unsigned*)((char*)ctx->fit_scratch.p + 2 * arr);
         unsigned* v_out = (unsigned*)((char*)ctx->fit_scratch.p + 3 * arr);
         void* tmp = (char*)ctx->fit_scratch.p + 4 * arr;
-        hipLaunchKernelGGL(sp_vp_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, xa,
-                           xb > xa ? 1024.0 / (xb - xa) : 0.0, ya, yb > ya ? 1024.0 / (yb - ya) : 0.0, ctx->pts32.as<float>(), k_in, v_in);
+        const double rh = 0.5 * std::hypot(xb - xa, yb - ya);    // every line through the box passes within rh of its centre
+        hipLaunchKernelGGL(sp_vp_rows_kernel, dim3(blocks), dim3(kSpBlock), 0, ctx->stream, ctx->pts.as<double>(), n, 0.5 * (xa + xb), 0.5 * (ya + yb),
+                           std::isfinite(rh) ? rh : 0.0, ctx->pts32.as<float>(), k_in, v_in);
         PGX_HIP(ctx, hipGetLastError());
         PGX_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, 30u, ctx->stream));
         PGX_TRY(ensure(ctx, ctx->pts_s, (size_t)n * d * sizeof(double)));

@@ -35,10 +35,10 @@ for cfg in ("C3", "C5", "C4"):
         tot = 0.0
         for name, calls, total, avg in stats.execute("select name,total_calls,total_duration,average from top_kernels"):
             if any(m in name for m in MINCUT):
-                print(f"{short(name)[:48]:48s} {calls:7d} {total / 1e3:12.1f} {avg / 1e3:9.2f}")
+                print(f"{short(name)[:48]:48s} {calls:7d} {total:12.1f} {avg:9.2f}")
                 tot += total
-        rec["kernel_us"] = tot / 1e3
-        print(f"{'all min-cut kernels':48s} {'':7s} {tot / 1e3:12.1f}")
+        rec["kernel_us"] = tot
+        print(f"{'all min-cut kernels':48s} {'':7s} {tot:12.1f}")
     for counter, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
         db = db_of(f"{prefix}{cfg}_{'fetch' if key == 'fetch_kib' else 'write'}")
         if db is None:
