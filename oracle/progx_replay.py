@@ -54,6 +54,7 @@ class TraceRecorder:
         self.proposals = []     # (descriptor or None, inliers, iterations)
         self.refits = []        # (inlier_number, [models], accepted or None)
         self.events = []        # (code, a, b, c, x, y)
+        self.walks = []         # one record per proposal from the proposal engine (oracle/progx_proposal.py replays them)
 
     def begin(self, info):
         self.info = info
@@ -65,6 +66,9 @@ class TraceRecorder:
     def refit(self, inlier_number, fits, accepted=None):
         self.refits.append((int(inlier_number), [np.array(f, dtype=np.float64).reshape(-1) for f in fits],
                             None if accepted is None else bool(accepted)))
+
+    def walk(self, rec):
+        self.walks.append(rec)
 
     def event(self, code, a=0, b=0, c=0, x=0.0, y=0.0):
         self.events.append((int(code), int(a), int(b), int(c), float(x), float(y)))

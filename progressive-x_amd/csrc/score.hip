@@ -744,7 +744,10 @@ static int score_dispatch(pgx_ctx* ctx, double T2, int has_compound, int want_ma
             // 146 (6), 140 (2) against 135-140 us (1, 3, 5, 7) on the metric batch.
             // (pose problems take 5 with the spread mapping as well: RANSAC-like batch 0.371 -> 0.353 ms; Sampson and vanishing-point
             // batches lose 15-20 % there and keep 8)
-            const int split_cfg = ctx->score_split > 0 ? ctx->score_split : ((group_xcd || MT == kPnP) ? 5 : 8);
+            // Round 6 (scripts/sweep_vp_geometry.py, after the Hough ordering of the segments): vanishing-point and Sampson batches take 16 -
+            // group kernel 301 -> 280 us and 123 -> 114 us against 8 (12: 284 / 118, 24: 284 / 115, 32: 296 / 119).
+            const int split_cfg = ctx->score_split > 0 ? ctx->score_split
+                                  : ((group_xcd || MT == kPnP) ? 5 : ((MT == kVanishingPoint || MT == kFundamental) ? 16 : 8));
             const int split = split_cfg < W ? split_cfg : W;
             const unsigned gblocks = (xcd_local & 1) ? (unsigned)((int64_t)((groups + 7) / 8) * 8 * split) : (unsigned)((int64_t)groups * split);
             if (want_masks) {

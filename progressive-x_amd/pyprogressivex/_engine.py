@@ -23,7 +23,8 @@ from . import _proposal
 #     .proposal(model_or_None, inliers_or_None, iterations)      what the outer loop took from the proposal engine
 #     .refit(inlier_number, fits, accepted)                      what PEARL took from the refit solver for one instance, and whether it kept it
 #     .event(code, a=0, b=0, c=0, x=0.0, y=0.0)                  a decision (codes below)
-# and optionally .begin(info) (the drop-in API describes the run: points, graph, settings).  It receives every input the loops take
+# and optionally .begin(info) (the drop-in API describes the run: points, graph, settings) and .walk(record) (one record per proposal from
+# the proposal engine: _proposal.WK_* events + what its walk saw; replayed by oracle/progx_proposal.c).  It receives every input the loops take
 # from the proposal engine / the refit solver and every decision they make; tests/ compares the stream with an independent replay of
 # progressive_x.h / PEARL.h (oracle/progx_replay.c, whose header documents the fields).  check_trace_hook() refuses an object that
 # lacks one of the three required methods when the loops are built, not in the middle of a run.
@@ -306,7 +307,7 @@ class ProgressiveX:
                            s.minimum_number_of_inliers, s.point_weights, 100, self.do_logging,
                            labeling_l0=getattr(s, "labeling_l0", "greedy"), trace=self.trace,
                            pearl_abs=getattr(s, "pearl_abs", "double"))                          # :527-534
-        self.engine = _proposal.ProposalEngine(self.ctx, self.est, self.pts, self.sampler, s, self.exchange)
+        self.engine = _proposal.ProposalEngine(self.ctx, self.est, self.pts, self.sampler, s, self.exchange, trace=self.trace)
 
     # progressive_x.h:565-591
     def is_putative_model_valid(self, model, inlier_number):

@@ -426,6 +426,17 @@ U15 = {
 }
 
 
+# decision events of one proposal (ProposalEngine.run -> trace.walk): (code, a, b, c, x)
+#   WK_BEST (h, iteration, inlier count, score)            a hypothesis became the so-far-best
+#   WK_LO_ROUND (branch, candidates, updated, best score)  one round of the graph-cut local optimisation (branch 1: inner RANSAC of refits,
+#                                                          2: one refit of all cut inliers, 0: too few inliers)
+#   WK_LO_END (cuts so far, best count, LO runs, score)    a local optimisation returned
+#   WK_WALK_END (iterations, best h or -1, LO runs, score) the main loop ended; `iterations` is what ProgressiveX::run is told
+#   WK_LSQ (steps, 0, 0, score)                            the final iterated least squares
+#   WK_FINAL (0, 0, 0, score)                              the score of the model handed back
+WK_BEST, WK_LO_ROUND, WK_LO_END, WK_WALK_END, WK_LSQ, WK_FINAL = range(1, 7)
+
+
 class ProposalEngine:
     """gcransac::GCRANSAC::run, restated [UPSTREAM-MEMORY, U-9] around ONE scoring launch per proposal:
 
@@ -438,9 +449,14 @@ class ProposalEngine:
           max_graph_cut_number (10), as upstream's statistics.graph_cut_number does;
         after the walk: one local optimisation if none ran, then the final iterated least squares (<= 10 refits)."""
 
-    def __init__(self, ctx, estimator, pts, sampler, settings, exchange=None):
+    def __init__(self, ctx, estimator, pts, sampler, settings, exchange=None, trace=None):
         self.ctx, self.est, self.pts, self.sampler, self.s = ctx, estimator, pts, sampler, settings
         self.exchange = exchange     # parallel.RcclExchange for multi-GPU sharding, None = single GPU
+        # diagnostics: a trace hook (pyprogressivex._engine) that ALSO has .walk(record) receives, per proposal, the score table the walk
+        # saw, what every local-optimisation round / least-squares step got back from the cut and the refit solver, and the decisions
+        # taken (WK_* below); tests/ replays the record through an independent restatement of the loop (oracle/progx_proposal.c)
+        self.trace = trace if callable(getattr(trace, "walk", None)) else None
+        self._rec = None
         self.n = pts.shape[0]
         self.lo_runs = 0             # statistics of the last proposal
         self.graph_cuts = 0
@@ -520,6 +536,14 @@ class ProposalEngine:
         lo_after = int(getattr(s, "min_iteration_number_before_lo", 0))
         every_best = getattr(s, "lo_cadence", "every_best") == "every_best"
         self.lo_runs, self.graph_cuts = 0, 0
+        rec = None
+        if self.trace is not None and not check and self._use_graph_cut() and U15["rank"] == "value" and not U15["stop_at_first"]:
+            rec = dict(n=int(self.n), samples=int(len(samples)), sample_size=int(est.sample_size),
+                       nonminimal_sample_size=int(est.nonminimal_sample_size), confidence=float(s.confidence), max_iters=int(max_iters),
+                       min_iters=min_iters, lo_after=lo_after, every_best=bool(every_best), max_cuts=int(getattr(s, "max_graph_cut_number", 10)),
+                       lsq_budget=int(getattr(s, "max_least_squares_iterations", 10)), counts=counts.copy(), scores=scores.copy(),
+                       src=np.asarray(src, dtype=np.int64).copy(), events=[], rounds=[], lsq=[])
+        self._rec = rec
         model, best_score, best_count, it_best = None, -np.inf, 0, 0
         bound = max_iters
         h, H = 0, len(counts)
@@ -561,6 +585,8 @@ class ProposalEngine:
                     cand, cand_score, cand_count = upd, float(one["scores"][0]), int(one["counts"][0])
             model = cand
             best_score, best_count, it_best = cand_score, cand_count, it
+            if rec is not None:
+                rec["events"].append((WK_BEST, int(h), it, cand_count, cand_score))
             ahead = None                    # (also after the local optimisation below: it only raises best_score further)
             if every_best and it > lo_after and c > est.sample_size:
                 model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
@@ -570,15 +596,25 @@ class ProposalEngine:
             if U15["stop_at_first"] and it > lo_after:     # [U-15 ii]
                 break
         iterations = int(max(it_best, min(max_iters, np.ceil(bound)), min(min_iters, len(samples)), 1))
+        if rec is not None:
+            last_best = [e[1] for e in rec["events"] if e[0] == WK_BEST]
+            rec["events"].append((WK_WALK_END, iterations, last_best[-1] if last_best else -1, self.lo_runs, float(best_score)))
         if model is None:
+            if rec is not None:
+                self._rec = None
+                self.trace.walk(rec)
             return dict(model=None, inliers=np.zeros(0, np.int64), iterations=iterations)
         if self.lo_runs == 0:               # "apply the local optimisation if it has not been applied yet"
             model, best_score, best_count = self._local_optimization(model, best_score, best_count, T2, has_compound,
                                                                       exponent, weights)
         if self._use_graph_cut():           # final iterated least squares on the inliers
             model, best_score = self._lsq_lo(model, best_score, T2, has_compound, exponent, weights,
-                                             budget=int(getattr(s, "max_least_squares_iterations", 10)))
+                                             budget=int(getattr(s, "max_least_squares_iterations", 10)), final=True)
         final = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
+        if rec is not None:
+            rec["events"].append((WK_FINAL, 0, 0, 0, float(final["scores"][0])))
+            self._rec = None
+            self.trace.walk(rec)
         return dict(model=model, inliers=self._mask_inliers(final), iterations=iterations,
                     score=float(final["scores"][0]))
 
@@ -598,24 +634,36 @@ class ProposalEngine:
             return m, sc, int(one["counts"][0])
         return model, score, count
 
-    def _lsq_lo(self, model, score, T2, has_compound, exponent, weights, budget):
+    def _lsq_lo(self, model, score, T2, has_compound, exponent, weights, budget, final=False):
         """iterated least-squares refits on the inliers, scored with the same compound term: a refit is kept while the
         score improves (gcransac's iteratedLeastSquaresFitting [UPSTREAM-MEMORY])"""
         est = self.est
+        rec = self._rec if final else None
+        steps = 0
         while budget > 0:
             budget -= 1
+            steps += 1
             one = self.ctx.score(model[None, :], T2, has_compound=has_compound, exponent=exponent, want_masks=True)
             inl = self._mask_inliers(one)
             if len(inl) < est.nonminimal_sample_size:
+                if rec is not None:
+                    rec["lsq"].append((len(inl), 0, 0, -np.inf))
                 break
             fits = est.nonminimal(self.ctx, ("index", inl), weights, init=model)
             if len(fits) != 1:
+                if rec is not None:
+                    rec["lsq"].append((len(inl), len(fits), 0, -np.inf))
                 break
             cand = self.ctx.score(fits[0][None, :], T2, has_compound=has_compound, exponent=exponent)
+            if rec is not None:
+                sc = float(cand["scores"][0])
+                rec["lsq"].append((len(inl), 1, int(cand["counts"][0]), sc if sc == sc else -np.inf))
             if float(cand["scores"][0]) > score and int(cand["counts"][0]) > 0:
                 model, score = np.asarray(fits[0], dtype=np.float64), float(cand["scores"][0])
             else:
                 break
+        if rec is not None:
+            rec["events"].append((WK_LSQ, steps, 0, 0, float(score)))
         return model, score
 
     def _cut_inliers(self, model, T2, has_compound, exponent):
@@ -650,18 +698,25 @@ class ProposalEngine:
         limit = 7 * est.sample_size
         trials = int(s.max_local_optimization_number)
         max_cuts = int(getattr(s, "max_graph_cut_number", 10))
+        rec = self._rec
         while self.graph_cuts < max_cuts:
             self.graph_cuts += 1
             inl = self._cut_inliers(model, T2, has_compound, exponent)
             size = min(limit, len(inl))
             cands = []
+            branch = 0
             if size < len(inl) and size >= est.nonminimal_sample_size:
+                branch = 1
                 picks = np.array([np.sort(rng.choice(inl, size, replace=False)) for _t in range(trials)])
                 for fits in est.nonminimal_batch(self.ctx, picks, weights, init=model):   # one launch per refit step
                     cands.extend(fits)
             elif est.sample_size < len(inl) and len(inl) >= est.nonminimal_sample_size:
+                branch = 2
                 cands.extend(est.nonminimal(self.ctx, ("index", inl), weights, init=model))
             if not cands:
+                if rec is not None:
+                    rec["rounds"].append((len(inl), np.zeros(0, np.int64), np.zeros(0)))
+                    rec["events"].append((WK_LO_ROUND, branch, 0, 0, float(score)))
                 break
             cands = np.asarray(cands, dtype=np.float64)
             # (multi-GPU: every rank scores the few refits itself - replicas, no exchange)
@@ -670,8 +725,15 @@ class ProposalEngine:
             for h in range(len(cands)):
                 if int(table["counts"][h]) > 0 and float(table["scores"][h]) > score:
                     model, score, count, updated = cands[h].copy(), float(table["scores"][h]), int(table["counts"][h]), True
+            if rec is not None:
+                tc = np.asarray(table["counts"], dtype=np.int64).copy()
+                ts = np.asarray(table["scores"], dtype=np.float64).copy()
+                rec["rounds"].append((len(inl), tc, np.where(np.isnan(ts), -np.inf, ts)))
+                rec["events"].append((WK_LO_ROUND, branch, len(cands), int(updated), float(score)))
             if not updated:
                 break
+        if rec is not None:
+            rec["events"].append((WK_LO_END, self.graph_cuts, int(count), self.lo_runs, float(score)))
         return model, score, count
 
 

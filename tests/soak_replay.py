@@ -16,6 +16,7 @@ import numpy as np
 import pyprogressivex as px
 from pyprogressivex import _api, datasets
 import progx_replay as R
+import progx_proposal as Q
 import replay_helpers as H
 
 
@@ -67,7 +68,7 @@ def problem(rng, trial):
 
 def soak(seed, trials, verbose=True, tie=1e-12):
     rng = np.random.default_rng(seed)
-    bad = ties = events = pearl = 0
+    bad = ties = events = pearl = walks = walk_events = 0
     t0 = time.time()
     for trial in range(trials):
         fn, args, kw, rows, s = problem(rng, trial)
@@ -89,9 +90,17 @@ def soak(seed, trials, verbose=True, tie=1e-12):
         if not ok:
             bad += 1
             print("MISMATCH trial", trial, fn.__name__, "data seed", s, kw, "-", diff, flush=True)
+        # ... and every proposal of the call against the independent restatement of the proposal loop (oracle/progx_proposal.c)
+        for k, w in enumerate(rec.walks):
+            wd = Q.compare(w)
+            walks += 1
+            walk_events += len(w["events"])
+            if wd is not None:
+                bad += 1
+                print("MISMATCH trial", trial, fn.__name__, "data seed", s, kw, "- proposal", k, wd, flush=True)
     if verbose:
         print(f"replay soak done: seed {seed}, {trials} calls, {events} decision events ({pearl} PEARL iterations), {ties} summation-order ties "
-              f"followed, {bad} mismatches, {time.time() - t0:.0f} s")
+              f"followed; {walks} proposals ({walk_events} proposal-loop decisions) against the proposal replay; {bad} mismatches, {time.time() - t0:.0f} s")
     return bad
 
 

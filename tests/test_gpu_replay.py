@@ -103,3 +103,49 @@ def test_c5_full_size_gpu_decisions_equal_the_replay(gpu_api):
                         minimum_point_number=2000, spatial_coherence_weight=0.05, neighborhood_ball_radius=10.0)
     assert H.assert_agree(out, rec, rep, 1) == 9
     assert sum(e[0] == R.EV_PEARL_ITER for e in rec.events) > 200
+
+
+# ---- the proposal engine against ITS independent restatement (oracle/progx_proposal.c) -----------------------
+def _walks_agree(fn, *a, **kw):
+    import progx_proposal as Q
+    rec = Q.WalkRecorder()
+    out = fn(*a, trace=rec, **kw)
+    assert rec.walks
+    for k, w in enumerate(rec.walks):
+        diff = Q.compare(w)
+        assert diff is None, f"proposal {k}: {diff}"
+    return out, rec
+
+
+def test_proposal_walks_on_the_gpu_equal_the_replay_c1_c2_pnp_philox(gpu_api):
+    """every proposal of C1, C2, a 3-object pose scene (min-cut local optimisation) and a run on device-drawn Philox batches: which
+    hypothesis becomes the so-far-best and when, the iteration bound, when the local optimisation fires, which refit it keeps, the
+    final least squares, the iteration count handed to ProgressiveX::run - recomputed by the replay from the score tables"""
+    import progx_proposal as Q
+    pts, gt, _ = datasets.make_lines(seed=0)
+    out, rec = _walks_agree(px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.99, sampler_id=0, seed=1, minimum_point_number=50)
+    assert len(rec.walks) == 10 and out[0].shape[0] == 3
+    pts, gt, _ = datasets.make_homographies(seed=0)
+    out, rec = _walks_agree(px.findHomographies, pts, 1000, 1000, 1000, 1000, threshold=3.0, conf=0.99, sampler_id=0, seed=1, minimum_point_number=50)
+    assert out[0].shape[0] // 3 == 5
+    assert any(e[0] == Q.EV_LO_ROUND and e[1] == 1 and e[3] == 1 for w in rec.walks for e in w["events"])
+    x1, x2, K, gt, poses = datasets.make_poses(n_per_object=400, n_objects=3, n_outliers=400, seed=0)
+    out, rec = _walks_agree(px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=30)
+    assert out[0].shape[0] // 3 == 3
+    pts, gt, _ = datasets.make_lines(seed=3)
+    _walks_agree(px.findLines, pts, np.array(0), 1000, 1000, threshold=2.0, conf=0.95, sampler_id=0, seed=5, minimum_point_number=40, sampler_rng="philox")
+
+
+def test_proposal_walks_at_full_size_equal_the_replay_c3_c5_c4(gpu_api):
+    """the same at the BASELINE sizes: C3 (1e5 correspondences, 2 000 seven-point samples x 3 slots per proposal), C5 (2e5 segments) and
+    C4 (1e6 correspondences, 2 048 P3P samples x 4 slots): the replay is a pass over the score table, so full size costs nothing"""
+    pts, gt, _ = datasets.make_two_view_motions(seed=0)
+    out, rec = _walks_agree(px.findTwoViewMotions, pts, 1000, 1000, 1000, 1000, threshold=0.75, conf=0.99, sampler_id=0, seed=1,
+                            minimum_point_number=1000, max_iters=2000)
+    assert max(len(w["counts"]) for w in rec.walks) == 6000
+    pts, gt, _ = datasets.make_vanishing_points(seed=0)
+    _walks_agree(px.findVanishingPoints, pts, np.array(0), 1000, 1000, threshold=1.5, conf=0.99, sampler_id=0, seed=1,
+                 minimum_point_number=2000, spatial_coherence_weight=0.05, neighborhood_ball_radius=10.0)
+    x1, x2, K, gt, poses = datasets.make_poses(seed=0)
+    out, rec = _walks_agree(px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048)
+    assert max(len(w["counts"]) for w in rec.walks) == 8192 and out[0].shape[0] // 3 == 9
