@@ -149,3 +149,33 @@ def test_proposal_walks_at_full_size_equal_the_replay_c3_c5_c4(gpu_api):
     x1, x2, K, gt, poses = datasets.make_poses(seed=0)
     out, rec = _walks_agree(px.find6DPoses, x1, x2, K, seed=1, minimum_point_number=5000, max_iters=2048)
     assert max(len(w["counts"]) for w in rec.walks) == 8192 and out[0].shape[0] // 3 == 9
+
+
+def test_c4_full_size_events_match_the_committed_replay_pin(gpu_api):
+    """`find6DPoses` on 1e6 correspondences (the metric's configuration) against the independent control-flow oracle
+    WITHOUT the 35 minutes of host Dinic: tests/golden/kat_c4_replay_v1.npz holds the ORACLE's decision stream, computed once from the
+    recorded proposals / refits of this very call (scripts/pin_c4_replay.py record + replay: 228 events, 23 PEARL iterations whose
+    labellings of 1e6 sites the oracle's expansion recomputed; agreed event for event, 2 summation-order ties followed).  This test
+    runs the call again (~1 s): the replay's inputs must be the recorded ones byte for byte (else the pin does not apply and must be
+    regenerated - a different failure from a wrong decision), every decision must equal the pinned oracle stream, and the labels and
+    models must be the oracle's."""
+    import hashlib
+    import importlib.util
+    import os
+    pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_c4_replay_v1.npz"), allow_pickle=False)
+    spec = importlib.util.spec_from_file_location("pin_c4_replay", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts", "pin_c4_replay.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    x1, x2, K, gt, poses = datasets.make_poses(seed=0)
+    rec = R.TraceRecorder()
+    models, labels = px.find6DPoses(x1, x2, K, trace=rec, **tool.ARGS)
+    assert tool.inputs_digest(rec.proposals, rec.refits) == str(pin["inputs_sha256"]), \
+        "the proposals / refits of the call are not the recorded ones: regenerate the pin (scripts/pin_c4_replay.py), this is not a decision mismatch"
+    oracle_events = [tuple(int(v) for v in e[:4]) + (float(e[4]), float(e[5])) for e in pin["oracle_events"]]
+    diff = R.compare_events(rec.events, oracle_events)
+    assert diff is None, diff
+    assert len(rec.events) == 228 and sum(e[0] == R.EV_PEARL_ITER for e in rec.events) == 23
+    assert hashlib.sha256(np.asarray(labels, dtype=np.int64).tobytes()).hexdigest() == str(pin["labels_sha256"])
+    assert np.array_equal(np.bincount(np.asarray(labels, dtype=np.int64), minlength=len(pin["label_histogram"])), pin["label_histogram"])
+    assert models.shape[0] // 3 == pin["models"].shape[0] == 9
+    assert np.array_equal(models.reshape(9, -1), pin["models"].reshape(9, -1))
