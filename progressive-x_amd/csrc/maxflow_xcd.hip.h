@@ -14,9 +14,9 @@
 //
 // Two kernels:
 //  * mf_k_xcd_search: one global relabel = the level-synchronous reverse BFS of maxflow_driver.inl (bfs_reset, bfs_init, bfs_level
-//    x depth, bfs_finish, count_active) with the level loop inside the launch.  Taken when no site holds hub flow (f == 0
-//    everywhere: hub_exists never 2, no alpha hub), where the hub pass of the BFS labels nobody and the hubs only need their
-//    distances (1 + the nearest labelled member); declines otherwise.
+//    x depth, bfs_finish, count_active) with the level loop inside the launch, beta hubs included: a hub's distance is 1 + its
+//    nearest labelled member, published level by level, and a hub that some member has pulled from hands it on to its members
+//    with f > 0 one level later (the hub pass).  Declines only with a materialised alpha hub (never under the product's gate).
 //  * mf_k_xcd_rounds: the later rounds of a hard move - { search | drop the listed sites that no longer reach t | list sweeps
 //    until the list is empty, the budget is spent or nothing has reached t for longer than the search was deep } - hub-free
 //    (maxflow_body.hip.h mf_body_tail_step), until no listed site reaches t.
@@ -68,6 +68,8 @@ struct XcdStage {
     int base;
     int ok, me, part;
     int hub[64];           // per-label minimum of (distance + 1) over this workgroup's labelled members (search kernel)
+    int hubsent[64];       // ... what of it this workgroup has already published to bfs_hub_d
+    unsigned long long evmask;   // labels whose hub hands its distance on at the level being run
 };
 
 struct XcdRt {             // per-thread view of the launch
@@ -89,7 +91,7 @@ __device__ __forceinline__ bool xcd_join(XcdCtl* c, XcdStage& st, XcdRt& rt)
         __hip_atomic_fetch_add(&c->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         st.count = 0;
     }
-    if (threadIdx.x < 64) st.hub[threadIdx.x] = kMfInf;
+    if (threadIdx.x < 64) { st.hub[threadIdx.x] = kMfInf; st.hubsent[threadIdx.x] = kMfInf; }
     __syncthreads();
     if (st.me < 0) return false;
     if (threadIdx.x == 0) {
@@ -160,6 +162,16 @@ __device__ __forceinline__ void xcd_flush_if_half(XcdStage& st, int* counter, in
     __syncthreads();
 }
 
+// this workgroup's per-label minima of (member distance + 1) -> bfs_hub_d, one atomic per label whose minimum improved
+__device__ __forceinline__ void xcd_publish_hubs(const MfView& v, XcdStage& st)
+{
+    __syncthreads();
+    if ((int)threadIdx.x < v.L && st.hub[threadIdx.x] < st.hubsent[threadIdx.x]) {
+        atomicMin(&v.bfs_hub_d[threadIdx.x], st.hub[threadIdx.x]);
+        st.hubsent[threadIdx.x] = st.hub[threadIdx.x];
+    }
+}
+
 // One reverse BFS from the sites with residual capacity to t over the n-links.  HUBS: also record, per label with a hub, the
 // distance of its nearest labelled member + 1 in st.hub (maxflow_body.hip.h mf_bfs_label: y_beta -> u has infinite capacity).
 // Level 1 is not listed (it is most of the graph in a steady-state move and a whole cluster in a hard one): level 2 runs
@@ -187,6 +199,7 @@ __device__ __forceinline__ int xcd_bfs(const MfView& v, XcdStage& st, XcdRt& rt,
         const unsigned long long m1 = __ballot(any1);   // one store per wave that labelled somebody
         if (m1 != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m1) - 1) __hip_atomic_store(&c->level1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (HUBS) xcd_publish_hubs(v, st);
     if (!xcd_sync(st, rt)) return -1;
     XCD_PROF(rt, 1)
     for (int64_t u0 = (int64_t)rt.me * kXcdBlock; u0 < n_round; u0 += T) {
@@ -201,14 +214,30 @@ __device__ __forceinline__ int xcd_bfs(const MfView& v, XcdStage& st, XcdRt& rt,
         xcd_flush_if_half(st, &c->fcount[2], v.order);
     }
     xcd_flush(st, &c->fcount[2], v.order);
+    if (HUBS) xcd_publish_hubs(v, st);
     if (!xcd_sync(st, rt)) return -1;
     XCD_PROF(rt, 2)
     int k = 3;
     int depth = xcd_load(&c->level1) != 0 ? 1 : 0;
     for (;; ++k) {
         const int fprev = xcd_load(&c->fcount[(k - 1) % 3]);
-        if (fprev == 0) break;
-        depth = k - 1;
+        // hub events of level k (mf_bfs_hub_events): a beta hub some member has pulled from (hub_exists == 2: only then can a member
+        // hold f > 0, i.e. residual u -> y_beta) received distance k - 1 from a member labelled at level k - 2: its members with f > 0
+        // that are still unlabelled get k.  The distances were published before the barrier that ended level k - 1.
+        unsigned long long ev = 0;
+        if (HUBS) {
+            if (threadIdx.x < 64) {
+                const int l = (int)threadIdx.x;
+                const bool e = l < v.L && v.hub_exists[l] == 2 && xcd_load(&v.bfs_hub_d[l]) == k - 1;
+                const unsigned long long m = __ballot(e);
+                if (l == 0) st.evmask = m;
+            }
+            __syncthreads();
+            ev = st.evmask;
+            __syncthreads();
+        }
+        if (fprev == 0 && ev == 0) break;
+        if (fprev > 0) depth = k - 1;
         const int pbase = xcd_load(&c->fbase[(k - 1) % 3]);
         const int kbase = pbase + fprev;
         if (rt.tid == 0) { c->fbase[k % 3] = kbase; c->fcount[(k + 1) % 3] = 0; }
@@ -230,8 +259,22 @@ __device__ __forceinline__ int xcd_bfs(const MfView& v, XcdStage& st, XcdRt& rt,
             }
             xcd_flush_if_half(st, &c->fcount[k % 3], v.order + kbase);
         }
+        if (HUBS && ev != 0) {   // the hub pass: every site once (rare: at most one event per hub and search)
+            for (int64_t u0 = (int64_t)rt.me * kXcdBlock; u0 < n_round; u0 += T) {
+                const int64_t u = u0 + threadIdx.x;
+                bool want = false;
+                if (u < n) {
+                    const int lu = v.labels[u];
+                    if (lu != v.alpha && ((ev >> lu) & 1ull) && v.f[u] > 0 && mf_hd_load32(&v.d[u]) == kMfInf && mf_hd_cas32(&v.d[u], kMfInf, k)) want = true;
+                }
+                xcd_stage(st, (int)u, want);
+                xcd_flush_if_half(st, &c->fcount[k % 3], v.order + kbase);
+            }
+        }
         xcd_flush(st, &c->fcount[k % 3], v.order + kbase);
+        if (HUBS) xcd_publish_hubs(v, st);
         if (!xcd_sync(st, rt)) return -1;
+        if (HUBS && ev != 0 && xcd_load(&c->fcount[k % 3]) > 0) depth = k;   // (a level that only the hub pass filled)
     }
     *levels += k;
     XCD_PROF(rt, 3)
@@ -250,9 +293,8 @@ __global__ __launch_bounds__(kXcdBlock) void mf_k_xcd_search(MfView v, XcdCtl* c
     __shared__ XcdStage st;
     XcdRt rt;
     if (!xcd_join(c, st, rt)) return;
-    // hubs must be passive: nobody holds flow received from a beta hub (f > 0 only after a pull, which sets hub_exists = 2)
-    bool passive = v.has_alpha_hub[0] == 0;
-    for (int l = 0; l < v.L; ++l) passive = passive && v.hub_exists[l] != 2;     // (written by earlier kernels: plain reads)
+    // a materialised alpha hub (never with the stranded-excess gate the product runs with) is not handled here
+    const bool passive = v.has_alpha_hub[0] == 0;
     if (!passive) {
         if (rt.tid == 0) { c->out[3] = 3; c->out[4] = (int)rt.part; }
         return;
@@ -261,9 +303,7 @@ __global__ __launch_bounds__(kXcdBlock) void mf_k_xcd_search(MfView v, XcdCtl* c
     int levels = 0;
     const int depth = xcd_bfs<true>(v, st, rt, spp, &levels);
     if (depth < 0) return;
-    // hub distances: one atomic per (workgroup, label with a labelled member); bfs_reset stored "unreached" before the first barrier
-    if ((int)threadIdx.x < v.L && st.hub[threadIdx.x] != kMfInf) atomicMin(&v.bfs_hub_d[threadIdx.x], st.hub[threadIdx.x]);
-    if (!xcd_sync(st, rt)) return;
+    // (hub distances: published level by level - bfs_reset stored "unreached" before the first barrier)
     if (rt.tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the bodies below read with plain loads what other CUs wrote by atomics
         v.flags[0] = depth;

@@ -31,7 +31,7 @@ def run(name, mt, pts, models, thr, lam, h, graph, reps):
     st = ctx.expansion_stats()
     print(json.dumps(dict(config=name, best_ms=round(1e3 * min(ts), 2), all_ms=[round(1e3 * t, 1) for t in ts], cycles=cycles,
                           sweeps=st["sweeps"] // reps, relabels=st["global_relabels"] // reps, levels=st["bfs_levels"] // reps,
-                          crc=zlib.crc32(ctx.get_labels().tobytes()), env={k: v for k, v in os.environ.items() if k.startswith("PGX_MF")})), flush=True)
+                          crc=zlib.crc32(ctx.get_labels().tobytes()), schedule={k: v // reps for k, v in ctx.expansion_schedule().items()}, paths=ctx.expansion_paths(), env={k: v for k, v in os.environ.items() if k.startswith("PGX_MF")})), flush=True)
     ctx.close()
 
 

@@ -157,7 +157,6 @@ struct EmuBackend {
     {
         if (!xcd_on) return false;
         if (v.has_alpha_hub[0]) return false;
-        for (int l = 0; l < v.L; ++l) if (v.hub_exists[l] == 2) return false;
         mf_body_bfs_reset(v);
         std::vector<int> fr, nf;
         bool any1 = false;
@@ -171,15 +170,25 @@ struct EmuBackend {
             if (v.labels[u] != v.alpha && v.d[u] == kMfInf && mf_body_tail_level2(v, u)) fr.push_back((int)u);
         for (int u : fr) { v.d[u] = 2; hub(u, 2); }
         int k = 3, depth = any1 ? 1 : 0;
-        for (; !fr.empty(); ++k) {
-            depth = k - 1;
+        for (;; ++k) {
+            unsigned long long ev = 0;   // hubs that hand their distance on at this level (a member pulled from them before)
+            for (int l = 0; l < v.L; ++l) if (v.hub_exists[l] == 2 && v.bfs_hub_d[l] == k - 1) ev |= 1ull << l;
+            if (fr.empty() && ev == 0) break;
+            if (!fr.empty()) depth = k - 1;
             nf.clear();
             if (shuffle) std::shuffle(fr.begin(), fr.end(), rng);
+            std::vector<std::pair<int, int>> hubs_seen;   // (published after the level, as the device does)
             for (int w : fr)
                 for (int a = v.off[w]; a < v.off[w + 1]; ++a) {
                     const int u = v.idx[a];
-                    if (v.tot[a] - v.cap[a] > 0 && v.d[u] == kMfInf) { v.d[u] = k; hub(u, k); nf.push_back(u); }
+                    if (v.tot[a] - v.cap[a] > 0 && v.d[u] == kMfInf) { v.d[u] = k; hubs_seen.push_back({u, k}); nf.push_back(u); }
                 }
+            if (ev != 0)
+                for (int64_t u = 0; u < v.n; ++u) {
+                    const int lu = v.labels[u];
+                    if (lu != v.alpha && ((ev >> lu) & 1ull) && v.f[u] > 0 && v.d[u] == kMfInf) { v.d[u] = k; hubs_seen.push_back({(int)u, k}); nf.push_back((int)u); }
+                }
+            for (auto& h2 : hubs_seen) hub(h2.first, h2.second);
             fr.swap(nf);
         }
         v.flags[0] = depth;
