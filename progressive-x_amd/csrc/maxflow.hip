@@ -652,7 +652,10 @@ __device__ __forceinline__ void mf_sweep_epilogue_wave(const MfView& v, int cur,
         v.flags[1] = 0;
         v.flags[11] = moved ? 0 : stall + 1;   // as mf_body_sweep_epilogue
         v.flags[8] = 0;
-        if (consumed >= 0) v.acnt[consumed] = 0;
+        if (consumed >= 0) {
+            if (v.swept) v.swept[0] += v.acnt[consumed];   // (as mf_body_sweep_epilogue: what the list sweep visited, for the labelling roofline)
+            v.acnt[consumed] = 0;
+        }
     }
 }
 
