@@ -34,6 +34,8 @@ struct MaxflowState {
     int64_t mark_n = 0;
     DevBuf xcd;              // XcdCtl of the persistent one-XCD rounds (maxflow_xcd.hip.h)
     int* h_xcd = nullptr;    // pinned host copy of its result words
+    bool xcd_broken = false; // a persistent launch came back without participants (its workgroups never became co-resident, e.g. a partitioned GPU):
+                             // never tried again on this context - its registration waits seconds before it gives up
     int64_t xcd_launches = 0, xcd_rounds = 0, xcd_done = 0, xcd_swept16 = 0, xcd_searches = 0, xcd_levels = 0, xcd_sweeps = 0;
     int bfs_hint[2] = {0, 0};  // last labelled level of the previous first / later search of a move (MfTuning::bfs_hint)
 };
@@ -963,7 +965,7 @@ struct HipBackend {
     bool xcd_rounds(const MfView& v, const MfTuning& tune, int out[8])
     {
         const int spp = xcd_spp();
-        if (!xcd_enabled || spp < 4 || v.n > xcd_max_n) return false;   // (spp < 4: rows too long for the staging buffer)
+        if (!xcd_enabled || st->xcd_broken || spp < 4 || v.n > xcd_max_n) return false;   // (spp < 4: rows too long for the staging buffer)
         XcdCtl* c = xcd_prepare();
         if (!c) return false;
         const int stamp0 = take_stamps(v, tune.xcd_max_rounds * (tune.sweeps_list + 3) + 8);
@@ -975,6 +977,7 @@ struct HipBackend {
         if (e != hipSuccess) { if (err == hipSuccess) err = e; return false; }
         for (int k = 0; k < 8; ++k) out[k] = st->h_xcd[k];
         if (tune.debug) xcd_prof(c, "rounds");
+        if (out[4] <= 0) { st->xcd_broken = true; return false; }
         st->xcd_launches += 1;
         st->xcd_rounds += out[0];
         st->xcd_done += out[3] == 1 ? 1 : 0;
@@ -987,7 +990,7 @@ struct HipBackend {
     bool xcd_search(const MfView& v, int slot, int fl[kMfFlags], int* cnt_alpha, int* levels)
     {
         const int spp = xcd_spp();
-        if (!xcd_enabled || spp < 4 || v.n > xcd_max_n) return false;
+        if (!xcd_enabled || st->xcd_broken || spp < 4 || v.n > xcd_max_n) return false;
         XcdCtl* c = xcd_prepare();
         if (!c) return false;
         hipLaunchKernelGGL(mf_k_xcd_search, dim3(kXcdGrid), dim3(kXcdBlock), 0, ctx->stream, v, c, slot, spp);
@@ -996,7 +999,8 @@ struct HipBackend {
         hipError_t e = hipMemcpyAsync(st->h_xcd, c->out, (8 + 16) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);   // out[8] | flags[16]
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { if (err == hipSuccess) err = e; return false; }
-        if (st->h_xcd[3] != 1) return false;   // declined (hub flow in play) or nobody on XCC 0
+        if (st->h_xcd[4] <= 0) st->xcd_broken = true;   // nobody took part: see MaxflowState::xcd_broken
+        if (st->h_xcd[3] != 1) return false;   // declined (a materialised alpha hub) or nobody on XCC 0
         for (int k = 0; k < kMfFlags; ++k) fl[k] = st->h_xcd[8 + k];
         *cnt_alpha = st->h_xcd[8 + kMfFlags];
         *levels = st->h_xcd[1];
