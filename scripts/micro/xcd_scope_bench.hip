@@ -103,6 +103,47 @@ __global__ void k_xbar(unsigned* ctr, int rounds, int flavour, int* data, int nw
     if (threadIdx.x == 0 && me == 0) out[0] = wall_clock64() - t0;
 }
 
+// ---- (4) all 8 XCDs, no fences: per-XCD arrival counter -> the XCD's last arriver bumps a top counter -> the top's last arriver
+// bumps a generation word every workgroup polls; data exchanged with agent-scope (sc1) stores and loads only
+struct HBar { unsigned xc[8 * 16]; unsigned top[16]; unsigned gen[16]; };
+__device__ __forceinline__ void hier_barrier(HBar* b, unsigned round, unsigned per_xcd, unsigned xcds, unsigned xcc)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = __hip_atomic_fetch_add(&b->xc[xcc * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1 == (round + 1) * per_xcd) {
+            const unsigned t = __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == (round + 1) * xcds) __hip_atomic_store(&b->gen[0], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned spins = 0;
+        while (LOAD_SC1(&b->gen[0]) < round + 1) { if (++spins > 20000000u) break; }
+    }
+    __syncthreads();
+}
+__global__ void k_hbar(HBar* b, int rounds, int* data, int nwrite, unsigned long long* out, int flat)
+{
+    const unsigned xcc = xcc_id() & 7u, me = blockIdx.x, part = gridDim.x;
+    const unsigned long long t0 = wall_clock64();
+    int acc = 0;
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < nwrite; i += blockDim.x) __hip_atomic_store(&data[me * nwrite + i], r + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flat) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (LOAD_SC1(&b->top[0]) < (unsigned)(r + 1) * part) { if (++spins > 20000000u) break; }
+            }
+            __syncthreads();
+        } else hier_barrier(b, (unsigned)r, part / 8, 8, xcc);
+        for (int i = threadIdx.x; i < nwrite; i += blockDim.x) acc += LOAD_SC1(&data[((me + 9) % part) * nwrite + i]) - (r + i);   // a workgroup of another XCD
+    }
+    if (threadIdx.x == 0) atomicAdd(&out[1], (unsigned long long)(acc != 0));
+    if (threadIdx.x == 0 && me == 0) out[0] = wall_clock64() - t0;
+}
+
 int main()
 {
     int* next; unsigned* flag; unsigned long long* out; int* data;
@@ -152,6 +193,21 @@ int main()
                 }
                 printf("barrier %2d workgroups of one XCD, %4d ints exchanged, %-46s: %6.2f us per round (stale reads in %llu workgroups)\n", wgs, nwrite, bn[f],
                        h[0] * tick_ns / 2000 / 1000, h[1]);
+            }
+    HBar* hb; hipMalloc(&hb, sizeof(HBar));
+    for (int block : {256, 1024})
+        for (int nwrite : {0, 1024})
+            for (int flat : {1, 0}) {
+                unsigned long long h[2] = {0, 0};
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipMemset(hb, 0, sizeof(HBar)); hipMemset(out, 0, 64);
+                    hipLaunchKernelGGL(k_hbar, dim3(256), dim3(block), 0, 0, hb, 2000, data, nwrite, out, flat);
+                    hipError_t e = hipDeviceSynchronize();
+                    if (e != hipSuccess) printf("error %s\n", hipGetErrorString(e));
+                    hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
+                }
+                printf("barrier 256 workgroups x %4d threads on all 8 XCDs, no fences, sc1 data, %4d ints exchanged, %-12s: %6.2f us per round (stale reads in %llu workgroups)\n", block, nwrite,
+                       flat ? "one counter" : "hierarchical", h[0] * tick_ns / 2000 / 1000, h[1]);
             }
     return 0;
 }
