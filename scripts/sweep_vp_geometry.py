@@ -41,7 +41,7 @@ for name, mt, make, m, S, thr in (("C5 vanishing points", _lib.VANISHING_POINT, 
     T2 = 2.25 * thr * thr
     st = ctx.score_stats(T2, has_compound=False)
     print(name, {k: st[k] for k in ("group_pairs", "surviving_group_steps", "exact_evaluations", "inlier_pairs")}, flush=True)
-    for split in (0,):
+    for split in (0, 16):
         for dense in (32,):
             ctx.score_debug_geometry(split=split, dense_min=dense)
             step, k = measure(ctx, T2)
