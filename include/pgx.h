@@ -288,6 +288,16 @@ int pgx_epipolar_support(pgx_ctx *ctx, const double *F, double T2, double S2, in
 int pgx_pnp_refine_batch(pgx_ctx *ctx, const double *inits, const int32_t *index, int B, int m, const double *weights_sel,
                          int weight_power, int iterations, double *out, int32_t *status);
 
+/* The small dense solve of the non-minimal refits behind the C ABI (round 6; first step towards one call per local-optimisation
+ * round): the eigenvector of the SMALLEST eigenvalue of B symmetric q x q matrices (q <= 9: the 9 x 9 A^T A of the normalised DLT /
+ * 8-point rows, the 3 x 3 of the vanishing-point solver).  Replaces Eigen::SelfAdjointEigenSolver as the refit solvers use it
+ * (solver_vanishing_point_two_lines.h:227 in-tree; estimateModelNonminimal of the absent submodule, PEARL.h:374-380), until now
+ * numpy's LAPACK on the host.  Cyclic Jacobi in FP64, one lane per matrix, in the operation order of the oracle's
+ * pgxo_eigh_smallest: device and oracle return the same bits; both agree with LAPACK to ~1e-13 on the (sign-normalised)
+ * eigenvector for well-separated eigenvalues.  A [B][q*q] row-major (host); vec [B][q], val [B] (host).  The drop-in calls use it
+ * when refit_solver="jacobi" (default "lapack": unchanged results). */
+int pgx_eigh_smallest_batch(pgx_ctx *ctx, const double *A, int q, int64_t B, double *vec, double *val);
+
 /* ---- the inlier/outlier graph cut of GC-RANSAC's local optimisation.
  * Replaces gcransac::GCRANSAC::labeling as reached from proposal_engine->run (progressive_x.h:294-299; settings
  * spatial_coherence_weight / threshold at :541-545).  The graph-cut-ransac sources are absent from the snapshot, so the

@@ -1315,3 +1315,55 @@ int pgxo_sample_pnapsac(const double *pts, int64_t n, int d, const double *sizes
     free(pairs); free(run0); free(runlen); free(hits); free(subset); free(layer); free(others);
     return 0;
 }
+
+
+/* ---- smallest eigenpair by cyclic Jacobi (pgx_oracle.h; same operation order as csrc/fit.hip eigh_smallest_kernel) ---------------- */
+void pgxo_eigh_smallest(const double* A, int q, int64_t B, double* vec, double* val, int32_t* sweeps)
+{
+    for (int64_t b = 0; b < B; ++b) {
+        double a[9][9] = {{0}}, v[9][9] = {{0}};
+        for (int i = 0; i < q; ++i)
+            for (int j = 0; j < q; ++j) {
+                a[i][j] = A[(size_t)b * q * q + (size_t)i * q + j];
+                v[i][j] = i == j ? 1.0 : 0.0;
+            }
+        int sweep = 0;
+        for (; sweep < 50; ++sweep) {
+            double off = 0.0, dg = 0.0;
+            for (int p = 0; p < q; ++p) {
+                dg = dg + a[p][p] * a[p][p];
+                for (int r = p + 1; r < q; ++r) off = off + a[p][r] * a[p][r];
+            }
+            if (!(off > 4.930380657631324e-32 * dg)) break;      /* eps^2; also leaves on NaN */
+            for (int p = 0; p < q - 1; ++p)
+                for (int r = p + 1; r < q; ++r) {
+                    const double apr = a[p][r];
+                    if (apr == 0.0) continue;
+                    const double theta = (a[r][r] - a[p][p]) / (2.0 * apr);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                    for (int k = 0; k < q; ++k) {
+                        const double akp = a[k][p], akr = a[k][r];
+                        a[k][p] = c * akp - sn * akr;
+                        a[k][r] = sn * akp + c * akr;
+                    }
+                    for (int k = 0; k < q; ++k) {
+                        const double apk = a[p][k], ark = a[r][k];
+                        a[p][k] = c * apk - sn * ark;
+                        a[r][k] = sn * apk + c * ark;
+                    }
+                    for (int k = 0; k < q; ++k) {
+                        const double vkp = v[k][p], vkr = v[k][r];
+                        v[k][p] = c * vkp - sn * vkr;
+                        v[k][r] = sn * vkp + c * vkr;
+                    }
+                }
+        }
+        int best = 0;
+        for (int p = 1; p < q; ++p)
+            if (a[p][p] < a[best][best]) best = p;
+        for (int k = 0; k < q; ++k) vec[(size_t)b * q + k] = v[k][best];
+        val[b] = a[best][best];
+        if (sweeps) sweeps[b] = sweep;
+    }
+}

@@ -132,4 +132,11 @@ int pgxo_sample_pnapsac(const double *pts, int64_t n, int d, const double *sizes
 #ifdef __cplusplus
 }
 #endif
+/* Smallest eigenpair of B symmetric q x q matrices (q <= 9) by cyclic Jacobi rotations in FP64 - the small dense solve of the
+ * non-minimal refits (the reference reaches Eigen::SelfAdjointEigenSolver: solver_vanishing_point_two_lines.h:227; the DLT / 8-point
+ * solvers of the absent submodule do the same on A^T A).  Restated in the SAME operation order as csrc/fit.hip eigh_smallest_kernel:
+ * sweeps over the pairs (p, r), p < r, row-cyclic; rotation t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (a_rr - a_pp) /
+ * (2 a_pr); stop when the off-diagonal sum of squares is <= eps^2 times the diagonal's, or after 50 sweeps; the eigenvector of the
+ * smallest diagonal entry (first on ties).  A [B][q*q] row-major; vec [B][q]; val [B]; sweeps [B] (may be NULL). */
+void pgxo_eigh_smallest(const double* A, int q, int64_t B, double* vec, double* val, int32_t* sweeps);
 #endif

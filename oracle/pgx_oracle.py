@@ -526,3 +526,19 @@ def gram(kind, pts, index, params=None, weights=None, wpow=2):
         A = np.where(bad[:, None], 0.0, A)
         G = G + (A * w[:, None]).T @ A
     return G, int(len(index)), int(bad.sum())
+
+
+def eigh_smallest(A):
+    """pgxo_eigh_smallest: (vec [B, q], val [B], sweeps [B]) of the symmetric matrices A [B, q, q] (q <= 9), cyclic Jacobi in the
+    operation order of the device kernel (csrc/fit.hip eigh_smallest_kernel)"""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B, q, _ = A.shape
+    assert q <= 9 and A.shape[2] == q
+    vec = np.zeros((B, q))
+    val = np.zeros(B)
+    sw = np.zeros(B, dtype=np.int32)
+    fn = lib().pgxo_eigh_smallest
+    fn.restype = None
+    fn(A.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(q), C.c_int64(B), vec.ctypes.data_as(C.POINTER(C.c_double)),
+       val.ctypes.data_as(C.POINTER(C.c_double)), sw.ctypes.data_as(C.POINTER(C.c_int32)))
+    return vec, val, sw

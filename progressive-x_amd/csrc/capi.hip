@@ -1174,6 +1174,12 @@ int pgx_pnp_refine_batch(pgx_ctx* ctx, const double* inits, const int32_t* index
     return pnp_refine_batch_launch(ctx, inits, index, B, m, weights_sel, weight_power, iterations, out, status);
 }
 
+int pgx_eigh_smallest_batch(pgx_ctx* ctx, const double* A, int q, int64_t B, double* vec, double* val)
+{
+    CTX_GUARD(ctx);
+    return eigh_smallest_launch(ctx, A, q, B, vec, val);
+}
+
 int pgx_gc_labeling(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count)
 {
     CTX_GUARD(ctx);

@@ -734,4 +734,80 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
     return PGX_OK;
 }
 
+
+// ---- smallest eigenpair of small symmetric matrices: the dense solve of the non-minimal refits behind the C ABI (round 6) -------
+// Replaces: Eigen::SelfAdjointEigenSolver as the refit solvers use it (solver_vanishing_point_two_lines.h:227 in-tree; the DLT /
+// 8-point solvers of the absent submodule on A^T A), so far numpy's LAPACK on the host.  Cyclic Jacobi in FP64, ONE LANE PER
+// MATRIX in the operation order of the CPU restatement the tests hold (no contraction, IEEE division and square root): the
+// device and that restatement return the same bits (tests), and both agree with LAPACK to ~1e-13 on the eigenvector (tests, tolerance
+// stated there).  B is tens of matrices per call (one local-optimisation round): latency, not throughput.
+__global__ __launch_bounds__(64) void eigh_smallest_kernel(const double* __restrict__ A, int q, int64_t B, double* __restrict__ vec,
+                                                            double* __restrict__ val)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double a[9][9], v[9][9];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) {
+            a[i][j] = (i < q && j < q) ? A[b * q * q + (int64_t)i * q + j] : 0.0;
+            v[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < q; ++p) {
+            dg = dg + a[p][p] * a[p][p];
+            for (int r = p + 1; r < q; ++r) off = off + a[p][r] * a[p][r];
+        }
+        if (!(off > 4.930380657631324e-32 * dg)) break;
+        for (int p = 0; p < q - 1; ++p)
+            for (int r = p + 1; r < q; ++r) {
+                const double apr = a[p][r];
+                if (apr == 0.0) continue;
+                const double theta = (a[r][r] - a[p][p]) / (2.0 * apr);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < q; ++k) {
+                    const double akp = a[k][p], akr = a[k][r];
+                    a[k][p] = c * akp - sn * akr;
+                    a[k][r] = sn * akp + c * akr;
+                }
+                for (int k = 0; k < q; ++k) {
+                    const double apk = a[p][k], ark = a[r][k];
+                    a[p][k] = c * apk - sn * ark;
+                    a[r][k] = sn * apk + c * ark;
+                }
+                for (int k = 0; k < q; ++k) {
+                    const double vkp = v[k][p], vkr = v[k][r];
+                    v[k][p] = c * vkp - sn * vkr;
+                    v[k][r] = sn * vkp + c * vkr;
+                }
+            }
+    }
+    int best = 0;
+    for (int p = 1; p < q; ++p)
+        if (a[p][p] < a[best][best]) best = p;
+    for (int k = 0; k < q; ++k) vec[b * q + k] = v[k][best];
+    val[b] = a[best][best];
+}
+
+int eigh_smallest_launch(pgx_ctx* ctx, const double* A, int q, int64_t B, double* vec, double* val)
+{
+    if (!A || !vec || !val) return fail(ctx, PGX_ERR_INVALID, "pgx_eigh_smallest_batch: NULL argument");
+    if (q < 1 || q > 9) return fail(ctx, PGX_ERR_INVALID, "pgx_eigh_smallest_batch: q = %d (1..9)", q);
+    if (B <= 0) return PGX_OK;
+    if (B > (1 << 20)) return fail(ctx, PGX_ERR_INVALID, "pgx_eigh_smallest_batch: at most 2^20 matrices per call");
+    const size_t in_bytes = (size_t)B * q * q * sizeof(double), out_bytes = (size_t)B * (q + 1) * sizeof(double);
+    PGX_TRY(ensure(ctx, ctx->fit_scratch, in_bytes + out_bytes + 256));
+    double* d_A = (double*)ctx->fit_scratch.p;
+    double* d_vec = (double*)((char*)ctx->fit_scratch.p + ((in_bytes + 255) & ~(size_t)255));
+    double* d_val = d_vec + (size_t)B * q;
+    PGX_HIP(ctx, hipMemcpyAsync(d_A, A, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(eigh_smallest_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, d_A, q, B, d_vec, d_val);
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(vec, d_vec, (size_t)B * q * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipMemcpyAsync(val, d_val, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
 }  // namespace pgx

@@ -260,6 +260,7 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
                     int64_t h_q, int alpha, int64_t* changed, bool source_reach = false);
 void maxflow_free(pgx_ctx* ctx);
 int maxflow_schedule_stats(pgx_ctx* ctx, int64_t out[8]);   // maxflow.hip
+int eigh_smallest_launch(pgx_ctx* ctx, const double* A, int q, int64_t B, double* vec, double* val);   // fit.hip
 constexpr int PGX_TILE_FALLBACK = 1000;   // expand_alpha_tile: not handled, run the level-synchronous path (labels untouched)
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha,
                       int64_t* changed, const long long* wq = nullptr);

@@ -7,6 +7,8 @@ findTwoViewMotions ignores scoring_exponent, findLines ignores weights, only fin
 Extensions that do not change the reference behaviour when left at their defaults (keyword-only):
   seed=None                     reproducible sampling (the reference seeds from std::random_device)
   sampler_rng="numpy"           "philox": the samplers draw from the in-repo counter-based generator (_rng.py) - uniform, NAPSAC and PROSAC on the device inside the solver's launch, Progressive NAPSAC (sequential) in libpgx's host code
+  refit_solver="lapack"         "jacobi": the refits' smallest-eigenvector solves run through pgx_eigh_smallest_batch (batched cyclic Jacobi
+                                on the device, bitwise a CPU restatement, ~1e-13 from LAPACK) instead of numpy.linalg.eigh: round 6
   distributed=None              True: shard the proposal batches over the ranks of this launch (every rank must make the same
                                 call on the same data; checked).  None: only if PGX_MULTI_GPU=1.  Never implicit.
   max_outer_iterations=10       the reference's hard cap on proposals per call (progressive_x.h:272)
@@ -75,10 +77,13 @@ def _unknown_sampler(sampler_id):
 def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, conf, spatial_coherence_weight,
          maximum_tanimoto_similarity, max_iters, minimum_point_number, maximum_model_number, scoring_exponent=2,
          do_logging=False, weights=None, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-         local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
+         local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     n = pts.shape[0]
     if sampler_rng not in ("numpy", "philox"):
         raise ValueError("sampler_rng should be 'numpy' or 'philox'")
+    if refit_solver not in ("lapack", "jacobi"):
+        raise ValueError("refit_solver should be 'lapack' or 'jacobi'")
+    estimator.refit_solver = str(refit_solver)   # the refits' small eigen-solves: numpy on the host / pgx_eigh_smallest_batch (_estimators.py)
     if getattr(sampler_factory, "unknown", False):
         # progressivex_python.cpp:240-245: message on stderr, zero models, labelling left at its initial zeros
         _unknown_sampler(sampler_factory.sampler_id)
@@ -95,7 +100,7 @@ def _run(estimator, pts, graph_points, radius, sampler_factory, *, threshold, co
             type(estimator).__name__, float(radius), getattr(sampler_factory, "sampler_id", None), float(threshold), float(conf),
             float(spatial_coherence_weight), float(maximum_tanimoto_similarity), int(max_iters), int(minimum_point_number),
             int(maximum_model_number), int(scoring_exponent), seed, int(max_outer_iterations), str(neighborhood),
-            str(local_optimization), str(labeling_l0), str(sampler_rng), getattr(estimator, "validity", None), str(pearl_abs)))
+            str(local_optimization), str(labeling_l0), str(sampler_rng), getattr(estimator, "validity", None), str(pearl_abs), str(refit_solver)))
         if seed is None:
             seed = parallel.shared_seed()
     rng = np.random.default_rng(seed)
@@ -183,7 +188,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                      neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                      minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                      do_logging=False, *, seed=None, max_outer_iterations=10, residual="transfer", neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     """bindings.cpp:99-166, progressivex_python.cpp:173-304.  Returns (H[(3K),3] float64, labels[n] int32)."""
     corrs = _as_f64(corrs)
     n, dim = _shape2(corrs)
@@ -202,7 +207,7 @@ def findHomographies(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_coh
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs, refit_solver=refit_solver)
     return _stack(est, models, 3), labels
 
 
@@ -210,7 +215,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                        neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                        minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=3,
                        do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="off", sampler_rng="numpy", trace=None, pearl_abs="double"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, validity="off", sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     """bindings.cpp:324-392, progressivex_python.cpp:537-666.  Returns (F[(3K),3], labels[n]).
     validity [U-14, keyword-only, not in the reference's signature]: which of the estimator's model-validity stages run -
     "off" (the default: strict restatement of what is in the snapshot, i.e. none), "oriented", "symmetric" (oriented +
@@ -236,7 +241,7 @@ def findTwoViewMotions(corrs, w1, h1, w2, h2, threshold=4.0, conf=0.5, spatial_c
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=2, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs, refit_solver=refit_solver)
     return _stack(est, models, 3), labels
 
 
@@ -247,7 +252,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                         neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
                         minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
                         do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     """bindings.cpp:168-245, progressivex_python.cpp:306-423.  Returns (vp[K,3], labels[n]).  Only sampler ids 0/1
     exist for this driver, so the DEFAULT id 3 returns zero models, as in the reference."""
     lines = _as_f64(lines)
@@ -264,7 +269,7 @@ def findVanishingPoints(lines, weights, w, h, threshold=4.0, conf=0.5, spatial_c
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=bool(do_logging),     # :401
                              weights=_weights(weights, n), seed=seed, max_outer_iterations=max_outer_iterations,
-                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
+                             neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs, refit_solver=refit_solver)
     return _stack(est, models, 3), labels
 
 
@@ -272,7 +277,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
               neighborhood_ball_radius=200.0, maximum_tanimoto_similarity=0.4, max_iters=1000,
               minimum_point_number=10, maximum_model_number=-1, sampler_id=3, scoring_exponent=2,
               do_logging=False, *, seed=None, max_outer_iterations=10, neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     """bindings.cpp:247-322, progressivex_python.cpp:425-535.  Returns (lines[K,3], labels[n]).  Sampler ids 0/1/2
     (2 = NAPSAC here); the default 3 returns zero models; `weights` is parsed and ignored, as in the reference."""
     points = _as_f64(points)
@@ -290,7 +295,7 @@ def findLines(points, weights, w, h, threshold=2.0, conf=0.5, spatial_coherence_
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=scoring_exponent, do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs, refit_solver=refit_solver)
     return _stack(est, models, 3), labels
 
 
@@ -298,7 +303,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                 neighborhood_ball_radius=20.0, maximum_tanimoto_similarity=0.9, max_iters=400,
                 minimum_point_number=2 * 3, maximum_model_number=-1, *, seed=None, max_outer_iterations=10, scoring_exponent=2,
                 neighborhood="flann_like",
-                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double"):
+                     local_optimization="auto", labeling_l0="greedy", distributed=None, sampler_rng="numpy", trace=None, pearl_abs="double", refit_solver="lapack"):
     """bindings.cpp:9-97, progressivex_python.cpp:41-171.  Returns (P[(3K),4], labels[n]).
     scoring_exponent [keyword-only, not in the reference's signature]: the driver never calls setScoringExponent, so the class default
     2 applies (progressive_x.h:183) - the default here.  The compound-model score is value - shared^exponent
@@ -339,5 +344,5 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, conf=0.90, spatial_coherence_wei
                              maximum_tanimoto_similarity=maximum_tanimoto_similarity, max_iters=max_iters,
                              minimum_point_number=minimum_point_number, maximum_model_number=maximum_model_number,
                              scoring_exponent=int(scoring_exponent), do_logging=False, seed=seed,
-                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs)
+                             max_outer_iterations=max_outer_iterations, neighborhood=neighborhood, local_optimization=local_optimization, labeling_l0=labeling_l0, distributed=distributed, sampler_rng=sampler_rng, trace=trace, pearl_abs=pearl_abs, refit_solver=refit_solver)
     return _stack(est, models, 4), labels

@@ -22,6 +22,20 @@ class Estimator:
     rows_per_model = 1       # rows of the returned model array per instance (3 for 3x3 / 3x4 matrices)
     cols = 3
 
+    # The small dense solve of the refits: "lapack" (default) = numpy.linalg.eigh on the host; "jacobi" (round 6, keyword
+    # refit_solver= of the drop-in calls) = the context's batched cyclic-Jacobi solver (pgx_eigh_smallest_batch: on the device,
+    # bitwise the CPU restatement the tests hold; agrees with LAPACK to ~1e-13 on the eigenvector) - the eigen-solves behind the
+    # C ABI, the first step towards one C call per local-optimisation round.
+    refit_solver = "lapack"
+    _eig_ctx = None            # the context of the refit being run (set by nonminimal / nonminimal_labels / nonminimal_batch)
+
+    def _smallest(self, A):
+        """eigenvectors of the smallest eigenvalue of the symmetric matrices A [B, q, q] -> [B, q]"""
+        ctx = self._eig_ctx
+        if self.refit_solver == "jacobi" and ctx is not None and hasattr(ctx, "eigh_smallest_batch"):
+            return ctx.eigh_smallest_batch(A)[0]
+        return np.linalg.eigh(A)[1][:, :, 0]
+
     def minimal(self, pts, samples):
         """samples [S, m] -> (models [H, P], sample_of_model [H]); several or zero solutions per sample allowed."""
         raise NotImplementedError
@@ -51,6 +65,7 @@ class Estimator:
         """Least-squares fit to the selected resident points -> list of models (the reference accepts the refit only
         if exactly 1).  sel = ("index", indices) or ("label", k); the data pass runs on the device (ctx.gram =
         pgx_gram: weighted Gram matrix of the design rows), the small dense solve here."""
+        self._eig_ctx = ctx
         gen = self._fit(init)
         try:
             req = next(gen)
@@ -65,6 +80,7 @@ class Estimator:
         every step is ONE pgx_gram_labels launch for all labels (PEARL refits every instance per iteration; one host round
         trip per instance and step made that loop latency-bound).  Labels in `skip` are not fitted.  The Gram matrices
         are bit-identical to the single-label calls, so the results are those of K separate `nonminimal` calls."""
+        self._eig_ctx = ctx
         if hasattr(self, "_fit_many"):          # refit vectorised over the instances (same Gram launches, stacked small solves)
             live = [k for k in range(K) if k not in skip]
             out = [[] for _ in range(K)]
@@ -114,6 +130,7 @@ class Estimator:
         lockstep, each step is ONE pgx_gram_batch launch.  Returns a list of B model lists."""
         index = np.asarray(index)
         B, m = index.shape
+        self._eig_ctx = ctx
         if hasattr(self, "_fit_many"):           # refit vectorised over the batch (same Gram launches, stacked small solves)
             def gram(kind, prm, use_w, wpow, rows):
                 G, bad = ctx.gram_batch(kind, index[rows], params=prm, weights=weights if use_w else None, wpow=wpow)
@@ -230,8 +247,11 @@ class VanishingPointEstimator(Estimator):
         AtA, cnt, _ = yield (_lib.GRAM_VP, None, True, 2)
         if cnt < 2:
             return []
-        evals, evecs = np.linalg.eigh(AtA)                                        # :227 SelfAdjointEigenSolver
-        v = evecs[:, int(np.argmin(evals))]                                       # :230-233
+        if self.refit_solver == "jacobi":
+            v = self._smallest(AtA[None])[0]
+        else:
+            evals, evecs = np.linalg.eigh(AtA)                                    # :227 SelfAdjointEigenSolver
+            v = evecs[:, int(np.argmin(evals))]                                   # :230-233
         n = np.linalg.norm(v)
         return [v / n] if n > 0 else []
 
@@ -243,10 +263,14 @@ class VanishingPointEstimator(Estimator):
         idx = np.nonzero((cnt >= 2) & np.isfinite(AtA).all(axis=(1, 2)))[0]
         if idx.size == 0:
             return out
-        evals, evecs = np.linalg.eigh(AtA[idx])
-        pick = np.argmin(evals, axis=1)
+        if self.refit_solver == "jacobi":
+            vs = self._smallest(AtA[idx])
+        else:
+            evals, evecs = np.linalg.eigh(AtA[idx])
+            pick = np.argmin(evals, axis=1)
+            vs = np.array([evecs[k][:, int(pick[k])] for k in range(len(idx))])
         for k, b in enumerate(idx):
-            v = evecs[k][:, int(pick[k])]
+            v = vs[k]
             n = np.linalg.norm(v)
             if n > 0:
                 out[b] = [v / n]
@@ -368,7 +392,7 @@ class HomographyEstimator(Estimator):
         if cnt < 4:
             return []
         AtA, _, _ = yield (_lib.GRAM_DLT_H, prm, True, 2)                                  # normalised DLT rows
-        Hn = _smallest_eigenvector(AtA).reshape(3, 3)
+        Hn = (self._smallest(AtA[None])[0] if self.refit_solver == "jacobi" else _smallest_eigenvector(AtA)).reshape(3, 3)
         H = np.linalg.inv(T2) @ Hn @ T1
         if not np.isfinite(H).all() or abs(H[2, 2]) < 1e-300:
             return []
@@ -389,7 +413,7 @@ class HomographyEstimator(Estimator):
         if not fin.any():
             return out
         sel = np.nonzero(fin)[0]
-        Hn = np.linalg.eigh(AtA[sel])[1][:, :, 0].reshape(-1, 3, 3)
+        Hn = self._smallest(AtA[sel]).reshape(-1, 3, 3)
         H = np.linalg.inv(T2[sel]) @ Hn @ T1[sel]
         for k, r in enumerate(sel):
             Hb = H[k]
@@ -638,7 +662,7 @@ class FundamentalEstimator(Estimator):
         if cnt < 8:
             return []
         AtA, _, _ = yield (_lib.GRAM_EPI_F, prm, True, 2)                                  # normalised 8-point rows
-        F = _smallest_eigenvector(AtA).reshape(3, 3)
+        F = (self._smallest(AtA[None])[0] if self.refit_solver == "jacobi" else _smallest_eigenvector(AtA)).reshape(3, 3)
         u, s, v = np.linalg.svd(F)
         F = u @ np.diag([s[0], s[1], 0.0]) @ v
         F = T2.T @ F @ T1
@@ -661,7 +685,7 @@ class FundamentalEstimator(Estimator):
         sel = np.nonzero(np.isfinite(AtA).all(axis=(1, 2)))[0]
         if sel.size == 0:
             return out
-        F = np.linalg.eigh(AtA[sel])[1][:, :, 0].reshape(-1, 3, 3)
+        F = self._smallest(AtA[sel]).reshape(-1, 3, 3)
         okf = np.isfinite(F).all(axis=(1, 2))
         sel, F = sel[okf], F[okf]
         if sel.size == 0:

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch", "pgx_score_debug_geometry",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
-    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_graph_size",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_graph_size", "pgx_eigh_smallest_batch",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
@@ -633,6 +633,19 @@ class Context:
         self._ck(self._lib.pgx_expansion_paths(self._h, _ptr(st, C.c_int64)), "pgx_expansion_paths")
         return dict(one_workgroup=int(st[0]), memo=int(st[1]), region=int(st[2]), level_synchronous=int(st[3]),
                     region_declined=int(st[4]), tile_handed_back=int(st[5]))
+
+    def eigh_smallest_batch(self, A):
+        """pgx_eigh_smallest_batch: (vec [B, q], val [B]) - eigenvector and eigenvalue of the smallest eigenvalue of the symmetric
+        matrices A [B, q, q], q <= 9 (cyclic Jacobi on the device, one lane per matrix; bitwise the CPU restatement the tests hold)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if A.ndim != 3 or A.shape[1] != A.shape[2]:
+            raise PgxError("eigh_smallest_batch: A must be [B, q, q]")
+        B, q = A.shape[0], A.shape[1]
+        vec = np.zeros((B, q), dtype=np.float64)
+        val = np.zeros(B, dtype=np.float64)
+        self._ck(self._lib.pgx_eigh_smallest_batch(self._h, _ptr(A, C.c_double), C.c_int(q), C.c_int64(B), _ptr(vec, C.c_double),
+                                                   _ptr(val, C.c_double)), "pgx_eigh_smallest_batch")
+        return vec, val
 
     def expansion_schedule(self):
         """How the level-synchronous min-cut spent its dependent steps (include/pgx.h pgx_expansion_schedule)."""

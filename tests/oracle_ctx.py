@@ -112,6 +112,10 @@ class OracleContext:
                       wpow=wpow) for b in range(index.shape[0])]
         return np.array([r[0] for r in res]), np.array([r[2] for r in res], dtype=np.int32)
 
+    def eigh_smallest_batch(self, A):
+        vec, val, _ = O.eigh_smallest(A)
+        return vec, val
+
     def graph_build(self, points, kind, radius=0.0, k=5, fetch=True):
         self.graph = O.graph_build(points, kind, radius=radius, k=k)
         return self.graph if fetch else len(self.graph[1])

@@ -183,7 +183,7 @@ def soak(seed, trials, verbose=True, only=None):
                   neighborhood=str(rng.choice(["flann_like", "knn:6", "radius"])),
                   local_optimization=str(rng.choice(["auto", "lsq"])),
                   labeling_l0=str(rng.choice(["greedy", "expansion"])),
-                  sampler_rng=str(rng.choice(["numpy", "philox"])))
+                  sampler_rng=str(rng.choice(["numpy", "philox"])), refit_solver=str(rng.choice(["lapack", "lapack", "jacobi"])))
         K = int(rng.integers(1, 5))
         per = int(rng.choice([40, 150, 400, 1500]))
         nout = int(rng.choice([0, 50, 400]))

@@ -32,7 +32,7 @@ def problem(rng, trial):
               local_optimization=str(rng.choice(["auto", "lsq"])),
               labeling_l0=str(rng.choice(["greedy", "expansion"])),
               sampler_rng=str(rng.choice(["numpy", "philox"])),
-              pearl_abs=str(rng.choice(["double", "double", "int"])),
+              pearl_abs=str(rng.choice(["double", "double", "int"])), refit_solver=str(rng.choice(["lapack", "lapack", "jacobi"])),
               max_outer_iterations=int(rng.choice([10, 10, 14])))
     K = int(rng.integers(1, 5))
     per = int(rng.choice([40, 150, 400, 1000]))

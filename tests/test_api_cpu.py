@@ -121,3 +121,25 @@ def test_samplers_return_distinct_indices_even_when_n_is_close_to_m():
     # the exact fallback is uniform: every index equally likely in every column
     s = _proposal.UniformSampler(8, rng).draw(40000, 7)
     assert np.abs(np.bincount(s[:, 0], minlength=8) / 40000 - 0.125).max() < 0.01
+
+
+def test_refit_solver_switch_on_the_cpu_restatement(monkeypatch):
+    """refit_solver="jacobi" (round 6): the refits' eigen-solves through the context's batched Jacobi solver instead of numpy.  Same
+    labels and the same models to 1e-9 on a homography and a vanishing-point scene; an unknown value is refused."""
+    import pyprogressivex as px
+    from oracle_ctx import OracleContext
+    from pyprogressivex import _api, datasets
+    monkeypatch.setattr(_api, "_ctx", OracleContext())
+    pts, gt, _ = datasets.make_homographies(n_per_plane=200, n_planes=3, n_outliers=200, seed=3)
+    kw = dict(threshold=3.0, conf=0.99, sampler_id=0, seed=4, minimum_point_number=40, max_iters=300)
+    H0, l0 = px.findHomographies(pts, 1000, 1000, 1000, 1000, **kw)
+    H1, l1 = px.findHomographies(pts, 1000, 1000, 1000, 1000, refit_solver="jacobi", **kw)
+    assert H0.shape == H1.shape and H0.shape[0] >= 9 and np.array_equal(l0, l1) and np.allclose(H0, H1, rtol=1e-9, atol=1e-12)
+    seg, gt, _ = datasets.make_vanishing_points(n_inliers=900, n_vps=3, n_outliers=300, seed=2)
+    kw = dict(threshold=1.5, conf=0.99, sampler_id=0, seed=1, minimum_point_number=100)
+    V0, l0 = px.findVanishingPoints(seg, np.array(0), 1000, 1000, **kw)
+    V1, l1 = px.findVanishingPoints(seg, np.array(0), 1000, 1000, refit_solver="jacobi", **kw)
+    assert V0.shape == V1.shape and V0.shape[0] >= 3 and np.array_equal(l0, l1)
+    assert np.allclose(np.abs((V0 * V1).sum(1)), 1.0, atol=1e-9)          # unit vectors up to sign
+    with pytest.raises(ValueError):
+        px.findHomographies(pts, 1000, 1000, 1000, 1000, refit_solver="eigen", threshold=3.0)

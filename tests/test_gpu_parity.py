@@ -2044,3 +2044,50 @@ def test_graph_fetch_sizes_follow_the_resident_graph(gpu_ctx, oracle):
     again = gpu_ctx.graph_build(small, _lib.GRAPH_KNN, k=3)
     for a, b in zip(again, built):
         assert np.array_equal(a, b)
+
+
+def test_device_jacobi_eigen_solver_is_bitwise_the_oracles(gpu_ctx, oracle):
+    """pgx_eigh_smallest_batch (round 6: the refits' small dense solve behind the C ABI): one lane per matrix runs the cyclic Jacobi
+    of the oracle's pgxo_eigh_smallest in the same operation order - eigenvectors and eigenvalues must be array_equal, for every
+    size the refits use, badly scaled and degenerate matrices included (the LAPACK agreement of that algorithm, with its stated
+    tolerance, is the CPU test tests/test_oracle.py)."""
+    rng = np.random.default_rng(44)
+    for q in (1, 2, 3, 6, 9):
+        X = rng.standard_normal((257, 25, q))
+        A = np.einsum("bni,bnj->bij", X, X)
+        A[:30] *= 1e-12
+        A[30:60] *= 1e12
+        A[60:70] = 0.0
+        A[70] = np.eye(q)
+        A[71, 0, 0] = np.nan
+        A[72:80, :, 0] *= 1e-5
+        A[72:80, 0, :] *= 1e-5
+        vec, val = gpu_ctx.eigh_smallest_batch(A)
+        rvec, rval, _ = oracle.eigh_smallest(A)
+        assert np.array_equal(vec, rvec, equal_nan=True) and np.array_equal(val, rval, equal_nan=True), q
+    with pytest.raises(_lib.PgxError):
+        gpu_ctx.eigh_smallest_batch(np.zeros((2, 10, 10)))
+
+
+def test_refit_solver_jacobi_on_the_gpu_equals_the_cpu_restatement(monkeypatch):
+    """the drop-in calls with refit_solver="jacobi": GPU (device Jacobi) against the same host code on the oracle context (the oracle's
+    Jacobi) - labels equal, models to 1e-9 (the Gram sums differ by summation order, as with LAPACK) - and against the default solver"""
+    import pyprogressivex as px
+    from oracle_ctx import OracleContext
+    from pyprogressivex import _api
+    pts, gt, _ = datasets.make_homographies(n_per_plane=300, n_planes=3, n_outliers=400, seed=5)
+    kw = dict(threshold=3.0, conf=0.99, sampler_id=0, seed=2, minimum_point_number=40)
+    monkeypatch.setattr(_api, "_ctx", None)
+    Hg, lg = px.findHomographies(pts, 1000, 1000, 1000, 1000, refit_solver="jacobi", **kw)
+    Hd, ld = px.findHomographies(pts, 1000, 1000, 1000, 1000, **kw)
+    monkeypatch.setattr(_api, "_ctx", OracleContext())
+    Hc, lc = px.findHomographies(pts, 1000, 1000, 1000, 1000, refit_solver="jacobi", **kw)
+    assert Hg.shape[0] >= 9 and np.array_equal(lg, lc) and np.allclose(Hg, Hc, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(lg, ld) and np.allclose(Hg, Hd, rtol=1e-9, atol=1e-12)
+    p3, g3, _ = datasets.make_two_view_motions(n_per_motion=400, n_motions=2, n_outliers=300, seed=9)
+    kw = dict(threshold=0.75, conf=0.99, sampler_id=0, seed=3, minimum_point_number=50, max_iters=500)
+    monkeypatch.setattr(_api, "_ctx", None)
+    Fg, lg = px.findTwoViewMotions(p3, 1000, 1000, 1000, 1000, refit_solver="jacobi", **kw)
+    monkeypatch.setattr(_api, "_ctx", OracleContext())
+    Fc, lc = px.findTwoViewMotions(p3, 1000, 1000, 1000, 1000, refit_solver="jacobi", **kw)
+    assert Fg.shape == Fc.shape and Fg.shape[0] >= 3 and np.array_equal(lg, lc)

@@ -505,3 +505,39 @@ def test_round2_golden_vectors(oracle):
     cid, members = pn.cells[-1]                     # coarsest layer (2 cells per dimension)
     local = sum(set(r[:3]).issubset(set(members[int(cid[r[3]])].tolist())) for r in draw[:150])
     assert local >= 100                             # the rest fell through to the global PROSAC sampler
+
+
+def test_jacobi_eigen_solver_against_lapack_and_by_hand(oracle):
+    """Round 6: the refits' small dense solve restated as cyclic Jacobi (pgxo_eigh_smallest; the device kernel runs the same operation
+    order and must return the same bits: tests/test_gpu_parity.py).  Against numpy's LAPACK, tolerance stated: the eigenVALUE to
+    64 eps relative to the spectral radius; the sign-normalised eigenVECTOR to 1e-12 when the smallest eigenvalue is separated from the
+    next by >= 1e-3 of the spectral radius (the refits' A^T A of noisy data), and always an eigenvector in the residual sense
+    |A v - val v| <= 1e-13 |A|.  Known answers: diag(3, 1, 2) -> e_2; [[2, 1], [1, 2]] -> (1, -1) / sqrt 2 with value 1."""
+    vec, val, sw = oracle.eigh_smallest(np.array([np.diag([3.0, 1.0, 2.0])]))
+    assert np.array_equal(vec[0], [0.0, 1.0, 0.0]) and val[0] == 1.0 and sw[0] == 0
+    vec, val, _ = oracle.eigh_smallest(np.array([[[2.0, 1.0], [1.0, 2.0]]]))
+    assert abs(val[0] - 1.0) < 1e-15 and np.allclose(np.abs(vec[0]), np.sqrt(0.5), atol=1e-15) and vec[0][0] * vec[0][1] < 0
+    rng = np.random.default_rng(12)
+    for q in (2, 3, 7, 9):
+        X = rng.standard_normal((300, 30, q))
+        A = np.einsum("bni,bnj->bij", X, X)
+        A[:40] *= 1e-9
+        A[40:80] *= 1e9
+        A[80:100, :, 0] *= 1e-4              # badly scaled columns (what Hartley normalisation is there to avoid)
+        A[80:100, 0, :] *= 1e-4
+        vec, val, sw = oracle.eigh_smallest(A)
+        w, V = np.linalg.eigh(A)
+        rad = np.abs(w).max(axis=1)
+        assert (np.abs(val - w[:, 0]) <= 64 * 2.3e-16 * rad).all()
+        res = np.abs(np.einsum("bij,bj->bi", A, vec) - val[:, None] * vec).max(axis=1)
+        assert (res <= 1e-13 * rad).all() and np.allclose((vec * vec).sum(1), 1.0, atol=1e-14)
+        gap = (w[:, 1] - w[:, 0]) >= 1e-3 * rad
+        sgn = np.sign((V[:, :, 0] * vec).sum(axis=1))
+        assert gap.sum() > 100 and np.abs(vec * sgn[:, None] - V[:, :, 0])[gap].max() <= 1e-12
+        assert sw.max() <= 12
+    # NaN / Inf / zero matrices come back without hanging (NaN rows stay NaN, the zero matrix gives e_0 with value 0)
+    bad = np.zeros((3, 3, 3))
+    bad[0, 1, 1] = np.nan
+    bad[1, 0, 2] = bad[1, 2, 0] = np.inf
+    vec, val, sw = oracle.eigh_smallest(bad)
+    assert np.array_equal(vec[2], [1.0, 0.0, 0.0]) and val[2] == 0.0
