@@ -237,6 +237,12 @@ int pgx_expansion_paths(pgx_ctx *ctx, int64_t paths[6]);
  * launched one by one (the labelling roofline charges a list sweep by its list, not by the graph), [6]=BFS levels and [7]=list
  * sweeps that ran inside those persistent launches (dependent steps that were not launches) */
 int pgx_expansion_schedule(pgx_ctx *ctx, int64_t out[8]);
+/* whole-graph one-workgroup moves (pgx_expansion_paths [0]) ENQUEUED since pgx_create, by kernel: [0]=the LDS-resident solver
+ * (graphs of <= 1024 sites and <= 8192 arcs: arc capacities, excesses, heights and hub words in LDS, the site's own state in the
+ * registers of its thread - csrc/maxflow_tile.hip t_mini_kernel; PGX_TILE_MINI=0 switches it off), [1]=the solver that keeps the
+ * capacities in memory (<= 8192 sites, t_move_kernel).  Same binary problem and cut as every other schedule; tests use the counts to
+ * know which kernel they compared with the oracle. */
+int pgx_one_workgroup_launches(pgx_ctx *ctx, int64_t out[2]);
 
 /* ---- a9 (SURVEY 8f "next", rank 3): the data pass of estimator.estimateModelNonminimal(...) as called by
  * PEARL::parameterEstimation (PEARL.h:374-380) and by the proposal engine's local optimisation.  The device accumulates

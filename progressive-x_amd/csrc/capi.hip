@@ -116,6 +116,8 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_MF_XCD_MIN_DEPTH")) ctx->mf_xcd_min_depth = std::atoi(b);
     if (const char* b = std::getenv("PGX_MF_XCD_MAXN")) ctx->mf_xcd_max_n = std::atoll(b);
     if (const char* b = std::getenv("PGX_MF_SWEEPS")) ctx->mf_sweeps = std::atoi(b);
+    if (const char* b = std::getenv("PGX_TILE_MINI")) ctx->tile_mini = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_MINI_SWEEPS")) { const int v = std::atoi(b); ctx->tile_mini_sweeps = v < 1 ? 1 : v; }
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
     return PGX_OK;
@@ -1130,6 +1132,14 @@ int pgx_expansion_schedule(pgx_ctx* ctx, int64_t out[8])
 {
     if (!ctx || !out) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion_schedule: NULL argument");
     return maxflow_schedule_stats(ctx, out);
+}
+
+int pgx_one_workgroup_launches(pgx_ctx* ctx, int64_t out[2])
+{
+    if (!ctx || !out) return fail(ctx, PGX_ERR_INVALID, "pgx_one_workgroup_launches: NULL argument");
+    out[0] = ctx->tile_launches[0];
+    out[1] = ctx->tile_launches[1];
+    return PGX_OK;
 }
 
 int pgx_bucket(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)

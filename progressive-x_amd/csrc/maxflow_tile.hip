@@ -700,6 +700,335 @@ __global__ __launch_bounds__(NT) void t_move_kernel(TView v, int sweeps, int max
     }
 }
 
+// ---- the whole move in LDS: graphs of <= 1024 sites and <= 8192 arcs -------------------------------------------------------------
+// t_move_kernel keeps heights and excesses in LDS but arc capacities, t-links and hub words in memory: on the reference's own scenes
+// (unionhouse: 332 sites, 2 168 arcs) a move was 118 us - a few hundred dependent trips to the L2 (an atomic on an arc, a hub word, a
+// row of capacities), whatever the width of the workgroup.  Here EVERYTHING the move touches lives in LDS or in its site's registers -
+// arc tables, capacities, excesses, heights, the hubs' excess and height in LDS; the site's t-link, hub flow, label and row bounds in
+// the registers of the ONE thread that owns the site (the workgroup is at least as wide as the graph) - and memory is read once
+// (labels, unary costs, the CSR: two dependent round trips) and written once (the labels of the sites that take alpha).  With the
+// hubs in LDS a hub is an ordinary node: when no member with a t-link is left below it, a member WITHOUT one pulls the excess and
+// passes it on (t_move_kernel hands such a move back to maxflow.hip).
+// The move is the same binary problem with the same answer (unique minimal sink side, fixed-point capacities): any schedule of
+// capacity-respecting pushes is a preflow, and the move ends when an exact search from scratch shows that no excess reaches t.
+// Every row scan loads its arcs eight at a time BEFORE it looks at any of them: two dependent LDS round trips per eight arcs instead
+// of three per arc (with one-arc-at-a-time loops a step of the search was 3.2 us on 332 sites and a sweep 3.9 us: nothing but that chain).
+constexpr int kMiniSites = 1024, kMiniArcs = 8192;
+
+struct MiniLds {
+    long long cap[kMiniArcs];
+    long long ex[kMiniSites];
+    int d[kMiniSites];
+    unsigned short idx[kMiniArcs], rev[kMiniArcs];
+    unsigned char lab[kMiniSites];
+    long long hube[kMaxL];
+    unsigned long long pool[kMaxL];
+    int hubd[kMaxL], cnt[kMaxL];
+    unsigned char hubx[kMaxL];
+    int note[3];               // per step: bit 0 something changed / was pushed, bit 1 flow reached t (three slots in rotation: one barrier per step)
+    int s_open;
+    unsigned long long s_stuck;
+};
+
+// take up to `want` out of an LDS budget (reserve_ag above, workgroup scope)
+__device__ __forceinline__ long long mini_reserve(long long* budget, long long want)
+{
+    if (want <= 0) return 0;
+    const long long old = (long long)atomicAdd((unsigned long long*)budget, (unsigned long long)(-want));
+    if (old >= want) return want;
+    const long long got = old > 0 ? old : 0;
+    atomicAdd((unsigned long long*)budget, (unsigned long long)(want - got));
+    return got;
+}
+
+// one barrier per step: every WAVE ORs its bits into the step's slot and everybody reads it behind the barrier; thread 0 clears the slot
+// read one step earlier (nobody reads it again, and it is written next two barriers from now).  The wave's OR is two ballots: an
+// atomicOr of every lane on one LDS word is turned by the compiler into a scalar loop over the active lanes (~30 clocks per lane: 2 us
+// per step with the workgroup's lanes active - scripts/micro/lds_chain_bench.hip), which was most of a step.
+__device__ __forceinline__ int mini_vote(MiniLds& L, int& step, const int bits)
+{
+    const int slot = step % 3;
+    const int wb = (__ballot(bits & 1) ? 1 : 0) | (__ballot(bits & 2) ? 2 : 0);
+    if (wb && (threadIdx.x & 63) == 0) atomicOr(&L.note[slot], wb);
+    __syncthreads();
+    const int r = L.note[slot];
+    if (threadIdx.x == 0) L.note[(step + 2) % 3] = 0;
+    ++step;
+    return r;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void t_mini_kernel(TView v, int sweeps, int max_rounds)
+{
+    __shared__ MiniLds L;
+    const int tid = (int)threadIdx.x;
+    if (v.ctl) {   // a move of a batch (t_move_kernel)
+        if (batch_skips(v.ctl, v.skip_rel)) return;
+        if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
+    }
+    const int n = (int)v.n;   // <= NT (the host picks the width): thread i owns site i
+    unsigned long long tprev = wall_clock64();
+    auto lap = [&](int k) {   // (debug) time since the last lap goes to slot k
+        if (v.dbg && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
+    };
+    // ---- the problem into LDS and registers.  Round trip 1: the site's place and row; 2: its label, costs and (all threads together)
+    // the arc tables; behind the barrier the rows turn the arc weights into capacities.
+    const bool valid = tid < n;
+    const int64_t o = valid ? v.perm[tid] : 0;
+    const int a0 = valid ? v.off[tid] : 0, a1 = valid ? v.off[tid + 1] : 0;
+    const int E = v.off[n];
+    if (tid < kMaxL) { L.cnt[tid] = 0; L.pool[tid] = 0ull; }
+    if (tid < 3) L.note[tid] = 0;
+    if (tid == 0) { L.s_open = 0; L.s_stuck = 0; }
+    __syncthreads();
+    const int lu = valid ? v.labels[o] : v.alpha;
+    const long long take = valid ? v.dq[(int64_t)v.alpha * v.n + o] : 0;
+    for (int a = tid; a < E; a += NT) {
+        L.idx[a] = (unsigned short)v.idx[a];
+        L.rev[a] = (unsigned short)v.rev[a];
+        if (!v.wq) L.cap[a] = v.lambda_q * (long long)v.mult[a];
+    }
+    const bool mine_alpha = lu == v.alpha;   // (a site that carries alpha takes no part)
+    long long keep = (valid && !mine_alpha) ? v.dq[(int64_t)lu * v.n + o] : 0;
+    if (valid) { L.lab[tid] = (unsigned char)lu; atomicAdd(&L.cnt[lu], 1); L.d[tid] = kInf; }
+    if (v.wq && valid) {   // per-arc weights in the ORIGINAL arc order: rows keep their entry order
+        const long long* const wrow = v.wq + v.goff[o] - a0;
+        for (int a = a0; a < a1; ++a) L.cap[a] = wrow[a];
+    }
+    __syncthreads();
+    if (tid < kMaxL) {
+        const bool ex = tid < v.L && v.h_q > 0 && tid != v.alpha && L.cnt[tid] > 0;
+        L.hubx[tid] = ex ? 1 : 0;
+        L.hube[tid] = ex ? v.h_q : 0ll;
+        L.hubd[tid] = kInf;
+    }
+    const int cnt_alpha = L.cnt[v.alpha];
+    long long rt = 0, f = 0;   // the site's t-link and what it holds of its hub's flow: only its own thread touches them
+    if (valid) {
+        long long e0 = 0;
+        for (int ab = a0; ab < a1; ab += 8) {
+            long long w[8];
+            int lq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int a = ab + q < a1 ? ab + q : a1 - 1; w[q] = L.cap[a]; lq[q] = L.idx[a]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lq[q] = L.lab[lq[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (ab + q >= a1) continue;
+                long long c;
+                if (mine_alpha || lq[q] == v.alpha) { keep += w[q]; c = 0; }
+                else if (lq[q] == lu) c = w[q];
+                else { keep += w[q] / 2; c = w[q] / 2; }
+                L.cap[ab + q] = c;
+            }
+        }
+        if (!mine_alpha) {
+            if (keep > take) e0 = keep - take;
+            else rt = take - keep;
+            if (rt <= 0) L.s_open = 1;
+            else if (v.h_q > 0) atomicAdd(&L.pool[lu], (unsigned long long)rt);
+        }
+        L.ex[tid] = e0;
+    }
+    __syncthreads();
+    // a move nobody can want (t_move_kernel): no site without a t-link and every hub drains into its members' t-links with room to spare
+    const bool thin = tid < kMaxL && L.hubx[tid] && L.pool[tid] <= (unsigned long long)v.h_q;
+    const int thin_any = __syncthreads_or(thin ? 1 : 0);
+    if (L.s_open == 0 && thin_any == 0) return;   // flags stay zero: nothing relabelled, no rounds, not given up
+    const bool any_hub = __syncthreads_or((tid < kMaxL && L.hubx[tid]) ? 1 : 0) != 0;
+    const bool part = valid && !mine_alpha;           // the site is in the move's graph
+    // the row's first 16 neighbours stay in registers (slots beyond the row name the site itself: harmless in a min over heights): the LDS
+    // serves every wave of the workgroup one instruction at a time, and a step's cost is the number of LDS instructions its waves issue
+    int nb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) nb[q] = (part && a0 + q < a1) ? (int)L.idx[a0 + q] : (valid ? tid : 0);
+    const bool long_row = part && a1 - a0 > 16;
+    const bool any_long = __syncthreads_or(long_row ? 1 : 0) != 0;
+    const bool my_hub = part && L.hubx[lu] != 0;      // its label has a hub
+    lap(0);
+    int rounds = 0, gave_up = 0, step = 0;
+    int du = kInf;
+    int n_steps = 0, n_sweeps = 0;   // (debug)
+    for (;; ++rounds) {
+        // ---- search: exact distances to t by label correction from "unreachable" (values only fall, each witnessed by a residual path;
+        // the fixpoint of d = 1 + min over residual arcs is the distance labelling).  A hub is a node: below every member (inf arc
+        // y -> member), above a member that holds hub flow (f > 0).
+        du = (part && rt > 0) ? 1 : kInf;
+        if (valid) L.d[tid] = du;
+        if (tid < kMaxL) L.hubd[tid] = kInf;
+        __syncthreads();
+        lap(1);
+        const bool open = part && !(rt > 0);
+        unsigned resm = 0;   // residual arcs among the row's first 16 (capacities do not change during a search)
+        if (open) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const long long c = L.cap[a0 + q < a1 ? a0 + q : a0]; if (a0 + q < a1 && c > 0) resm |= 1u << q; }
+        }
+        for (bool first = true;; first = false) {
+            int bits = 0;
+            bool lowered = false;
+            if (open) {
+                int m = kInf;
+                {
+                    int h[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) h[q] = L.d[nb[q]];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (((resm >> q) & 1u) && h[q] < m) m = h[q];
+                }
+                if (any_long)
+                    for (int a = a0 + 16; a < a1; ++a)
+                        if (L.cap[a] > 0) { const int h = L.d[L.idx[a]]; m = h < m ? h : m; }
+                if (my_hub && f > 0) { const int h = L.hubd[lu]; m = h < m ? h : m; }
+                const int nd = m >= kInf ? kInf : m + 1;
+                if (nd < du) { du = nd; L.d[tid] = nd; lowered = true; bits = 1; }
+            }
+            if (my_hub && (first || lowered) && du < kInf && du + 1 < L.hubd[lu])
+                if (atomicMin(&L.hubd[lu], du + 1) > du + 1) bits = 1;
+            ++n_steps;
+            if (!mini_vote(L, step, bits)) break;
+        }
+        lap(2);
+        // ---- who holds excess that reaches t
+        {
+            int bits = (part && du < kInf && L.ex[tid] > 0) ? 1 : 0;
+            if (any_hub && tid < kMaxL && L.hubx[tid] && L.hube[tid] > 0 && L.hubd[tid] < kInf) bits |= 2;
+            const int r = mini_vote(L, step, bits);
+            lap(5);
+            if (r == 0) break;   // no site and no hub holds excess that reaches t
+        }
+        if (rounds >= max_rounds) { gave_up = 1; break; }
+        // ---- discharge: sweeps over all sites, one barrier each
+        int stall = 0;
+        for (int s = 0; s < sweeps; ++s) {
+            int bits = 0;
+            if (part && du < kInf) {
+                // the hub above this site holds excess: a member with a t-link takes what the link carries (hub -> member -> t), a member
+                // without one takes it all and passes it on below
+                if (my_hub && du < L.hubd[lu]) {
+                    const long long he = L.hube[lu];
+                    if (he > 0) {
+                        const long long got = mini_reserve(&L.hube[lu], rt > 0 ? rt : he);
+                        if (got > 0) {
+                            f += got;
+                            if (rt > 0) { rt -= got; bits |= 3; }
+                            else { atomicAdd((unsigned long long*)&L.ex[tid], (unsigned long long)got); bits |= 1; }
+                        }
+                    }
+                }
+                long long e = L.ex[tid];
+                if (e > 0) {
+                    bits |= 1;
+                    long long pushed = 0;
+                    if (rt > 0) {
+                        const long long dl = e < rt ? e : rt;
+                        rt -= dl;
+                        e -= dl;
+                        pushed += dl;
+                        bits |= 2;
+                    }
+                    if (e > 0) {
+                        int minh = kInf;
+                        {   // the row's first 16 arcs: neighbours from registers, capacities and heights in two rounds of loads
+                            long long c[16];
+                            int h[16];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) c[q] = L.cap[a0 + q < a1 ? a0 + q : a0];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) h[q] = L.d[nb[q]];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                if (a0 + q >= a1 || c[q] <= 0) continue;
+                                if (h[q] < du && e > 0) {
+                                    const long long dl = e < c[q] ? e : c[q];
+                                    atomicAdd((unsigned long long*)&L.cap[a0 + q], (unsigned long long)(-dl));
+                                    atomicAdd((unsigned long long*)&L.cap[L.rev[a0 + q]], (unsigned long long)dl);
+                                    atomicAdd((unsigned long long*)&L.ex[nb[q]], (unsigned long long)dl);
+                                    e -= dl;
+                                    pushed += dl;
+                                    c[q] -= dl;
+                                }
+                                if (c[q] > 0 && h[q] < minh) minh = h[q];
+                            }
+                        }
+                        if (any_long)
+                            for (int a = a0 + 16; a < a1; ++a) {
+                                long long c = L.cap[a];
+                                if (c <= 0) continue;
+                                const int w = L.idx[a];
+                                const int h = L.d[w];
+                                if (h < du && e > 0) {
+                                    const long long dl = e < c ? e : c;
+                                    atomicAdd((unsigned long long*)&L.cap[a], (unsigned long long)(-dl));
+                                    atomicAdd((unsigned long long*)&L.cap[L.rev[a]], (unsigned long long)dl);
+                                    atomicAdd((unsigned long long*)&L.ex[w], (unsigned long long)dl);
+                                    e -= dl;
+                                    pushed += dl;
+                                    c -= dl;
+                                }
+                                if (c > 0 && h < minh) minh = h;
+                            }
+                        if (e > 0 && my_hub && f > 0) {   // residual site -> hub: what the site received from it
+                            const int hd = L.hubd[lu];
+                            long long left = f;
+                            if (hd < du) {
+                                const long long dl = e < f ? e : f;
+                                f -= dl;
+                                atomicAdd((unsigned long long*)&L.hube[lu], (unsigned long long)dl);
+                                e -= dl;
+                                pushed += dl;
+                                left = f;
+                            }
+                            if (left > 0 && hd < minh) minh = hd;
+                        }
+                        if (e > 0) {   // nothing admissible left: relabel (heights only rise here; the next search resets them)
+                            const int nd = minh >= kInf ? kInf : minh + 1;
+                            if (nd > du) { du = nd; L.d[tid] = nd; }
+                        }
+                    }
+                    if (pushed > 0) atomicAdd((unsigned long long*)&L.ex[tid], (unsigned long long)(-pushed));
+                }
+            }
+            ++n_sweeps;
+            const int r = mini_vote(L, step, bits);
+            if (!(r & 1)) break;                 // no site holds excess it could move, no hub was pulled
+            stall = (r & 2) ? 0 : stall + 1;     // nothing has reached t for a while: the next exact search settles what is left
+            if (stall >= 6) break;
+        }
+        lap(8);
+    }
+    lap(7);
+    int changed = 0;
+    if (!gave_up) {
+        bool apply = true;
+        if (cnt_alpha == 0 && v.h_q > 0) {   // alpha is not in use: taking it costs h once (maxflow_body.hip.h, gate)
+            // stranded excess: of the sites that do not reach t (du: the distance of the LAST search) and of the hubs (none reaches t here)
+            if (part && du == kInf) { const long long e = L.ex[tid]; if (e > 0) atomicAdd(&L.s_stuck, (unsigned long long)e); }
+            if (tid < kMaxL && L.hubx[tid] && L.hube[tid] > 0) atomicAdd(&L.s_stuck, (unsigned long long)L.hube[tid]);
+            __syncthreads();
+            apply = (long long)L.s_stuck >= v.h_q;
+        }
+        if (apply) {
+            const bool takes = part && du == kInf;   // cannot reach t => takes alpha (du: the distance of the LAST search, no sweep behind it)
+            if (takes) v.labels[o] = v.alpha_apply;
+            changed = __syncthreads_count(takes ? 1 : 0);
+        }
+    }
+    lap(10);
+    if (v.dbg && tid == 0) { v.dbg[11] += n_steps; v.dbg[12] += rounds; v.dbg[13] += n_sweeps; }
+    if (tid == 0) {
+        if (changed) add32_ag(&v.flags[1], changed);
+        st32<SC_AG>(&v.flags[4], rounds + 1);
+        st32<SC_AG>(&v.flags[5], gave_up);
+        if (v.ctl) {
+            if (gave_up) st32<SC_AG>(&v.ctl[0], 1);
+            else if (changed) add32_ag(&v.ctl[1], 1);
+        }
+    }
+}
+
 // ---- region moves: the few sites without a t-link, compacted, solved by one workgroup ------------------------------------------
 // In a steady-state move almost every active site has residual capacity to t (it prefers its label): such a site is level 1 of
 // every search and a sink for its neighbours.  What a search and the pushes actually work on are the OPEN sites - no t-link:
@@ -1032,8 +1361,14 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     }
     if (!defer) PGX_HIP(ctx, hipMemsetAsync(sp, 0, SmallLayout::bytes, ctx->stream));
     const int sweeps = ctx->tile_sweeps, max_rounds = 4096;
-    if (n <= 4096) hipLaunchKernelGGL((t_move_kernel<1024, 4, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
+    if (ctx->tile_mini && n <= kMiniSites && E <= kMiniArcs) {   // everything in LDS (t_mini_kernel)
+        if (n <= 256) hipLaunchKernelGGL(t_mini_kernel<256>, dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_mini_sweeps, max_rounds);
+        else if (n <= 512) hipLaunchKernelGGL(t_mini_kernel<512>, dim3(1), dim3(512), 0, ctx->stream, v, ctx->tile_mini_sweeps, max_rounds);
+        else hipLaunchKernelGGL(t_mini_kernel<1024>, dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_mini_sweeps, max_rounds);
+        ctx->tile_launches[0] += 1;
+    } else if (n <= 4096) hipLaunchKernelGGL((t_move_kernel<1024, 4, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
     else hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, sweeps, max_rounds);
+    if (!(ctx->tile_mini && n <= kMiniSites && E <= kMiniArcs)) ctx->tile_launches[1] += 1;
     PGX_HIP(ctx, hipGetLastError());
     if (defer) return PGX_REGION_PENDING;
     char* hs = (char*)ts->h_small;
@@ -1049,9 +1384,10 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
             std::fprintf(stderr, "[tile] alpha=%d rounds=%d gave_up=%d changed=%d\n", alpha, h_flags[4], h_flags[5], h_flags[1]);
         if (ts->dbg_moves % 500 == 0 || ctx->tile_debug >= 2) {
             const double m = 100.0 * (double)ts->dbg_moves;
-            std::fprintf(stderr, "[tile] %lld moves, us per move: setup %.1f | reset %.1f search %.1f | count %.1f | decide %.1f discharge %.1f | apply %.1f\n",
+            std::fprintf(stderr, "[tile] %lld moves, us per move: setup %.1f | reset %.1f search %.1f | count %.1f | decide %.1f discharge %.1f | apply %.1f; per move (LDS-resident kernel only): search steps %.1f, discharges %.2f, sweeps %.1f\n",
                          ts->dbg_moves, ts->dbg_acc[0] / m, ts->dbg_acc[1] / m, ts->dbg_acc[2] / m, ts->dbg_acc[5] / m, ts->dbg_acc[7] / m,
-                         ts->dbg_acc[8] / m, ts->dbg_acc[10] / m);
+                         ts->dbg_acc[8] / m, ts->dbg_acc[10] / m, (double)ts->dbg_acc[11] / (double)ts->dbg_moves, (double)ts->dbg_acc[12] / (double)ts->dbg_moves,
+                         (double)ts->dbg_acc[13] / (double)ts->dbg_moves);
         }
     }
     if (h_flags[5] != 0) return PGX_TILE_FALLBACK;

@@ -155,6 +155,9 @@ struct pgx_ctx {
     int mf_sweeps = 0;           // PGX_MF_SWEEPS: sweeps per round, list mode and all-sites alike (0 = the measured defaults; tests shorten the rounds)
     int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
+    int tile_mini = 1;           // PGX_TILE_MINI=0: graphs of <= 1024 sites and <= 8192 arcs go through t_move_kernel too (A/B; default: the LDS-resident t_mini_kernel)
+    int64_t tile_launches[2] = {0, 0};   // pgx_one_workgroup_launches: whole-graph moves enqueued on t_mini_kernel / on t_move_kernel
+    int tile_mini_sweeps = 24;   // PGX_TILE_MINI_SWEEPS: sweeps between two exact searches of t_mini_kernel
     int64_t paths[6] = {0, 0, 0, 0, 0, 0};   // pgx_expansion_paths
     int region_defer = 0;        // region moves are enqueued without a host round trip (pgx_expansion's batches): slot / skip rule below
     int region_slot = 0;

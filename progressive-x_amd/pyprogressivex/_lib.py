@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch", "pgx_score_debug_geometry",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
-    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_graph_size", "pgx_eigh_smallest_batch",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_one_workgroup_launches", "pgx_graph_size", "pgx_eigh_smallest_batch",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
@@ -653,6 +653,12 @@ class Context:
         self._ck(self._lib.pgx_expansion_schedule(self._h, _ptr(st, C.c_int64)), "pgx_expansion_schedule")
         return dict(xcd_round_launches=int(st[0]), xcd_rounds=int(st[1]), xcd_launches_finished=int(st[2]), xcd_searches=int(st[3]),
                     xcd_list_sites=int(st[4]), list_sites=int(st[5]), xcd_levels=int(st[6]), xcd_sweeps=int(st[7]))
+
+    def one_workgroup_launches(self):
+        """Whole-graph one-workgroup moves enqueued so far, by kernel (include/pgx.h pgx_one_workgroup_launches)."""
+        st = np.zeros(2, dtype=np.int64)
+        self._ck(self._lib.pgx_one_workgroup_launches(self._h, _ptr(st, C.c_int64)), "pgx_one_workgroup_launches")
+        return dict(lds_resident=int(st[0]), memory_resident=int(st[1]))
 
     def bucket(self, L, want_order=True):
         counts = np.zeros(L, dtype=np.int64)

@@ -561,7 +561,10 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
 MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0"},
-                "region": {"PGX_MF_TILE": "0"}}
+                "region": {"PGX_MF_TILE": "0"},
+                # the one-workgroup solver that keeps the capacities in memory, also where the LDS-resident one would take the move
+                "one_workgroup_memory": {"PGX_TILE_MINI": "0"}}
+MINCUT_COUNTED_AS = {"one_workgroup_memory": "one_workgroup"}
 
 
 @pytest.fixture
@@ -569,12 +572,13 @@ def mincut_ctx(request, monkeypatch):
     """A context per min-cut schedule (the switches are read when the context is created): the default (a graph of <= 8192
     sites is one workgroup, one launch per move), maxflow.hip's level-synchronous launches for everything, and region moves
     (the open sites of a move compacted and solved by one workgroup, enqueued a cycle at a time) even for small graphs."""
-    for key in ("PGX_MF_TILE", "PGX_MF_REGION"):
+    for key in ("PGX_MF_TILE", "PGX_MF_REGION", "PGX_TILE_MINI"):
         monkeypatch.delenv(key, raising=False)
     for key, val in MINCUT_PATHS[request.param].items():
         monkeypatch.setenv(key, val)
     ctx = _lib.Context(0)
-    ctx.path_name = request.param
+    ctx.path_name = MINCUT_COUNTED_AS.get(request.param, request.param)
+    ctx.fixture_name = request.param
     yield ctx
     ctx.close()
 
@@ -643,6 +647,78 @@ def test_each_mincut_path_is_the_one_that_ran(mincut_ctx, oracle):
     assert paths[mincut_ctx.path_name] > 0
     if mincut_ctx.path_name == "one_workgroup":
         assert paths["level_synchronous"] == 0 and paths["region"] == 0 and paths["tile_handed_back"] == 0
+        # 3000 sites: beyond the LDS-resident kernel either way
+        assert mincut_ctx.one_workgroup_launches()["lds_resident"] == 0 and mincut_ctx.one_workgroup_launches()["memory_resident"] > 0
+
+
+def _dense_rows_graph(rng, n, deg):
+    """Symmetric graph in which every site has about `deg` neighbours, some rows well beyond 16 arcs."""
+    iu, ju = [], []
+    for i in range(n):
+        k = int(rng.integers(max(1, deg // 2), deg + 1)) if i % 7 else min(n - 1, 3 * deg)
+        nb = rng.choice(n, size=min(k, n - 1), replace=False)
+        for j in nb:
+            if j != i:
+                iu.append(min(i, j)); ju.append(max(i, j))
+    pairs = np.unique(np.stack([iu, ju], 1), axis=0)
+    return csr_from_pairs(n, pairs[:, 0], pairs[:, 1], rng.integers(1, 3, pairs.shape[0]))
+
+
+@pytest.mark.parametrize("mini", ["1", "0"])
+def test_lds_resident_one_workgroup_moves_match_oracle(oracle, monkeypatch, mini):
+    """Round 6, csrc/maxflow_tile.hip t_mini_kernel: graphs of <= 1024 sites and <= 8192 arcs are solved with the whole move in LDS
+    (one site per thread; 256, 512 or 1024 threads).  Single moves against the oracle's min-cut, bit for bit, at the widths' edges
+    (255..257, 511..513, 1023..1024 sites), on rows longer than the 16 arcs a thread keeps in registers, with label costs from
+    zero to larger than any data term (a hub that reaches t only through members WITHOUT a t-link is passed on inside this kernel;
+    the memory-resident kernel hands such a move back), on labellings that do not use alpha (the gate) and on uniform labellings.
+    The launch counters say which kernel was compared; PGX_TILE_MINI=0 runs the same cases through t_move_kernel."""
+    monkeypatch.setenv("PGX_TILE_MINI", mini)
+    ctx = _lib.Context(0)
+    try:
+        rng = np.random.default_rng(606)
+        sizes = [2, 3, 64, 65, 255, 256, 257, 300, 511, 512, 513, 700, 1023, 1024]
+        moves = 0
+        for trial, n in enumerate(sizes * 2):
+            L = int(rng.integers(2, 8))
+            kind = trial % 4
+            if kind == 0:
+                graph = random_sym_graph(rng, n, min(1.0, 6.0 / max(n, 2)))
+            elif kind == 1:
+                graph = _dense_rows_graph(rng, n, 3 if n > 600 else 7)       # rows of up to 3 * deg arcs: beyond the register table
+            elif kind == 2:
+                graph = realistic_labeling_problem(n, L=max(L, 2), lam=0.2, seed=trial)[1] if 64 <= n <= 600 else random_sym_graph(rng, n, min(1.0, 5.0 / n))
+            else:
+                graph = random_sym_graph(rng, n, min(1.0, 3.0 / max(n, 2)))
+            assert graph[1].shape[0] <= 8192, "the case is meant for the LDS-resident kernel"
+            Dq = (rng.integers(0, 1 << 20, (n, L)) << 12).astype(np.int64)
+            if trial % 5 == 0:
+                Dq[:, rng.integers(0, L)] >>= 6      # one label nearly free: most sites lose their t-link in its move
+            lam = float(rng.choice([0.0, 0.1, 0.45]))
+            h = float(rng.choice([0.0, 0.0005, 0.01, 2.0, 300.0]))
+            lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+            labels = rng.integers(0, L, n).astype(np.int32)
+            if trial % 3 == 0:
+                labels[:] = rng.integers(0, L)
+            elif trial % 3 == 1:
+                labels[labels == L - 1] = 0          # the last label is not in use: its move goes through the gate
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(labels)
+            for alpha in list(rng.permutation(L)) + [L - 1]:
+                ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, int(alpha), labels)
+                changed = ctx.expand_alpha(lam, h, int(alpha))
+                assert np.array_equal(ctx.get_labels(), ref), f"trial {trial} n {n} alpha {alpha} h {h}: labels differ from the oracle min-cut"
+                assert changed == ref_changed
+                labels = ref
+                moves += 1
+        launches = ctx.one_workgroup_launches()
+        if mini == "1":
+            assert launches["lds_resident"] > 0 and launches["memory_resident"] == 0 and moves > 100
+            assert ctx.expansion_paths()["tile_handed_back"] == 0
+        else:
+            assert launches["lds_resident"] == 0 and launches["memory_resident"] > 0
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("mode", ["rounds", "searches", "both", "both_one_xcd_budget"])
