@@ -48,6 +48,46 @@ void release(DevBuf& b)
     b.cap = 0;
 }
 
+constexpr size_t kStageRing = 256 << 10, kStageMax = 32 << 10;
+
+int d2h(pgx_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return PGX_OK;
+    if (bytes > kStageMax || ctx->h_rb_used + bytes > kStageRing) {
+        PGX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return PGX_OK;
+    }
+    if (!ctx->h_rb) PGX_HIP(ctx, hipHostMalloc(&ctx->h_rb, kStageRing, hipHostMallocDefault));
+    const size_t off = ctx->h_rb_used;
+    ctx->h_rb_used += (bytes + 63) & ~(size_t)63;
+    PGX_HIP(ctx, hipMemcpyAsync((char*)ctx->h_rb + off, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->rb.push_back(StagedCopy{dst, off, bytes});
+    return PGX_OK;
+}
+
+int sync_deliver(pgx_ctx* ctx)
+{
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        for (const StagedCopy& c : ctx->rb) memcpy(c.dst, (const char*)ctx->h_rb + c.off, c.bytes);
+    ctx->rb.clear();
+    ctx->h_rb_used = 0;
+    if (e != hipSuccess) return fail(ctx, PGX_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    return PGX_OK;
+}
+
+int host_staging(pgx_ctx* ctx, size_t bytes, void** p)
+{
+    if (ctx->h_res_cap < bytes) {
+        if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+        ctx->h_res = nullptr; ctx->h_res_cap = 0;
+        PGX_HIP(ctx, hipHostMalloc(&ctx->h_res, bytes * 2, hipHostMallocDefault));
+        ctx->h_res_cap = bytes * 2;
+    }
+    *p = ctx->h_res;
+    return PGX_OK;
+}
+
 }  // namespace pgx
 
 using namespace pgx;
@@ -141,6 +181,7 @@ void pgx_destroy(pgx_ctx* ctx)
     for (DevBuf* b : bufs) release(*b);
     for (DevBuf& b : ctx->slots) release(b);
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
     if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
     if (ctx->h_samples) (void)hipHostFree(ctx->h_samples);
     if (ctx->h_models) (void)hipHostFree(ctx->h_models);
@@ -160,6 +201,8 @@ const char* pgx_last_error(const pgx_ctx* ctx) { return ctx ? ctx->err.c_str() :
         if (!(ctx)) return fail(nullptr, PGX_ERR_INVALID, "ctx is NULL");        \
         hipError_t e_ = hipSetDevice((ctx)->device);                              \
         if (e_ != hipSuccess) return fail(ctx, PGX_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e_)); \
+        (ctx)->rb.clear();                                                        \
+        (ctx)->h_rb_used = 0;                                                     \
     } while (0)
 
 int pgx_sync(pgx_ctx* ctx)
@@ -310,8 +353,8 @@ int pgx_get_compound(pgx_ctx* ctx, double* compound)
 {
     CTX_GUARD(ctx);
     if (ctx->n <= 0 || !compound) return fail(ctx, PGX_ERR_INVALID, "pgx_get_compound: points not set");
-    PGX_HIP(ctx, hipMemcpyAsync(compound, ctx->comp.p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, compound, ctx->comp.p, (size_t)ctx->n * sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -570,8 +613,8 @@ int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)
         if (bytes != want) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: buffer 5 holds %lld bytes, asked for %lld", (long long)want, (long long)bytes);
         PGX_TRY(ensure(ctx, ctx->g_counts, (size_t)want));
         PGX_TRY(score_acc_export(ctx, (unsigned long long*)ctx->g_counts.p, ctx->stream));
-        PGX_HIP(ctx, hipMemcpyAsync(out, ctx->g_counts.p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, out, ctx->g_counts.p, (size_t)bytes));
+        PGX_TRY(sync_deliver(ctx));
         return PGX_OK;
     }
     const DevBuf* b = nullptr;
@@ -585,8 +628,8 @@ int pgx_score_debug_fetch(pgx_ctx* ctx, int what, void* out, int64_t bytes)
     default: return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: unknown buffer %d", what);
     }
     if (bytes != have) return fail(ctx, PGX_ERR_INVALID, "pgx_score_debug_fetch: buffer %d holds %lld bytes, asked for %lld", what, (long long)have, (long long)bytes);
-    PGX_HIP(ctx, hipMemcpyAsync(out, b->p, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, out, b->p, (size_t)bytes));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -637,8 +680,8 @@ int pgx_score_stats(pgx_ctx* ctx, double T2, int has_compound, int64_t stats[8])
     stats[7] = ctx->last_score_filtered;
     if (ctx->last_score_path == 2) {
         unsigned long long h[8];
-        PGX_HIP(ctx, hipMemcpyAsync(h, ctx->stats_buf.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, h, ctx->stats_buf.p, sizeof(h)));
+        PGX_TRY(sync_deliver(ctx));
         stats[1] = groups * (int64_t)ctx->M;  // (hypothesis, group) bound tests an un-hierarchical cull would run
         stats[2] = (int64_t)h[0];             // surviving (hypothesis, group) steps: 64 f32 filter evaluations each
         stats[3] = (int64_t)h[1];             // exact FP64 residual evaluations
@@ -676,8 +719,8 @@ int pgx_preference(pgx_ctx* ctx, const double* model, double T2, int slot, doubl
     if (pref_sqnorm) *pref_sqnorm = out3[1];
     if (comp_sqnorm) *comp_sqnorm = out3[2];
     if (pref_out) {
-        PGX_HIP(ctx, hipMemcpyAsync(pref_out, d_pref, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, pref_out, d_pref, (size_t)ctx->n * sizeof(double)));
+        PGX_TRY(sync_deliver(ctx));
     }
     return PGX_OK;
 }
@@ -687,8 +730,8 @@ int pgx_get_preference(pgx_ctx* ctx, int slot, double* pref_out)
     CTX_GUARD(ctx);
     if (slot < 0 || slot >= (int)ctx->slots.size() || !ctx->slots[slot].p || !pref_out)
         return fail(ctx, PGX_ERR_INVALID, "pgx_get_preference: slot %d is empty", slot);
-    PGX_HIP(ctx, hipMemcpyAsync(pref_out, ctx->slots[slot].p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, pref_out, ctx->slots[slot].p, (size_t)ctx->n * sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -729,8 +772,8 @@ int pgx_pearl_unary(pgx_ctx* ctx, const double* models, int K, double threshold,
     ctx->dq_max = (int64_t)1 << 33;  // 2 (1 - lambda) <= 2 in 2^-32 fixed point (PEARL.h:123)
     if (Dq_out) {  // ABI layout is point-major N x L (as the reference's per-point functor); device is label-major
         std::vector<int64_t> tmp((size_t)L * (size_t)ctx->n);
-        PGX_HIP(ctx, hipMemcpyAsync(tmp.data(), ctx->dq.p, tmp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, tmp.data(), ctx->dq.p, tmp.size() * sizeof(int64_t)));
+        PGX_TRY(sync_deliver(ctx));
         for (int l = 0; l < L; ++l)
             for (int64_t i = 0; i < ctx->n; ++i) Dq_out[i * L + l] = tmp[(size_t)l * ctx->n + i];
     } else {
@@ -785,8 +828,8 @@ int pgx_get_labels(pgx_ctx* ctx, int32_t* labels)
 {
     CTX_GUARD(ctx);
     if (!labels || ctx->labels_n <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_get_labels: labels not set");
-    PGX_HIP(ctx, hipMemcpyAsync(labels, ctx->labels.p, (size_t)ctx->labels_n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, labels, ctx->labels.p, (size_t)ctx->labels_n * sizeof(int32_t)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 

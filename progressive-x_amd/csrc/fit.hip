@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "pgx_internal.h"
@@ -523,9 +524,9 @@ int pnp_refine_batch_launch(pgx_ctx* ctx, const double* inits, const int32_t* in
     hipLaunchKernelGGL(pnp_refine_batch_kernel, dim3((unsigned)B), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), d_in, d_idx, m,
                        wsel ? d_w : nullptr, wpow, iterations, d_out, d_st);
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, prm_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(status, d_st, st_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, out, d_out, prm_bytes));
+    PGX_TRY(d2h(ctx, status, d_st, st_bytes));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -586,9 +587,9 @@ int gram_batch_launch(pgx_ctx* ctx, int kind, const double* params, int nparams,
     default: launch_batch<GenPnpGn>(ctx, B, d_prm, d_idx, m, ww, wpow, d_out, d_bad); break;
     }
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (bad) PGX_HIP(ctx, hipMemcpyAsync(bad, d_bad, bad_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, out, d_out, out_bytes));
+    if (bad) PGX_TRY(d2h(ctx, bad, d_bad, bad_bytes));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -627,11 +628,13 @@ int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams
     double* d_out = (double*)(base + part_bytes);
     int* d_cnt = (int*)(base + part_bytes + out_bytes);
     double* d_prm = (double*)(base + part_bytes + out_bytes + cnt_bytes);
-    std::vector<double> hp((size_t)K * 12, 0.0);
+    // counters (zero) | parameter blocks are adjacent: ONE upload clears the first and fills the second; result | counters are
+    // adjacent too: ONE copy back, into pinned memory.  (A fill, two uploads' worth of commands and two blocking copies into pageable
+    // memory before: a third of the call on a 300-point scene, scripts/bench_small_calls.py.)
+    std::vector<double> hp(cnt_bytes / 8 + (size_t)K * 12, 0.0);
     for (int k = 0; k < K; ++k)
-        for (int j = 0; j < nparams; ++j) hp[(size_t)k * 12 + j] = params[(size_t)k * nparams + j];
-    PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, cnt_bytes, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(d_prm, hp.data(), prm_bytes, hipMemcpyHostToDevice, ctx->stream));
+        for (int j = 0; j < nparams; ++j) hp[cnt_bytes / 8 + (size_t)k * 12 + j] = params[(size_t)k * nparams + j];
+    PGX_HIP(ctx, hipMemcpyAsync(d_cnt, hp.data(), cnt_bytes + prm_bytes, hipMemcpyHostToDevice, ctx->stream));
     const int D = ctx->D;
     switch (kind) {
     case PGX_GRAM_AFFINE:
@@ -647,10 +650,12 @@ int gram_labels_launch(pgx_ctx* ctx, int kind, const double* params, int nparams
     PGX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(gram_final_labels_kernel, dim3((unsigned)K), dim3(1024), 0, ctx->stream, d_part, blocks, nv, d_out);
     PGX_HIP(ctx, hipGetLastError());
-    std::vector<int> cnt((size_t)2 * K, 0);
-    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)2 * K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void* hs = nullptr;
+    PGX_TRY(host_staging(ctx, out_bytes + cnt_bytes, &hs));
+    PGX_TRY(d2h(ctx, hs, d_out, out_bytes + (size_t)2 * K * sizeof(int)));
+    PGX_TRY(sync_deliver(ctx));
+    memcpy(out, hs, out_bytes);
+    const int* cnt = (const int*)((const char*)hs + out_bytes);
     for (int k = 0; k < K; ++k) {
         if (count) count[k] = cnt[2 * k];
         if (bad) bad[k] = cnt[2 * k + 1];
@@ -708,8 +713,16 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
     double* d_out = (double*)(base + part_bytes);
     int* d_cnt = (int*)(base + part_bytes + 64 * sizeof(double));
     int* d_idx = (int*)(base + part_bytes + 64 * sizeof(double) + 64);
-    PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-    if (idx_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // counters (64 bytes, zero) | index list are adjacent: a short list is uploaded together with the zeros (one command instead of two)
+    std::vector<int32_t> up;   // (alive until the stream has been synchronised below)
+    if (idx_bytes && m <= 65536) {
+        up.assign(16 + (size_t)m, 0);
+        memcpy(up.data() + 16, index, idx_bytes);
+        PGX_HIP(ctx, hipMemcpyAsync(d_cnt, up.data(), 64 + idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        PGX_HIP(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        if (idx_bytes) PGX_HIP(ctx, hipMemcpyAsync(d_idx, index, idx_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     const int* ix = sel == PGX_SEL_INDEX ? d_idx : nullptr;
     switch (kind) {
     case PGX_GRAM_AFFINE:
@@ -725,10 +738,13 @@ int gram_launch(pgx_ctx* ctx, int kind, const double* params, int nparams, int s
     PGX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(gram_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_part, blocks, nv, d_out);
     PGX_HIP(ctx, hipGetLastError());
-    int cnt[2] = {0, 0};
-    PGX_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // result (64 doubles) | counters are adjacent: one copy back, into pinned memory
+    void* hs = nullptr;
+    PGX_TRY(host_staging(ctx, 64 * sizeof(double) + 8, &hs));
+    PGX_TRY(d2h(ctx, hs, d_out, 64 * sizeof(double) + 8));
+    PGX_TRY(sync_deliver(ctx));
+    memcpy(out, hs, (size_t)nv * sizeof(double));
+    const int* cnt = (const int*)((const char*)hs + 64 * sizeof(double));
     if (count) *count = cnt[0];
     if (bad) *bad = cnt[1];
     return PGX_OK;
@@ -804,9 +820,9 @@ int eigh_smallest_launch(pgx_ctx* ctx, const double* A, int q, int64_t B, double
     PGX_HIP(ctx, hipMemcpyAsync(d_A, A, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(eigh_smallest_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, d_A, q, B, d_vec, d_val);
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(vec, d_vec, (size_t)B * q * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipMemcpyAsync(val, d_val, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, vec, d_vec, (size_t)B * q * sizeof(double)));
+    PGX_TRY(d2h(ctx, val, d_val, (size_t)B * sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 

@@ -505,8 +505,8 @@ int grid_pass(pgx_ctx* ctx, GraphScratch& gs, int64_t n, int d, const double mn[
     hipLaunchKernelGGL(g_scatter_kernel, dim3(nb), dim3(kGBlock), 0, ctx->stream, gs.dpts.as<double>(), n, d, gs.key.as<int>(),
                        gs.start.as<int>(), gs.cursor.as<int>(), gs.sidx.as<int>(), gs.spts.as<double>());
     int nblocks = 0;
-    PGX_HIP(ctx, hipMemcpyAsync(&nblocks, gs.blk.as<int>() + cells, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, &nblocks, gs.blk.as<int>() + cells, sizeof(int)));
+    PGX_TRY(sync_deliver(ctx));
     if (grid_out) {  // the caller runs its own kernels over the sorted grid (exhaustive ball)
         *grid_out = g;
         *nblocks_out = nblocks;
@@ -525,8 +525,8 @@ int grid_pass(pgx_ctx* ctx, GraphScratch& gs, int64_t n, int d, const double mn[
     PGX_HIP(ctx, hipGetLastError());
     int pend = 0;
     if (knn_mode) {
-        PGX_HIP(ctx, hipMemcpyAsync(&pend, gs.small.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, &pend, gs.small.p, sizeof(int)));
+        PGX_TRY(sync_deliver(ctx));
     }
     *pending_out = pend;
     return PGX_OK;
@@ -580,8 +580,8 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
         if (nblocks > 0) run(0, nullptr, nullptr, nullptr);
         PGX_HIP(c, hipGetLastError());
         unsigned long long total = 0;
-        PGX_HIP(c, hipMemcpyAsync(&total, g_s.small.as<int>() + 2, sizeof(total), hipMemcpyDeviceToHost, c->stream));
-        PGX_HIP(c, hipStreamSynchronize(c->stream));
+        PGX_TRY(d2h(c, &total, g_s.small.as<int>() + 2, sizeof(total)));
+        PGX_TRY(sync_deliver(c));
         if (total >= (1ull << 31)) return fail(c, PGX_ERR_INVALID, "pgx_graph_build: %llu arcs inside the ball (limit 2^31 - 1): choose a smaller radius", total);
         hipLaunchKernelGGL(g_scan_kernel, dim3(1), dim3(1024), 0, c->stream, g_s.deg.as<int>(), c->goff.as<int>(), nn, 0);
         const int E = (int)total;
@@ -594,8 +594,8 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
             PGX_HIP(c, hipMemsetAsync(g_s.small.p, 0, 16, c->stream));
             hipLaunchKernelGGL(g_rowsort_kernel, dim3(nb), dim3(kGBlock), 0, c->stream, nn, c->goff.as<int>(), c->gidx.as<int>(),
                                c->gmult.as<int>(), g_s.small.as<int>());
-            PGX_HIP(c, hipMemcpyAsync(stats, g_s.small.p, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
-            PGX_HIP(c, hipStreamSynchronize(c->stream));
+            PGX_TRY(d2h(c, stats, g_s.small.p, sizeof(stats)));
+            PGX_TRY(sync_deliver(c));
         }
         PGX_HIP(c, hipGetLastError());
         c->gn = nn; c->gE = E; c->max_degree = stats[0]; c->max_row_mult = stats[1];
@@ -653,8 +653,8 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
             hipLaunchKernelGGL(g_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, gs.deg.as<int>(), ctx->goff.as<int>(), n, 0);
         }
         int E = 0;
-        PGX_HIP(ctx, hipMemcpyAsync(&E, ctx->goff.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, &E, ctx->goff.as<int>() + n, sizeof(int)));
+        PGX_TRY(sync_deliver(ctx));
         PGX_TRY(ensure(ctx, ctx->gidx, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
         PGX_TRY(ensure(ctx, ctx->gmult, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
         PGX_TRY(ensure(ctx, ctx->grev, (size_t)(E > 0 ? E : 1) * sizeof(int32_t)));
@@ -667,8 +667,8 @@ int graph_build_launch(pgx_ctx* ctx, const double* pts, int64_t n, int d, int ki
                                ctx->gmult.as<int>());
             hipLaunchKernelGGL(g_rowsort_kernel, dim3(nb), dim3(kGBlock), 0, ctx->stream, n, ctx->goff.as<int>(), ctx->gidx.as<int>(),
                                ctx->gmult.as<int>(), gs.small.as<int>());
-            PGX_HIP(ctx, hipMemcpyAsync(stats, gs.small.p, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
-            PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            PGX_TRY(d2h(ctx, stats, gs.small.p, sizeof(stats)));
+            PGX_TRY(sync_deliver(ctx));
         }
         PGX_HIP(ctx, hipGetLastError());
         ctx->gn = n; ctx->gE = E; ctx->max_degree = stats[0]; ctx->max_row_mult = stats[1];
@@ -689,10 +689,10 @@ int graph_fetch_launch(pgx_ctx* ctx, int32_t* off, int32_t* idx, int32_t* mult)
 {
     if (ctx->gn <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_fetch: no graph resident");
     if (!off) return fail(ctx, PGX_ERR_INVALID, "pgx_graph_fetch: off is NULL");
-    PGX_HIP(ctx, hipMemcpyAsync(off, ctx->goff.p, (size_t)(ctx->gn + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->gE > 0 && idx) PGX_HIP(ctx, hipMemcpyAsync(idx, ctx->gidx.p, (size_t)ctx->gE * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->gE > 0 && mult) PGX_HIP(ctx, hipMemcpyAsync(mult, ctx->gmult.p, (size_t)ctx->gE * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, off, ctx->goff.p, (size_t)(ctx->gn + 1) * sizeof(int32_t)));
+    if (ctx->gE > 0 && idx) PGX_TRY(d2h(ctx, idx, ctx->gidx.p, (size_t)ctx->gE * sizeof(int32_t)));
+    if (ctx->gE > 0 && mult) PGX_TRY(d2h(ctx, mult, ctx->gmult.p, (size_t)ctx->gE * sizeof(int32_t)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 

@@ -704,8 +704,8 @@ int graph_build_reverse(pgx_ctx* ctx)
                        ctx->goff.as<int>(), ctx->gidx.as<int>(), ctx->grev.as<int>(), (int*)ctx->scratch.p);
     PGX_HIP(ctx, hipGetLastError());
     int bad = 0;
-    PGX_HIP(ctx, hipMemcpyAsync(&bad, ctx->scratch.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, &bad, ctx->scratch.p, 4));
+    PGX_TRY(sync_deliver(ctx));
     if (bad) {
         ctx->gn = 0;
         ctx->gE = 0;
@@ -1086,8 +1086,8 @@ static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* change
                        ctx->labels.as<int>(), n, L, alpha, d_sums);
     PGX_HIP(ctx, hipGetLastError());
     std::vector<unsigned char> host(bytes);
-    PGX_HIP(ctx, hipMemcpyAsync(host.data(), st->small.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, host.data(), st->small.p, bytes));
+    PGX_TRY(sync_deliver(ctx));
     const long long* sums = (const long long*)host.data();
     const int* cnt = (const int*)(host.data() + (size_t)2 * L * 8);
     if ((int64_t)cnt[alpha] == n) return PGX_OK;
@@ -1102,8 +1102,8 @@ static int expand_alpha_l0(pgx_ctx* ctx, int64_t h_q, int alpha, int64_t* change
                        ctx->labels.as<int>(), n, alpha, arg, d_changed);
     PGX_HIP(ctx, hipGetLastError());
     int ch = 0;
-    PGX_HIP(ctx, hipMemcpyAsync(&ch, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, &ch, d_changed, sizeof(int)));
+    PGX_TRY(sync_deliver(ctx));
     *changed = ch;
     ctx->stats[4] += ch;
     return PGX_OK;
@@ -1146,8 +1146,8 @@ int expand_cycle_l0(pgx_ctx* ctx, int64_t h_q, int64_t* changed, int* evaluated)
     }
     PGX_HIP(ctx, hipGetLastError());
     std::vector<int> host((size_t)2 * L);
-    PGX_HIP(ctx, hipMemcpyAsync(host.data(), d_changed, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, host.data(), d_changed, res_bytes));
+    PGX_TRY(sync_deliver(ctx));
     for (int alpha = 0; alpha < L; ++alpha) {
         changed[alpha] = host[(size_t)alpha];
         evaluated[alpha] = host[(size_t)L + alpha];

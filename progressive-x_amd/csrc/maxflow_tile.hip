@@ -27,6 +27,7 @@
 // members without t-links) falls back to maxflow.hip: the function returns PGX_TILE_FALLBACK before touching the labels.
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -1316,7 +1317,7 @@ constexpr size_t kRegionHostOff = SmallLayout::flags;   // the host mirror has t
 int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* labels, int64_t lambda_q, int64_t h_q, int alpha, int64_t* changed,
                       const long long* wq)
 {
-    if (n > ctx->tile_single_max || n > 8192 || L > kMaxL) return PGX_TILE_FALLBACK;
+    if (n > ctx->tile_single_max || n > 8192 || L > kMaxL) { ctx->tile_pre_sync = nullptr; return PGX_TILE_FALLBACK; }
     PGX_TRY(tile_graph_prepare(ctx));
     TileState* ts = ctx->tile;
     const int64_t E = ts->E;
@@ -1372,9 +1373,14 @@ int expand_alpha_tile(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* 
     PGX_HIP(ctx, hipGetLastError());
     if (defer) return PGX_REGION_PENDING;
     char* hs = (char*)ts->h_small;
+    std::function<int()> hook;
+    hook.swap(ctx->tile_pre_sync);
+    ctx->tile_pre_sync_ran = false;
+    if (hook) PGX_TRY(hook());   // (the caller's work behind the move: shares the synchronisation below)
     PGX_HIP(ctx, hipMemcpyAsync(hs, sp, SmallLayout::bytes, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int* h_flags = (const int*)(hs + SmallLayout::flags);
+    ctx->tile_pre_sync_ran = (bool)hook && h_flags[5] == 0;
     if (ctx->tile_debug) {
         unsigned long long t[16];
         (void)hipMemcpy(t, ts->dbg.p, sizeof(t), hipMemcpyDeviceToHost);

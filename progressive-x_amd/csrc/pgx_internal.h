@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,7 @@
 namespace pgx {
 
 // growable device buffer
+struct StagedCopy { void* dst; size_t off, bytes; };
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -155,6 +157,11 @@ struct pgx_ctx {
     int mf_sweeps = 0;           // PGX_MF_SWEEPS: sweeps per round, list mode and all-sites alike (0 = the measured defaults; tests shorten the rounds)
     int mf_region = 1;           // PGX_MF_REGION=0: no region moves (maxflow_tile.hip expand_alpha_region)
     int tile_sweeps = 24;        // push-relabel sweeps per discharge launch
+    // a caller of a single whole-graph move (the inlier / outlier cut) may leave work here that expand_alpha_tile enqueues BEHIND the move and
+    // BEFORE its one synchronisation (the compaction of the cut's flags and its copy back): one host round trip for both.  Consumed
+    // (cleared) by the move; tile_pre_sync_ran says it ran and the move was solved (not handed back)
+    std::function<int()> tile_pre_sync;
+    bool tile_pre_sync_ran = false;
     int tile_mini = 1;           // PGX_TILE_MINI=0: graphs of <= 1024 sites and <= 8192 arcs go through t_move_kernel too (A/B; default: the LDS-resident t_mini_kernel)
     int64_t tile_launches[2] = {0, 0};   // pgx_one_workgroup_launches: whole-graph moves enqueued on t_mini_kernel / on t_move_kernel
     int tile_mini_sweeps = 24;   // PGX_TILE_MINI_SWEEPS: sweeps between two exact searches of t_mini_kernel
@@ -169,6 +176,9 @@ struct pgx_ctx {
     pgx::DevBuf prosac_tops;              // pgx_sampler_prosac_set: subset size per sample number (int32 x prosac_count)
     int prosac_count = 0;
     int64_t prosac_points_version = -1;   // the table belongs to these points
+    void* h_rb = nullptr;       // pinned ring of d2h() / sync_deliver()
+    size_t h_rb_used = 0;
+    std::vector<pgx::StagedCopy> rb;
     void* h_res = nullptr;      // pinned host staging for result read-backs (pageable targets make the copies synchronous)
     size_t h_res_cap = 0;
     // Host mirror of the score triples: score_finish_kernel also writes (count, value, shared) in the batch's device order
@@ -198,6 +208,14 @@ namespace pgx {
 
 int fail(pgx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(pgx_ctx* ctx, DevBuf& b, size_t bytes);
+// Small read-backs go through pinned memory: a copy into a pageable target is a BLOCKING command (14 us against 4 for one into pinned
+// memory, scripts/micro/small_copy_bench.hip), and an entry point that returns three small arrays paid it three times.  d2h() enqueues the
+// copy into a slice of a pinned ring and remembers where the bytes belong; sync_deliver() synchronises the stream once and hands them
+// over.  (Copies beyond 32 KB, or when the ring is full, go straight to the target as before.)  Pairs live inside one function body;
+// every entry point starts with an empty list (CTX_GUARD).
+int d2h(pgx_ctx* ctx, void* dst, const void* src, size_t bytes);
+int sync_deliver(pgx_ctx* ctx);
+int host_staging(pgx_ctx* ctx, size_t bytes, void** p);   // ctx->h_res grown to at least `bytes` (pinned: a copy into it is one asynchronous command; a pageable target makes every copy a blocking one)
 void release(DevBuf& b);
 
 #define PGX_HIP(ctx, call)                                                                        \

@@ -142,8 +142,8 @@ int preference_launch(pgx_ctx* ctx, const double* model, double T2, double* d_pr
     hipLaunchKernelGGL((final_sum_kernel<3>), dim3(1), dim3(kPwBlock), 0, ctx->stream,
                        ctx->red_partials.as<double>(), blocks, ctx->red_out.as<double>());
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(out3, ctx->red_out.p, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, out3, ctx->red_out.p, 3 * sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -283,6 +283,53 @@ __global__ __launch_bounds__(kPwBlock) void gc_terms_kernel(const double* __rest
     labels[i] = start_label;
 }
 
+// ---- ascending indices of the set flags of a SMALL array (the reference's own scenes: a few hundred points) ----------------------
+// hipcub's select is two launches behind a flags kernel, and the count has to come back before the indices can be copied: two host
+// round trips.  Up to kCompactSmall items one workgroup does it in one launch - each thread takes a run of consecutive items, a
+// wave scan + 16 wave totals place them - and writes count | indices into ONE buffer that goes back in one copy.
+constexpr int64_t kCompactSmall = 8192;
+
+template <bool MASK>
+__global__ __launch_bounds__(1024) void compact_small_kernel(const unsigned long long* __restrict__ row, const int* __restrict__ flags, int n,
+                                                             int* __restrict__ out)
+{
+    __shared__ int wsum[16];
+    const int tid = (int)threadIdx.x;
+    const int per = (n + 1023) / 1024;   // <= 8
+    const int i0 = tid * per;
+    unsigned m = 0;
+    int c = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        const bool f = i < n && (MASK ? ((row[i >> 6] >> (i & 63)) & 1ull) != 0ull : flags[i] != 0);
+        if (f) { m |= 1u << k; ++c; }
+    }
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += t; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    int pos = base + incl - c;
+    for (int k = 0; k < per; ++k)
+        if ((m >> k) & 1u) out[1 + pos++] = i0 + k;
+    if (tid == 1023) out[0] = base + incl;
+}
+
+// enqueue: count | indices of the flagged items into ctx->gc_sel and from there into the pinned staging buffer (the caller synchronises)
+template <bool MASK>
+static int compact_small_enqueue(pgx_ctx* ctx, const unsigned long long* row, const int* flags, int64_t n)
+{
+    PGX_TRY(ensure(ctx, ctx->gc_sel, (size_t)(n + 1) * 4));
+    void* hs = nullptr;
+    PGX_TRY(host_staging(ctx, (size_t)(n + 1) * 4, &hs));
+    hipLaunchKernelGGL((compact_small_kernel<MASK>), dim3(1), dim3(1024), 0, ctx->stream, row, flags, (int)n, ctx->gc_sel.as<int>());
+    PGX_HIP(ctx, hipGetLastError());
+    PGX_HIP(ctx, hipMemcpyAsync(hs, ctx->gc_sel.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return PGX_OK;
+}
+
 int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lambda, int32_t* flags, int64_t* count, bool want_index)
 {
     const int64_t n = ctx->n;
@@ -328,8 +375,24 @@ int gc_labeling_launch(pgx_ctx* ctx, const double* model, double T2, double lamb
                        wq, labels, flip ? 0 : 1);
     PGX_HIP(ctx, hipGetLastError());
     int64_t changed = 0;
-    PGX_TRY(expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, flip ? 1 : 0, &changed, flip));
+    // a small scene's cut is one one-workgroup launch: the compaction of its flags and the copy back ride behind it, before the one
+    // synchronisation of the move (two round trips before)
+    const bool small = want_index && !flip && n <= kCompactSmall;
+    if (small) ctx->tile_pre_sync = [ctx, labels, n]() { return compact_small_enqueue<false>(ctx, nullptr, labels, n); };
+    ctx->tile_pre_sync_ran = false;
+    const int rc = expand_alpha_on(ctx, n, 2, dq, labels, wq, lambda_q, 0, flip ? 1 : 0, &changed, flip);
+    ctx->tile_pre_sync = nullptr;
+    const bool have_small = ctx->tile_pre_sync_ran;
+    ctx->tile_pre_sync_ran = false;
+    PGX_TRY(rc);
     const int64_t inliers = flip ? changed : n - changed;
+    if (have_small) {
+        const int* hs = (const int*)ctx->h_res;
+        if (hs[0] != (int)inliers) return fail(ctx, PGX_ERR_INVALID, "pgx_gc_inliers (internal): %d indices for %lld inliers", hs[0], (long long)inliers);
+        memcpy(flags, hs + 1, (size_t)inliers * sizeof(int32_t));
+        if (count) *count = inliers;
+        return PGX_OK;
+    }
     if (want_index) {
         // the inliers' indices in ascending order instead of n flags: the caller (the local optimisation's sampler) used to copy
         // 4 n bytes back and scan them with numpy.flatnonzero - 1.9 ms per cut at n = 10^6, as long as the cut itself
@@ -366,6 +429,14 @@ int score_inliers_launch(pgx_ctx* ctx, int row, int32_t* index, int64_t* count)
     const int64_t n = ctx->n;
     if (!ctx->have_masks || ctx->M <= 0) return fail(ctx, PGX_ERR_INVALID, "pgx_score_inliers: the last launch produced no masks");
     if (row < 0 || row >= ctx->M) return fail(ctx, PGX_ERR_INVALID, "pgx_score_inliers: row %d of %d", row, ctx->M);
+    if (n <= kCompactSmall) {   // one launch, one copy, one synchronisation
+        PGX_TRY(compact_small_enqueue<true>(ctx, ctx->masks.as<unsigned long long>() + (size_t)row * (size_t)ctx->words, nullptr, n));
+        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int* hs = (const int*)ctx->h_res;
+        memcpy(index, hs + 1, (size_t)hs[0] * sizeof(int32_t));
+        *count = hs[0];
+        return PGX_OK;
+    }
     size_t temp_bytes = 0;
     hipcub::CountingInputIterator<int> ids(0);
     PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, temp_bytes, ids, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int)n, ctx->stream));
@@ -380,11 +451,11 @@ int score_inliers_launch(pgx_ctx* ctx, int row, int32_t* index, int64_t* count)
     PGX_HIP(ctx, hipGetLastError());
     PGX_HIP(ctx, hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, ids, d_flags, d_sel, d_num, (int)n, ctx->stream));
     int num = 0;
-    PGX_HIP(ctx, hipMemcpyAsync(&num, d_num, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, &num, d_num, sizeof(int)));
+    PGX_TRY(sync_deliver(ctx));
     if (num > 0) {
-        PGX_HIP(ctx, hipMemcpyAsync(index, d_sel, (size_t)num * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, index, d_sel, (size_t)num * sizeof(int32_t)));
+        PGX_TRY(sync_deliver(ctx));
     }
     *count = num;
     return PGX_OK;
@@ -471,8 +542,8 @@ int residual_sums_launch(pgx_ctx* ctx, const double* models, int K, double* sums
     PGX_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(final_sums_kernel, dim3((unsigned)K), dim3(kPwBlock), 0, ctx->stream, part, blocks, ctx->red_out.as<double>());
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(sums, ctx->red_out.p, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, sums, ctx->red_out.p, (size_t)K * sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -502,8 +573,8 @@ int residual_sum_launch(pgx_ctx* ctx, const double* model, int label, double* su
     hipLaunchKernelGGL((final_sum_kernel<1>), dim3(1), dim3(kPwBlock), 0, ctx->stream, part, blocks,
                        ctx->red_out.as<double>());
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(sum, ctx->red_out.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, sum, ctx->red_out.p, sizeof(double)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -557,8 +628,8 @@ int epipolar_support_launch(pgx_ctx* ctx, const double* F, double T2, double S2,
     const int blocks = (int)((ctx->n + kPwBlock - 1) / kPwBlock);
     hipLaunchKernelGGL(epipolar_support_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n, mdl, T2, S2, out);
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(counts, out, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, counts, out, 16));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -665,10 +736,10 @@ int bucket_launch(pgx_ctx* ctx, int L, int64_t* counts, int32_t* order)
         hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)blocks), dim3(kPwBlock), 0, ctx->stream,
                            ctx->labels.as<int>(), n, L, bc, d_starts, d_order);
     PGX_HIP(ctx, hipGetLastError());
-    PGX_HIP(ctx, hipMemcpyAsync(counts, d_counts, (size_t)L * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    PGX_TRY(d2h(ctx, counts, d_counts, (size_t)L * sizeof(long long)));
     if (order)
-        PGX_HIP(ctx, hipMemcpyAsync(order, d_order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, order, d_order, (size_t)n * sizeof(int)));
+    PGX_TRY(sync_deliver(ctx));
     return PGX_OK;
 }
 
@@ -719,8 +790,8 @@ int energy_launch(pgx_ctx* ctx, int64_t lambda_q, int64_t h_q, int64_t* energy_q
                        ctx->gidx.as<int>(), ctx->gmult.as<int>(), (long long)lambda_q, d_e, d_used);
     PGX_HIP(ctx, hipGetLastError());
     std::vector<unsigned char> host(16 + (size_t)L * sizeof(unsigned));
-    PGX_HIP(ctx, hipMemcpyAsync(host.data(), ctx->scratch.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(d2h(ctx, host.data(), ctx->scratch.p, host.size()));
+    PGX_TRY(sync_deliver(ctx));
     int64_t e = (int64_t)(*(unsigned long long*)host.data());
     const unsigned* used = (const unsigned*)(host.data() + 16);
     for (int l = 0; l < L; ++l) if (used[l]) e += h_q;
@@ -861,8 +932,8 @@ int greedy_labeling_launch(pgx_ctx* ctx, int64_t h_q, int64_t* energy_q, int* op
         }
         PGX_HIP(ctx, hipGetLastError());
         unsigned long long h_state[4];
-        PGX_HIP(ctx, hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, h_state, d_state, sizeof(h_state)));
+        PGX_TRY(sync_deliver(ctx));
         count = (int)h_state[2];
     }
     int64_t eq = 0;

@@ -569,8 +569,8 @@ int solve_minimal_sampled_launch(pgx_ctx* ctx, int sampler, uint64_t key, uint32
                            ctx->prosac_tops.as<int>(), m, ctx->scratch.as<int>());
     PGX_HIP(ctx, hipGetLastError());
     if (samples_out) {
-        PGX_HIP(ctx, hipMemcpyAsync(samples_out, ctx->scratch.p, (size_t)S * m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGX_TRY(d2h(ctx, samples_out, ctx->scratch.p, (size_t)S * m * sizeof(int32_t)));
+        PGX_TRY(sync_deliver(ctx));
     }
     return solve_minimal_launch(ctx, nullptr, S, models_out, true);
 }
