@@ -543,10 +543,9 @@ int pgx_score_fetch(pgx_ctx* ctx, int exponent, int64_t* counts, double* values,
     if (!mirrored) PGX_HIP(ctx, hipMemcpyAsync(c, ctx->counts.p, need, hipMemcpyDeviceToHost, ctx->stream));
     if (masks) {
         if (!ctx->have_masks) return fail(ctx, PGX_ERR_INVALID, "pgx_score_fetch: masks were not requested at launch");
-        PGX_HIP(ctx, hipMemcpyAsync(masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        PGX_TRY(d2h(ctx, masks, ctx->masks.p, (size_t)M * (size_t)ctx->words * sizeof(uint64_t)));
     }
-    PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGX_TRY(sync_deliver(ctx));
     if (mirrored) {   // device order -> the caller's order
         const int64_t* mc = (const int64_t*)ctx->h_mirror;
         const double* mv = (const double*)ctx->h_mirror + Mp;

@@ -480,9 +480,10 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         hipLaunchKernelGGL(solve_f7_kernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
-        if (models_out)
-            PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) {
+            PGX_TRY(d2h(ctx, models_out, ctx->models.p, (size_t)Mtot * 9 * sizeof(double)));
+            PGX_TRY(sync_deliver(ctx));
+        }
         ctx->M = Mtot; ctx->last_acc = nullptr;
         return PGX_OK;
     }
@@ -495,9 +496,10 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         hipLaunchKernelGGL(solve_p3p_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
-        if (models_out)
-            PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)Mtot * 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) {
+            PGX_TRY(d2h(ctx, models_out, ctx->models.p, (size_t)Mtot * 12 * sizeof(double)));
+            PGX_TRY(sync_deliver(ctx));
+        }
         ctx->M = Mtot; ctx->last_acc = nullptr;
         return PGX_OK;
     }
@@ -510,9 +512,10 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         hipLaunchKernelGGL(solve_h4_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->fscale, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
         PGX_HIP(ctx, hipGetLastError());
-        if (models_out)
-            PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 9 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (models_out) {
+            PGX_TRY(d2h(ctx, models_out, ctx->models.p, (size_t)S * 9 * sizeof(double)));
+            PGX_TRY(sync_deliver(ctx));
+        }
         ctx->M = S; ctx->last_acc = nullptr;
         return PGX_OK;
     }
@@ -530,9 +533,10 @@ int solve_minimal_launch(pgx_ctx* ctx, const int32_t* samples, int S, double* mo
         hipLaunchKernelGGL((solve_kernel<kVanishingPoint>), dim3(blocks), dim3(kSolveBlock), 0, ctx->stream, ctx->pts.as<double>(), ctx->n,
                            ctx->scratch.as<int>(), S, ctx->models.as<double>(), ctx->perm.as<int>(), ctx->Mpad);
     PGX_HIP(ctx, hipGetLastError());
-    if (models_out)
-        PGX_HIP(ctx, hipMemcpyAsync(models_out, ctx->models.p, (size_t)S * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (models_out) PGX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (models_out) {
+        PGX_TRY(d2h(ctx, models_out, ctx->models.p, (size_t)S * 3 * sizeof(double)));
+        PGX_TRY(sync_deliver(ctx));
+    }
     ctx->M = S; ctx->last_acc = nullptr;
     return PGX_OK;
 }

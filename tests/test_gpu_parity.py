@@ -714,6 +714,23 @@ def test_lds_resident_one_workgroup_moves_match_oracle(oracle, monkeypatch, mini
         launches = ctx.one_workgroup_launches()
         if mini == "1":
             assert launches["lds_resident"] > 0 and launches["memory_resident"] == 0 and moves > 100
+            # a graph of few sites but more arcs than the LDS tables hold goes to the memory-resident kernel
+            n, L = 600, 3
+            graph = _dense_rows_graph(rng, n, 14)
+            assert graph[1].shape[0] > 8192
+            Dq = (rng.integers(0, 1 << 20, (n, L)) << 12).astype(np.int64)
+            labels = rng.integers(0, L, n).astype(np.int32)
+            ctx.set_unary_q(Dq)
+            ctx.set_graph(*graph)
+            ctx.set_labels(labels)
+            lq, hq = oracle.quantize_lambda(0.1), oracle.quantize(0.01)
+            for alpha in range(L):
+                ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, labels)
+                assert ctx.expand_alpha(0.1, 0.01, alpha) == ref_changed and np.array_equal(ctx.get_labels(), ref)
+                labels = ref
+            assert ctx.one_workgroup_launches()["memory_resident"] == L
+            launches = ctx.one_workgroup_launches()
+            launches["memory_resident"] = 0
             assert ctx.expansion_paths()["tile_handed_back"] == 0
         else:
             assert launches["lds_resident"] == 0 and launches["memory_resident"] > 0
