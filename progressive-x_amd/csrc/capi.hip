@@ -157,6 +157,7 @@ int pgx_create(int device_id, pgx_ctx** out)
     if (const char* b = std::getenv("PGX_MF_XCD_MAXN")) ctx->mf_xcd_max_n = std::atoll(b);
     if (const char* b = std::getenv("PGX_MF_SWEEPS")) ctx->mf_sweeps = std::atoi(b);
     if (const char* b = std::getenv("PGX_TILE_MINI")) ctx->tile_mini = std::atoi(b) ? 1 : 0;
+    if (const char* b = std::getenv("PGX_TILE_EXPANSION_MAX")) { const int v = std::atoi(b); ctx->tile_expansion_max = v < 0 ? 0 : v; }
     if (const char* b = std::getenv("PGX_TILE_MINI_SWEEPS")) { const int v = std::atoi(b); ctx->tile_mini_sweeps = v < 1 ? 1 : v; }
     if (const char* b = std::getenv("PGX_MF_DEBUG")) ctx->tile_debug = std::atoi(b);
     *out = ctx;
@@ -1055,7 +1056,7 @@ int pgx_expansion(pgx_ctx* ctx, double lambda, double label_cost, int max_cycles
             PGX_TRY(expand_cycle_l0(ctx, hq, ch.data(), ev.data()));
             for (int alpha = 0; alpha < ctx->L; ++alpha) changed_total += ch[(size_t)alpha];
         } else if ((ctx->mf_tile && ctx->mf_tile_batch && ctx->dq_n <= ctx->tile_single_max && ctx->dq_n <= 8192 && ctx->L <= 64) ||
-                   (region_moves_apply(ctx) && !(ctx->mf_tile && ctx->dq_n <= ctx->tile_single_max))) {
+                   (region_moves_apply(ctx) && !(ctx->mf_tile && ctx->dq_n <= ctx->tile_single_max && ctx->dq_n <= ctx->tile_expansion_max))) {
             // (graphs of <= 8192 sites - the reference's own scenes: every move is ONE launch of the one-workgroup solver,
             //  maxflow_tile.hip expand_alpha_tile; batched the same way, a read-back per move was two thirds of a move's time)
             // Region moves (maxflow_tile.hip): the moves of the cycle are enqueued back to back and resolved together - one

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Best-of-N wall time of one alpha-expansion from zeros on the BASELINE shapes (first-cycle memo off: every repetition solves every
-min-cut), for A/B runs of the schedule switches (PGX_MF_*: read once per process).  usage: ab_expansion.py C3 C5 C4 [--reps 4]"""
+min-cut), for A/B runs of the schedule switches (PGX_MF_*: read once per process).  usage: ab_expansion.py [C1 C2] C3 C5 C4 [--reps 4]"""
 import json
 import os
 import sys
@@ -38,6 +38,12 @@ def run(name, mt, pts, models, thr, lam, h, graph, reps):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["C3", "C5", "C4"]
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 4
+    if "C2" in which:
+        pts, gt, models = datasets.make_homographies(seed=0)
+        run("C2", _lib.HOMOGRAPHY, pts, models, 3.0, 0.05, 10.0, (pts, _lib.GRAPH_KNN_IN_BALL, 200.0, 5), reps)
+    if "C1" in which:
+        pts, gt, models = datasets.make_lines(seed=0)
+        run("C1", _lib.LINE2D, pts, models, 2.0, 0.05, 10.0, (pts, _lib.GRAPH_KNN_IN_BALL, 50.0, 5), reps)
     if "C3" in which:
         pts, gt, models = datasets.make_two_view_motions(seed=0)
         run("C3", _lib.FUNDAMENTAL, pts, models, 0.75, 0.1, 14.0, (pts, _lib.GRAPH_KNN_IN_BALL, 50.0, 5), reps)

@@ -799,6 +799,7 @@ def test_batched_one_workgroup_moves_equal_unbatched(oracle, monkeypatch, n, lam
     lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
     ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
     seen = {}
+    monkeypatch.setenv("PGX_TILE_EXPANSION_MAX", "8192")   # every move on the whole-graph kernel (default: beyond 4 096 sites the region path goes first)
     for batch in ("1", "0"):
         monkeypatch.setenv("PGX_MF_TILE_BATCH", batch)
         ctx = _lib.Context(0)
@@ -816,6 +817,36 @@ def test_batched_one_workgroup_moves_equal_unbatched(oracle, monkeypatch, n, lam
         finally:
             ctx.close()
     assert seen["1"] == seen["0"]
+
+
+@pytest.mark.parametrize("n,lam,h,L", [(5000, 0.2, 3.0, 6), (8000, 0.1, 10.0, 5), (4500, 0.45, 0.5, 4)])
+def test_mid_size_graphs_region_first_then_whole_graph_kernel(oracle, n, lam, h, L):
+    """Graphs of 4 097 .. 8 192 sites (C2: 5 000): an expansion move tries the region path first and, declined, is solved by the one-workgroup
+    whole-graph kernel (not by the level-synchronous launches).  Labels, energy, cycles of the oracle; both solvers took moves."""
+    Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=11 * n + L)
+    lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
+    ref_labels, ref_e, ref_cycles = oracle.expansion(Dq, graph, lq, hq, np.zeros(n, np.int32))
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_unary_q(Dq)
+        ctx.set_graph(*graph)
+        ctx.set_labels(np.zeros(n, np.int32))
+        eq, _, cycles = ctx.expansion(lam, h)
+        assert np.array_equal(ctx.get_labels(), ref_labels) and eq == ref_e and cycles == ref_cycles
+        paths = ctx.expansion_paths()
+        assert paths["region"] > 0 and paths["level_synchronous"] == 0, paths
+        assert paths["region_declined"] == 0 or paths["one_workgroup"] > 0, paths
+        # single moves (unbatched) take the same route
+        rng = np.random.default_rng(n)
+        labels = rng.integers(0, L, n).astype(np.int32)
+        ctx.set_labels(labels)
+        for alpha in range(L):
+            ref, ref_changed, _ = oracle.expand_alpha(Dq, graph, lq, hq, alpha, labels)
+            assert ctx.expand_alpha(lam, h, alpha) == ref_changed and np.array_equal(ctx.get_labels(), ref)
+            labels = ref
+        assert ctx.expansion_paths()["level_synchronous"] == 0
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("n,lam,h,L", [(30000, 0.15, 4.0, 6), (60000, 0.3, 0.0, 5), (60000, 0.05, 12.0, 9)])
