@@ -758,99 +758,36 @@ __device__ __forceinline__ int mini_vote(MiniLds& L, int& step, const int bits)
     return r;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void t_mini_kernel(TView v, int sweeps, int max_rounds)
+// per-thread state of the LDS-resident solver: thread i owns site i
+struct MiniSite {
+    bool valid, part, my_hub;   // a site of the graph | of the move's graph (does not carry alpha) | its label has a hub
+    int lu, a0, a1;             // label, row bounds in the LDS arc tables
+    long long rt, f;            // t-link and hub flow: only the owner touches them
+    int du;                     // its height (the copy other threads read is L.d[i])
+    int nb[16];                 // the first 16 neighbours of the row (slots beyond the row name the site itself)
+    bool any_long, any_hub;     // some row is longer than 16 arcs | some label has a hub (workgroup-uniform)
+};
+
+// rounds of { exact search | who holds excess that reaches t | sweeps } on the problem in LDS until no excess reaches t.  On return
+// s.du is the distance of the LAST search (no sweep behind it): kInf = the site does not reach t.
+template <int NT, class Lap>
+__device__ __forceinline__ void mini_solve(MiniLds& L, const TView& v, MiniSite& s, int sweeps, const int max_rounds, int& rounds, int& gave_up,
+                                           int& n_steps, int& n_sweeps, Lap lap)
 {
-    __shared__ MiniLds L;
     const int tid = (int)threadIdx.x;
-    if (v.ctl) {   // a move of a batch (t_move_kernel)
-        if (batch_skips(v.ctl, v.skip_rel)) return;
-        if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
-    }
-    const int n = (int)v.n;   // <= NT (the host picks the width): thread i owns site i
-    unsigned long long tprev = wall_clock64();
-    auto lap = [&](int k) {   // (debug) time since the last lap goes to slot k
-        if (v.dbg && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
-    };
-    // ---- the problem into LDS and registers.  Round trip 1: the site's place and row; 2: its label, costs and (all threads together)
-    // the arc tables; behind the barrier the rows turn the arc weights into capacities.
-    const bool valid = tid < n;
-    const int64_t o = valid ? v.perm[tid] : 0;
-    const int a0 = valid ? v.off[tid] : 0, a1 = valid ? v.off[tid + 1] : 0;
-    const int E = v.off[n];
-    if (tid < kMaxL) { L.cnt[tid] = 0; L.pool[tid] = 0ull; }
-    if (tid < 3) L.note[tid] = 0;
-    if (tid == 0) { L.s_open = 0; L.s_stuck = 0; }
-    __syncthreads();
-    const int lu = valid ? v.labels[o] : v.alpha;
-    const long long take = valid ? v.dq[(int64_t)v.alpha * v.n + o] : 0;
-    for (int a = tid; a < E; a += NT) {
-        L.idx[a] = (unsigned short)v.idx[a];
-        L.rev[a] = (unsigned short)v.rev[a];
-        if (!v.wq) L.cap[a] = v.lambda_q * (long long)v.mult[a];
-    }
-    const bool mine_alpha = lu == v.alpha;   // (a site that carries alpha takes no part)
-    long long keep = (valid && !mine_alpha) ? v.dq[(int64_t)lu * v.n + o] : 0;
-    if (valid) { L.lab[tid] = (unsigned char)lu; atomicAdd(&L.cnt[lu], 1); L.d[tid] = kInf; }
-    if (v.wq && valid) {   // per-arc weights in the ORIGINAL arc order: rows keep their entry order
-        const long long* const wrow = v.wq + v.goff[o] - a0;
-        for (int a = a0; a < a1; ++a) L.cap[a] = wrow[a];
-    }
-    __syncthreads();
-    if (tid < kMaxL) {
-        const bool ex = tid < v.L && v.h_q > 0 && tid != v.alpha && L.cnt[tid] > 0;
-        L.hubx[tid] = ex ? 1 : 0;
-        L.hube[tid] = ex ? v.h_q : 0ll;
-        L.hubd[tid] = kInf;
-    }
-    const int cnt_alpha = L.cnt[v.alpha];
-    long long rt = 0, f = 0;   // the site's t-link and what it holds of its hub's flow: only its own thread touches them
-    if (valid) {
-        long long e0 = 0;
-        for (int ab = a0; ab < a1; ab += 8) {
-            long long w[8];
-            int lq[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int a = ab + q < a1 ? ab + q : a1 - 1; w[q] = L.cap[a]; lq[q] = L.idx[a]; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) lq[q] = L.lab[lq[q]];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (ab + q >= a1) continue;
-                long long c;
-                if (mine_alpha || lq[q] == v.alpha) { keep += w[q]; c = 0; }
-                else if (lq[q] == lu) c = w[q];
-                else { keep += w[q] / 2; c = w[q] / 2; }
-                L.cap[ab + q] = c;
-            }
-        }
-        if (!mine_alpha) {
-            if (keep > take) e0 = keep - take;
-            else rt = take - keep;
-            if (rt <= 0) L.s_open = 1;
-            else if (v.h_q > 0) atomicAdd(&L.pool[lu], (unsigned long long)rt);
-        }
-        L.ex[tid] = e0;
-    }
-    __syncthreads();
-    // a move nobody can want (t_move_kernel): no site without a t-link and every hub drains into its members' t-links with room to spare
-    const bool thin = tid < kMaxL && L.hubx[tid] && L.pool[tid] <= (unsigned long long)v.h_q;
-    const int thin_any = __syncthreads_or(thin ? 1 : 0);
-    if (L.s_open == 0 && thin_any == 0) return;   // flags stay zero: nothing relabelled, no rounds, not given up
-    const bool any_hub = __syncthreads_or((tid < kMaxL && L.hubx[tid]) ? 1 : 0) != 0;
-    const bool part = valid && !mine_alpha;           // the site is in the move's graph
-    // the row's first 16 neighbours stay in registers (slots beyond the row name the site itself: harmless in a min over heights): the LDS
-    // serves every wave of the workgroup one instruction at a time, and a step's cost is the number of LDS instructions its waves issue
+    const bool valid = s.valid, part = s.part, my_hub = s.my_hub, any_long = s.any_long, any_hub = s.any_hub;
+    const int lu = s.lu, a0 = s.a0, a1 = s.a1;
+    long long rt = s.rt, f = s.f;
+    int du = kInf;
     int nb[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) nb[q] = (part && a0 + q < a1) ? (int)L.idx[a0 + q] : (valid ? tid : 0);
-    const bool long_row = part && a1 - a0 > 16;
-    const bool any_long = __syncthreads_or(long_row ? 1 : 0) != 0;
-    const bool my_hub = part && L.hubx[lu] != 0;      // its label has a hub
-    lap(0);
-    int rounds = 0, gave_up = 0, step = 0;
-    int du = kInf;
-    int n_steps = 0, n_sweeps = 0;   // (debug)
+    for (int q = 0; q < 16; ++q) nb[q] = s.nb[q];
+    int step = 0;
+    rounds = 0;
+    gave_up = 0;
+    du = kInf;
+    n_steps = 0;
+    n_sweeps = 0;
     for (;; ++rounds) {
         // ---- search: exact distances to t by label correction from "unreachable" (values only fall, each witnessed by a residual path;
         // the fixpoint of d = 1 + min over residual arcs is the distance labelling).  A hub is a node: below every member (inf arc
@@ -1000,6 +937,109 @@ __global__ __launch_bounds__(NT) void t_mini_kernel(TView v, int sweeps, int max
         }
         lap(8);
     }
+    s.rt = rt;
+    s.f = f;
+    s.du = du;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void t_mini_kernel(TView v, int sweeps, int max_rounds)
+{
+    __shared__ MiniLds L;
+    const int tid = (int)threadIdx.x;
+    if (v.ctl) {   // a move of a batch (t_move_kernel)
+        if (batch_skips(v.ctl, v.skip_rel)) return;
+        if (tid == 0) st32<SC_AG>(&v.flags[6], 1);
+    }
+    const int n = (int)v.n;   // <= NT (the host picks the width): thread i owns site i
+    unsigned long long tprev = wall_clock64();
+    auto lap = [&](int k) {   // (debug) time since the last lap goes to slot k
+        if (v.dbg && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
+    };
+    // ---- the problem into LDS and registers.  Round trip 1: the site's place and row; 2: its label, costs and (all threads together)
+    // the arc tables; behind the barrier the rows turn the arc weights into capacities.
+    const bool valid = tid < n;
+    const int64_t o = valid ? v.perm[tid] : 0;
+    const int a0 = valid ? v.off[tid] : 0, a1 = valid ? v.off[tid + 1] : 0;
+    const int E = v.off[n];
+    if (tid < kMaxL) { L.cnt[tid] = 0; L.pool[tid] = 0ull; }
+    if (tid < 3) L.note[tid] = 0;
+    if (tid == 0) { L.s_open = 0; L.s_stuck = 0; }
+    __syncthreads();
+    const int lu = valid ? v.labels[o] : v.alpha;
+    const long long take = valid ? v.dq[(int64_t)v.alpha * v.n + o] : 0;
+    for (int a = tid; a < E; a += NT) {
+        L.idx[a] = (unsigned short)v.idx[a];
+        L.rev[a] = (unsigned short)v.rev[a];
+        if (!v.wq) L.cap[a] = v.lambda_q * (long long)v.mult[a];
+    }
+    const bool mine_alpha = lu == v.alpha;   // (a site that carries alpha takes no part)
+    long long keep = (valid && !mine_alpha) ? v.dq[(int64_t)lu * v.n + o] : 0;
+    if (valid) { L.lab[tid] = (unsigned char)lu; atomicAdd(&L.cnt[lu], 1); L.d[tid] = kInf; }
+    if (v.wq && valid) {   // per-arc weights in the ORIGINAL arc order: rows keep their entry order
+        const long long* const wrow = v.wq + v.goff[o] - a0;
+        for (int a = a0; a < a1; ++a) L.cap[a] = wrow[a];
+    }
+    __syncthreads();
+    if (tid < kMaxL) {
+        const bool ex = tid < v.L && v.h_q > 0 && tid != v.alpha && L.cnt[tid] > 0;
+        L.hubx[tid] = ex ? 1 : 0;
+        L.hube[tid] = ex ? v.h_q : 0ll;
+        L.hubd[tid] = kInf;
+    }
+    const int cnt_alpha = L.cnt[v.alpha];
+    long long rt = 0, f = 0;   // the site's t-link and what it holds of its hub's flow: only its own thread touches them
+    if (valid) {
+        long long e0 = 0;
+        for (int ab = a0; ab < a1; ab += 8) {
+            long long w[8];
+            int lq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int a = ab + q < a1 ? ab + q : a1 - 1; w[q] = L.cap[a]; lq[q] = L.idx[a]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lq[q] = L.lab[lq[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (ab + q >= a1) continue;
+                long long c;
+                if (mine_alpha || lq[q] == v.alpha) { keep += w[q]; c = 0; }
+                else if (lq[q] == lu) c = w[q];
+                else { keep += w[q] / 2; c = w[q] / 2; }
+                L.cap[ab + q] = c;
+            }
+        }
+        if (!mine_alpha) {
+            if (keep > take) e0 = keep - take;
+            else rt = take - keep;
+            if (rt <= 0) L.s_open = 1;
+            else if (v.h_q > 0) atomicAdd(&L.pool[lu], (unsigned long long)rt);
+        }
+        L.ex[tid] = e0;
+    }
+    __syncthreads();
+    // a move nobody can want (t_move_kernel): no site without a t-link and every hub drains into its members' t-links with room to spare
+    const bool thin = tid < kMaxL && L.hubx[tid] && L.pool[tid] <= (unsigned long long)v.h_q;
+    const int thin_any = __syncthreads_or(thin ? 1 : 0);
+    if (L.s_open == 0 && thin_any == 0) return;   // flags stay zero: nothing relabelled, no rounds, not given up
+    const bool any_hub = __syncthreads_or((tid < kMaxL && L.hubx[tid]) ? 1 : 0) != 0;
+    const bool part = valid && !mine_alpha;           // the site is in the move's graph
+    // the row's first 16 neighbours stay in registers (slots beyond the row name the site itself: harmless in a min over heights): the LDS
+    // serves every wave of the workgroup one instruction at a time, and a step's cost is the number of LDS instructions its waves issue
+    int nb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) nb[q] = (part && a0 + q < a1) ? (int)L.idx[a0 + q] : (valid ? tid : 0);
+    const bool long_row = part && a1 - a0 > 16;
+    const bool any_long = __syncthreads_or(long_row ? 1 : 0) != 0;
+    const bool my_hub = part && L.hubx[lu] != 0;      // its label has a hub
+    lap(0);
+    MiniSite st;
+    st.valid = valid; st.part = part; st.my_hub = my_hub; st.lu = lu; st.a0 = a0; st.a1 = a1; st.rt = rt; st.f = f; st.du = kInf;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st.nb[q] = nb[q];
+    st.any_long = any_long; st.any_hub = any_hub;
+    int rounds = 0, gave_up = 0, n_steps = 0, n_sweeps = 0;
+    mini_solve<NT>(L, v, st, sweeps, max_rounds, rounds, gave_up, n_steps, n_sweeps, lap);
+    const int du = st.du;
     lap(7);
     int changed = 0;
     if (!gave_up) {
@@ -1019,6 +1059,119 @@ __global__ __launch_bounds__(NT) void t_mini_kernel(TView v, int sweeps, int max
     }
     lap(10);
     if (v.dbg && tid == 0) { v.dbg[11] += n_steps; v.dbg[12] += rounds; v.dbg[13] += n_sweeps; }
+    if (tid == 0) {
+        if (changed) add32_ag(&v.flags[1], changed);
+        st32<SC_AG>(&v.flags[4], rounds + 1);
+        st32<SC_AG>(&v.flags[5], gave_up);
+        if (v.ctl) {
+            if (gave_up) st32<SC_AG>(&v.ctl[0], 1);
+            else if (changed) add32_ag(&v.ctl[1], 1);
+        }
+    }
+}
+
+// ---- a region move of <= 1 024 open sites and <= 8 192 arcs between them, solved in LDS --------------------------------------------
+// The problem expand_alpha_region prepares (r_build_kernel: rows of uniform stride, absent arcs marked by head == the site itself, no hubs)
+// compacted into the LDS tables of t_mini_kernel - a site's real arcs are counted, a workgroup scan places its row, the position of a
+// reverse arc is the neighbour's row start + the rank of the arc among the neighbour's real arcs (one 32-bit mask per site) - and solved by the same
+// rounds (mini_solve).  Launched ahead of t_move_kernel's region instance, which returns at once when this kernel took the move
+// (flags[6]) and solves what it leaves (more sites or arcs).  C5: the solver's share of a region move 45.6 -> see DESIGN.md 4.3.
+__global__ __launch_bounds__(1024) void t_region_mini_kernel(TView v, int stride, int sweeps, int max_rounds)
+{
+    constexpr int NT = 1024;
+    __shared__ MiniLds L;
+    __shared__ unsigned s_mask[kMiniSites];
+    __shared__ int s_off[kMiniSites + 1];
+    __shared__ int s_wsum[16];
+    const int tid = (int)threadIdx.x;
+    if (v.flags[6] != 0) return;        // (plain read: written by an earlier kernel)
+    if (batch_skips(v.ctl, v.skip_rel)) return;
+    const int c = v.rg->count;
+    if (c > kRegionCapTotal || v.rg->bad) {   // not built / not valid: the caller runs the general path (as t_move_kernel)
+        if (tid == 0) {
+            st32<SC_AG>(&v.flags[5], 4);
+            if (v.ctl) st32<SC_AG>(&v.ctl[0], 1);
+        }
+        return;
+    }
+    if (c > kMiniSites || stride > 32) return;   // the next launch takes it
+    unsigned long long tprev = wall_clock64();
+    auto lap = [&](int k) {
+        if (v.dbg && tid == 0) { const unsigned long long t = wall_clock64(); v.dbg[k] += t - tprev; tprev = t; }
+    };
+    const bool valid = tid < c;
+    const int base = tid * stride;
+    // real arcs of the row: head != the site itself
+    unsigned mask = 0;
+    if (valid)
+        for (int j = 0; j < stride; ++j)
+            if (v.idx[base + j] != tid) mask |= 1u << j;
+    const int rdeg = __popc(mask);
+    if (tid < 3) L.note[tid] = 0;
+    if (tid == 0) L.s_stuck = 0;
+    if (valid) s_mask[tid] = mask;
+    // exclusive scan of the real degrees over the workgroup
+    int incl = rdeg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += t; }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const int x = s_wsum[w]; if (w < (tid >> 6)) wbase += x; total += x; }
+    if (total > kMiniArcs) return;   // (workgroup-uniform) too many arcs for the LDS tables: the next launch takes it
+    const int a0 = wbase + incl - rdeg, a1 = a0 + rdeg;
+    if (valid) s_off[tid] = a0;
+    if (tid == 0) st32<SC_AG>(&v.flags[6], 1);   // this kernel takes the move
+    __syncthreads();
+    MiniSite st;
+    st.valid = valid; st.part = valid; st.my_hub = false; st.lu = 0; st.a0 = a0; st.a1 = a1; st.f = 0; st.du = kInf;
+    st.rt = valid ? v.rt[tid] : 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st.nb[q] = valid ? tid : 0;
+    if (valid) {
+        L.ex[tid] = v.ex[tid];
+        L.d[tid] = kInf;
+        int k = 0;
+        for (int j = 0; j < stride; ++j) {
+            if (!((mask >> j) & 1u)) continue;
+            const int head = v.idx[base + j], r = v.rev[base + j];
+            const int jj = r - head * stride;   // the reverse arc's slot in the head's row
+            L.idx[a0 + k] = (unsigned short)head;
+            L.rev[a0 + k] = (unsigned short)(s_off[head] + __popc(s_mask[head] & ((1u << jj) - 1u)));
+            L.cap[a0 + k] = v.cap[base + j];
+            if (k < 16) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) if (q == k) st.nb[q] = head;
+            }
+            ++k;
+        }
+    }
+    st.any_long = __syncthreads_or((valid && rdeg > 16) ? 1 : 0) != 0;
+    st.any_hub = false;
+    lap(0);
+    int rounds = 0, gave_up = 0, n_steps = 0, n_sweeps = 0;
+    mini_solve<NT>(L, v, st, sweeps, max_rounds, rounds, gave_up, n_steps, n_sweeps, lap);
+    lap(7);
+    int changed = 0;
+    if (!gave_up) {
+        // the hubs were left out (t_move_kernel, region mode): a label's hub must drain outside the region with room to spare
+        const bool in_play = tid < kMaxL && v.h_q > 0 && tid != v.alpha_apply && v.rg->cnt[tid] > 0 && v.rg->pool[tid] - v.rg->needsum[tid] <= v.h_q;
+        if (__syncthreads_or(in_play ? 1 : 0)) gave_up = 4;
+    }
+    if (!gave_up) {
+        bool apply = true;
+        if (v.rg->cnt[v.alpha_apply] == 0 && v.h_q > 0) {   // alpha is not in use: taking it costs h once (the gate; no hub excess in a region)
+            if (valid && st.du == kInf) { const long long e = L.ex[tid]; if (e > 0) atomicAdd(&L.s_stuck, (unsigned long long)e); }
+            __syncthreads();
+            apply = (long long)L.s_stuck >= v.h_q;
+        }
+        if (apply) {
+            const bool takes = valid && st.du == kInf;
+            if (takes) v.labels[v.perm[tid]] = v.alpha_apply;
+            changed = __syncthreads_count(takes ? 1 : 0);
+        }
+    }
+    lap(10);
     if (tid == 0) {
         if (changed) add32_ag(&v.flags[1], changed);
         st32<SC_AG>(&v.flags[4], rounds + 1);
@@ -1473,7 +1626,10 @@ int expand_alpha_region(pgx_ctx* ctx, const MfView& mv, int64_t* changed)
                        ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), (const int*)v.ctl, v.skip_rel);
     hipLaunchKernelGGL(r_build_kernel, dim3(kRegionCap / 256), dim3(256), 0, ctx->stream, rg, mv.alpha, stride, mv.labels, mv.off, mv.idx, mv.rev,
                        mv.cap, mv.ex, mv.rt, ts->rg_slot.as<int>(), ts->rg_site.as<int>(), ts->rg_need.as<long long>(), v);
-    hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096);
+    // the solver: the LDS-resident kernel for regions of <= 1 024 sites / 8 192 arcs (nearly all of them), then the memory-resident one,
+    // which returns at once when the first took the move (PGX_TILE_MINI=0: the 256-thread memory-resident instance first, as before)
+    if (ctx->tile_mini) hipLaunchKernelGGL(t_region_mini_kernel, dim3(1), dim3(1024), 0, ctx->stream, v, stride, ctx->tile_mini_sweeps, 4096);
+    else hipLaunchKernelGGL((t_move_kernel<256, 4, 16>), dim3(1), dim3(256), 0, ctx->stream, v, ctx->tile_sweeps, 4096);
     hipLaunchKernelGGL((t_move_kernel<1024, 8, 16>), dim3(1), dim3(1024), 0, ctx->stream, v, ctx->tile_sweeps, 4096);
     PGX_HIP(ctx, hipGetLastError());
     static_assert(SmallLayout::flags + 8 * 4 == SmallLayout::bytes, "the flags end the small block: flags | region info head is one copy");

@@ -563,8 +563,10 @@ def test_residual_sum(gpu_ctx, oracle, name):
 MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0"},
                 "region": {"PGX_MF_TILE": "0"},
                 # the one-workgroup solver that keeps the capacities in memory, also where the LDS-resident one would take the move
-                "one_workgroup_memory": {"PGX_TILE_MINI": "0"}}
-MINCUT_COUNTED_AS = {"one_workgroup_memory": "one_workgroup"}
+                "one_workgroup_memory": {"PGX_TILE_MINI": "0"},
+                # region moves solved by the memory-resident instance (default: the LDS-resident t_region_mini_kernel first)
+                "region_memory": {"PGX_MF_TILE": "0", "PGX_TILE_MINI": "0"}}
+MINCUT_COUNTED_AS = {"one_workgroup_memory": "one_workgroup", "region_memory": "region"}
 
 
 @pytest.fixture
