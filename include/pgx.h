@@ -125,6 +125,12 @@ int pgx_pnapsac_create(const double *pts, int64_t n, int d, const double *sizes,
 int pgx_pnapsac_draw(pgx_pnapsac *sampler, uint64_t key, uint32_t batch, int32_t count, const int32_t *tops,
                      const int64_t *growth_local, int64_t max_local, int32_t *out);
 void pgx_pnapsac_destroy(pgx_pnapsac *sampler);
+/* host helpers of the samplers that draw from the CALLER's generator (the default numpy-stream samplers of pyprogressivex/_proposal.py: the
+ * uniform / NAPSAC / PROSAC samplers of progressivex_python.cpp:215-245 return distinct indices by construction): no GPU, no context.
+ * rows_with_duplicates: out_bad[r] = 1 iff row r of s [count][m] holds a repeated value.  fisher_yates_rows: row rows[t] of s [.][m]
+ * becomes the first m entries of a Fisher-Yates shuffle of its range whose step j swaps positions j and j + draws[t][j]. */
+int pgx_host_rows_with_duplicates(const int64_t *s, int64_t count, int m, uint8_t *out_bad);
+int pgx_host_fisher_yates_rows(const int64_t *draws, const int64_t *rows, int64_t k, int m, int64_t *s);
 int pgx_score_launch(pgx_ctx *ctx, double T2, int has_compound, int want_masks);   /* asynchronous */
 int pgx_score_fetch(pgx_ctx *ctx, int exponent, int64_t *counts, double *values, double *shared,
                     double *scores, uint64_t *masks);

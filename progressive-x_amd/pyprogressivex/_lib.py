@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pgx_score", "pgx_score_upload", "pgx_score_launch", "pgx_score_fetch", "pgx_score_algorithmic_bytes", "pgx_score_stats", "pgx_score_profile", "pgx_score_kernel_times", "pgx_score_debug_fetch", "pgx_score_debug_geometry",
     "pgx_preference", "pgx_get_preference", "pgx_compound_update",
     "pgx_pearl_unary", "pgx_set_unary_q", "pgx_set_graph", "pgx_graph_build", "pgx_graph_fetch", "pgx_set_weights", "pgx_gram", "pgx_solve_minimal",
-    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_one_workgroup_launches", "pgx_graph_size", "pgx_eigh_smallest_batch",
+    "pgx_set_labels", "pgx_get_labels", "pgx_energy", "pgx_expand_alpha", "pgx_expansion", "pgx_greedy_labeling", "pgx_expansion_stats", "pgx_expansion_paths", "pgx_expansion_schedule", "pgx_one_workgroup_launches", "pgx_host_rows_with_duplicates", "pgx_host_fisher_yates_rows", "pgx_graph_size", "pgx_eigh_smallest_batch",
     "pgx_bucket", "pgx_residual_sum", "pgx_gc_labeling", "pgx_gc_inliers", "pgx_epipolar_support", "pgx_gram_batch", "pgx_gram_labels", "pgx_residual_sums", "pgx_pnp_refine_batch",
     "pgx_comm_unique_id", "pgx_comm_init", "pgx_comm_destroy", "pgx_comm_barrier", "pgx_comm_allreduce_max_f64",
     "pgx_score_allgather", "pgx_score_fetch_all", "pgx_score_allgather_begin", "pgx_score_allgather_end", "pgx_compound_allreduce_max",
@@ -115,6 +115,27 @@ def comm_unique_id():
     if r != 0:
         raise PgxError(f"pgx_comm_unique_id failed ({r}): {lib.pgx_global_error().decode()}")
     return bytes(buf)
+
+
+def host_rows_with_duplicates(s):
+    """pgx_host_rows_with_duplicates: bool [count] - which rows of the int64 array s [count, m] hold a repeated value (host code, no GPU)."""
+    s = np.ascontiguousarray(s, dtype=np.int64)
+    out = np.empty(s.shape[0], dtype=np.uint8)
+    r = load().pgx_host_rows_with_duplicates(_ptr(s, C.c_int64), C.c_int64(s.shape[0]), C.c_int(s.shape[1]), _ptr(out, C.c_uint8))
+    if r != 0:
+        raise PgxError(f"pgx_host_rows_with_duplicates failed ({r})")
+    return out.view(np.bool_)
+
+
+def host_fisher_yates_rows(draws, rows, s):
+    """pgx_host_fisher_yates_rows: fills the rows `rows` of s [count, m] (int64, C-contiguous, in place) from the offsets draws [k, m]."""
+    draws = np.ascontiguousarray(draws, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    if s.dtype != np.int64 or not s.flags.c_contiguous:
+        raise ValueError("host_fisher_yates_rows: s must be a C-contiguous int64 array")
+    r = load().pgx_host_fisher_yates_rows(_ptr(draws, C.c_int64), _ptr(rows, C.c_int64), C.c_int64(rows.shape[0]), C.c_int(s.shape[1]), _ptr(s, C.c_int64))
+    if r != 0:
+        raise PgxError(f"pgx_host_fisher_yates_rows failed ({r})")
 
 
 class PnapsacSampler:

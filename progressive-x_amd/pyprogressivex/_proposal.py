@@ -17,6 +17,8 @@ absent from the snapshot (empty submodule), so the loop is restated [UPSTREAM-ME
 """
 import numpy as np
 
+from . import _lib
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # samplers  (ids as in progressivex_python.cpp:215-245)
@@ -32,14 +34,13 @@ def _distinct_rows(rng, tops, m, retries=4):
     if m < 2:
         return s
     dense = tops < 4 * m                      # rejection succeeds with probability < ~0.5 per round there: go exact at once
+    # (which rows hold a repeated index: libpgx's host code - the sort + compare + any of numpy was a third of a draw's time)
     for _ in range(retries):
-        srt = np.sort(s, axis=1)
-        bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1) & ~dense
+        bad = _lib.host_rows_with_duplicates(s) & ~dense
         if not bad.any():
             break
         s[bad] = (rng.random((int(bad.sum()), m)) * tops[bad][:, None]).astype(np.int64)
-    srt = np.sort(s, axis=1)
-    bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+    bad = np.nonzero(_lib.host_rows_with_duplicates(s))[0]
     _fisher_yates_rows(rng, s, tops, bad, m)
     return s
 
@@ -55,6 +56,9 @@ def _fisher_yates_rows(rng, s, tops, bad, m):
         return
     top = tops[bad]
     draws = rng.integers(0, top[:, None] - np.arange(m)[None, :])
+    if s.dtype == np.int64 and s.flags.c_contiguous:   # the table walk in libpgx's host code (same rows: tests/test_host_logic.py)
+        _lib.host_fisher_yates_rows(draws, bad, s)
+        return
     vals = np.tile(np.arange(m, dtype=np.int64), (k, 1))     # the value at positions 0 .. m-1
     epos = np.full((k, m), -1, dtype=np.int64)               # swap table for positions >= m: at most one new entry per step
     evals = np.zeros((k, m), dtype=np.int64)

@@ -438,3 +438,53 @@ def test_vectorised_fisher_yates_keeps_the_generator_stream():
         assert np.array_equal(a, b) and ra.random() == rb.random()
         for r in bad:
             assert len(set(a[r])) == m and a[r].max() < tops[r]
+        # the table walk runs in libpgx's host code for C-contiguous int64 rows (above) and in numpy otherwise: the same rows
+        wide = np.zeros((count, 2 * m), np.int64)
+        c = wide[:, ::2]
+        rc = np.random.default_rng(seed + 7)
+        P._fisher_yates_rows(rc, c, tops, bad, m)
+        assert np.array_equal(c, b)
+
+
+def test_host_row_helpers_of_libpgx_match_numpy():
+    """pgx_host_rows_with_duplicates against sort + compare, and _distinct_rows end to end: rows of distinct indices below their
+    tops, and the same rows and generator state as the all-numpy statement of the function."""
+    from pyprogressivex import _lib, _proposal as P
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        m = int(rng.integers(1, 9))
+        count = int(rng.integers(0, 400))
+        s = rng.integers(0, int(rng.choice([m, 2 * m, 50, 10 ** 6])) + 1, (count, m)).astype(np.int64)
+        srt = np.sort(s, axis=1)
+        ref = (srt[:, 1:] == srt[:, :-1]).any(axis=1) if m > 1 else np.zeros(count, bool)
+        assert np.array_equal(_lib.host_rows_with_duplicates(s), ref)
+
+    def distinct_rows_numpy(rng, tops, m, retries=4):   # the function as it was before the helpers (numpy only)
+        tops = np.asarray(tops, dtype=np.int64)
+        s = (rng.random((tops.shape[0], m)) * tops[:, None]).astype(np.int64)
+        if m < 2:
+            return s
+        dense = tops < 4 * m
+        for _ in range(retries):
+            srt = np.sort(s, axis=1)
+            bad = (srt[:, 1:] == srt[:, :-1]).any(axis=1) & ~dense
+            if not bad.any():
+                break
+            s[bad] = (rng.random((int(bad.sum()), m)) * tops[bad][:, None]).astype(np.int64)
+        srt = np.sort(s, axis=1)
+        bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+        P._fisher_yates_rows_scalar(rng, s, tops, bad, m)
+        return s
+
+    for seed in range(60):
+        r0 = np.random.default_rng(seed)
+        m = int(r0.integers(1, 8))
+        count = int(r0.integers(1, 1200))
+        tops = r0.integers(m, m + int(r0.choice([1, 4, 30, 2000])), count).astype(np.int64)
+        ra, rb = np.random.default_rng(seed + 99), np.random.default_rng(seed + 99)
+        a = P._distinct_rows(ra, tops, m)
+        b = distinct_rows_numpy(rb, tops, m)
+        assert np.array_equal(a, b) and ra.random() == rb.random()
+        assert (a < tops[:, None]).all() and (a >= 0).all()
+        if m > 1:
+            assert not _lib.host_rows_with_duplicates(a).any()
