@@ -428,6 +428,37 @@ def secondary_legs(_lib, datasets, parallel, ctx, pts, hyps, gt, T2, steps, warm
                                                   "step": "two batches in flight: launch(i) + pgx_score_allreduce_begin(i) [export of the integer accumulators, "
                                                           "ncclAllReduce(sum, uint64), conversion and copy to pinned memory on the exchange stream] + "
                                                           "pgx_score_allreduce_end(i - 1) + select"}
+            # the RANSAC-like step (leg 2) with two batches in flight: the samples of batch i are drawn and solved and its
+            # scoring launched BEFORE the table of batch i - 1 is taken and walked - the host's share (draw, fetch, select) overlaps the
+            # device's.  Its own leg: the serial step stays the headline, and the drop-in calls cannot use it (one proposal's walk and
+            # compound update precede the next proposal's samples: DESIGN.md, round-6 table)
+            try:
+                state["i"] = 0
+                cc.solve_minimal(draw(), fetch=False)
+                cc.score_launch(T2, has_compound=True)
+                cc.score_allgather_begin(0)
+                picks = []
+
+                def step_pipe_ransac():
+                    i = state["i"] = state["i"] + 1
+                    cc.solve_minimal(draw(), fetch=False)
+                    cc.score_launch(T2, has_compound=True)
+                    cc.score_allgather_begin(i & 1)
+                    res = cc.score_allgather_end((i - 1) & 1, exponent=2)
+                    return parallel.select_best(res["scores"], res["counts"])
+                for _ in range(warmup):
+                    step_pipe_ransac()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    picks.append(step_pipe_ransac())
+                cc.sync()
+                s = (time.perf_counter() - t0) / steps
+                cc.score_allgather_end(state["i"] & 1, exponent=2)
+                legs["pipelined_end_to_end"] = {"ms_per_step": 1e3 * s, "models_per_sec": M / s, "pipelined": True,
+                                                "step": f"the ransac_like_end_to_end step with two batches in flight on a 1-rank communicator: draw {S} samples + "
+                                                        "pgx_solve_minimal + launch of batch i, then pgx_score_allgather_end + select of batch i - 1"}
+            except Exception as e:
+                legs["pipelined_end_to_end"] = {"error": str(e)}
             cc.comm_destroy()
         finally:
             cc.close()
