@@ -1546,6 +1546,23 @@ def test_rccl_single_rank_allgather(gpu_ctx):
         gpu_ctx.comm_destroy()
 
 
+@pytest.mark.parametrize("n", [1023, 1024, 1025, 2049, 8191, 8192, 8193])
+def test_inlier_indices_at_the_one_launch_compaction_limits(gpu_ctx, oracle, n):
+    """Up to 8 192 points the inlier indices come from one launch (pointwise.hip compact_small_kernel: a run of <= 8 consecutive items per
+    thread, 1 024 threads), beyond from hipcub's select: the same ascending sets at the sizes where the run length and the path change,
+    for the scorer's mask rows and for the cut's flags (the cut's compaction rides behind the one-workgroup move)."""
+    mt, pts, models, thr = make_case("line", n, 3, seed=n)
+    T2 = 2.25 * thr * thr
+    gpu_ctx.set_points(mt, pts)
+    gpu_ctx.score(models, T2, want_masks=True)
+    for row in range(len(models)):
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(gpu_ctx.score_inliers(row), np.flatnonzero(oracle.squared_residuals(mt, pts, models[row]) < T2))
+    graph = gpu_ctx.graph_build(pts, _lib.GRAPH_KNN, k=4)
+    for m in models:
+        assert np.array_equal(gpu_ctx.gc_inliers(m, T2, 0.2), np.flatnonzero(oracle.gc_labeling(mt, pts, m, T2, 0.2, graph)))
+
+
 @pytest.mark.parametrize("name", ["pnp", "homography", "line"])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 5000, 100003])
 def test_score_inliers_are_the_mask_row(gpu_ctx, oracle, name, n):
