@@ -13,7 +13,7 @@ import sys
 
 tag, prefix = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MINCUT = ("mf_k_", "t_move_kernel", "r_init_mark_kernel", "r_promote_kernel", "r_build_kernel", "energy_kernel")
+MINCUT = ("mf_k_", "t_move_kernel", "t_mini_kernel", "t_region_mini_kernel", "r_init_mark_kernel", "r_promote_kernel", "r_build_kernel", "energy_kernel")
 
 
 def db_of(d):
