@@ -1259,43 +1259,47 @@ __global__ __launch_bounds__(1024) void r_promote_kernel(RegionInfo* __restrict_
                                                          const long long* __restrict__ rt, int* __restrict__ slot, int* __restrict__ site,
                                                          long long* __restrict__ need, const int* __restrict__ ctl, int skip_rel)
 {
-    __shared__ int s_hi;
+    // The kernel is ONE workgroup: the count of region sites and the list of the sites it appends live in LDS while it runs (the global
+    // copies are written for the kernels behind it) - a round no longer starts with two dependent device-scope loads (count, then site;
+    // typically 4-5 rounds per move at C5, ~5 us each: histogram in the notebook)
+    __shared__ int s_count;
+    __shared__ int s_site[kRegionCap];
     if (batch_skips(ctl, skip_rel)) return;
-    int lo = 0;
-    if (threadIdx.x == 0) s_hi = ld32<SC_AG>(&rg->count);
+    if (threadIdx.x == 0) s_count = ld32<SC_AG>(&rg->count);
     __syncthreads();
-    int hi = s_hi;
+    int lo = 0, hi = s_count;
     if (hi > kRegionCap) return;
+    for (int i = (int)threadIdx.x; i < hi; i += 1024) s_site[i] = site[i];   // (written by the kernel before this one)
+    __syncthreads();
     for (int round = 0; round < kPromoteRounds && lo < hi; ++round) {
         for (int i = lo + (int)threadIdx.x; i < hi; i += 1024) {
-            const int u = ld32<SC_AG>(&site[i]);
+            const int u = s_site[i];
             for (int a = off[u]; a < off[u + 1]; ++a) {
                 const long long c = cap[a];
                 const int q = idx[a];
                 if (c <= 0 || labels[q] == alpha || ld32<SC_AG>(&slot[q]) >= 0) continue;
                 const long long old = xadd64<SC_AG>(&need[q], c), r = rt[q];
                 if (old < r && old + c >= r) {   // this add reached the neighbour's sink capacity: exactly one add does
-                    const int j = __hip_atomic_fetch_add(&rg->count, 1, __ATOMIC_RELAXED, SC_AG);
-                    if (j < kRegionCap) { st32<SC_AG>(&site[j], q); st32<SC_AG>(&slot[q], j); }
+                    const int j = atomicAdd(&s_count, 1);
+                    if (j < kRegionCap) { s_site[j] = q; st32<SC_AG>(&site[j], q); st32<SC_AG>(&slot[q], j); }
                 }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) s_hi = ld32<SC_AG>(&rg->count);
-        __syncthreads();
         lo = hi;
-        hi = s_hi;
-        if (hi > kRegionCap) return;
+        hi = s_count;
+        if (hi > kRegionCap) break;
         __syncthreads();
     }
-    // members promoted in the last round have not added their own arcs to need[] yet: the checks of r_build_kernel would be made
-    // on incomplete sums - the region is not valid
-    if (lo < hi && threadIdx.x == 0) rg->bad = 1;
+    if (threadIdx.x == 0) {
+        st32<SC_AG>(&rg->count, hi);   // (> kRegionCap: the kernels behind this one decline the move)
+        // members promoted in the last round have not added their own arcs to need[] yet: the checks of r_build_kernel would be made
+        // on incomplete sums - the region is not valid
+        if (hi <= kRegionCap && lo < hi) rg->bad = 1;
+    }
 }
 
-// one thread per region site: its row in the compact graph; arcs into sites outside the region (all of them keep a t-link) are
-// folded into the site's own t-link, and every such neighbour is checked: need < rt, else the region is not valid (bad)
 __global__ __launch_bounds__(256) void r_build_kernel(RegionInfo* __restrict__ rg, int alpha, int stride, const int* __restrict__ labels,
                                                       const int* __restrict__ off, const int* __restrict__ idx, const int* __restrict__ rev,
                                                       const long long* __restrict__ cap, const long long* __restrict__ ex, const long long* __restrict__ rt,
