@@ -1186,9 +1186,10 @@ int expand_alpha_on(pgx_ctx* ctx, int64_t n, int L, const long long* dq, int* la
     if (source_reach && h_q != 0) return fail(ctx, PGX_ERR_INVALID, "expansion move: the source-side variant takes no label cost");
     const bool pair = true;
     if (ctx->gn != n) return fail(ctx, PGX_ERR_INVALID, "pgx_expansion: lambda > 0 needs a graph over %lld sites", (long long)n);
-    // Expansion moves on graphs of tile_expansion_max .. 8192 sites try the region path FIRST (measured at 5 000 sites, C2: 6.4 ms per expansion
-    // against 7.7 with every move on the whole-graph kernel, whose eight-sites-per-thread instance works out of memory); a move the region
-    // path declines goes to the whole-graph kernel (the caller re-runs it with the region path off; unbatched: below).
+    // Expansion moves on graphs of tile_expansion_max (1 024) .. 8192 sites try the region path FIRST (measured at 5 000 sites, C2: 6.2 ms per
+    // expansion against 7.7 with every move on the whole-graph kernel, which works out of memory beyond the LDS-resident kernel's 1 024 sites;
+    // 2 000 sites: 1.99 against 2.03); a move the region path declines goes to the whole-graph kernel (the caller re-runs it with the region
+    // path off; unbatched: below).
     const bool region_first = !source_reach && wq == nullptr && L <= 64 && n > ctx->tile_expansion_max && region_moves_apply(ctx);
     if (ctx->mf_tile && !source_reach && n <= ctx->tile_single_max && n <= 8192 && L <= 64 && !region_first) {   // (the sizes expand_alpha_tile takes)
         const int r = expand_alpha_tile(ctx, n, L, dq, labels, lambda_q, h_q, alpha, changed, wq);

@@ -150,7 +150,9 @@ struct pgx_ctx {
     int mf_tile = 1;             // PGX_MF_TILE=0: level-synchronous schedule of maxflow.hip for every move (A/B)
     int tile_order = 1;          // sites of the tile path in the Morton order of the graph's coordinates (0: the caller's order)
     int tile_single_max = 8192;  // graphs up to this many sites: the whole move in one launch of one workgroup
-    int tile_expansion_max = 4096;   // PGX_TILE_EXPANSION_MAX: expansion moves on larger graphs (up to tile_single_max) try the region path first (maxflow.hip expand_alpha_on)
+    int tile_expansion_max = 1024;   // PGX_TILE_EXPANSION_MAX: expansion moves on larger graphs (up to tile_single_max) try the region path first (maxflow.hip expand_alpha_on);
+                                     // = the LDS-resident whole-graph kernel's limit: beyond it the region path with ITS LDS-resident solver is as fast or faster
+                                     // (2 000 sites 1.99 vs 2.03 ms per expansion, 5 000 sites 6.2 vs 7.7; unihouse, 2 084 points: 74 -> 67 ms per call)
     int mf_xcd = 1;              // PGX_MF_XCD=0: no persistent one-XCD rounds (maxflow_xcd.hip.h); read at pgx_create like the switches above
     int mf_xcd_search = 1;       // PGX_MF_XCD_SEARCH=0: no one-launch global relabels
     int mf_xcd_min_depth = 24;   // PGX_MF_XCD_MIN_DEPTH: a search runs as one launch when the previous search of its kind was deeper than this

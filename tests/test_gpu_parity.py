@@ -560,10 +560,11 @@ def test_residual_sum(gpu_ctx, oracle, name):
 # ----------------------------------------------------------------------------------------------------------------------
 # a8 / a19 : energy, single expansion moves, full expansion
 # ----------------------------------------------------------------------------------------------------------------------
-MINCUT_PATHS = {"one_workgroup": {}, "level_synchronous": {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0"},
+MINCUT_PATHS = {"one_workgroup": {"PGX_TILE_EXPANSION_MAX": "8192"},    # every move of a graph of <= 8 192 sites on the whole-graph kernels (default: region first beyond 1 024)
+                "level_synchronous": {"PGX_MF_TILE": "0", "PGX_MF_REGION": "0"},
                 "region": {"PGX_MF_TILE": "0"},
                 # the one-workgroup solver that keeps the capacities in memory, also where the LDS-resident one would take the move
-                "one_workgroup_memory": {"PGX_TILE_MINI": "0"},
+                "one_workgroup_memory": {"PGX_TILE_MINI": "0", "PGX_TILE_EXPANSION_MAX": "8192"},
                 # region moves solved by the memory-resident instance (default: the LDS-resident t_region_mini_kernel first)
                 "region_memory": {"PGX_MF_TILE": "0", "PGX_TILE_MINI": "0"}}
 MINCUT_COUNTED_AS = {"one_workgroup_memory": "one_workgroup", "region_memory": "region"}
@@ -574,7 +575,7 @@ def mincut_ctx(request, monkeypatch):
     """A context per min-cut schedule (the switches are read when the context is created): the default (a graph of <= 8192
     sites is one workgroup, one launch per move), maxflow.hip's level-synchronous launches for everything, and region moves
     (the open sites of a move compacted and solved by one workgroup, enqueued a cycle at a time) even for small graphs."""
-    for key in ("PGX_MF_TILE", "PGX_MF_REGION", "PGX_TILE_MINI"):
+    for key in ("PGX_MF_TILE", "PGX_MF_REGION", "PGX_TILE_MINI", "PGX_TILE_EXPANSION_MAX"):
         monkeypatch.delenv(key, raising=False)
     for key, val in MINCUT_PATHS[request.param].items():
         monkeypatch.setenv(key, val)
@@ -821,9 +822,9 @@ def test_batched_one_workgroup_moves_equal_unbatched(oracle, monkeypatch, n, lam
     assert seen["1"] == seen["0"]
 
 
-@pytest.mark.parametrize("n,lam,h,L", [(5000, 0.2, 3.0, 6), (8000, 0.1, 10.0, 5), (4500, 0.45, 0.5, 4)])
+@pytest.mark.parametrize("n,lam,h,L", [(5000, 0.2, 3.0, 6), (8000, 0.1, 10.0, 5), (4500, 0.45, 0.5, 4), (1025, 0.3, 1.0, 5), (2084, 0.1, 4.0, 7)])
 def test_mid_size_graphs_region_first_then_whole_graph_kernel(oracle, n, lam, h, L):
-    """Graphs of 4 097 .. 8 192 sites (C2: 5 000): an expansion move tries the region path first and, declined, is solved by the one-workgroup
+    """Graphs of 1 025 .. 8 192 sites (C1: 2 000, C2: 5 000): an expansion move tries the region path first and, declined, is solved by the one-workgroup
     whole-graph kernel (not by the level-synchronous launches).  Labels, energy, cycles of the oracle; both solvers took moves."""
     Dq, graph = realistic_labeling_problem(n, L=L, lam=lam, seed=11 * n + L)
     lq, hq = oracle.quantize_lambda(lam), oracle.quantize(h)
